@@ -1,0 +1,366 @@
+"""go-kzg_amd -- host-side mirror of go-kzg's FFTSettings / KZGSettings / FK20*Settings API over libkzg_hip.so.
+
+The reference's host language is Go, which this image does not have; the drop-in boundary is the C ABI in
+include/kzg_hip.h (the cgo shim for it is in go-kzg_amd/goshim/ and INTEGRATION.md).  This module is the same
+thin binding written with ctypes so that the parity tests read like the reference's own tests:
+
+    fs = FFTSettings(4)                         # kzg.NewFFTSettings(4)              fft.go:44
+    ks = KZGSettings(fs, secret_g1)             # kzg.NewKZGSettings(fs, s1, s2)     kzg.go:21
+    c  = ks.commit_to_poly(poly)                # ks.CommitToPoly(poly)              kzg_single_proofs.go:17
+    fk = FK20SingleSettings(ks, 32)             # kzg.NewFK20SingleSettings(ks, 32)  kzg.go:43
+    pr = fk.da_using_fk20(poly)                 # fk.DAUsingFK20(poly)               fk20_single.go:176
+
+Values are numpy uint64 arrays holding the memory images of the reference's default backend:
+Fr -> (n, 4) Montgomery limbs; G1 -> (n, 3, 6) Jacobian Montgomery limbs (inf <=> Z == 0).
+
+There is NO CPU fallback: importing works anywhere (so the C ABI can be inspected), but constructing
+FFTSettings without a gfx950 device raises NoDeviceError, and a missing libkzg_hip.so raises ImportError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkzg_hip.so")
+
+OK, ERR_TOO_WIDE, ERR_NOT_POW2, ERR_LEN_MISMATCH, ERR_UPPER_HALF, ERR_BAD_ARG, ERR_BAD_POINT, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED = range(10)
+
+
+class KzgError(Exception):
+    """The reference returns an `error` (fft_fr.go:57-59,78-83; fft_g1.go:60-65)."""
+
+    def __init__(self, status, msg=""):
+        super().__init__("kzg_hip status %d %s" % (status, msg))
+        self.status = status
+
+
+class KzgPanic(KzgError):
+    """The reference panics (kzg.go:22-27,44-52,74-91; fk20_single.go:60-62,140-154; bls_kilic.go:133-135)."""
+
+
+class NoDeviceError(KzgError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Loads libkzg_hip.so (built by `make -C go-kzg_amd/csrc` / __graft_entry__.build()); fails loudly if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libkzg_hip.so is not built (run __graft_entry__.build()); there is no CPU fallback: " + LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u64, i32, u32 = C.c_void_p, C.c_uint64, C.c_int, C.c_uint
+    pp = C.POINTER(C.c_void_p)
+    sig = {
+        "kzg_hip_device_count": (i32, []), "kzg_hip_last_error": (C.c_char_p, []), "kzg_hip_version": (C.c_char_p, []),
+        "kzg_hip_fft_settings_new": (i32, [i32, u32, pp]), "kzg_hip_fft_settings_free": (None, [vp]),
+        "kzg_hip_fft_max_width": (u64, [vp]), "kzg_hip_fft_roots": (i32, [vp, i32, vp]),
+        "kzg_hip_fft_fr": (i32, [vp, vp, u64, i32, vp, C.POINTER(u64)]), "kzg_hip_inplace_fft_fr": (i32, [vp, vp, vp, u64, i32]),
+        "kzg_hip_fft_fr_batch": (i32, [vp, vp, u64, u64, i32, vp]), "kzg_hip_fft_g1": (i32, [vp, vp, u64, i32, vp]),
+        "kzg_hip_das_fft_extension": (i32, [vp, vp, u64]), "kzg_hip_das_fft_extension_batch": (i32, [vp, vp, u64, u64]),
+        "kzg_hip_lincomb_g1": (i32, [vp, vp, vp, u64, vp]), "kzg_hip_g1_to_compressed": (i32, [vp, vp, u64, vp]),
+        "kzg_hip_g1_from_compressed": (i32, [vp, vp, u64, vp]), "kzg_hip_g1_mul_vec": (i32, [vp, vp, vp, u64, vp]),
+        "kzg_hip_generate_testing_setup_g1": (i32, [vp, vp, u64, vp]),
+        "kzg_hip_kzg_settings_new": (i32, [vp, vp, u64, pp]), "kzg_hip_kzg_settings_free": (None, [vp]),
+        "kzg_hip_commit_to_poly": (i32, [vp, vp, u64, vp]), "kzg_hip_commit_to_poly_batch": (i32, [vp, vp, u64, u64, vp]),
+        "kzg_hip_commit_to_poly_batch_dev": (i32, [vp, vp, u64, u64, vp, vp]),
+        "kzg_hip_compute_proof_single": (i32, [vp, vp, u64, u64, vp]),
+        "kzg_hip_toeplitz_part2": (i32, [vp, vp, vp, u64, vp]), "kzg_hip_toeplitz_part3": (i32, [vp, vp, u64, vp]),
+        "kzg_hip_fk20_single_settings_new": (i32, [vp, u64, pp]), "kzg_hip_fk20_single_settings_free": (None, [vp]),
+        "kzg_hip_fk20_single_x_ext_fft": (i32, [vp, vp]), "kzg_hip_fk20_single": (i32, [vp, vp, u64, vp]),
+        "kzg_hip_fk20_single_da_optimized": (i32, [vp, vp, u64, vp]), "kzg_hip_da_using_fk20": (i32, [vp, vp, u64, vp]),
+        "kzg_hip_da_using_fk20_batch": (i32, [vp, vp, u64, u64, vp]), "kzg_hip_da_using_fk20_batch_dev": (i32, [vp, vp, u64, u64, vp, vp]),
+        "kzg_hip_fk20_multi_settings_new": (i32, [vp, u64, u64, pp]), "kzg_hip_fk20_multi_settings_free": (None, [vp]),
+        "kzg_hip_fk20_multi": (i32, [vp, vp, u64, vp]), "kzg_hip_fk20_multi_da_optimized": (i32, [vp, vp, u64, vp]),
+        "kzg_hip_da_using_fk20_multi": (i32, [vp, vp, u64, vp]),
+        "kzg_hip_da_using_fk20_multi_batch_dev": (i32, [vp, vp, u64, u64, vp, vp]),
+        "kzg_hip_fk20_multi_hext_slice_dev": (i32, [vp, vp, u64, u64, u64, vp, vp]),
+        "kzg_hip_fk20_multi_finish_dev": (i32, [vp, vp, i32, vp, vp]),
+        "kzg_hip_prof_reset": (None, [vp, i32]), "kzg_hip_prof_read": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64)]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)   # AttributeError here == header / library drift
+        f.restype, f.argtypes = res, args
+    _lib = L
+    return L
+
+
+API_SYMBOLS = None  # filled by tests from include/kzg_hip.h
+
+
+def device_count():
+    return lib().kzg_hip_device_count()
+
+
+_ERR_STATUS = (ERR_TOO_WIDE, ERR_NOT_POW2)
+
+
+def _chk(st, error_ok=False):
+    if st == OK:
+        return
+    msg = ""
+    if st == ERR_HIP:
+        msg = lib().kzg_hip_last_error().decode()
+    if st == ERR_NO_DEVICE:
+        raise NoDeviceError(st, "no gfx950 device visible (the HIP path is the only path)")
+    if error_ok and st in _ERR_STATUS:
+        raise KzgError(st, msg)
+    raise KzgPanic(st, msg)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _fr(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a.reshape(-1, 4)
+
+
+def _g1(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a.reshape(-1, 3, 6)
+
+
+def fr_empty(n):
+    return np.zeros((n, 4), dtype=np.uint64)
+
+
+def g1_empty(n):
+    return np.zeros((n, 3, 6), dtype=np.uint64)
+
+
+class FFTSettings:
+    """kzg.FFTSettings (fft.go:34-61) with a device-resident domain."""
+
+    def __init__(self, max_scale, device=0):
+        h = C.c_void_p()
+        _chk(lib().kzg_hip_fft_settings_new(device, max_scale, C.byref(h)))
+        self.h, self.max_scale, self.max_width, self.device = h, max_scale, 1 << max_scale, device
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().kzg_hip_fft_settings_free(self.h)
+            self.h = None
+
+    def expanded_roots_of_unity(self):
+        out = fr_empty(self.max_width + 1)
+        _chk(lib().kzg_hip_fft_roots(self.h, 0, _p(out)))
+        return out
+
+    def reverse_roots_of_unity(self):
+        out = fr_empty(self.max_width + 1)
+        _chk(lib().kzg_hip_fft_roots(self.h, 1, _p(out)))
+        return out
+
+    def fft(self, vals, inv=False):
+        """FFTSettings.FFT (fft_fr.go:55-74)"""
+        vals = _fr(vals)
+        n = vals.shape[0]
+        if n > self.max_width:
+            raise KzgError(ERR_TOO_WIDE)
+        np2 = 1 if n == 0 else 1 << (n - 1).bit_length()
+        out, on = fr_empty(np2), C.c_uint64(0)
+        _chk(lib().kzg_hip_fft_fr(self.h, _p(vals), n, int(inv), _p(out), C.byref(on)), error_ok=True)
+        return out
+
+    def inplace_fft(self, vals, inv=False):
+        """FFTSettings.InplaceFFT (fft_fr.go:76-105); returns `out`"""
+        vals = _fr(vals)
+        out = fr_empty(vals.shape[0])
+        _chk(lib().kzg_hip_inplace_fft_fr(self.h, _p(vals), _p(out), vals.shape[0], int(inv)), error_ok=True)
+        return out
+
+    def fft_batch(self, vals, inv=False):
+        vals = np.ascontiguousarray(vals, dtype=np.uint64)
+        b, n = vals.shape[0], vals.shape[1]
+        out = np.zeros_like(vals)
+        _chk(lib().kzg_hip_fft_fr_batch(self.h, _p(vals), n, b, int(inv), _p(out)), error_ok=True)
+        return out
+
+    def fft_g1(self, vals, inv=False):
+        """FFTSettings.FFTG1 (fft_g1.go:58-94)"""
+        vals = _g1(vals)
+        out = g1_empty(vals.shape[0])
+        _chk(lib().kzg_hip_fft_g1(self.h, _p(vals), vals.shape[0], int(inv), _p(out)), error_ok=True)
+        return out
+
+    def das_fft_extension(self, vals):
+        """FFTSettings.DASFFTExtension (das_extension.go:71-84); returns the odd values (the reference writes in place)"""
+        vals = _fr(vals).copy()
+        _chk(lib().kzg_hip_das_fft_extension(self.h, _p(vals), vals.shape[0]))
+        return vals
+
+    def das_fft_extension_batch(self, vals):
+        vals = np.ascontiguousarray(vals, dtype=np.uint64).copy()
+        _chk(lib().kzg_hip_das_fft_extension_batch(self.h, _p(vals), vals.shape[1], vals.shape[0]))
+        return vals
+
+    # ---- bls.* batch helpers that need a device context ----
+    def lin_comb_g1(self, numbers, factors):
+        """bls.LinCombG1 (bls/bls_kilic.go:132-150)"""
+        numbers, factors = _g1(numbers), _fr(factors)
+        if numbers.shape[0] != factors.shape[0]:
+            raise KzgPanic(ERR_LEN_MISMATCH, "got LinCombG1 numbers/factors length mismatch")
+        out = g1_empty(1)
+        _chk(lib().kzg_hip_lincomb_g1(self.h, _p(numbers), _p(factors), numbers.shape[0], _p(out)))
+        return out[0]
+
+    def to_compressed_g1(self, points):
+        points = _g1(points)
+        out = np.zeros((points.shape[0], 48), dtype=np.uint8)
+        _chk(lib().kzg_hip_g1_to_compressed(self.h, _p(points), points.shape[0], _p(out)))
+        return out
+
+    def from_compressed_g1(self, data):
+        data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1, 48)
+        out = g1_empty(data.shape[0])
+        _chk(lib().kzg_hip_g1_from_compressed(self.h, _p(data), data.shape[0], _p(out)))
+        return out
+
+    def mul_g1_vec(self, points, scalars):
+        points, scalars = _g1(points), _fr(scalars)
+        out = g1_empty(points.shape[0])
+        _chk(lib().kzg_hip_g1_mul_vec(self.h, _p(points), _p(scalars), points.shape[0], _p(out)))
+        return out
+
+    def generate_testing_setup_g1(self, secret_fr, n):
+        """GenerateTestingSetup (setup.go:9-26), G1 half; secret_fr is the Montgomery image of the secret"""
+        secret_fr = _fr(secret_fr)
+        out = g1_empty(n)
+        _chk(lib().kzg_hip_generate_testing_setup_g1(self.h, _p(secret_fr), n, _p(out)))
+        return out
+
+
+def commit_to_eval_poly(fs, secret_g1_ifft, eval_poly):
+    """kzg.CommitToEvalPoly (kzg_single_proofs.go:12-14)"""
+    return fs.lin_comb_g1(secret_g1_ifft, eval_poly)
+
+
+class KZGSettings:
+    """kzg.KZGSettings, prover side (kzg.go:11-36): SecretG1 is uploaded once and stays in HBM."""
+
+    def __init__(self, fs, secret_g1):
+        secret_g1 = _g1(secret_g1)
+        h = C.c_void_p()
+        _chk(lib().kzg_hip_kzg_settings_new(fs.h, _p(secret_g1), secret_g1.shape[0], C.byref(h)))
+        self.h, self.fs, self.n_setup = h, fs, secret_g1.shape[0]
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().kzg_hip_kzg_settings_free(self.h)
+            self.h = None
+
+    def commit_to_poly(self, coeffs):
+        coeffs = _fr(coeffs)
+        out = g1_empty(1)
+        _chk(lib().kzg_hip_commit_to_poly(self.h, _p(coeffs), coeffs.shape[0], _p(out)))
+        return out[0]
+
+    def commit_to_poly_batch(self, coeffs):
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64)
+        b, n = coeffs.shape[0], coeffs.shape[1]
+        out = g1_empty(b)
+        _chk(lib().kzg_hip_commit_to_poly_batch(self.h, _p(coeffs), n, b, _p(out)))
+        return out
+
+    def compute_proof_single(self, poly, x):
+        poly = _fr(poly)
+        out = g1_empty(1)
+        _chk(lib().kzg_hip_compute_proof_single(self.h, _p(poly), poly.shape[0], x, _p(out)))
+        return out[0]
+
+    def toeplitz_part2(self, toeplitz_coeffs, x_ext_fft):
+        toeplitz_coeffs, x_ext_fft = _fr(toeplitz_coeffs), _g1(x_ext_fft)
+        if toeplitz_coeffs.shape[0] != x_ext_fft.shape[0]:
+            raise KzgPanic(ERR_LEN_MISMATCH, "expected toeplitz coeffs to match xExtFFT length")
+        out = g1_empty(x_ext_fft.shape[0])
+        _chk(lib().kzg_hip_toeplitz_part2(self.h, _p(toeplitz_coeffs), _p(x_ext_fft), x_ext_fft.shape[0], _p(out)))
+        return out
+
+    def toeplitz_part3(self, h_ext_fft):
+        h_ext_fft = _g1(h_ext_fft)
+        out = g1_empty(h_ext_fft.shape[0] // 2)
+        _chk(lib().kzg_hip_toeplitz_part3(self.h, _p(h_ext_fft), h_ext_fft.shape[0], _p(out)))
+        return out
+
+
+class FK20SingleSettings:
+    """kzg.FK20SingleSettings (kzg.go:38-64; fk20_single.go:122-196)"""
+
+    def __init__(self, ks, n2):
+        h = C.c_void_p()
+        _chk(lib().kzg_hip_fk20_single_settings_new(ks.h, n2, C.byref(h)))
+        self.h, self.ks, self.n2 = h, ks, n2
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().kzg_hip_fk20_single_settings_free(self.h)
+            self.h = None
+
+    def x_ext_fft(self):
+        out = g1_empty(self.n2)
+        _chk(lib().kzg_hip_fk20_single_x_ext_fft(self.h, _p(out)))
+        return out
+
+    def fk20_single(self, poly):
+        poly = _fr(poly)
+        out = g1_empty(poly.shape[0])
+        _chk(lib().kzg_hip_fk20_single(self.h, _p(poly), poly.shape[0], _p(out)))
+        return out
+
+    def fk20_single_da_optimized(self, poly):
+        poly = _fr(poly)
+        out = g1_empty(poly.shape[0])
+        _chk(lib().kzg_hip_fk20_single_da_optimized(self.h, _p(poly), poly.shape[0], _p(out)))
+        return out
+
+    def da_using_fk20(self, poly):
+        poly = _fr(poly)
+        out = g1_empty(2 * poly.shape[0])
+        _chk(lib().kzg_hip_da_using_fk20(self.h, _p(poly), poly.shape[0], _p(out)))
+        return out
+
+    def da_using_fk20_batch(self, polys):
+        polys = np.ascontiguousarray(polys, dtype=np.uint64)
+        b, n = polys.shape[0], polys.shape[1]
+        out = np.zeros((b, 2 * n, 3, 6), dtype=np.uint64)
+        _chk(lib().kzg_hip_da_using_fk20_batch(self.h, _p(polys), n, b, _p(out)))
+        return out
+
+
+class FK20MultiSettings:
+    """kzg.FK20MultiSettings (kzg.go:66-116; fk20_multi.go:25-133)"""
+
+    def __init__(self, ks, n2, chunk_len):
+        h = C.c_void_p()
+        _chk(lib().kzg_hip_fk20_multi_settings_new(ks.h, n2, chunk_len, C.byref(h)))
+        self.h, self.ks, self.n2, self.chunk_len = h, ks, n2, chunk_len
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().kzg_hip_fk20_multi_settings_free(self.h)
+            self.h = None
+
+    def fk20_multi(self, poly):
+        poly = _fr(poly)
+        out = g1_empty(poly.shape[0] // self.chunk_len)
+        _chk(lib().kzg_hip_fk20_multi(self.h, _p(poly), poly.shape[0], _p(out)))
+        return out
+
+    def fk20_multi_da_optimized(self, poly):
+        poly = _fr(poly)
+        out = g1_empty(poly.shape[0] // self.chunk_len)
+        _chk(lib().kzg_hip_fk20_multi_da_optimized(self.h, _p(poly), poly.shape[0], _p(out)))
+        return out
+
+    def da_using_fk20_multi(self, poly):
+        poly = _fr(poly)
+        out = g1_empty(2 * poly.shape[0] // self.chunk_len)
+        _chk(lib().kzg_hip_da_using_fk20_multi(self.h, _p(poly), poly.shape[0], _p(out)))
+        return out

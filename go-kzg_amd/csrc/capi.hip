@@ -1,0 +1,719 @@
+// capi.hip -- the C ABI of include/kzg_hip.h: argument checks with the reference's error behaviour, device-resident
+// settings handles, and the pipelines that chain the kernels of k_fr.hip / k_g1.hip / k_msm.hip.
+// There is deliberately NO CPU fallback: without a gfx950 device every constructor returns KZG_HIP_ERR_NO_DEVICE.
+#include "../../include/kzg_hip.h"
+#include "internal.hpp"
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <cstring>
+
+using namespace kzg;
+
+static thread_local std::string g_last_error;
+
+#define HIPCHK(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) {                                                                              \
+            char buf_[512];                                                                                  \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            g_last_error = buf_;                                                                             \
+            return KZG_HIP_ERR_HIP;                                                                          \
+        }                                                                                                    \
+    } while (0)
+#define CHK(expr) do { int s_ = (expr); if (s_ != KZG_HIP_OK) return s_; } while (0)
+
+static bool is_pow2(uint64_t v) { return (v & (v - 1)) == 0; }   // bls.IsPowerOfTwo (bls/globals.go:72-74): true for 0
+static uint64_t next_pow2(uint64_t v) { if (v == 0) return 1; uint64_t p = 1; while (p < v) p <<= 1; return p; }   // fft.go:11-16
+static uint32_t ilog2(uint64_t v) { uint32_t r = 0; while ((1ull << r) < v) r++; return r; }
+
+// ---------------------------------------------------------------------------------------------------------
+// profiling hook: HIP events around named kernels on the stream they are launched on (bench.py roofline leg)
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+struct prof_rec { std::string name; hipEvent_t e0, e1; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<prof_rec> g_prof;
+}
+namespace kzg {
+void prof_begin(hipStream_t s, const char *name) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    prof_rec r; r.name = name;
+    hipEventCreate(&r.e0); hipEventCreate(&r.e1);
+    hipEventRecord(r.e0, s);
+    g_prof.push_back(r);
+}
+void prof_end(hipStream_t s, const char *name) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (size_t i = g_prof.size(); i-- > 0;)
+        if (g_prof[i].name == name) { hipEventRecord(g_prof[i].e1, s); break; }
+}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// handles
+// ---------------------------------------------------------------------------------------------------------
+struct kzg_hip_fft {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    unsigned max_scale = 0;
+    uint64_t W = 0;
+    std::vector<fr> h_expanded, h_reversed;
+    fr *d_expanded = nullptr, *d_reversed = nullptr;
+    fr *d_inv_pow2 = nullptr;   // (2^k)^-1, k = 0..63 (Montgomery)
+    std::mutex mu;
+};
+struct kzg_hip_kzg {
+    kzg_hip_fft *fs = nullptr;
+    uint64_t n_setup = 0;
+    g1j *d_secret = nullptr;     // SecretG1, normalised Jacobian images
+    g1a *d_secret_a = nullptr;   // affine table for the MSM
+    g1a *d_fixed = nullptr;      // fixed-base window table (lazily built)
+    msm_plan fixed_plan{};
+    void *d_ws = nullptr; size_t ws_bytes = 0;
+};
+struct fk20_core {
+    kzg_hip_kzg *ks = nullptr;
+    uint64_t n2 = 0, l = 1, k = 0;   // n2 = 2n, chunk length l, k = n / l
+    g1j *d_files = nullptr;          // l x 2k points: xExtFFT (single) / xExtFFTFiles (multi)
+};
+struct kzg_hip_fk20s { fk20_core c; };
+struct kzg_hip_fk20m { fk20_core c; };
+
+struct dev_guard {
+    kzg_hip_fft *fs; std::unique_lock<std::mutex> lk;
+    explicit dev_guard(kzg_hip_fft *f) : fs(f), lk(f->mu) { hipSetDevice(f->device); }
+};
+
+// stream-ordered temporary
+template <class T> struct dtmp {
+    T *p = nullptr; hipStream_t s;
+    dtmp(hipStream_t st) : s(st) {}
+    int alloc(size_t count) {
+        if (!count) count = 1;
+        HIPCHK(hipMallocAsync((void **)&p, count * sizeof(T), s));
+        return KZG_HIP_OK;
+    }
+    ~dtmp() { if (p) hipFreeAsync(p, s); }
+};
+
+extern "C" {
+
+int kzg_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int i = 0; i < n; i++) {
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, i) == hipSuccess && strncmp(pr.gcnArchName, "gfx950", 6) == 0) ok++;
+    }
+    return ok;
+}
+const char *kzg_hip_last_error(void) { return g_last_error.c_str(); }
+const char *kzg_hip_version(void) { return "kzg_hip 0.1 (gfx950)"; }
+
+// ---------------------------------------------------------------------------------------------------------
+// FFTSettings
+// ---------------------------------------------------------------------------------------------------------
+static fr scale2_root_of_unity(unsigned k) {   // 7^((r-1)/2^k), bls/globals.go:24-60
+    uint32_t e[8]; uint32_t br = 0;
+    for (int i = 0; i < 8; i++) e[i] = subb(FrP::mod(i), i == 0 ? 1u : 0u, br);
+    for (unsigned s = 0; s < k; s++)
+        for (int i = 0; i < 8; i++) e[i] = (e[i] >> 1) | (i < 7 ? e[i + 1] << 31 : 0);
+    fr seven = fr_from_u64(7), acc = one<FrP>();
+    for (int i = 255; i >= 0; i--) {
+        acc = sqr(acc);
+        if ((e[i / 32] >> (i % 32)) & 1u) acc = mul(acc, seven);
+    }
+    return acc;
+}
+
+int kzg_hip_fft_settings_new(int device, unsigned max_scale, kzg_hip_fft **out) {
+    if (!out || max_scale > 31) return KZG_HIP_ERR_BAD_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0 || device < 0 || device >= ndev) return KZG_HIP_ERR_NO_DEVICE;
+    HIPCHK(hipSetDevice(device));
+    kzg_hip_fft *fs = new kzg_hip_fft;
+    fs->device = device; fs->max_scale = max_scale; fs->W = 1ull << max_scale;
+    HIPCHK(hipStreamCreateWithFlags(&fs->stream, hipStreamNonBlocking));
+    // expandRootOfUnity (fft.go:21-32): W + 1 powers, first and last are 1; reversed copy (fft.go:49-54)
+    fr w = scale2_root_of_unity(max_scale);
+    fs->h_expanded.resize(fs->W + 1); fs->h_reversed.resize(fs->W + 1);
+    fs->h_expanded[0] = one<FrP>();
+    for (uint64_t i = 1; i <= fs->W; i++) fs->h_expanded[i] = mul(fs->h_expanded[i - 1], w);
+    for (uint64_t i = 0; i <= fs->W; i++) fs->h_reversed[i] = fs->h_expanded[fs->W - i];
+    size_t bytes = (fs->W + 1) * sizeof(fr);
+    HIPCHK(hipMalloc((void **)&fs->d_expanded, bytes));
+    HIPCHK(hipMalloc((void **)&fs->d_reversed, bytes));
+    HIPCHK(hipMemcpy(fs->d_expanded, fs->h_expanded.data(), bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(fs->d_reversed, fs->h_reversed.data(), bytes, hipMemcpyHostToDevice));
+    fr invs[64]; fr half = inv<FrP>(fr_from_u64(2));
+    invs[0] = one<FrP>();
+    for (int i = 1; i < 64; i++) invs[i] = mul(invs[i - 1], half);
+    HIPCHK(hipMalloc((void **)&fs->d_inv_pow2, sizeof invs));
+    HIPCHK(hipMemcpy(fs->d_inv_pow2, invs, sizeof invs, hipMemcpyHostToDevice));
+    *out = fs;
+    return KZG_HIP_OK;
+}
+void kzg_hip_fft_settings_free(kzg_hip_fft *fs) {
+    if (!fs) return;
+    hipSetDevice(fs->device);
+    hipStreamSynchronize(fs->stream);
+    hipFree(fs->d_expanded); hipFree(fs->d_reversed); hipFree(fs->d_inv_pow2);
+    hipStreamDestroy(fs->stream);
+    delete fs;
+}
+uint64_t kzg_hip_fft_max_width(const kzg_hip_fft *fs) { return fs ? fs->W : 0; }
+int kzg_hip_fft_roots(const kzg_hip_fft *fs, int reversed, void *out_fr) {
+    if (!fs || !out_fr) return KZG_HIP_ERR_BAD_ARG;
+    memcpy(out_fr, reversed ? fs->h_reversed.data() : fs->h_expanded.data(), (fs->W + 1) * sizeof(fr));
+    return KZG_HIP_OK;
+}
+
+// device-side (I)FFT over F_r on resident rows
+static void fr_fft_rows(kzg_hip_fft *fs, hipStream_t s, const fr *d_in, uint64_t in_stride, uint64_t n_in, fr *d_out, uint64_t n, uint64_t batch, int inv) {
+    launch_fr_fft(s, d_in, in_stride, n_in, d_out, n, batch, inv ? fs->d_reversed : fs->d_expanded, fs->W, inv ? fs->d_inv_pow2 + ilog2(n) : nullptr);
+}
+
+static int fft_fr_impl(kzg_hip_fft *fs, const void *vals, uint64_t n_in, uint64_t n, uint64_t batch, int inv, void *out) {
+    dev_guard g(fs);
+    hipStream_t s = fs->stream;
+    dtmp<fr> d_in(s), d_out(s);
+    CHK(d_in.alloc(n_in * batch)); CHK(d_out.alloc(n * batch));
+    if (n_in) HIPCHK(hipMemcpyAsync(d_in.p, vals, n_in * batch * sizeof(fr), hipMemcpyHostToDevice, s));
+    fr_fft_rows(fs, s, d_in.p, n_in, n_in, d_out.p, n, batch, inv);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d_out.p, n * batch * sizeof(fr), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return KZG_HIP_OK;
+}
+int kzg_hip_fft_fr(kzg_hip_fft *fs, const void *vals_fr, uint64_t n, int inv, void *out_fr, uint64_t *out_n) {
+    if (!fs || !out_fr || (!vals_fr && n)) return KZG_HIP_ERR_BAD_ARG;
+    if (n > fs->W) return KZG_HIP_ERR_TOO_WIDE;          // fft_fr.go:57-59
+    uint64_t np = next_pow2(n);                          // fft_fr.go:60
+    if (out_n) *out_n = np;
+    return fft_fr_impl(fs, vals_fr, n, np, 1, inv, out_fr);
+}
+int kzg_hip_inplace_fft_fr(kzg_hip_fft *fs, const void *vals_fr, void *out_fr, uint64_t n, int inv) {
+    if (!fs) return KZG_HIP_ERR_BAD_ARG;
+    if (n > fs->W) return KZG_HIP_ERR_TOO_WIDE;          // fft_fr.go:78-80
+    if (!is_pow2(n)) return KZG_HIP_ERR_NOT_POW2;        // fft_fr.go:81-83
+    if (n == 0) return KZG_HIP_OK;
+    if (!vals_fr || !out_fr) return KZG_HIP_ERR_BAD_ARG;
+    return fft_fr_impl(fs, vals_fr, n, n, 1, inv, out_fr);
+}
+int kzg_hip_fft_fr_batch(kzg_hip_fft *fs, const void *vals_fr, uint64_t n, uint64_t batch, int inv, void *out_fr) {
+    if (!fs) return KZG_HIP_ERR_BAD_ARG;
+    if (n > fs->W) return KZG_HIP_ERR_TOO_WIDE;
+    if (!is_pow2(n)) return KZG_HIP_ERR_NOT_POW2;
+    if (n == 0 || batch == 0) return KZG_HIP_OK;
+    if (!vals_fr || !out_fr) return KZG_HIP_ERR_BAD_ARG;
+    return fft_fr_impl(fs, vals_fr, n, n, batch, inv, out_fr);
+}
+
+// G1 FFT on resident rows: in (row stride in_stride, first n_valid entries used, the rest = inf) -> data (batch x n),
+// NOT scaled by 1/n (callers fold the scale where it is cheapest).
+static void g1_fft_rows(kzg_hip_fft *fs, hipStream_t s, const g1j *d_in, uint64_t in_stride, uint64_t n_valid, g1j *d_data, uint64_t n, uint64_t batch, int inv) {
+    launch_g1_bitrev_copy(s, d_in, in_stride, n_valid, d_data, n, batch);
+    const fr *roots = inv ? fs->d_reversed : fs->d_expanded;
+    for (uint64_t m = 1; m < n; m <<= 1) launch_g1_fft_stage(s, d_data, n, batch, m, roots, fs->W);
+}
+
+int kzg_hip_fft_g1(kzg_hip_fft *fs, const void *vals_g1, uint64_t n, int inv, void *out_g1) {
+    if (!fs) return KZG_HIP_ERR_BAD_ARG;
+    if (n > fs->W) return KZG_HIP_ERR_TOO_WIDE;          // fft_g1.go:60-62
+    if (!is_pow2(n)) return KZG_HIP_ERR_NOT_POW2;        // fft_g1.go:63-65
+    if (n == 0 || !vals_g1 || !out_g1) return KZG_HIP_ERR_BAD_ARG;   // n == 0: the reference divides by zero (fft_g1.go:76)
+    dev_guard g(fs);
+    hipStream_t s = fs->stream;
+    dtmp<g1j> d_in(s), d_data(s);
+    CHK(d_in.alloc(n)); CHK(d_data.alloc(n));
+    HIPCHK(hipMemcpyAsync(d_in.p, vals_g1, n * sizeof(g1j), hipMemcpyHostToDevice, s));
+    g1_fft_rows(fs, s, d_in.p, n, n, d_data.p, n, 1, inv);
+    if (inv) {   // fft_g1.go:72-85: every output times n^-1
+        launch_g1_mul_vec(s, d_data.p, n, fs->d_inv_pow2 + ilog2(n), 0, n, d_in.p);
+        launch_g1_normalize(s, d_in.p, d_data.p, n);
+    } else {
+        launch_g1_normalize(s, d_data.p, d_in.p, n);
+        std::swap(d_in.p, d_data.p);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_g1, d_data.p, n * sizeof(g1j), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return KZG_HIP_OK;
+}
+
+int kzg_hip_das_fft_extension_batch(kzg_hip_fft *fs, void *vals_fr, uint64_t n, uint64_t batch) {
+    if (!fs || !vals_fr) return KZG_HIP_ERR_BAD_ARG;
+    if (n * 2 > fs->W) return KZG_HIP_ERR_TOO_WIDE;      // panic das_extension.go:72-74
+    if (n < 2 || !is_pow2(n)) return KZG_HIP_ERR_BAD_ARG; // "bad usage" das_extension.go:22-24
+    if (!batch) return KZG_HIP_OK;
+    dev_guard g(fs);
+    hipStream_t s = fs->stream;
+    dtmp<fr> d(s);
+    CHK(d.alloc(n * batch));
+    HIPCHK(hipMemcpyAsync(d.p, vals_fr, n * batch * sizeof(fr), hipMemcpyHostToDevice, s));
+    launch_das_ext(s, d.p, n, batch, fs->d_expanded, fs->d_reversed, fs->W, fs->d_inv_pow2 + ilog2(n));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(vals_fr, d.p, n * batch * sizeof(fr), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return KZG_HIP_OK;
+}
+int kzg_hip_das_fft_extension(kzg_hip_fft *fs, void *vals_fr, uint64_t n) { return kzg_hip_das_fft_extension_batch(fs, vals_fr, n, 1); }
+
+// ---------------------------------------------------------------------------------------------------------
+// MSM
+// ---------------------------------------------------------------------------------------------------------
+static msm_plan classic_plan(uint64_t n) {
+    msm_plan p{};
+    int c = (int)ilog2(n) - 3;
+    if (c < 4) c = 4;
+    if (c > 12) c = 12;
+    p.c = (uint32_t)c; p.nwin = 255 / p.c + 1; p.nb = 1u << (p.c - 1); p.ngroups = p.nwin; p.fixed = 0; p.table_n = n;
+    return p;
+}
+static void set_inf_image(void *out_g1) { g1j z = g1_inf(); memcpy(out_g1, &z, sizeof z); }
+
+int kzg_hip_lincomb_g1(kzg_hip_fft *fs, const void *points_g1, const void *scalars_fr, uint64_t n, void *out_g1) {
+    if (!fs || !out_g1) return KZG_HIP_ERR_BAD_ARG;
+    if (n == 0) { set_inf_image(out_g1); return KZG_HIP_OK; }   // bls/bls_test.go:69-78
+    if (!points_g1 || !scalars_fr) return KZG_HIP_ERR_BAD_ARG;
+    dev_guard g(fs);
+    hipStream_t s = fs->stream;
+    msm_plan p = classic_plan(n);
+    dtmp<g1j> d_pts(s), d_out(s); dtmp<g1a> d_tab(s); dtmp<fr> d_sc(s); dtmp<uint8_t> d_ws(s);
+    CHK(d_pts.alloc(n)); CHK(d_out.alloc(2)); CHK(d_tab.alloc(n)); CHK(d_sc.alloc(n)); CHK(d_ws.alloc(msm_workspace_bytes(p, n, 1)));
+    HIPCHK(hipMemcpyAsync(d_pts.p, points_g1, n * sizeof(g1j), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_sc.p, scalars_fr, n * sizeof(fr), hipMemcpyHostToDevice, s));
+    launch_g1_to_affine(s, d_pts.p, d_tab.p, n);
+    launch_msm(s, p, d_tab.p, d_sc.p, n, 1, d_ws.p, d_out.p);
+    launch_g1_normalize(s, d_out.p, d_out.p + 1, 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_g1, d_out.p + 1, sizeof(g1j), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return KZG_HIP_OK;
+}
+
+int kzg_hip_g1_to_compressed(kzg_hip_fft *fs, const void *points_g1, uint64_t n, void *out48) {
+    if (!fs || (n && (!points_g1 || !out48))) return KZG_HIP_ERR_BAD_ARG;
+    if (!n) return KZG_HIP_OK;
+    dev_guard g(fs);
+    hipStream_t s = fs->stream;
+    dtmp<g1j> d_pts(s); dtmp<uint8_t> d_out(s);
+    CHK(d_pts.alloc(n)); CHK(d_out.alloc(48 * n));
+    HIPCHK(hipMemcpyAsync(d_pts.p, points_g1, n * sizeof(g1j), hipMemcpyHostToDevice, s));
+    launch_g1_compress(s, d_pts.p, d_out.p, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out48, d_out.p, 48 * n, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return KZG_HIP_OK;
+}
+int kzg_hip_g1_from_compressed(kzg_hip_fft *fs, const void *in48, uint64_t n, void *out_g1) {
+    if (!fs || (n && (!in48 || !out_g1))) return KZG_HIP_ERR_BAD_ARG;
+    if (!n) return KZG_HIP_OK;
+    dev_guard g(fs);
+    hipStream_t s = fs->stream;
+    dtmp<g1j> d_pts(s); dtmp<uint8_t> d_in(s); dtmp<uint32_t> d_flag(s);
+    CHK(d_pts.alloc(n)); CHK(d_in.alloc(48 * n)); CHK(d_flag.alloc(1));
+    HIPCHK(hipMemsetAsync(d_flag.p, 0, 4, s));
+    HIPCHK(hipMemcpyAsync(d_in.p, in48, 48 * n, hipMemcpyHostToDevice, s));
+    launch_g1_decompress(s, d_in.p, d_pts.p, n, d_flag.p);
+    HIPCHK(hipGetLastError());
+    uint32_t flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, d_flag.p, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out_g1, d_pts.p, n * sizeof(g1j), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return flag ? KZG_HIP_ERR_BAD_POINT : KZG_HIP_OK;
+}
+int kzg_hip_g1_mul_vec(kzg_hip_fft *fs, const void *points_g1, const void *scalars_fr, uint64_t n, void *out_g1) {
+    if (!fs || (n && (!points_g1 || !scalars_fr || !out_g1))) return KZG_HIP_ERR_BAD_ARG;
+    if (!n) return KZG_HIP_OK;
+    dev_guard g(fs);
+    hipStream_t s = fs->stream;
+    dtmp<g1j> d_pts(s), d_out(s); dtmp<fr> d_sc(s);
+    CHK(d_pts.alloc(n)); CHK(d_out.alloc(n)); CHK(d_sc.alloc(n));
+    HIPCHK(hipMemcpyAsync(d_pts.p, points_g1, n * sizeof(g1j), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_sc.p, scalars_fr, n * sizeof(fr), hipMemcpyHostToDevice, s));
+    launch_g1_mul_vec(s, d_pts.p, n, d_sc.p, 1, n, d_out.p);
+    launch_g1_normalize(s, d_out.p, d_pts.p, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_g1, d_pts.p, n * sizeof(g1j), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return KZG_HIP_OK;
+}
+int kzg_hip_generate_testing_setup_g1(kzg_hip_fft *fs, const void *secret_fr, uint64_t n, void *out_g1) {
+    if (!fs || !secret_fr || (n && !out_g1)) return KZG_HIP_ERR_BAD_ARG;
+    if (!n) return KZG_HIP_OK;
+    dev_guard g(fs);
+    hipStream_t s = fs->stream;
+    dtmp<g1j> d_a(s), d_b(s); dtmp<fr> d_pw(s), d_s(s);
+    CHK(d_a.alloc(n)); CHK(d_b.alloc(n)); CHK(d_pw.alloc(n)); CHK(d_s.alloc(1));
+    HIPCHK(hipMemcpyAsync(d_s.p, secret_fr, sizeof(fr), hipMemcpyHostToDevice, s));
+    launch_fr_powers(s, d_s.p, n, d_pw.p);
+    launch_g1_fixed_base_powers(s, d_pw.p, n, d_a.p);
+    launch_g1_normalize(s, d_a.p, d_b.p, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_g1, d_b.p, n * sizeof(g1j), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return KZG_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// KZGSettings
+// ---------------------------------------------------------------------------------------------------------
+int kzg_hip_kzg_settings_new(kzg_hip_fft *fs, const void *secret_g1, uint64_t n_setup, kzg_hip_kzg **out) {
+    if (!fs || !out || !secret_g1) return KZG_HIP_ERR_BAD_ARG;
+    *out = nullptr;
+    if (n_setup < fs->W) return KZG_HIP_ERR_LEN_MISMATCH;   // kzg.go:25-27
+    dev_guard g(fs);
+    hipStream_t s = fs->stream;
+    kzg_hip_kzg *ks = new kzg_hip_kzg;
+    ks->fs = fs; ks->n_setup = n_setup;
+    dtmp<g1j> d_raw(s);
+    CHK(d_raw.alloc(n_setup));
+    HIPCHK(hipMalloc((void **)&ks->d_secret, n_setup * sizeof(g1j)));
+    HIPCHK(hipMalloc((void **)&ks->d_secret_a, n_setup * sizeof(g1a)));
+    HIPCHK(hipMemcpyAsync(d_raw.p, secret_g1, n_setup * sizeof(g1j), hipMemcpyHostToDevice, s));
+    launch_g1_normalize(s, d_raw.p, ks->d_secret, n_setup);
+    launch_g1_to_affine(s, ks->d_secret, ks->d_secret_a, n_setup);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    *out = ks;
+    return KZG_HIP_OK;
+}
+void kzg_hip_kzg_settings_free(kzg_hip_kzg *ks) {
+    if (!ks) return;
+    hipSetDevice(ks->fs->device);
+    hipFree(ks->d_secret); hipFree(ks->d_secret_a); hipFree(ks->d_fixed); hipFree(ks->d_ws);
+    delete ks;
+}
+
+// MSM of `batch` resident scalar rows against SecretG1[:n]; out = batch normalised points (device)
+static int commit_rows(kzg_hip_kzg *ks, hipStream_t s, const fr *d_sc, uint64_t n, uint64_t batch, g1j *d_out) {
+    msm_plan p = classic_plan(n);
+    size_t need = msm_workspace_bytes(p, n, batch) + batch * sizeof(g1j);
+    if (need > ks->ws_bytes) {
+        if (ks->d_ws) { HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipFree(ks->d_ws)); ks->d_ws = nullptr; }
+        HIPCHK(hipMalloc(&ks->d_ws, need));
+        ks->ws_bytes = need;
+    }
+    g1j *d_raw = (g1j *)((uint8_t *)ks->d_ws + msm_workspace_bytes(p, n, batch));
+    launch_msm(s, p, ks->d_secret_a, d_sc, n, batch, ks->d_ws, d_raw);
+    launch_g1_normalize(s, d_raw, d_out, batch);
+    HIPCHK(hipGetLastError());
+    return KZG_HIP_OK;
+}
+
+int kzg_hip_commit_to_poly_batch_dev(kzg_hip_kzg *ks, const void *d_coeffs_fr, uint64_t n, uint64_t batch, void *d_out_g1, void *stream) {
+    if (!ks || !d_out_g1) return KZG_HIP_ERR_BAD_ARG;
+    if (n > ks->n_setup) return KZG_HIP_ERR_LEN_MISMATCH;   // slice bounds of SecretG1[:len(coeffs)], kzg_single_proofs.go:18
+    if (!batch) return KZG_HIP_OK;
+    if (n == 0 || !d_coeffs_fr) return KZG_HIP_ERR_BAD_ARG;
+    dev_guard g(ks->fs);
+    return commit_rows(ks, (hipStream_t)stream, (const fr *)d_coeffs_fr, n, batch, (g1j *)d_out_g1);
+}
+int kzg_hip_commit_to_poly_batch(kzg_hip_kzg *ks, const void *coeffs_fr, uint64_t n, uint64_t batch, void *out_g1) {
+    if (!ks || !out_g1) return KZG_HIP_ERR_BAD_ARG;
+    if (n > ks->n_setup) return KZG_HIP_ERR_LEN_MISMATCH;
+    if (!batch) return KZG_HIP_OK;
+    if (n == 0) { for (uint64_t b = 0; b < batch; b++) set_inf_image((uint8_t *)out_g1 + b * sizeof(g1j)); return KZG_HIP_OK; }
+    if (!coeffs_fr) return KZG_HIP_ERR_BAD_ARG;
+    dev_guard g(ks->fs);
+    hipStream_t s = ks->fs->stream;
+    dtmp<fr> d_sc(s); dtmp<g1j> d_out(s);
+    CHK(d_sc.alloc(n * batch)); CHK(d_out.alloc(batch));
+    HIPCHK(hipMemcpyAsync(d_sc.p, coeffs_fr, n * batch * sizeof(fr), hipMemcpyHostToDevice, s));
+    CHK(commit_rows(ks, s, d_sc.p, n, batch, d_out.p));
+    HIPCHK(hipMemcpyAsync(out_g1, d_out.p, batch * sizeof(g1j), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return KZG_HIP_OK;
+}
+int kzg_hip_commit_to_poly(kzg_hip_kzg *ks, const void *coeffs_fr, uint64_t n, void *out_g1) {
+    return kzg_hip_commit_to_poly_batch(ks, coeffs_fr, n, 1, out_g1);
+}
+
+int kzg_hip_compute_proof_single(kzg_hip_kzg *ks, const void *poly_fr, uint64_t n, uint64_t x, void *out_g1) {
+    if (!ks || !poly_fr || !out_g1 || n < 2) return KZG_HIP_ERR_BAD_ARG;
+    if (n - 1 > ks->n_setup) return KZG_HIP_ERR_LEN_MISMATCH;   // SecretG1[:len(quotient)], kzg_single_proofs.go:53
+    dev_guard g(ks->fs);
+    hipStream_t s = ks->fs->stream;
+    dtmp<fr> d_poly(s), d_q(s), d_x(s); dtmp<g1j> d_out(s);
+    CHK(d_poly.alloc(n)); CHK(d_q.alloc(n)); CHK(d_x.alloc(1)); CHK(d_out.alloc(1));
+    fr xf = fr_from_u64(x);   // bls.AsFr(&tmp, x), kzg_single_proofs.go:39-40
+    HIPCHK(hipMemcpyAsync(d_poly.p, poly_fr, n * sizeof(fr), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_x.p, &xf, sizeof xf, hipMemcpyHostToDevice, s));
+    launch_quotient_linear(s, d_poly.p, n, d_x.p, d_q.p);
+    CHK(commit_rows(ks, s, d_q.p, n - 1, 1, d_out.p));
+    HIPCHK(hipMemcpyAsync(out_g1, d_out.p, sizeof(g1j), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return KZG_HIP_OK;
+}
+
+int kzg_hip_toeplitz_part2(kzg_hip_kzg *ks, const void *coeffs_fr, const void *x_ext_fft_g1, uint64_t n, void *out_g1) {
+    if (!ks || !coeffs_fr || !x_ext_fft_g1 || !out_g1) return KZG_HIP_ERR_BAD_ARG;
+    kzg_hip_fft *fs = ks->fs;
+    if (n > fs->W) return KZG_HIP_ERR_TOO_WIDE;              // FFT error -> panic, fk20_single.go:63-66
+    if (!is_pow2(n) || n == 0) return KZG_HIP_ERR_LEN_MISMATCH;   // padded FFT length != len(xExtFFT): index panic in the reference
+    dev_guard g(fs);
+    hipStream_t s = fs->stream;
+    dtmp<fr> d_c(s), d_cf(s); dtmp<g1j> d_x(s), d_h(s);
+    CHK(d_c.alloc(n)); CHK(d_cf.alloc(n)); CHK(d_x.alloc(n)); CHK(d_h.alloc(n));
+    HIPCHK(hipMemcpyAsync(d_c.p, coeffs_fr, n * sizeof(fr), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_x.p, x_ext_fft_g1, n * sizeof(g1j), hipMemcpyHostToDevice, s));
+    fr_fft_rows(fs, s, d_c.p, n, n, d_cf.p, n, 1, 0);
+    launch_g1_mul_vec(s, d_x.p, n, d_cf.p, 1, n, d_h.p);
+    launch_g1_normalize(s, d_h.p, d_x.p, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_g1, d_x.p, n * sizeof(g1j), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return KZG_HIP_OK;
+}
+int kzg_hip_toeplitz_part3(kzg_hip_kzg *ks, const void *h_ext_fft_g1, uint64_t n, void *out_g1) {
+    if (!ks) return KZG_HIP_ERR_BAD_ARG;
+    std::vector<g1j> full(n ? n : 1);
+    CHK(kzg_hip_fft_g1(ks->fs, h_ext_fft_g1, n, 1, full.data()));   // fk20_single.go:80-87
+    memcpy(out_g1, full.data(), (n / 2) * sizeof(g1j));
+    return KZG_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// FK20 (single == multi with chunk length 1)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_fk20_x(const g1j *secret, uint64_t n, uint64_t l, uint64_t k, g1j *x /* l x k */) {
+    // kzg.go:53-58 (single) / :101-111 (multi): x_off[i] = SecretG1[n - l - 1 - off - i l] for i < k - 1, x_off[k-1] = inf
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= l * k) return;
+    uint64_t off = t / k, i = t % k;
+    x[t] = (i + 1 < k) ? secret[n - l - 1 - off - i * l] : g1_inf();
+}
+
+static int fk20_core_new(kzg_hip_kzg *ks, uint64_t n2, uint64_t l, fk20_core *c) {
+    kzg_hip_fft *fs = ks->fs;
+    dev_guard g(fs);
+    hipStream_t s = fs->stream;
+    uint64_t n = n2 / 2, k = n / l, k2 = 2 * k;
+    c->ks = ks; c->n2 = n2; c->l = l; c->k = k;
+    dtmp<g1j> d_x(s), d_f(s);
+    CHK(d_x.alloc(l * k)); CHK(d_f.alloc(l * k2));
+    HIPCHK(hipMalloc((void **)&c->d_files, l * k2 * sizeof(g1j)));
+    hipLaunchKernelGGL(k_fk20_x, dim3((uint32_t)((l * k + 255) / 256)), dim3(256), 0, s, ks->d_secret, n, l, k, d_x.p);
+    g1_fft_rows(fs, s, d_x.p, k, k, d_f.p, k2, l, 0);   // toeplitzPart1: FFTG1(x || inf^k), fk20_single.go:40-56
+    launch_g1_normalize(s, d_f.p, c->d_files, l * k2);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    return KZG_HIP_OK;
+}
+
+// steps 1-3: Toeplitz coefficients (pre-scaled by 1/2k, which folds the inverse FFT's scale into the scalars),
+// FFT_Fr, and hExtFFT[j] = sum_f C_f[j] * X_f[j] for j in [j0, j0 + cnt)
+static int fk20_hext(fk20_core *c, hipStream_t s, const fr *d_poly, uint64_t poly_stride, uint64_t n, uint64_t batch, uint64_t j0, uint64_t cnt, g1j *d_hext) {
+    kzg_hip_fft *fs = c->ks->fs;
+    uint64_t l = c->l, k2 = 2 * c->k;
+    dtmp<fr> d_tc(s), d_cf(s);
+    CHK(d_tc.alloc(batch * l * k2)); CHK(d_cf.alloc(batch * l * k2));
+    launch_toeplitz_coeffs(s, d_poly, poly_stride, n, l, batch, d_tc.p, fs->d_inv_pow2 + ilog2(k2));
+    fr_fft_rows(fs, s, d_tc.p, k2, k2, d_cf.p, k2, batch * l, 0);
+    if (l == 1 && j0 == 0 && cnt == k2) launch_g1_mul_vec(s, c->d_files, k2, d_cf.p, 1, batch * k2, d_hext);
+    else launch_g1_file_msm(s, c->d_files, d_cf.p, l, k2, j0, cnt, batch, d_hext);
+    HIPCHK(hipGetLastError());
+    return KZG_HIP_OK;
+}
+// steps 4-7: h = IFFT_G1(hExtFFT)[:k] (scale already folded), out = FFT_G1(h || inf^k) (da) or FFT_G1(h) (plain),
+// optional reverse-bit-order, normalise
+static int fk20_finish(fk20_core *c, hipStream_t s, const g1j *d_hext, uint64_t batch, int da, int bit_reverse, g1j *d_out) {
+    kzg_hip_fft *fs = c->ks->fs;
+    uint64_t k = c->k, k2 = 2 * k, on = da ? k2 : k;
+    dtmp<g1j> d_a(s), d_b(s);
+    CHK(d_a.alloc(batch * k2)); CHK(d_b.alloc(batch * k2));
+    g1_fft_rows(fs, s, d_hext, k2, k2, d_a.p, k2, batch, 1);          // ToeplitzPart3, fk20_single.go:80-87
+    g1_fft_rows(fs, s, d_a.p, k2, k, d_b.p, on, batch, 0);            // fk20_single.go:163-167 / :129
+    if (bit_reverse) { launch_g1_bitrev_copy(s, d_b.p, on, on, d_a.p, on, batch); launch_g1_normalize(s, d_a.p, d_out, batch * on); }
+    else launch_g1_normalize(s, d_b.p, d_out, batch * on);
+    HIPCHK(hipGetLastError());
+    return KZG_HIP_OK;
+}
+static int fk20_run_dev(fk20_core *c, hipStream_t s, const fr *d_poly, uint64_t poly_stride, uint64_t n, uint64_t batch, int da, int bit_reverse, g1j *d_out) {
+    uint64_t k2 = 2 * c->k;
+    dtmp<g1j> d_hext(s);
+    CHK(d_hext.alloc(batch * k2));
+    CHK(fk20_hext(c, s, d_poly, poly_stride, n, batch, 0, k2, d_hext.p));
+    return fk20_finish(c, s, d_hext.p, batch, da, bit_reverse, d_out);
+}
+// host-buffer front end: poly rows of `row_len` values of which the first n are the coefficients
+static int fk20_run_host(fk20_core *c, const void *poly_fr, uint64_t row_len, uint64_t n, uint64_t batch, int check_upper, int da, int bit_reverse, void *out_g1) {
+    kzg_hip_fft *fs = c->ks->fs;
+    dev_guard g(fs);
+    hipStream_t s = fs->stream;
+    uint64_t on = da ? 2 * c->k : c->k;
+    dtmp<fr> d_poly(s); dtmp<g1j> d_out(s); dtmp<uint32_t> d_flag(s);
+    CHK(d_poly.alloc(batch * row_len)); CHK(d_out.alloc(batch * on)); CHK(d_flag.alloc(1));
+    HIPCHK(hipMemcpyAsync(d_poly.p, poly_fr, batch * row_len * sizeof(fr), hipMemcpyHostToDevice, s));
+    if (check_upper) {   // "bad input, second half should be zeroed", fk20_single.go:150-154 / fk20_multi.go:65-69
+        HIPCHK(hipMemsetAsync(d_flag.p, 0, 4, s));
+        launch_fr_any_nonzero(s, d_poly.p + n, row_len - n, d_flag.p);
+        uint32_t flag = 0;
+        HIPCHK(hipMemcpyAsync(&flag, d_flag.p, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (flag) return KZG_HIP_ERR_UPPER_HALF;
+    }
+    CHK(fk20_run_dev(c, s, d_poly.p, row_len, n, batch, da, bit_reverse, d_out.p));
+    HIPCHK(hipMemcpyAsync(out_g1, d_out.p, batch * on * sizeof(g1j), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return KZG_HIP_OK;
+}
+
+int kzg_hip_fk20_single_settings_new(kzg_hip_kzg *ks, uint64_t n2, kzg_hip_fk20s **out) {
+    if (!ks || !out) return KZG_HIP_ERR_BAD_ARG;
+    *out = nullptr;
+    if (n2 > ks->fs->W) return KZG_HIP_ERR_TOO_WIDE;     // kzg.go:44-46
+    if (!is_pow2(n2)) return KZG_HIP_ERR_NOT_POW2;       // kzg.go:47-49
+    if (n2 < 2) return KZG_HIP_ERR_BAD_ARG;              // kzg.go:50-52
+    kzg_hip_fk20s *fk = new kzg_hip_fk20s;
+    int st = fk20_core_new(ks, n2, 1, &fk->c);
+    if (st) { delete fk; return st; }
+    *out = fk;
+    return KZG_HIP_OK;
+}
+void kzg_hip_fk20_single_settings_free(kzg_hip_fk20s *fk) {
+    if (!fk) return;
+    hipSetDevice(fk->c.ks->fs->device);
+    hipFree(fk->c.d_files);
+    delete fk;
+}
+int kzg_hip_fk20_single_x_ext_fft(const kzg_hip_fk20s *fk, void *out_g1) {
+    if (!fk || !out_g1) return KZG_HIP_ERR_BAD_ARG;
+    dev_guard g(fk->c.ks->fs);
+    HIPCHK(hipMemcpy(out_g1, fk->c.d_files, fk->c.n2 * sizeof(g1j), hipMemcpyDeviceToHost));
+    return KZG_HIP_OK;
+}
+int kzg_hip_fk20_single(kzg_hip_fk20s *fk, const void *poly_fr, uint64_t n, void *out_g1) {
+    if (!fk || !poly_fr || !out_g1) return KZG_HIP_ERR_BAD_ARG;
+    if (2 * n != fk->c.n2) return KZG_HIP_ERR_LEN_MISMATCH;   // ToeplitzPart2 length panic, fk20_single.go:60-62
+    return fk20_run_host(&fk->c, poly_fr, n, n, 1, 0, 0, 0, out_g1);
+}
+int kzg_hip_fk20_single_da_optimized(kzg_hip_fk20s *fk, const void *poly_fr, uint64_t n2, void *out_g1) {
+    if (!fk || !poly_fr || !out_g1) return KZG_HIP_ERR_BAD_ARG;
+    if (n2 > fk->c.ks->fs->W) return KZG_HIP_ERR_TOO_WIDE;    // fk20_single.go:140-144
+    if (!is_pow2(n2)) return KZG_HIP_ERR_NOT_POW2;            // fk20_single.go:146-148
+    if (n2 != fk->c.n2) return KZG_HIP_ERR_LEN_MISMATCH;
+    return fk20_run_host(&fk->c, poly_fr, n2, n2 / 2, 1, 1, 1, 0, out_g1);
+}
+int kzg_hip_da_using_fk20_batch(kzg_hip_fk20s *fk, const void *poly_fr, uint64_t n, uint64_t batch, void *out_g1) {
+    if (!fk || !poly_fr || !out_g1) return KZG_HIP_ERR_BAD_ARG;
+    if (n > fk->c.ks->fs->W / 2) return KZG_HIP_ERR_TOO_WIDE;   // fk20_single.go:178-180
+    if (!is_pow2(n)) return KZG_HIP_ERR_NOT_POW2;               // fk20_single.go:181-183
+    if (2 * n != fk->c.n2) return KZG_HIP_ERR_LEN_MISMATCH;
+    if (!batch) return KZG_HIP_OK;
+    return fk20_run_host(&fk->c, poly_fr, n, n, batch, 0, 1, 1, out_g1);
+}
+int kzg_hip_da_using_fk20(kzg_hip_fk20s *fk, const void *poly_fr, uint64_t n, void *out_g1) {
+    return kzg_hip_da_using_fk20_batch(fk, poly_fr, n, 1, out_g1);
+}
+int kzg_hip_da_using_fk20_batch_dev(kzg_hip_fk20s *fk, const void *d_poly_fr, uint64_t n, uint64_t batch, void *d_out_g1, void *stream) {
+    if (!fk || !d_poly_fr || !d_out_g1) return KZG_HIP_ERR_BAD_ARG;
+    if (n > fk->c.ks->fs->W / 2) return KZG_HIP_ERR_TOO_WIDE;
+    if (!is_pow2(n)) return KZG_HIP_ERR_NOT_POW2;
+    if (2 * n != fk->c.n2) return KZG_HIP_ERR_LEN_MISMATCH;
+    if (!batch) return KZG_HIP_OK;
+    dev_guard g(fk->c.ks->fs);
+    return fk20_run_dev(&fk->c, (hipStream_t)stream, (const fr *)d_poly_fr, n, n, batch, 1, 1, (g1j *)d_out_g1);
+}
+
+int kzg_hip_fk20_multi_settings_new(kzg_hip_kzg *ks, uint64_t n2, uint64_t chunk_len, kzg_hip_fk20m **out) {
+    if (!ks || !out) return KZG_HIP_ERR_BAD_ARG;
+    *out = nullptr;
+    if (n2 > ks->fs->W) return KZG_HIP_ERR_TOO_WIDE;          // kzg.go:74-76
+    if (!is_pow2(n2)) return KZG_HIP_ERR_NOT_POW2;            // kzg.go:77-79
+    if (n2 < 2) return KZG_HIP_ERR_BAD_ARG;                   // kzg.go:80-82
+    if (chunk_len > n2 / 2) return KZG_HIP_ERR_BAD_ARG;       // kzg.go:83-85
+    if (!is_pow2(chunk_len)) return KZG_HIP_ERR_NOT_POW2;     // kzg.go:86-88
+    if (chunk_len < 1) return KZG_HIP_ERR_BAD_ARG;            // kzg.go:89-91
+    kzg_hip_fk20m *fk = new kzg_hip_fk20m;
+    int st = fk20_core_new(ks, n2, chunk_len, &fk->c);
+    if (st) { delete fk; return st; }
+    *out = fk;
+    return KZG_HIP_OK;
+}
+void kzg_hip_fk20_multi_settings_free(kzg_hip_fk20m *fk) {
+    if (!fk) return;
+    hipSetDevice(fk->c.ks->fs->device);
+    hipFree(fk->c.d_files);
+    delete fk;
+}
+int kzg_hip_fk20_multi(kzg_hip_fk20m *fk, const void *poly_fr, uint64_t n, void *out_g1) {
+    if (!fk || !poly_fr || !out_g1) return KZG_HIP_ERR_BAD_ARG;
+    if (fk->c.ks->fs->W < 2 * n) return KZG_HIP_ERR_TOO_WIDE;     // fk20_multi.go:28-31
+    if (2 * n != fk->c.n2) return KZG_HIP_ERR_LEN_MISMATCH;
+    return fk20_run_host(&fk->c, poly_fr, n, n, 1, 0, 0, 0, out_g1);
+}
+int kzg_hip_fk20_multi_da_optimized(kzg_hip_fk20m *fk, const void *poly_fr, uint64_t n2, void *out_g1) {
+    if (!fk || !poly_fr || !out_g1) return KZG_HIP_ERR_BAD_ARG;
+    if (fk->c.ks->fs->W < n2) return KZG_HIP_ERR_TOO_WIDE;        // fk20_multi.go:60-63
+    if (n2 != fk->c.n2) return KZG_HIP_ERR_LEN_MISMATCH;
+    return fk20_run_host(&fk->c, poly_fr, n2, n2 / 2, 1, 1, 1, 0, out_g1);
+}
+int kzg_hip_da_using_fk20_multi(kzg_hip_fk20m *fk, const void *poly_fr, uint64_t n, void *out_g1) {
+    if (!fk || !poly_fr || !out_g1) return KZG_HIP_ERR_BAD_ARG;
+    if (n > fk->c.ks->fs->W / 2) return KZG_HIP_ERR_TOO_WIDE;     // fk20_multi.go:115-117
+    if (!is_pow2(n)) return KZG_HIP_ERR_NOT_POW2;                 // fk20_multi.go:118-120
+    if (2 * n != fk->c.n2) return KZG_HIP_ERR_LEN_MISMATCH;
+    return fk20_run_host(&fk->c, poly_fr, n, n, 1, 0, 1, 1, out_g1);
+}
+int kzg_hip_da_using_fk20_multi_batch_dev(kzg_hip_fk20m *fk, const void *d_poly_fr, uint64_t n, uint64_t batch, void *d_out_g1, void *stream) {
+    if (!fk || !d_poly_fr || !d_out_g1) return KZG_HIP_ERR_BAD_ARG;
+    if (n > fk->c.ks->fs->W / 2) return KZG_HIP_ERR_TOO_WIDE;
+    if (!is_pow2(n)) return KZG_HIP_ERR_NOT_POW2;
+    if (2 * n != fk->c.n2) return KZG_HIP_ERR_LEN_MISMATCH;
+    if (!batch) return KZG_HIP_OK;
+    dev_guard g(fk->c.ks->fs);
+    return fk20_run_dev(&fk->c, (hipStream_t)stream, (const fr *)d_poly_fr, n, n, batch, 1, 1, (g1j *)d_out_g1);
+}
+int kzg_hip_fk20_multi_hext_slice_dev(kzg_hip_fk20m *fk, const void *d_poly_fr, uint64_t n, uint64_t j0, uint64_t cnt, void *d_out_g1, void *stream) {
+    if (!fk || !d_poly_fr || !d_out_g1) return KZG_HIP_ERR_BAD_ARG;
+    if (2 * n != fk->c.n2) return KZG_HIP_ERR_LEN_MISMATCH;
+    if (j0 + cnt > 2 * fk->c.k) return KZG_HIP_ERR_BAD_ARG;
+    if (!cnt) return KZG_HIP_OK;
+    dev_guard g(fk->c.ks->fs);
+    return fk20_hext(&fk->c, (hipStream_t)stream, (const fr *)d_poly_fr, n, n, 1, j0, cnt, (g1j *)d_out_g1);
+}
+int kzg_hip_fk20_multi_finish_dev(kzg_hip_fk20m *fk, const void *d_hext_g1, int bit_reverse, void *d_out_g1, void *stream) {
+    if (!fk || !d_hext_g1 || !d_out_g1) return KZG_HIP_ERR_BAD_ARG;
+    dev_guard g(fk->c.ks->fs);
+    return fk20_finish(&fk->c, (hipStream_t)stream, (const g1j *)d_hext_g1, 1, 1, bit_reverse, (g1j *)d_out_g1);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// instrumentation
+// ---------------------------------------------------------------------------------------------------------
+void kzg_hip_prof_reset(kzg_hip_fft *fs, int enable) {
+    (void)fs;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto &r : g_prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    g_prof.clear();
+    g_prof_on = enable != 0;
+}
+int kzg_hip_prof_read(kzg_hip_fft *fs, const char *kernel, double *total_ms, uint64_t *launches) {
+    if (!fs || !kernel) return KZG_HIP_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    double tot = 0; uint64_t cnt = 0;
+    for (auto &r : g_prof) {
+        if (r.name != kernel) continue;
+        HIPCHK(hipEventSynchronize(r.e1));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, r.e0, r.e1));
+        tot += ms; cnt++;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = cnt;
+    return KZG_HIP_OK;
+}
+
+}  // extern "C"

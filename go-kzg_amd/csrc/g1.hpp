@@ -1,0 +1,141 @@
+// g1.hpp -- BLS12-381 G1 group law for gfx950 lanes (one point per lane), y^2 = x^3 + 4.
+//
+// Replaces bls.AddG1 / SubG1 / MulG1 / ClearG1 / EqualG1 (bls/bls_kilic.go:33-53,106) -> Kilic G1.Add /
+// Sub / MulScalar.  Jacobian (X, Y, Z) with Montgomery coordinates, inf <=> Z == 0, byte-identical to
+// Kilic's PointG1.  Every add handles the exceptional cases exactly (inf + P, P + P,
+// P + (-P)): in FK20 half of every FFT input is the point at infinity and twiddles include 1, so these
+// are routine, not rare (SURVEY.md 7 "hard parts").
+#pragma once
+#include "field.hpp"
+
+namespace kzg {
+
+struct g1j { fp x, y, z; };   // Jacobian, 144 B (= bls.G1Point)
+struct g1a { fp x, y; };      // affine, 96 B; (0, 0) encodes inf (not on the curve: 0 != 0 + 4)
+
+KZG_HD bool is_inf(const g1j &p) { return is_zero<FpP>(p.z); }
+KZG_HD bool is_inf(const g1a &p) { return is_zero<FpP>(p.x) && is_zero<FpP>(p.y); }
+KZG_HD g1j g1_inf() { g1j o; o.x = zero<FpP>(); o.y = one<FpP>(); o.z = zero<FpP>(); return o; }   // Kilic Zero(): (0, 1, 0)
+KZG_HD g1a g1a_inf() { g1a o; o.x = zero<FpP>(); o.y = zero<FpP>(); return o; }
+KZG_HD g1j g1_neg(const g1j &p) { g1j o = p; o.y = neg<FpP>(p.y); return o; }
+KZG_HD g1a g1_neg(const g1a &p) { g1a o = p; o.y = neg<FpP>(p.y); return o; }
+KZG_HD g1j to_jac(const g1a &p) {
+    g1j o;
+    if (is_inf(p)) return g1_inf();
+    o.x = p.x; o.y = p.y; o.z = one<FpP>();
+    return o;
+}
+
+// dbl-2009-l (a = 0): 2M + 5S
+KZG_HD g1j g1_dbl(const g1j &p) {
+    if (is_inf(p)) return g1_inf();
+    fp a = sqr(p.x), b = sqr(p.y), c = sqr(b);
+    fp t = add(p.x, b); t = sqr(t); t = sub(t, a); t = sub(t, c);
+    fp d = add(t, t);
+    fp e = add(add(a, a), a);
+    fp f = sqr(e);
+    g1j o;
+    o.x = sub(f, add(d, d));
+    o.z = mul(p.y, p.z); o.z = add(o.z, o.z);
+    fp c8 = add(c, c); c8 = add(c8, c8); c8 = add(c8, c8);
+    o.y = sub(mul(e, sub(d, o.x)), c8);
+    return o;
+}
+
+// add-2007-bl: 11M + 5S, exceptional cases handled
+KZG_HD g1j g1_add(const g1j &p, const g1j &q) {
+    if (is_inf(p)) return q;
+    if (is_inf(q)) return p;
+    fp z1z1 = sqr(p.z), z2z2 = sqr(q.z);
+    fp u1 = mul(p.x, z2z2), u2 = mul(q.x, z1z1);
+    fp s1 = mul(mul(p.y, q.z), z2z2), s2 = mul(mul(q.y, p.z), z1z1);
+    if (equal<FpP>(u1, u2)) {
+        if (equal<FpP>(s1, s2)) return g1_dbl(p);
+        return g1_inf();
+    }
+    fp h = sub(u2, u1);
+    fp i = add(h, h); i = sqr(i);
+    fp j = mul(h, i);
+    fp r = sub(s2, s1); r = add(r, r);
+    fp v = mul(u1, i);
+    g1j o;
+    o.x = sub(sub(sub(sqr(r), j), v), v);
+    fp t = mul(s1, j); t = add(t, t);
+    o.y = sub(mul(r, sub(v, o.x)), t);
+    o.z = mul(sub(sub(sqr(add(p.z, q.z)), z1z1), z2z2), h);
+    return o;
+}
+
+// madd-2007-bl (q affine, Z2 = 1): 7M + 4S, exceptional cases handled
+KZG_HD g1j g1_madd(const g1j &p, const g1a &q) {
+    if (is_inf(q)) return p;
+    if (is_inf(p)) return to_jac(q);
+    fp z1z1 = sqr(p.z);
+    fp u2 = mul(q.x, z1z1);
+    fp s2 = mul(mul(q.y, p.z), z1z1);
+    if (equal<FpP>(p.x, u2)) {
+        if (equal<FpP>(p.y, s2)) return g1_dbl(p);
+        return g1_inf();
+    }
+    fp h = sub(u2, p.x);
+    fp hh = sqr(h);
+    fp i = add(hh, hh); i = add(i, i);
+    fp j = mul(h, i);
+    fp r = sub(s2, p.y); r = add(r, r);
+    fp v = mul(p.x, i);
+    g1j o;
+    o.x = sub(sub(sub(sqr(r), j), v), v);
+    fp t = mul(p.y, j); t = add(t, t);
+    o.y = sub(mul(r, sub(v, o.x)), t);
+    o.z = sub(sub(sqr(add(p.z, h)), z1z1), hh);
+    return o;
+}
+
+KZG_HD g1j g1_sub(const g1j &p, const g1j &q) { return g1_add(p, g1_neg(q)); }
+
+// Projective equality (bls.EqualG1)
+KZG_HD bool g1_equal(const g1j &p, const g1j &q) {
+    bool pi = is_inf(p), qi = is_inf(q);
+    if (pi || qi) return pi && qi;
+    fp z1z1 = sqr(p.z), z2z2 = sqr(q.z);
+    if (!equal<FpP>(mul(p.x, z2z2), mul(q.x, z1z1))) return false;
+    return equal<FpP>(mul(mul(p.y, q.z), z2z2), mul(mul(q.y, p.z), z1z1));
+}
+
+// Normalise one point (one F_p inversion).  Output: Z = R (Montgomery one) or Kilic's inf image (0, 1, 0).
+KZG_HD g1j g1_normalize(const g1j &p) {
+    if (is_inf(p)) return g1_inf();
+    fp zi = inv<FpP>(p.z), zi2 = sqr(zi);
+    g1j o; o.x = mul(p.x, zi2); o.y = mul(p.y, mul(zi2, zi)); o.z = one<FpP>();
+    return o;
+}
+
+// 4-bit digit of a standard-form scalar (k.l = 8 x u32), window w in 0..63
+KZG_HD uint32_t nibble(const fr &k, int w) { return (k.l[w >> 3] >> ((w & 7) * 4)) & 15u; }
+
+// k * P, k in STANDARD form (the caller does Kilic's FromRed, bls/bls_kilic.go:42-43).
+// Fixed 4-bit windows, MSB first: every lane of a wave executes the same dbl/add schedule.
+// `tbl` is caller-provided storage for 15 multiples (per-lane: private scratch or LDS).
+KZG_HD g1j g1_mul_windowed(const g1j &p, const fr &k, g1j *tbl) {
+    tbl[0] = p;
+    for (int i = 1; i < 15; i++) tbl[i] = (i & 1) ? g1_dbl(tbl[i >> 1]) : g1_add(tbl[i - 1], p);   // tbl[i] = (i+1) P
+    g1j acc = g1_inf();
+    for (int w = 63; w >= 0; w--) {
+        acc = g1_dbl(g1_dbl(g1_dbl(g1_dbl(acc))));
+        uint32_t d = nibble(k, w);
+        if (d) acc = g1_add(acc, tbl[d - 1]);
+    }
+    return acc;
+}
+
+// Plain MSB-first double-and-add (no table); used where the scalar is short.
+KZG_HD g1j g1_mul_small(const g1j &p, uint32_t k) {
+    g1j acc = g1_inf();
+    for (int b = 31; b >= 0; b--) {
+        acc = g1_dbl(acc);
+        if ((k >> b) & 1u) acc = g1_add(acc, p);
+    }
+    return acc;
+}
+
+}  // namespace kzg

@@ -1,0 +1,66 @@
+// internal.hpp -- launcher prototypes shared by the kernel translation units and the C ABI (capi.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "field.hpp"
+#include "g1.hpp"
+
+namespace kzg {
+
+// ---------------- k_fr.hip ----------------
+// Batched radix-2 FFT over F_r (replaces _fft / InplaceFFT, fft_fr.go:30-105).
+//   in  : batch x in_stride Fr, of which the first n_in of each row are used (rest zero-padded to n)
+//   out : batch x n Fr, natural order.  roots = ExpandedRootsOfUnity or ReverseRootsOfUnity (W + 1 entries).
+//   scale != nullptr: every output is multiplied by *scale (device pointer; n^-1 for the inverse).
+void launch_fr_fft(hipStream_t s, const fr *in, uint64_t in_stride, uint64_t n_in, fr *out, uint64_t n, uint64_t batch,
+                   const fr *roots, uint64_t W, const fr *scale);
+// DASFFTExtension (das_extension.go:7-84), in place on batch rows of n values.
+void launch_das_ext(hipStream_t s, fr *vals, uint64_t n, uint64_t batch, const fr *expanded, const fr *reversed, uint64_t W,
+                    const fr *inv_n);
+// toeplitzCoeffsStepStrided (fk20_single.go:89-103): out[b][file][0..2k) from poly[b][0..n), optionally scaled.
+void launch_toeplitz_coeffs(hipStream_t s, const fr *poly, uint64_t poly_stride, uint64_t n, uint64_t l, uint64_t batch, fr *out,
+                            const fr *scale);
+// quotient of poly by (X - x) (polyLongDiv with divisor [-x, 1], poly.go:14-40): q has n - 1 entries
+void launch_quotient_linear(hipStream_t s, const fr *poly, uint64_t n, const fr *x, fr *q);
+// returns (via *flag != 0) whether any of vals[0..n) is non-zero
+void launch_fr_any_nonzero(hipStream_t s, const fr *vals, uint64_t n, uint32_t *flag);
+void launch_fr_powers(hipStream_t s, const fr *base, uint64_t n, fr *out);   // out[i] = base^i
+
+// ---------------- k_g1.hip ----------------
+// out[i] = scalars[i * s_stride] * pts[(i % pts_mod)]   (element-wise bls.MulG1; scalars in Montgomery form)
+void launch_g1_mul_vec(hipStream_t s, const g1j *pts, uint64_t pts_mod, const fr *scalars, uint64_t s_stride, uint64_t n, g1j *out);
+// acc[i] = sum over f < nfiles of scalars[b][f][j] * files[f][j]  -- the FK20-multi Toeplitz stage (fk20_multi.go:79-91)
+void launch_g1_file_msm(hipStream_t s, const g1j *files, const fr *scalars, uint64_t nfiles, uint64_t k2, uint64_t j0, uint64_t cnt,
+                        uint64_t batch, g1j *out);
+// out[b][rev(i)] = i < n_valid ? in[b][i] : inf     (bit-reversal + "h[:n] || inf" padding, fk20_single.go:163-166)
+void launch_g1_bitrev_copy(hipStream_t s, const g1j *in, uint64_t in_stride, uint64_t n_valid, g1j *out, uint64_t n, uint64_t batch);
+// one radix-2 DIT stage on bit-reversed data (replaces the loop of _fftG1, fft_g1.go:44-55)
+void launch_g1_fft_stage(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, uint64_t m, const fr *roots, uint64_t W);
+void launch_g1_normalize(hipStream_t s, const g1j *in, g1j *out, uint64_t n);
+void launch_g1_to_affine(hipStream_t s, const g1j *in, g1a *out, uint64_t n);
+void launch_g1_compress(hipStream_t s, const g1j *in, uint8_t *out48, uint64_t n);
+void launch_g1_decompress(hipStream_t s, const uint8_t *in48, g1j *out, uint64_t n, uint32_t *bad_flag);
+void launch_g1_fixed_base_powers(hipStream_t s, const fr *powers, uint64_t n, g1j *out);   // out[i] = powers[i] * G
+
+// ---------------- k_msm.hip ----------------
+struct msm_plan {
+    uint32_t c;        // window bits (signed digits in [-2^(c-1), 2^(c-1)])
+    uint32_t nwin;     // windows
+    uint32_t nb;       // buckets per group = 2^(c-1)
+    uint32_t ngroups;  // nwin (per-window bucket sets) or 1 (fixed base: windows folded into the table)
+    uint32_t fixed;    // table holds 2^(c w) P_i at [w * table_n + i]
+    uint64_t table_n;  // points per window row of the table
+};
+size_t msm_workspace_bytes(const msm_plan &p, uint64_t n, uint64_t batch);
+// batch MSMs over the same affine table: out[b] = sum_i scalars[b][i] * P_i  (Jacobian, not normalised)
+void launch_msm(hipStream_t s, const msm_plan &p, const g1a *table, const fr *scalars, uint64_t n, uint64_t batch, void *workspace,
+                g1j *out);
+// fixed-base window table: out[w * n + i] = 2^(c w) * pts[i], affine
+void launch_msm_window_table(hipStream_t s, const g1a *pts, uint64_t n, uint32_t c, uint32_t nwin, g1j *tmp, g1a *out);
+
+// profiling hook (HIP events around the dominant kernel), see capi.hip
+struct prof_slot { const char *name; hipEvent_t e0, e1; };
+void prof_begin(hipStream_t s, const char *name);
+void prof_end(hipStream_t s, const char *name);
+
+}  // namespace kzg

@@ -1,0 +1,290 @@
+// k_fr.hip -- F_r kernels: batched radix-2 (I)FFT, DAS FFT extension, Toeplitz coefficient gather,
+// quotient by (X - x).  Replaces fft_fr.go:30-105, das_extension.go:7-84, fk20_single.go:89-119 and
+// poly.go:14-40 of the reference.  Whole transforms of <= 4096 points live in LDS (4096 x 32 B = 128 KiB of
+// the CU's 160 KiB), limb-major so that consecutive lanes hit consecutive banks.
+#include "internal.hpp"
+
+namespace kzg {
+
+static constexpr uint32_t FR_TILE_LOG = 12;          // 4096 points per LDS tile
+static constexpr uint32_t FR_TILE = 1u << FR_TILE_LOG;
+
+__device__ __forceinline__ uint32_t bitrev32(uint32_t v, uint32_t bits) { return bits ? (__brev(v) >> (32 - bits)) : 0; }
+
+// limb-major LDS view: limb k of element i at s[k * n + i]
+struct lds_view {
+    uint32_t *s; uint32_t n;
+    __device__ __forceinline__ fr get(uint32_t i) const {
+        fr v;
+#pragma unroll
+        for (int k = 0; k < 8; k++) v.l[k] = s[k * n + i];
+        return v;
+    }
+    __device__ __forceinline__ void put(uint32_t i, const fr &v) const {
+#pragma unroll
+        for (int k = 0; k < 8; k++) s[k * n + i] = v.l[k];
+    }
+};
+struct glob_view {
+    fr *p;
+    __device__ __forceinline__ fr get(uint64_t i) const { return p[i]; }
+    __device__ __forceinline__ void put(uint64_t i, const fr &v) const { p[i] = v; }
+};
+
+// one DIT butterfly group stage over `cnt` butterflies with half-size m (data already bit-reversed)
+template <class V>
+__device__ __forceinline__ void fft_butterfly(const V &v, uint64_t bf, uint64_t m, const fr *roots, uint64_t rstride) {
+    uint64_t j = bf & (m - 1);
+    uint64_t i0 = ((bf - j) << 1) + j, i1 = i0 + m;
+    fr x = v.get(i0), y = v.get(i1);
+    if (j) y = mul(y, roots[j * rstride]);   // w^0 = 1: the reference multiplies anyway (fft_fr.go:49), same value
+    v.put(i0, add(x, y));
+    v.put(i1, sub(x, y));
+}
+
+// Tile kernel: log2(tn) stages in LDS.  BITREV: tile == whole transform, input read in natural order from `in`
+// (zero-padded beyond n_in) and scattered bit-reversed; otherwise the tile is read in place from `data`.
+template <bool BITREV>
+__global__ __launch_bounds__(1024) void k_fr_fft_tile(const fr *in, uint64_t in_stride, uint64_t n_in, fr *data, uint32_t log_tn,
+                                                      uint64_t tiles_per_row, const fr *roots, uint64_t W, const fr *scale) {
+    extern __shared__ uint32_t smem[];
+    const uint32_t tn = 1u << log_tn, T = blockDim.x, tid = threadIdx.x;
+    lds_view v{smem, tn};
+    const uint64_t tile = blockIdx.x;
+    fr *dst = data + tile * tn;
+    if (BITREV) {
+        const fr *src = in + tile * in_stride;   // tiles_per_row == 1: tile index == batch index
+        for (uint32_t i = tid; i < tn; i += T) {
+            fr x = (i < n_in) ? src[i] : zero<FrP>();
+            v.put(bitrev32(i, log_tn), x);
+        }
+    } else {
+        for (uint32_t i = tid; i < tn; i += T) v.put(i, dst[i]);
+    }
+    __syncthreads();
+    for (uint32_t m = 1; m < tn; m <<= 1) {
+        uint64_t rstride = W / (2ull * m);
+        for (uint32_t bf = tid; bf < tn / 2; bf += T) fft_butterfly(v, bf, m, roots, rstride);
+        __syncthreads();
+    }
+    const bool last = (tiles_per_row == 1);
+    fr sc;
+    if (last && scale) sc = *scale;
+    for (uint32_t i = tid; i < tn; i += T) {
+        fr x = v.get(i);
+        if (last && scale) x = mul(x, sc);
+        dst[i] = x;
+    }
+}
+
+__global__ void k_fr_bitrev_copy(const fr *in, uint64_t in_stride, uint64_t n_in, fr *out, uint32_t logn, uint64_t total) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    uint64_t n = 1ull << logn, b = t >> logn, i = t & (n - 1);
+    fr x = (i < n_in) ? in[b * in_stride + i] : zero<FrP>();
+    out[b * n + bitrev32((uint32_t)i, logn)] = x;
+}
+__global__ void k_fr_fft_stage_glob(fr *data, uint32_t logn, uint64_t m, const fr *roots, uint64_t W, uint64_t total, const fr *scale) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    uint64_t half = 1ull << (logn - 1), b = t / half, bf = t % half;
+    glob_view v{data + (b << logn)};
+    uint64_t j = bf & (m - 1);
+    uint64_t i0 = ((bf - j) << 1) + j, i1 = i0 + m;
+    fr x = v.get(i0), y = v.get(i1);
+    if (j) y = mul(y, roots[j * (W / (2 * m))]);
+    fr o0 = add(x, y), o1 = sub(x, y);
+    if (scale) { fr sc = *scale; o0 = mul(o0, sc); o1 = mul(o1, sc); }
+    v.put(i0, o0); v.put(i1, o1);
+}
+
+static uint32_t ilog2(uint64_t v) { uint32_t r = 0; while ((1ull << r) < v) r++; return r; }
+
+void launch_fr_fft(hipStream_t s, const fr *in, uint64_t in_stride, uint64_t n_in, fr *out, uint64_t n, uint64_t batch, const fr *roots,
+                   uint64_t W, const fr *scale) {
+    if (n == 0 || batch == 0) return;
+    uint32_t logn = ilog2(n);
+    if (n <= FR_TILE) {
+        uint32_t T = (uint32_t)(n / 2 < 64 ? 64 : (n / 2 > 1024 ? 1024 : n / 2));
+        size_t sh = (size_t)n * 32;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fr_fft_tile<true>), hipFuncAttributeMaxDynamicSharedMemorySize, FR_TILE * 32);
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fr_fft_tile<false>), hipFuncAttributeMaxDynamicSharedMemorySize, FR_TILE * 32);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_fr_fft_tile<true>, dim3((uint32_t)batch), dim3(T), sh, s, in, in_stride, n_in, out, logn, (uint64_t)1, roots, W, scale);
+        return;
+    }
+    // n > 4096: bit-reversal copy, 12 stages per 4096-tile in LDS, remaining stages through global memory
+    uint64_t total = n * batch;
+    hipLaunchKernelGGL(k_fr_bitrev_copy, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, in, in_stride, n_in, out, logn, total);
+    static bool attr_set2 = false;
+    if (!attr_set2) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fr_fft_tile<false>), hipFuncAttributeMaxDynamicSharedMemorySize, FR_TILE * 32);
+        attr_set2 = true;
+    }
+    uint64_t tiles_per_row = n / FR_TILE;
+    hipLaunchKernelGGL(k_fr_fft_tile<false>, dim3((uint32_t)(tiles_per_row * batch)), dim3(1024), (size_t)FR_TILE * 32, s, (const fr *)nullptr,
+                       (uint64_t)0, (uint64_t)0, out, FR_TILE_LOG, tiles_per_row, roots, W, (const fr *)nullptr);
+    uint64_t bfs = total / 2;
+    for (uint64_t m = FR_TILE; m < n; m <<= 1) {
+        const fr *sc = (m * 2 == n) ? scale : nullptr;
+        hipLaunchKernelGGL(k_fr_fft_stage_glob, dim3((uint32_t)((bfs + 255) / 256)), dim3(256), 0, s, out, logn, m, roots, W, bfs, sc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// DAS FFT extension (das_extension.go:7-84).  Unrolled recursion: "down" stages for block lengths n .. 2
+// (a0 = a + b, a1 = (a - b) * rev[2 i s]) followed by "up" stages for block lengths 2 .. n
+// (x +- y * ex[(1 + 2 i) s]), s = n / block length; then a scale by 1/n.  Table indices are NOT rescaled to
+// the input length -- exactly as the reference, which always walks the full-width domain (:38, :59).
+// ---------------------------------------------------------------------------------------------------------
+template <class V>
+__device__ __forceinline__ void das_down(const V &v, uint64_t bf, uint64_t h, uint64_t sp, const fr *reversed) {
+    uint64_t i = bf & (h - 1), base = (bf - i) << 1;
+    fr a = v.get(base + i), b = v.get(base + h + i);
+    v.put(base + i, add(a, b));
+    fr d = sub(a, b);
+    if (i) d = mul(d, reversed[2 * i * sp]);
+    v.put(base + h + i, d);
+}
+template <class V>
+__device__ __forceinline__ void das_up(const V &v, uint64_t bf, uint64_t h, uint64_t sp, const fr *expanded) {
+    uint64_t i = bf & (h - 1), base = (bf - i) << 1;
+    fr x = v.get(base + i), y = v.get(base + h + i);
+    fr yr = mul(y, expanded[(1 + 2 * i) * sp]);
+    v.put(base + i, add(x, yr));
+    v.put(base + h + i, sub(x, yr));
+}
+__global__ __launch_bounds__(1024) void k_das_ext_lds(fr *vals, uint32_t logn, const fr *expanded, const fr *reversed, const fr *inv_n) {
+    extern __shared__ uint32_t smem[];
+    const uint32_t n = 1u << logn, T = blockDim.x, tid = threadIdx.x;
+    lds_view v{smem, n};
+    fr *row = vals + (uint64_t)blockIdx.x * n;
+    for (uint32_t i = tid; i < n; i += T) v.put(i, row[i]);
+    __syncthreads();
+    for (uint32_t h = n / 2; h >= 1; h >>= 1) {
+        uint64_t sp = n / (2 * h);
+        for (uint32_t bf = tid; bf < n / 2; bf += T) das_down(v, bf, h, sp, reversed);
+        __syncthreads();
+    }
+    for (uint32_t h = 1; h < n; h <<= 1) {
+        uint64_t sp = n / (2 * h);
+        for (uint32_t bf = tid; bf < n / 2; bf += T) das_up(v, bf, h, sp, expanded);
+        __syncthreads();
+    }
+    fr sc = *inv_n;
+    for (uint32_t i = tid; i < n; i += T) row[i] = mul(v.get(i), sc);
+}
+__global__ void k_das_stage_glob(fr *vals, uint32_t logn, uint64_t h, int up, const fr *tbl, uint64_t total) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    uint64_t half = 1ull << (logn - 1), b = t / half, bf = t % half, n = 1ull << logn;
+    glob_view v{vals + (b << logn)};
+    if (up) das_up(v, bf, h, n / (2 * h), tbl); else das_down(v, bf, h, n / (2 * h), tbl);
+}
+__global__ void k_fr_scale(fr *vals, const fr *sc, uint64_t total) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    vals[t] = mul(vals[t], *sc);
+}
+void launch_das_ext(hipStream_t s, fr *vals, uint64_t n, uint64_t batch, const fr *expanded, const fr *reversed, uint64_t W, const fr *inv_n) {
+    (void)W;
+    uint32_t logn = ilog2(n);
+    if (n <= FR_TILE) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_das_ext_lds), hipFuncAttributeMaxDynamicSharedMemorySize, FR_TILE * 32);
+            attr_set = true;
+        }
+        uint32_t T = (uint32_t)(n / 2 < 64 ? 64 : (n / 2 > 1024 ? 1024 : n / 2));
+        hipLaunchKernelGGL(k_das_ext_lds, dim3((uint32_t)batch), dim3(T), (size_t)n * 32, s, vals, logn, expanded, reversed, inv_n);
+        return;
+    }
+    uint64_t bfs = n * batch / 2;
+    dim3 g((uint32_t)((bfs + 255) / 256)), b(256);
+    for (uint64_t h = n / 2; h >= 1; h >>= 1) hipLaunchKernelGGL(k_das_stage_glob, g, b, 0, s, vals, logn, h, 0, reversed, bfs);
+    for (uint64_t h = 1; h < n; h <<= 1) hipLaunchKernelGGL(k_das_stage_glob, g, b, 0, s, vals, logn, h, 1, expanded, bfs);
+    hipLaunchKernelGGL(k_fr_scale, dim3((uint32_t)((n * batch + 255) / 256)), b, 0, s, vals, inv_n, n * batch);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// toeplitzCoeffsStepStrided (fk20_single.go:89-103), all `l` offsets of all `batch` polynomials at once:
+// out[b][f][0] = p[n-1-f]; out[b][f][1..k+1] = 0; out[b][f][k+2+t] = p[2l - f - 1 + t l]
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_toeplitz_coeffs(const fr *poly, uint64_t poly_stride, uint64_t n, uint64_t l, uint64_t total, fr *out, const fr *scale) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    uint64_t k = n / l, k2 = 2 * k;
+    uint64_t i = t % k2, f = (t / k2) % l, b = t / (k2 * l);
+    const fr *p = poly + b * poly_stride;
+    fr v = zero<FrP>();
+    if (i == 0) v = p[n - 1 - f];
+    else if (i >= k + 2) v = p[2 * l - f - 1 + (i - (k + 2)) * l];
+    if (scale && (i == 0 || i >= k + 2)) v = mul(v, *scale);
+    out[t] = v;
+}
+void launch_toeplitz_coeffs(hipStream_t s, const fr *poly, uint64_t poly_stride, uint64_t n, uint64_t l, uint64_t batch, fr *out, const fr *scale) {
+    uint64_t total = batch * l * 2 * (n / l);
+    if (!total) return;
+    hipLaunchKernelGGL(k_toeplitz_coeffs, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, poly, poly_stride, n, l, total, out, scale);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// q = p / (X - x): q[nq-1] = p[n-1], q[i] = p[i+1] + x q[i+1]  (what polyLongDiv computes for the monic linear
+// divisor, poly.go:14-40; the reference spends one InvModFr per step on the constant 1).  Blocked Horner:
+// 256 lanes each run a contiguous segment with carry-in 0, one lane chains the 256 segment carries, then every
+// lane adds x^(distance) * carry.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_quotient_linear(const fr *poly, uint64_t n, const fr *xp, fr *q) {
+    __shared__ fr head[256], xpow[256], cin[256];
+    const uint32_t t = threadIdx.x;
+    const uint64_t nq = n - 1, m = (nq + 255) / 256;
+    const uint64_t lo = (uint64_t)t * m, hi = (lo + m < nq) ? lo + m : nq;
+    const fr x = *xp;
+    fr acc = zero<FrP>(), pw = one<FrP>();
+    if (lo < nq) {
+        for (uint64_t i = hi; i-- > lo;) { acc = add(poly[i + 1], mul(x, acc)); q[i] = acc; pw = mul(pw, x); }
+    }
+    head[t] = acc; xpow[t] = pw; cin[t] = zero<FrP>();
+    __syncthreads();
+    if (t == 0) {
+        fr c = zero<FrP>();
+        for (int s = 255; s >= 0; s--) { cin[s] = c; c = add(head[s], mul(xpow[s], c)); }
+    }
+    __syncthreads();
+    if (lo < nq) {
+        fr c = cin[t];
+        if (!is_zero<FrP>(c)) {
+            fr p = one<FrP>();
+            for (uint64_t i = hi; i-- > lo;) { p = mul(p, x); q[i] = add(q[i], mul(p, c)); }
+        }
+    }
+}
+void launch_quotient_linear(hipStream_t s, const fr *poly, uint64_t n, const fr *x, fr *q) {
+    hipLaunchKernelGGL(k_quotient_linear, dim3(1), dim3(256), 0, s, poly, n, x, q);
+}
+
+__global__ void k_fr_any_nonzero(const fr *vals, uint64_t n, uint32_t *flag) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t < n && !is_zero<FrP>(vals[t])) atomicOr(flag, 1u);
+}
+void launch_fr_any_nonzero(hipStream_t s, const fr *vals, uint64_t n, uint32_t *flag) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_fr_any_nonzero, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, vals, n, flag);
+}
+
+__global__ void k_fr_powers(const fr *base, uint64_t n, fr *out) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    fr acc = one<FrP>(), pw = *base;
+    for (uint64_t e = t; e; e >>= 1) { if (e & 1) acc = mul(acc, pw); pw = mul(pw, pw); }
+    out[t] = acc;
+}
+void launch_fr_powers(hipStream_t s, const fr *base, uint64_t n, fr *out) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_fr_powers, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, base, n, out);
+}
+
+}  // namespace kzg

@@ -1,0 +1,228 @@
+// k_g1.hip -- G1 kernels, one point per lane: element-wise scalar multiplication, the radix-2 G1 FFT stages,
+// normalisation (Jacobian -> Z = R), ZCash (de)compression.  Replaces the loops of fft_g1.go:33-94,
+// fk20_single.go:72-74 (ToeplitzPart2), fk20_multi.go:86-89 and bls.To/FromCompressedG1 (bls/bls_kilic.go:114-121).
+#include "internal.hpp"
+
+namespace kzg {
+
+#define G1_BLOCK 128
+
+__device__ __forceinline__ uint32_t bitrev32g(uint32_t v, uint32_t bits) { return bits ? (__brev(v) >> (32 - bits)) : 0; }
+
+// k (Montgomery form, as the Go side stores it) * P.  Kilic's MulG1 first leaves Montgomery form (FromRed,
+// bls/bls_kilic.go:42-43); the 15-entry window table lives in the lane's private scratch.
+__device__ __forceinline__ g1j g1_mul_fr(const g1j &p, const fr &k_mont) {
+    if (is_inf(p)) return g1_inf();
+    g1j tbl[15];
+    return g1_mul_windowed(p, from_mont<FrP>(k_mont), tbl);
+}
+
+__global__ __launch_bounds__(G1_BLOCK) void k_g1_mul_vec(const g1j *pts, uint64_t pts_mod, const fr *scalars, uint64_t s_stride, uint64_t n,
+                                                         g1j *out) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    g1j p = pts[t % pts_mod];
+    fr k = scalars[t * s_stride];
+    out[t] = g1_mul_fr(p, k);
+}
+void launch_g1_mul_vec(hipStream_t s, const g1j *pts, uint64_t pts_mod, const fr *scalars, uint64_t s_stride, uint64_t n, g1j *out) {
+    if (!n) return;
+    prof_begin(s, "g1_mul_vec");
+    hipLaunchKernelGGL(k_g1_mul_vec, dim3((uint32_t)((n + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, pts, pts_mod, scalars, s_stride, n, out);
+    prof_end(s, "g1_mul_vec");
+}
+
+// FK20-multi Toeplitz stage (fk20_multi.go:79-91): hExtFFT[j] = sum_f C_f[j] * X_f[j].
+// tmp[b][f][jj] = scalars[b][f][j0 + jj] * files[f][j0 + jj], then summed over f.
+__global__ __launch_bounds__(G1_BLOCK) void k_g1_file_mul(const g1j *files, const fr *scalars, uint64_t nfiles, uint64_t k2, uint64_t j0, uint64_t cnt,
+                                                          uint64_t total, g1j *tmp) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    uint64_t jj = t % cnt, f = (t / cnt) % nfiles, b = t / (cnt * nfiles);
+    g1j p = files[f * k2 + j0 + jj];
+    fr k = scalars[(b * nfiles + f) * k2 + j0 + jj];
+    tmp[t] = g1_mul_fr(p, k);
+}
+__global__ __launch_bounds__(G1_BLOCK) void k_g1_sum_files(const g1j *tmp, uint64_t nfiles, uint64_t cnt, uint64_t total, g1j *out) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    uint64_t jj = t % cnt, b = t / cnt;
+    g1j acc = g1_inf();
+    for (uint64_t f = 0; f < nfiles; f++) acc = g1_add(acc, tmp[(b * nfiles + f) * cnt + jj]);
+    out[t] = acc;
+}
+void launch_g1_file_msm(hipStream_t s, const g1j *files, const fr *scalars, uint64_t nfiles, uint64_t k2, uint64_t j0, uint64_t cnt, uint64_t batch,
+                        g1j *out) {
+    uint64_t total = batch * nfiles * cnt;
+    if (!total) return;
+    g1j *tmp = nullptr;
+    hipMallocAsync((void **)&tmp, total * sizeof(g1j), s);
+    prof_begin(s, "g1_mul_vec");
+    hipLaunchKernelGGL(k_g1_file_mul, dim3((uint32_t)((total + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, files, scalars, nfiles, k2, j0, cnt, total, tmp);
+    prof_end(s, "g1_mul_vec");
+    uint64_t outs = batch * cnt;
+    hipLaunchKernelGGL(k_g1_sum_files, dim3((uint32_t)((outs + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, tmp, nfiles, cnt, outs, out);
+    hipFreeAsync(tmp, s);
+}
+
+__global__ void k_g1_bitrev_copy(const g1j *in, uint64_t in_stride, uint64_t n_valid, g1j *out, uint32_t logn, uint64_t total) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    uint64_t n = 1ull << logn, b = t >> logn, i = t & (n - 1);
+    g1j p = (i < n_valid) ? in[b * in_stride + i] : g1_inf();
+    out[b * n + bitrev32g((uint32_t)i, logn)] = p;
+}
+static uint32_t ilog2g(uint64_t v) { uint32_t r = 0; while ((1ull << r) < v) r++; return r; }
+void launch_g1_bitrev_copy(hipStream_t s, const g1j *in, uint64_t in_stride, uint64_t n_valid, g1j *out, uint64_t n, uint64_t batch) {
+    uint64_t total = n * batch;
+    if (!total) return;
+    hipLaunchKernelGGL(k_g1_bitrev_copy, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, in, in_stride, n_valid, out, ilog2g(n), total);
+}
+
+// One DIT stage with half-size m on bit-reversed data: (x, y) -> (x + w y, x - w y), w = roots[j * W / (2m)].
+// This is the butterfly loop of _fftG1 (fft_g1.go:44-55); the recursion's 4-point leaves (simpleFTG1, :11-31) are
+// the same linear map, so outputs are identical as group elements.
+__global__ __launch_bounds__(G1_BLOCK) void k_g1_fft_stage(g1j *data, uint32_t logn, uint64_t m, const fr *roots, uint64_t W, uint64_t total) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    uint64_t half = 1ull << (logn - 1), b = t / half, bf = t % half;
+    g1j *row = data + (b << logn);
+    uint64_t j = bf & (m - 1);
+    uint64_t i0 = ((bf - j) << 1) + j, i1 = i0 + m;
+    g1j y = row[i1];
+    if (j) y = g1_mul_fr(y, roots[j * (W / (2 * m))]);
+    g1j x = row[i0];
+    row[i0] = g1_add(x, y);
+    row[i1] = g1_add(x, g1_neg(y));
+}
+void launch_g1_fft_stage(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, uint64_t m, const fr *roots, uint64_t W) {
+    uint64_t total = n / 2 * batch;
+    if (!total) return;
+    prof_begin(s, "g1_fft_stage");
+    hipLaunchKernelGGL(k_g1_fft_stage, dim3((uint32_t)((total + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, data, ilog2g(n), m, roots, W, total);
+    prof_end(s, "g1_fft_stage");
+}
+
+__global__ __launch_bounds__(G1_BLOCK) void k_g1_normalize(const g1j *in, g1j *out, uint64_t n) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    out[t] = g1_normalize(in[t]);
+}
+void launch_g1_normalize(hipStream_t s, const g1j *in, g1j *out, uint64_t n) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_g1_normalize, dim3((uint32_t)((n + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, in, out, n);
+}
+__global__ __launch_bounds__(G1_BLOCK) void k_g1_to_affine(const g1j *in, g1a *out, uint64_t n) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    g1j p = in[t];
+    g1a o;
+    if (is_inf(p)) o = g1a_inf();
+    else {
+        if (!equal<FpP>(p.z, one<FpP>())) p = g1_normalize(p);
+        o.x = p.x; o.y = p.y;
+    }
+    out[t] = o;
+}
+void launch_g1_to_affine(hipStream_t s, const g1j *in, g1a *out, uint64_t n) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_g1_to_affine, dim3((uint32_t)((n + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, in, out, n);
+}
+
+// (p - 1) / 2 in standard form, limb i
+__device__ __forceinline__ uint32_t half_pm1(int i) {
+    uint32_t lo = FpP::mod(i) - (i == 0 ? 1u : 0u);
+    uint32_t hi = (i < 11) ? FpP::mod(i + 1) : 0u;
+    return (lo >> 1) | (hi << 31);
+}
+__device__ __forceinline__ bool y_is_larger(const fp &y_std) {   // y > (p - 1) / 2
+    for (int i = 11; i >= 0; i--) {
+        uint32_t h = half_pm1(i);
+        if (y_std.l[i] > h) return true;
+        if (y_std.l[i] < h) return false;
+    }
+    return false;
+}
+// ZCash compressed form: big-endian x, bit7 compressed, bit6 inf, bit5 y > (p-1)/2
+__global__ __launch_bounds__(G1_BLOCK) void k_g1_compress(const g1j *in, uint8_t *out48, uint64_t n) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    g1j p = in[t];
+    uint8_t *o = out48 + 48 * t;
+    if (is_inf(p)) {
+        o[0] = 0xc0;
+        for (int i = 1; i < 48; i++) o[i] = 0;
+        return;
+    }
+    if (!equal<FpP>(p.z, one<FpP>())) p = g1_normalize(p);
+    fp x = from_mont<FpP>(p.x), y = from_mont<FpP>(p.y);
+    for (int i = 0; i < 48; i++) o[47 - i] = (uint8_t)(x.l[i >> 2] >> (8 * (i & 3)));
+    o[0] |= 0x80 | (y_is_larger(y) ? 0x20 : 0);
+}
+void launch_g1_compress(hipStream_t s, const g1j *in, uint8_t *out48, uint64_t n) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_g1_compress, dim3((uint32_t)((n + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, in, out48, n);
+}
+__global__ __launch_bounds__(G1_BLOCK) void k_g1_decompress(const uint8_t *in48, g1j *out, uint64_t n, uint32_t *bad) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint8_t *b = in48 + 48 * t;
+    uint8_t f = b[0];
+    if (!(f & 0x80)) { atomicOr(bad, 1u); out[t] = g1_inf(); return; }
+    if (f & 0x40) {
+        uint32_t rest = f & 0x3f;
+        for (int i = 1; i < 48; i++) rest |= b[i];
+        if (rest) atomicOr(bad, 1u);
+        out[t] = g1_inf();
+        return;
+    }
+    fp x = zero<FpP>();
+    for (int i = 0; i < 48; i++) {
+        uint32_t v = b[47 - i];
+        if (i == 47) v &= 0x1f;
+        x.l[i >> 2] |= v << (8 * (i & 3));
+    }
+    // x < p
+    bool lt = false;
+    for (int i = 11; i >= 0; i--) { uint32_t m = FpP::mod(i); if (x.l[i] < m) { lt = true; break; } if (x.l[i] > m) break; }
+    if (!lt) { atomicOr(bad, 1u); out[t] = g1_inf(); return; }
+    fp xm = to_mont<FpP>(x);
+    fp four = one<FpP>(); four = add(four, four); four = add(four, four);
+    fp y2 = add(mul(sqr(xm), xm), four);
+    // y = y2^((p + 1) / 4)
+    fp acc = one<FpP>();
+    for (int i = 11; i >= 0; i--) {
+        uint32_t lo = FpP::mod(i) + (i == 0 ? 1u : 0u);   // p + 1: low limb 0xffffaaab + 1, no carry
+        uint32_t hi = (i < 11) ? FpP::mod(i + 1) : 0u;
+        uint32_t e = (lo >> 2) | (hi << 30);
+        for (int bit = 31; bit >= 0; bit--) { acc = sqr(acc); if ((e >> bit) & 1u) acc = mul(acc, y2); }
+    }
+    if (!equal<FpP>(sqr(acc), y2)) { atomicOr(bad, 1u); out[t] = g1_inf(); return; }
+    if (y_is_larger(from_mont<FpP>(acc)) != ((f & 0x20) != 0)) acc = neg<FpP>(acc);
+    g1j o; o.x = xm; o.y = acc; o.z = one<FpP>();
+    out[t] = o;
+}
+void launch_g1_decompress(hipStream_t s, const uint8_t *in48, g1j *out, uint64_t n, uint32_t *bad_flag) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_g1_decompress, dim3((uint32_t)((n + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, in48, out, n, bad_flag);
+}
+
+// GenerateTestingSetup's G1 loop (setup.go:18-24): out[i] = powers[i] * G
+__global__ __launch_bounds__(G1_BLOCK) void k_g1_fixed_base_powers(const fr *powers, uint64_t n, g1j *out) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t gx[12] = {0xfd530c16u, 0x5cb38790u, 0x9976fff5u, 0x7817fc67u, 0x143ba1c1u, 0x154f95c7u,
+                             0xf3d0e747u, 0xf0ae6acdu, 0x21dbf440u, 0xedce6eccu, 0x9e0bfb75u, 0x12017741u};
+    const uint32_t gy[12] = {0x0ce72271u, 0xbaac93d5u, 0x7918fd8eu, 0x8c22631au, 0x570725ceu, 0xdd595f13u,
+                             0x50405194u, 0x51ac5829u, 0xad0059c0u, 0x0e1c8c3fu, 0x5008a26au, 0x0bbc3efcu};
+    g1j g;
+    for (int i = 0; i < 12; i++) { g.x.l[i] = gx[i]; g.y.l[i] = gy[i]; }
+    g.z = one<FpP>();
+    out[t] = g1_mul_fr(g, powers[t]);
+}
+void launch_g1_fixed_base_powers(hipStream_t s, const fr *powers, uint64_t n, g1j *out) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_g1_fixed_base_powers, dim3((uint32_t)((n + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, powers, n, out);
+}
+
+}  // namespace kzg

@@ -1,0 +1,213 @@
+// k_msm.hip -- Pippenger multi-scalar multiplication, batched over polynomials ("blobs") that share one point
+// table.  Replaces bls.LinCombG1 -> Kilic G1.MultiExp (bls/bls_kilic.go:132-150) behind CommitToPoly /
+// ComputeProofSingle (kzg_single_proofs.go:17-19,36-54).
+//
+// Pipeline per blob (grid dimension = blob, so a batch fills the 256 CUs):
+//   sort       : scalars leave Montgomery form (Kilic FromRed, bls_kilic.go:141-147), are cut into signed c-bit
+//                digits, and (digit, point) pairs are counting-sorted by bucket inside one workgroup (LDS histogram,
+//                LDS atomics for the scatter cursor).
+//   accumulate : one lane per bucket walks its sorted list with mixed additions (affine table in HBM/L2).
+//   reduce     : one wavefront per bucket group computes sum_k k * B_k by segment running sums + an LDS tree.
+//   combine    : Horner over the window groups (c doublings per window), one lane per blob.
+// Two table modes: per-window bucket groups over the plain points (any caller-supplied points), or "fixed base":
+// the table also holds 2^(c w) P_i so all windows share ONE bucket group and no doublings remain.
+// Bucket contents are summed in a data-dependent order; the group law is commutative and the result is
+// normalised afterwards, so the output bytes do not depend on that order.
+#include "internal.hpp"
+
+namespace kzg {
+
+#define MSM_SORT_T 1024
+#define MSM_ACC_BLOCK 128
+
+struct msm_ws_layout {
+    size_t entries_off, offsets_off, buckets_off, gsum_off, per_blob;
+    uint64_t K, nent;
+};
+static msm_ws_layout ws_layout(const msm_plan &p, uint64_t n) {
+    msm_ws_layout L;
+    L.K = (uint64_t)p.ngroups * p.nb;
+    L.nent = n * p.nwin;
+    size_t o = 0;
+    L.entries_off = o; o += ((L.nent * 4 + 15) / 16) * 16;
+    L.offsets_off = o; o += (((L.K + 1) * 4 + 15) / 16) * 16;
+    L.buckets_off = o; o += L.K * sizeof(g1j);
+    L.gsum_off = o; o += (size_t)p.ngroups * sizeof(g1j);
+    L.per_blob = o;
+    return L;
+}
+size_t msm_workspace_bytes(const msm_plan &p, uint64_t n, uint64_t batch) { return ws_layout(p, n).per_blob * batch; }
+
+__device__ __forceinline__ uint32_t scalar_bits(const fr &k, uint32_t off, uint32_t c) {
+    uint32_t idx = off >> 5, sh = off & 31;
+    if (idx >= 8) return 0;
+    uint64_t v = k.l[idx];
+    if (idx + 1 < 8) v |= (uint64_t)k.l[idx + 1] << 32;
+    return (uint32_t)(v >> sh) & ((1u << c) - 1u);
+}
+
+// visits every non-zero signed digit of scalar k: f(window, |digit|, negative)
+template <class Fn> __device__ __forceinline__ void for_each_digit(const fr &k, uint32_t c, uint32_t nwin, uint32_t nb, Fn f) {
+    uint32_t carry = 0;
+    for (uint32_t w = 0; w < nwin; w++) {
+        uint32_t raw = scalar_bits(k, w * c, c) + carry;
+        if (raw > nb) { carry = 1; f(w, (1u << c) - raw, 1u); }
+        else { carry = 0; if (raw) f(w, raw, 0u); }
+    }
+}
+
+__global__ __launch_bounds__(MSM_SORT_T) void k_msm_sort(msm_plan p, const fr *scalars, uint64_t n, uint8_t *ws, size_t per_blob, size_t entries_off,
+                                                         size_t offsets_off, uint32_t K) {
+    extern __shared__ uint32_t smem[];
+    uint32_t *hist = smem, *part = smem + K;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t b = blockIdx.x;
+    const fr *sc = scalars + b * n;
+    uint32_t *entries = (uint32_t *)(ws + b * per_blob + entries_off);
+    uint32_t *offsets = (uint32_t *)(ws + b * per_blob + offsets_off);
+    for (uint32_t i = tid; i < K; i += MSM_SORT_T) hist[i] = 0;
+    __syncthreads();
+    for (uint64_t i = tid; i < n; i += MSM_SORT_T) {
+        fr k = from_mont<FrP>(sc[i]);
+        for_each_digit(k, p.c, p.nwin, p.nb, [&](uint32_t w, uint32_t mag, uint32_t) {
+            uint32_t key = (p.fixed ? 0u : w * p.nb) + mag - 1;
+            atomicAdd(&hist[key], 1u);
+        });
+    }
+    __syncthreads();
+    // exclusive prefix sum over K bins: per-thread chunk sums, block scan of the 1024 partials, write back
+    const uint32_t per = (K + MSM_SORT_T - 1) / MSM_SORT_T;
+    uint32_t lo = tid * per, hi = lo + per < K ? lo + per : K, sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += hist[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < MSM_SORT_T; off <<= 1) {
+        uint32_t v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - sum;
+    for (uint32_t i = lo; i < hi; i++) { uint32_t cnt = hist[i]; offsets[i] = run; hist[i] = run; run += cnt; }
+    if (tid == MSM_SORT_T - 1) offsets[K] = part[tid];
+    __syncthreads();
+    for (uint64_t i = tid; i < n; i += MSM_SORT_T) {
+        fr k = from_mont<FrP>(sc[i]);
+        for_each_digit(k, p.c, p.nwin, p.nb, [&](uint32_t w, uint32_t mag, uint32_t neg) {
+            uint32_t key = (p.fixed ? 0u : w * p.nb) + mag - 1;
+            uint32_t slot = atomicAdd(&hist[key], 1u);
+            uint32_t tidx = p.fixed ? (uint32_t)(w * p.table_n + i) : (uint32_t)i;
+            entries[slot] = (tidx << 1) | neg;
+        });
+    }
+}
+
+__global__ __launch_bounds__(MSM_ACC_BLOCK) void k_msm_accumulate(const g1a *table, uint8_t *ws, size_t per_blob, size_t entries_off, size_t offsets_off,
+                                                                  size_t buckets_off, uint32_t K, uint64_t total) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    uint64_t b = t / K; uint32_t key = (uint32_t)(t % K);
+    const uint32_t *entries = (const uint32_t *)(ws + b * per_blob + entries_off);
+    const uint32_t *offsets = (const uint32_t *)(ws + b * per_blob + offsets_off);
+    g1j *buckets = (g1j *)(ws + b * per_blob + buckets_off);
+    uint32_t s = offsets[key], e = offsets[key + 1];
+    g1j acc = g1_inf();
+#pragma nounroll
+    for (uint32_t i = s; i < e; i++) {
+        uint32_t en = entries[i];
+        g1a q = table[en >> 1];
+        if (en & 1u) q.y = neg<FpP>(q.y);
+        acc = g1_madd(acc, q);
+    }
+    buckets[key] = acc;
+}
+
+// sum_{k=1..nb} k * B_k for one (blob, group): 64 lanes x segments of m = nb / 64 buckets
+__global__ __launch_bounds__(64) void k_msm_reduce(uint8_t *ws, size_t per_blob, size_t buckets_off, size_t gsum_off, uint32_t nb, uint32_t ngroups) {
+    __shared__ g1j buf[64];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t b = blockIdx.x / ngroups; const uint32_t g = blockIdx.x % ngroups;
+    const g1j *buckets = (const g1j *)(ws + b * per_blob + buckets_off) + (uint64_t)g * nb;
+    g1j *gsum = (g1j *)(ws + b * per_blob + gsum_off);
+    const uint32_t m = nb >= 64 ? nb / 64 : 1;
+    const uint32_t lo = lane * m, hi = lo + m;
+    g1j s = g1_inf(), w = g1_inf();
+    if (lo < nb) {
+#pragma nounroll
+        for (uint32_t k = hi; k-- > lo;) { s = g1_add(s, buckets[k]); w = g1_add(w, s); }
+    }
+    // T1 = sum_L w_L
+    buf[lane] = w;
+    __syncthreads();
+#pragma nounroll
+    for (uint32_t off = 32; off >= 1; off >>= 1) {
+        if (lane < off) buf[lane] = g1_add(buf[lane], buf[lane + off]);
+        __syncthreads();
+    }
+    g1j t1 = buf[0];
+    __syncthreads();
+    // T2 = sum_L L * s_L
+    buf[lane] = g1_mul_small(s, lane);
+    __syncthreads();
+#pragma nounroll
+    for (uint32_t off = 32; off >= 1; off >>= 1) {
+        if (lane < off) buf[lane] = g1_add(buf[lane], buf[lane + off]);
+        __syncthreads();
+    }
+    if (lane == 0) gsum[g] = g1_add(t1, g1_mul_small(buf[0], m));
+}
+
+__global__ __launch_bounds__(64) void k_msm_combine(uint8_t *ws, size_t per_blob, size_t gsum_off, uint32_t c, uint32_t ngroups, uint64_t batch, g1j *out) {
+    uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const g1j *gsum = (const g1j *)(ws + b * per_blob + gsum_off);
+    g1j acc = g1_inf();
+#pragma nounroll
+    for (uint32_t g = ngroups; g-- > 0;) {
+#pragma nounroll
+        for (uint32_t j = 0; j < c; j++) acc = g1_dbl(acc);
+        acc = g1_add(acc, gsum[g]);
+    }
+    out[b] = acc;
+}
+
+void launch_msm(hipStream_t s, const msm_plan &p, const g1a *table, const fr *scalars, uint64_t n, uint64_t batch, void *workspace, g1j *out) {
+    if (!batch) return;
+    msm_ws_layout L = ws_layout(p, n);
+    uint8_t *ws = (uint8_t *)workspace;
+    uint32_t K = (uint32_t)L.K;
+    size_t sh = (size_t)(K + MSM_SORT_T) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_msm_sort), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_msm_sort, dim3((uint32_t)batch), dim3(MSM_SORT_T), sh, s, p, scalars, n, ws, L.per_blob, L.entries_off, L.offsets_off, K);
+    uint64_t total = batch * L.K;
+    prof_begin(s, "msm_accumulate");
+    hipLaunchKernelGGL(k_msm_accumulate, dim3((uint32_t)((total + MSM_ACC_BLOCK - 1) / MSM_ACC_BLOCK)), dim3(MSM_ACC_BLOCK), 0, s, table, ws, L.per_blob,
+                       L.entries_off, L.offsets_off, L.buckets_off, K, total);
+    prof_end(s, "msm_accumulate");
+    hipLaunchKernelGGL(k_msm_reduce, dim3((uint32_t)(batch * p.ngroups)), dim3(64), 0, s, ws, L.per_blob, L.buckets_off, L.gsum_off, p.nb, p.ngroups);
+    hipLaunchKernelGGL(k_msm_combine, dim3((uint32_t)((batch + 63) / 64)), dim3(64), 0, s, ws, L.per_blob, L.gsum_off, p.c, p.ngroups, batch, out);
+}
+
+// fixed-base table rows: tmp[w * n + i] = 2^(c w) * P_i (Jacobian), then normalised to affine by launch_g1_to_affine
+__global__ __launch_bounds__(MSM_ACC_BLOCK) void k_msm_window_rows(const g1a *pts, uint64_t n, uint32_t c, uint32_t nwin, g1j *tmp) {
+    uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    g1j q = to_jac(pts[i]);
+#pragma nounroll
+    for (uint32_t w = 0; w < nwin; w++) {
+        tmp[(uint64_t)w * n + i] = q;
+#pragma nounroll
+        for (uint32_t j = 0; j < c; j++) q = g1_dbl(q);
+    }
+}
+void launch_msm_window_table(hipStream_t s, const g1a *pts, uint64_t n, uint32_t c, uint32_t nwin, g1j *tmp, g1a *out) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_msm_window_rows, dim3((uint32_t)((n + MSM_ACC_BLOCK - 1) / MSM_ACC_BLOCK)), dim3(MSM_ACC_BLOCK), 0, s, pts, n, c, nwin, tmp);
+    launch_g1_to_affine(s, tmp, out, n * nwin);
+}
+
+}  // namespace kzg

@@ -1,0 +1,126 @@
+/*
+ * kzg_hip.h -- C ABI of libkzg_hip.so: the MI355X (gfx950) implementation of go-kzg's commitment /
+ * proof hot path.  Each entry point replaces one batch-level method of the reference's Go API
+ * (file:line relative to protolambda/go-kzg); the cgo binding a maintainer would add is in
+ * INTEGRATION.md and go-kzg_amd/goshim/.
+ *
+ * Data crossing the boundary uses the memory images of the reference's default (Kilic) backend, so Go
+ * slices are passed zero-copy:
+ *   Fr  : 32 B  = 4 x u64 little-endian limbs, Montgomery form (R = 2^256 mod r)      bls/bignum_kilic.go:21-23
+ *   G1  : 144 B = 3 x 6 x u64 (X, Y, Z) Jacobian, Montgomery (R = 2^384 mod p), inf <=> Z == 0
+ *                                                                                     bls/bls_kilic.go:30-35
+ * Returned points are normalised: Z == R (affine) or Kilic's infinity image (0, R, 0), so that byte
+ * comparison with any correct backend is meaningful.  Callers own all buffers; the library keeps no
+ * caller pointer after a call returns (cgo rule).  All calls are blocking and thread-safe per handle.
+ *
+ * Functions ending in _dev take DEVICE pointers (HBM-resident inputs/outputs) and a hipStream_t passed
+ * as void*; they enqueue work and return without synchronising.
+ */
+#ifndef KZG_HIP_H
+#define KZG_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+#pragma GCC visibility push(default)
+
+/* status codes.  The Go shim maps 1-2 to `error` (fft_fr.go:57-59,78-83; fft_g1.go:60-65) and 3-6 to panic
+ * (bls/bls_kilic.go:133-135; kzg.go:22-27,44-52,74-91; fk20_single.go:60-62,140-154; fk20_multi.go:28-31,60-69). */
+#define KZG_HIP_OK 0
+#define KZG_HIP_ERR_TOO_WIDE 1      /* more values than roots of unity */
+#define KZG_HIP_ERR_NOT_POW2 2      /* length is not a power of two */
+#define KZG_HIP_ERR_LEN_MISMATCH 3  /* slice lengths do not match / setup too short */
+#define KZG_HIP_ERR_UPPER_HALF 4    /* "bad input, second half should be zeroed" */
+#define KZG_HIP_ERR_BAD_ARG 5       /* other misuse (n < 2, chunk length, NULL, ...) */
+#define KZG_HIP_ERR_BAD_POINT 6     /* invalid compressed G1 */
+#define KZG_HIP_ERR_NO_DEVICE 7     /* no gfx950 device visible: the library has NO CPU fallback */
+#define KZG_HIP_ERR_HIP 8           /* HIP runtime error, see kzg_hip_last_error() */
+#define KZG_HIP_ERR_UNSUPPORTED 9
+
+typedef struct kzg_hip_fft kzg_hip_fft;                 /* *kzg.FFTSettings         fft.go:34-42   */
+typedef struct kzg_hip_kzg kzg_hip_kzg;                 /* *kzg.KZGSettings         kzg.go:11-19   */
+typedef struct kzg_hip_fk20s kzg_hip_fk20s; /* *kzg.FK20SingleSettings  kzg.go:38-41   */
+typedef struct kzg_hip_fk20m kzg_hip_fk20m; /* *kzg.FK20MultiSettings   kzg.go:66-71   */
+
+/* ---- library / device ---- */
+int kzg_hip_device_count(void);                 /* number of usable gfx950 devices (0 when none)            */
+const char *kzg_hip_last_error(void);           /* thread-local text of the last KZG_HIP_ERR_HIP            */
+const char *kzg_hip_version(void);
+
+/* ---- FFTSettings: NewFFTSettings (fft.go:44-61) ---- */
+int kzg_hip_fft_settings_new(int device, unsigned max_scale, kzg_hip_fft **out);
+void kzg_hip_fft_settings_free(kzg_hip_fft *fs);
+uint64_t kzg_hip_fft_max_width(const kzg_hip_fft *fs);
+/* copies ExpandedRootsOfUnity (reversed == 0) or ReverseRootsOfUnity (reversed != 0): max_width + 1 Fr */
+int kzg_hip_fft_roots(const kzg_hip_fft *fs, int reversed, void *out_fr);
+
+/* FFTSettings.FFT (fft_fr.go:55-74): zero-pads n to the next power of two np; out must hold np Fr; *out_n = np */
+int kzg_hip_fft_fr(kzg_hip_fft *fs, const void *vals_fr, uint64_t n, int inv, void *out_fr, uint64_t *out_n);
+/* FFTSettings.InplaceFFT (fft_fr.go:76-105): n must be a power of two, out != vals */
+int kzg_hip_inplace_fft_fr(kzg_hip_fft *fs, const void *vals_fr, void *out_fr, uint64_t n, int inv);
+/* `batch` independent transforms of n (power of two) contiguous values each */
+int kzg_hip_fft_fr_batch(kzg_hip_fft *fs, const void *vals_fr, uint64_t n, uint64_t batch, int inv, void *out_fr);
+/* FFTSettings.FFTG1 (fft_g1.go:58-94) */
+int kzg_hip_fft_g1(kzg_hip_fft *fs, const void *vals_g1, uint64_t n, int inv, void *out_g1);
+/* FFTSettings.DASFFTExtension (das_extension.go:71-84): in place, n even-index values -> n odd-index values */
+int kzg_hip_das_fft_extension(kzg_hip_fft *fs, void *vals_fr, uint64_t n);
+int kzg_hip_das_fft_extension_batch(kzg_hip_fft *fs, void *vals_fr, uint64_t n, uint64_t batch);
+
+/* ---- bls.LinCombG1 (bls/bls_kilic.go:132-150): Pippenger MSM; n == 0 -> infinity ---- */
+int kzg_hip_lincomb_g1(kzg_hip_fft *fs, const void *points_g1, const void *scalars_fr, uint64_t n, void *out_g1);
+/* bls.ToCompressedG1 over a slice (bls/bls_kilic.go:114-116): n points -> n x 48 B ZCash form */
+int kzg_hip_g1_to_compressed(kzg_hip_fft *fs, const void *points_g1, uint64_t n, void *out48);
+/* bls.FromCompressedG1 over a slice (bls/bls_kilic.go:118-121) */
+int kzg_hip_g1_from_compressed(kzg_hip_fft *fs, const void *in48, uint64_t n, void *out_g1);
+/* element-wise bls.MulG1 (bls/bls_kilic.go:41-45): out[i] = scalars[i] * points[i] */
+int kzg_hip_g1_mul_vec(kzg_hip_fft *fs, const void *points_g1, const void *scalars_fr, uint64_t n, void *out_g1);
+/* GenerateTestingSetup, G1 half (setup.go:9-26): out[i] = [secret^i] G1 */
+int kzg_hip_generate_testing_setup_g1(kzg_hip_fft *fs, const void *secret_fr, uint64_t n, void *out_g1);
+
+/* ---- KZGSettings: NewKZGSettings, prover side (kzg.go:21-36); the setup is uploaded once and stays in HBM ---- */
+int kzg_hip_kzg_settings_new(kzg_hip_fft *fs, const void *secret_g1, uint64_t n_setup, kzg_hip_kzg **out);
+void kzg_hip_kzg_settings_free(kzg_hip_kzg *ks);
+/* KZGSettings.CommitToPoly (kzg_single_proofs.go:17-19) */
+int kzg_hip_commit_to_poly(kzg_hip_kzg *ks, const void *coeffs_fr, uint64_t n, void *out_g1);
+/* `batch` polynomials of n coefficients each -> `batch` commitments */
+int kzg_hip_commit_to_poly_batch(kzg_hip_kzg *ks, const void *coeffs_fr, uint64_t n, uint64_t batch, void *out_g1);
+int kzg_hip_commit_to_poly_batch_dev(kzg_hip_kzg *ks, const void *d_coeffs_fr, uint64_t n, uint64_t batch, void *d_out_g1, void *stream);
+/* KZGSettings.ComputeProofSingle (kzg_single_proofs.go:36-54; poly.go:14-40): x is a uint64 as in the reference */
+int kzg_hip_compute_proof_single(kzg_hip_kzg *ks, const void *poly_fr, uint64_t n, uint64_t x, void *out_g1);
+/* KZGSettings.ToeplitzPart2 / ToeplitzPart3 (fk20_single.go:59-87); part3 writes n/2 points */
+int kzg_hip_toeplitz_part2(kzg_hip_kzg *ks, const void *coeffs_fr, const void *x_ext_fft_g1, uint64_t n, void *out_g1);
+int kzg_hip_toeplitz_part3(kzg_hip_kzg *ks, const void *h_ext_fft_g1, uint64_t n, void *out_g1);
+
+/* ---- FK20 single (kzg.go:43-64; fk20_single.go:122-196) ---- */
+int kzg_hip_fk20_single_settings_new(kzg_hip_kzg *ks, uint64_t n2, kzg_hip_fk20s **out);
+void kzg_hip_fk20_single_settings_free(kzg_hip_fk20s *fk);
+int kzg_hip_fk20_single_x_ext_fft(const kzg_hip_fk20s *fk, void *out_g1 /* n2 points */);
+int kzg_hip_fk20_single(kzg_hip_fk20s *fk, const void *poly_fr, uint64_t n, void *out_g1 /* n */);
+int kzg_hip_fk20_single_da_optimized(kzg_hip_fk20s *fk, const void *poly_fr, uint64_t n2, void *out_g1 /* n2 */);
+int kzg_hip_da_using_fk20(kzg_hip_fk20s *fk, const void *poly_fr, uint64_t n, void *out_g1 /* 2n */);
+/* `batch` polynomials of n coefficients -> batch x 2n proofs (DAUsingFK20 on each) */
+int kzg_hip_da_using_fk20_batch(kzg_hip_fk20s *fk, const void *poly_fr, uint64_t n, uint64_t batch, void *out_g1);
+int kzg_hip_da_using_fk20_batch_dev(kzg_hip_fk20s *fk, const void *d_poly_fr, uint64_t n, uint64_t batch, void *d_out_g1, void *stream);
+
+/* ---- FK20 multi (kzg.go:73-116; fk20_multi.go:25-133) ---- */
+int kzg_hip_fk20_multi_settings_new(kzg_hip_kzg *ks, uint64_t n2, uint64_t chunk_len, kzg_hip_fk20m **out);
+void kzg_hip_fk20_multi_settings_free(kzg_hip_fk20m *fk);
+int kzg_hip_fk20_multi(kzg_hip_fk20m *fk, const void *poly_fr, uint64_t n, void *out_g1 /* n / chunk_len */);
+int kzg_hip_fk20_multi_da_optimized(kzg_hip_fk20m *fk, const void *poly_fr, uint64_t n2, void *out_g1 /* n2 / chunk_len */);
+int kzg_hip_da_using_fk20_multi(kzg_hip_fk20m *fk, const void *poly_fr, uint64_t n, void *out_g1 /* 2n / chunk_len */);
+int kzg_hip_da_using_fk20_multi_batch_dev(kzg_hip_fk20m *fk, const void *d_poly_fr, uint64_t n, uint64_t batch, void *d_out_g1, void *stream);
+/* Sharded form for one process per GPU: this rank computes hExtFFT for output positions
+ * [j0, j0 + cnt) only and writes cnt normalised points; ranks all-gather the slices (RCCL, bytes) and call
+ * kzg_hip_fk20_multi_finish on the gathered 2k points. */
+int kzg_hip_fk20_multi_hext_slice_dev(kzg_hip_fk20m *fk, const void *d_poly_fr, uint64_t n, uint64_t j0, uint64_t cnt, void *d_out_g1, void *stream);
+int kzg_hip_fk20_multi_finish_dev(kzg_hip_fk20m *fk, const void *d_hext_g1, int bit_reverse, void *d_out_g1, void *stream);
+
+/* ---- instrumentation for bench.py: HIP-event time of the dominant kernel since the last reset (ms) and launch count ---- */
+void kzg_hip_prof_reset(kzg_hip_fft *fs, int enable);
+int kzg_hip_prof_read(kzg_hip_fft *fs, const char *kernel, double *total_ms, uint64_t *launches);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,26 @@
+// Host build of the device arithmetic headers (go-kzg_amd/csrc/field.hpp, g1.hpp) so that the exact
+// source the HIP kernels inline is checked against the oracle on a machine without a GPU.
+// TEST INFRASTRUCTURE: built by tests/test_host_arith.py into tests/host/_build/, never shipped.
+#include "field.hpp"
+#include "g1.hpp"
+#include <string.h>
+using namespace kzg;
+extern "C" {
+void he_fr_mul(fr *o, const fr *a, const fr *b) { *o = mul(*a, *b); }
+void he_fr_add(fr *o, const fr *a, const fr *b) { *o = add(*a, *b); }
+void he_fr_sub(fr *o, const fr *a, const fr *b) { *o = sub(*a, *b); }
+void he_fr_inv(fr *o, const fr *a) { *o = inv<FrP>(*a); }
+void he_fr_from_u64(fr *o, uint64_t v) { *o = fr_from_u64(v); }
+void he_fr_from_mont(fr *o, const fr *a) { *o = from_mont<FrP>(*a); }
+void he_g1_add(g1j *o, const g1j *a, const g1j *b) { *o = g1_add(*a, *b); }
+void he_g1_sub(g1j *o, const g1j *a, const g1j *b) { *o = g1_sub(*a, *b); }
+void he_g1_dbl(g1j *o, const g1j *a) { *o = g1_dbl(*a); }
+void he_g1_madd(g1j *o, const g1j *a, const g1j *b_affine_image) {   // b must have Z = R or be inf
+    g1a q; if (is_inf(*b_affine_image)) q = g1a_inf(); else { q.x = b_affine_image->x; q.y = b_affine_image->y; }
+    *o = g1_madd(*a, q);
+}
+void he_g1_mul(g1j *o, const g1j *a, const fr *k_mont) { g1j tbl[15]; *o = g1_mul_windowed(*a, from_mont<FrP>(*k_mont), tbl); }
+void he_g1_mul_small(g1j *o, const g1j *a, uint32_t k) { *o = g1_mul_small(*a, k); }
+void he_g1_normalize(g1j *o, const g1j *a) { *o = g1_normalize(*a); }
+int he_g1_equal(const g1j *a, const g1j *b) { return g1_equal(*a, *b); }
+}

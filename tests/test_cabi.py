@@ -1,0 +1,49 @@
+"""The C-ABI library loads on a machine without a GPU, exports every symbol include/kzg_hip.h declares, and
+refuses to run without a device (no CPU fallback).  CPU only; no compute calls."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "kzg_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(kzg_hip_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_boundary():
+    syms = declared_symbols()
+    for must in ("kzg_hip_fft_fr", "kzg_hip_fft_g1", "kzg_hip_das_fft_extension", "kzg_hip_lincomb_g1", "kzg_hip_commit_to_poly",
+                 "kzg_hip_compute_proof_single", "kzg_hip_da_using_fk20", "kzg_hip_da_using_fk20_multi", "kzg_hip_fk20_single",
+                 "kzg_hip_fk20_multi", "kzg_hip_toeplitz_part2", "kzg_hip_toeplitz_part3"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    import gokzg_amd
+    lib = ctypes.CDLL(gokzg_amd.LIB_PATH)
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert not missing, missing
+    gokzg_amd.lib()   # the binding's own signature table must resolve too
+
+
+def test_no_cpu_fallback():
+    import gokzg_amd
+    if gokzg_amd.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(gokzg_amd.NoDeviceError):
+        gokzg_amd.FFTSettings(4)
+
+
+def test_product_does_not_touch_the_oracle():
+    """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use oracle/"""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "go-kzg_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", ".go")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "koracle" not in txt and "kzg_oracle" not in txt and "pyref" not in txt, os.path.join(dirpath, f)
+    assert "oracle" not in open(os.path.join(ROOT, "include", "kzg_hip.h")).read()

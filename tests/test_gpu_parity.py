@@ -1,0 +1,435 @@
+"""Parity of the HIP path (through the C ABI, via the gokzg_amd binding) with the CPU oracle and with the
+golden fixtures.  Every test here needs a real MI355X: run with `-m gpu`.  Integer work: bit-exact.
+
+The structure follows the reference's tests: fft_fr_test.go, das_extension_test.go, bls/bls_test.go,
+kzg_single_proofs_test.go, fk20_single_test.go, fk20_multi_test.go.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import koracle as ko
+from oracle import pyref
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+KATS = json.load(open(os.path.join(GOLDEN, "reference_kats.json")))
+DERIVED = json.load(open(os.path.join(GOLDEN, "derived_vectors.json")))
+PINS = json.load(open(os.path.join(GOLDEN, "trusted_setup_sha256.json")))
+S_TEST = int(KATS["test_secret"]["value"])
+TEST_POLY = KATS["test_poly"]["values"]
+
+
+@pytest.fixture(scope="module")
+def kz():
+    import gokzg_amd
+    assert gokzg_amd.device_count() >= 1, "no gfx950 device: the HIP path is the only path"
+    return gokzg_amd
+
+
+def rand_fr(rng, n):
+    return ko.fr_from_ints([int.from_bytes(rng.bytes(32), "little") % ko.R_MOD for _ in range(n)])
+
+
+def comp_hex(pts):
+    return [c.tobytes().hex() for c in ko.g1_compress(pts)]
+
+
+def assert_points_equal(got, want):
+    """bit-exact on the normalised images AND on the compressed bytes"""
+    got, want = np.asarray(got).reshape(-1, 3, 6), np.asarray(want).reshape(-1, 3, 6)
+    assert got.shape == want.shape
+    wn = ko.g1_affine(want)
+    bad = np.nonzero((got != wn).any(axis=(1, 2)))[0]
+    assert bad.size == 0, "first mismatching indices: %s" % bad[:8]
+
+
+# ------------------------------------------------------------------ F_r FFT (fft_fr_test.go)
+def test_fft_settings_roots(kz):
+    for scale in (4, 12):
+        fs, ofs = kz.FFTSettings(scale), ko.FFTSettings(scale)
+        assert np.array_equal(fs.expanded_roots_of_unity(), ofs.expanded_roots())
+        assert np.array_equal(fs.reverse_roots_of_unity(), ofs.reverse_roots())
+        fs.close()
+
+
+def test_inv_fft_kat(kz):
+    k = KATS["test_inv_fft"]
+    fs = kz.FFTSettings(k["scale"])
+    res = fs.fft(ko.fr_from_ints(k["input"]), inv=True)
+    assert ko.fr_to_ints(res) == [int(v) for v in k["expected"]]
+    fs.close()
+
+
+def test_fft_roundtrip(kz):
+    fs = kz.FFTSettings(4)
+    data = ko.fr_from_ints(range(16))
+    coeffs = fs.fft(data)
+    assert np.array_equal(fs.fft(coeffs, inv=True), data)
+    fs.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 4, 8, 64, 100, 1024, 4096, 5000, 8192, 65536])
+def test_fft_fr_matches_oracle(kz, n):
+    scale = 16
+    fs, ofs = kz.FFTSettings(scale), ko.FFTSettings(scale)
+    rng = np.random.default_rng(n)
+    vals = rand_fr(rng, n)
+    for inv in (False, True):
+        assert np.array_equal(fs.fft(vals, inv), ofs.fft(vals, inv)), (n, inv)
+    fs.close()
+
+
+def test_fft_fr_batch_and_config1_roundtrip(kz):
+    # BASELINE config 1: FFT_Fr scale 12 forward + inverse round trip on blob(seed 12)
+    fs, ofs = kz.FFTSettings(12), ko.FFTSettings(12)
+    blobs = np.stack([ko.synthetic_blob(12 + b) for b in range(5)])
+    f = fs.fft_batch(blobs)
+    assert np.array_equal(f[0], ofs.fft(blobs[0]))
+    assert np.array_equal(f[4], ofs.fft(blobs[4]))
+    assert np.array_equal(fs.fft_batch(f, inv=True), blobs)
+    fs.close()
+
+
+def test_fft_errors(kz):
+    fs = kz.FFTSettings(4)
+    with pytest.raises(kz.KzgError) as e:
+        fs.fft(ko.fr_empty(17))
+    assert e.value.status == kz.ERR_TOO_WIDE
+    with pytest.raises(kz.KzgError) as e:
+        fs.inplace_fft(ko.fr_empty(12))
+    assert e.value.status == kz.ERR_NOT_POW2
+    with pytest.raises(kz.KzgError) as e:
+        fs.fft_g1(ko.g1_zero(12))
+    assert e.value.status == kz.ERR_NOT_POW2
+    with pytest.raises(kz.KzgError) as e:
+        fs.fft_g1(ko.g1_zero(32))
+    assert e.value.status == kz.ERR_TOO_WIDE
+    with pytest.raises(kz.KzgPanic) as e:
+        fs.das_fft_extension(ko.fr_empty(16))
+    assert e.value.status == kz.ERR_TOO_WIDE
+    fs.close()
+
+
+# ------------------------------------------------------------------ DAS extension (das_extension_test.go)
+def test_das_fft_extension_kat(kz):
+    k = KATS["test_das_fft_extension"]
+    fs = kz.FFTSettings(k["scale"])
+    res = fs.das_fft_extension(ko.fr_from_ints(k["input"]))
+    assert ko.fr_to_ints(res) == [int(v) for v in k["expected"]]
+    fs.close()
+
+
+@pytest.mark.parametrize("scale", [2, 4, 5, 9, 12, 14])
+def test_parametrized_das_fft_extension(kz, scale):
+    fs, ofs = kz.FFTSettings(scale), ko.FFTSettings(scale)
+    rng = np.random.default_rng(scale)
+    even = rand_fr(rng, fs.max_width // 2)
+    odd = fs.das_fft_extension(even)
+    assert np.array_equal(odd, ofs.das_fft_extension(even))
+    data = np.empty((fs.max_width, 4), dtype=np.uint64)
+    data[0::2], data[1::2] = even, odd
+    coeffs = fs.fft(data, inv=True)       # das_extension_test.go:59-77: upper half of the coefficients is zero
+    assert not coeffs[fs.max_width // 2:].any()
+    fs.close()
+
+
+def test_das_smaller_than_domain(kz):
+    # the reference walks the full-width tables whatever the input length (das_extension.go:38,59)
+    fs, ofs = kz.FFTSettings(8), ko.FFTSettings(8)
+    even = rand_fr(np.random.default_rng(5), 16)
+    assert np.array_equal(fs.das_fft_extension(even), ofs.das_fft_extension(even))
+    fs.close()
+
+
+# ------------------------------------------------------------------ G1 primitives (bls/bls_test.go)
+@pytest.fixture(scope="module")
+def fs16(kz):
+    fs = kz.FFTSettings(16)
+    yield fs
+    fs.close()
+
+
+def edge_points():
+    gen = ko.g1_generator()
+    rng = np.random.default_rng(99)
+    pts = [ko.g1_mul(gen, k) for k in rand_fr(rng, 5)]
+    pts += [ko.g1_zero()[0], gen, ko.g1_affine(pts[0])[0], ko.g1_sub(ko.g1_zero()[0], pts[0]), pts[1].copy()]
+    return np.stack(pts)
+
+
+def test_point_compression_kat(kz, fs16):
+    k = KATS["test_point_compression"]
+    x = ko.fr_from_ints([int(k["scalar"])])
+    pt = fs16.mul_g1_vec(ko.g1_generator()[None], x)
+    assert list(fs16.to_compressed_g1(pt)[0]) == k["expected_bytes"]
+    back = fs16.from_compressed_g1(np.array(k["expected_bytes"], dtype=np.uint8))
+    assert_points_equal(back, pt)
+
+
+def test_compress_decompress_edge_cases(kz, fs16):
+    pts = edge_points()
+    comp = fs16.to_compressed_g1(pts)
+    assert np.array_equal(comp, ko.g1_compress(pts))
+    assert_points_equal(fs16.from_compressed_g1(comp), pts)
+    bad = comp.copy()
+    bad[0, 0] &= 0x7F                         # not flagged as compressed
+    with pytest.raises(kz.KzgPanic) as e:
+        fs16.from_compressed_g1(bad)
+    assert e.value.status == kz.ERR_BAD_POINT
+    notoncurve = np.zeros((1, 48), dtype=np.uint8)
+    notoncurve[0, 0] = 0x80
+    notoncurve[0, 47] = 0x01                  # x = 1: 1 + 4 = 5 is not a square mod p? checked against the oracle
+    try:
+        ko.g1_decompress(notoncurve)
+        ok = True
+    except ValueError:
+        ok = False
+    if not ok:
+        with pytest.raises(kz.KzgPanic):
+            fs16.from_compressed_g1(notoncurve)
+
+
+def test_mul_g1_vec_matches_oracle(kz, fs16):
+    pts = edge_points()
+    rng = np.random.default_rng(4)
+    scalars = np.concatenate([rand_fr(rng, 5), ko.fr_from_ints([0, 1, 2, ko.R_MOD - 1, 16])])
+    want = np.stack([ko.g1_mul(p, k) for p, k in zip(pts, scalars)])
+    assert_points_equal(fs16.mul_g1_vec(pts, scalars), want)
+
+
+def test_empty_lincomb(kz, fs16):
+    out = fs16.lin_comb_g1(ko.g1_empty(0), ko.fr_empty(0))
+    assert ko.g1_equal(out, ko.g1_zero()[0])
+    assert np.array_equal(out, ko.g1_zero()[0])
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 31, 32, 100, 1000])
+def test_lincomb_matches_oracle(kz, fs16, n):
+    rng = np.random.default_rng(n)
+    gen = ko.g1_generator()
+    pts = np.stack([ko.g1_mul(gen, k) for k in rand_fr(rng, n)])
+    if n >= 5:
+        pts[1] = ko.g1_zero()[0]
+        pts[2] = pts[3]                                  # duplicate points: P + P inside a bucket
+        pts[4] = ko.g1_sub(ko.g1_zero()[0], pts[3])      # and P + (-P)
+    scalars = rand_fr(rng, n)
+    if n >= 5:
+        scalars[0] = ko.fr_from_ints([0])[0]
+        scalars[2] = scalars[3]
+        scalars[4] = scalars[3]
+    assert_points_equal(fs16.lin_comb_g1(pts, scalars), ko.lincomb_g1(pts, scalars))
+    with pytest.raises(kz.KzgPanic):
+        fs16.lin_comb_g1(pts, ko.fr_empty(n + 1))
+
+
+def test_generate_testing_setup(kz, fs16):
+    s = ko.fr_from_ints([S_TEST])
+    got = fs16.generate_testing_setup_g1(s, 33)
+    assert_points_equal(got, ko.generate_testing_setup_g1(S_TEST, 33))
+
+
+# ------------------------------------------------------------------ commitments / single proofs (kzg_single_proofs_test.go)
+@pytest.fixture(scope="module")
+def ks16(kz):
+    fs = kz.FFTSettings(4)
+    ks = kz.KZGSettings(fs, ko.generate_testing_setup_g1(S_TEST, 17))
+    yield ks
+    ks.close()
+    fs.close()
+
+
+def test_vector_A_commit_to_poly(kz, ks16):
+    c = ks16.commit_to_poly(ko.fr_from_ints(TEST_POLY))
+    assert comp_hex(c)[0] == DERIVED["A_commit_test_poly"]
+
+
+def test_vector_B_compute_proof_single(kz, ks16):
+    poly = ko.fr_from_ints(TEST_POLY)
+    proof = ks16.compute_proof_single(poly, 17)
+    assert comp_hex(proof)[0] == DERIVED["B_proof_single_x17"]
+    d = pyref.single_proof_dlog(TEST_POLY, S_TEST, 17)     # pairing-free CheckProofSingle (kzg_single_proofs_test.go:58)
+    assert ko.g1_equal(proof, ko.g1_mul(ko.g1_generator(), ko.fr_from_ints([d])[0]))
+
+
+def test_commit_to_eval_poly(kz, ks16):
+    # kzg_single_proofs_test.go:11-31
+    fs = ks16.fs
+    poly = ko.fr_from_ints(TEST_POLY)
+    eval_poly = fs.fft(poly)
+    setup = ko.generate_testing_setup_g1(S_TEST, 17)
+    secret_ifft = fs.fft_g1(setup[:16], inv=True)
+    by_eval = kz.commit_to_eval_poly(fs, secret_ifft, eval_poly)
+    by_coeffs = ks16.commit_to_poly(poly)
+    assert ko.g1_equal(by_eval, by_coeffs)
+    assert np.array_equal(by_eval, by_coeffs)
+
+
+def test_kzg_settings_errors(kz):
+    fs = kz.FFTSettings(4)
+    with pytest.raises(kz.KzgPanic) as e:
+        kz.KZGSettings(fs, ko.generate_testing_setup_g1(S_TEST, 8))    # kzg.go:25-27
+    assert e.value.status == kz.ERR_LEN_MISMATCH
+    fs.close()
+
+
+@pytest.fixture(scope="module")
+def setup_1337():
+    raw = np.frombuffer(open(os.path.join(GOLDEN, "trusted_setup_g1.bin"), "rb").read(), dtype=np.uint8)
+    return ko.g1_decompress(raw)
+
+
+@pytest.fixture(scope="module")
+def ks4096(kz, setup_1337):
+    fs = kz.FFTSettings(12)
+    ks = kz.KZGSettings(fs, setup_1337)
+    yield ks
+    ks.close()
+    fs.close()
+
+
+def test_vector_F_and_batch_commit_4096(kz, ks4096, setup_1337):
+    # BASELINE config 2: CommitToPoly on 4096-coefficient blobs, eth/trusted_setup.json
+    blobs = np.stack([ko.synthetic_blob(1 + b) for b in range(6)])
+    got = ks4096.commit_to_poly_batch(blobs)
+    assert comp_hex(got[0])[0] == DERIVED["F_blob_seed1"]["commit_monomial_s1337"]
+    assert_points_equal(got[5], ko.lincomb_g1(setup_1337, blobs[5]))
+    assert_points_equal(ks4096.commit_to_poly(blobs[3]), got[3])
+    short = blobs[2][:1000]                                # CommitToPoly uses SecretG1[:len(coeffs)]
+    assert_points_equal(ks4096.commit_to_poly(short), ko.lincomb_g1(setup_1337[:1000], short))
+    # eth.PolynomialToKZGCommitment: MSM against the bit-reversed Lagrange setup (eth/globals.go:48)
+    lag = ko.g1_decompress(np.frombuffer(open(os.path.join(GOLDEN, "trusted_setup_g1_lagrange.bin"), "rb").read(), dtype=np.uint8))
+    c = ks4096.fs.lin_comb_g1(ko.reverse_bit_order(lag), blobs[0])
+    assert comp_hex(c)[0] == DERIVED["F_blob_seed1"]["commit_eth_bitrev_lagrange"]
+
+
+def test_commit_linearity_full_size(kz, ks4096):
+    # size-independent property at full size: commit(a) + commit(b) == commit(a + b)
+    a, b = ko.synthetic_blob(101), ko.synthetic_blob(102)
+    s = ko.fr_from_ints([(x + y) % ko.R_MOD for x, y in zip(ko.fr_to_ints(a), ko.fr_to_ints(b))])
+    ca, cb, cs = ks4096.commit_to_poly_batch(np.stack([a, b, s]))
+    assert ko.g1_equal(ko.g1_add(ca, cb), cs)
+
+
+def test_proof_single_4096(kz, ks4096, setup_1337):
+    blob = ko.synthetic_blob(7)
+    proof = ks4096.compute_proof_single(blob, 17)
+    d = pyref.single_proof_dlog(ko.fr_to_ints(blob), 1337, 17)
+    assert ko.g1_equal(proof, ko.g1_mul(ko.g1_generator(), ko.fr_from_ints([d])[0]))
+
+
+# ------------------------------------------------------------------ G1 FFT (fft_g1.go)
+@pytest.mark.parametrize("n", [1, 2, 4, 8, 32])
+def test_fft_g1_small_matches_oracle(kz, n):
+    fs, ofs = kz.FFTSettings(6), ko.FFTSettings(6)
+    pts = edge_points()
+    vals = np.stack([pts[i % len(pts)] for i in range(n)])
+    for inv in (False, True):
+        assert_points_equal(fs.fft_g1(vals, inv), ofs.fft_g1(vals, inv))
+    fs.close()
+
+
+def test_fft_g1_4096_trusted_setup_lagrange(kz, setup_1337):
+    # BASELINE config 3: FFTG1(setup_G1, inv) == setup_G1_lagrange, 4096 x 48 B from eth/trusted_setup.json
+    fs = kz.FFTSettings(12)
+    lag = fs.fft_g1(setup_1337, inv=True)
+    comp = fs.to_compressed_g1(lag).tobytes()
+    assert hashlib.sha256(comp).hexdigest() == PINS["setup_G1_lagrange"]
+    assert comp == open(os.path.join(GOLDEN, "trusted_setup_g1_lagrange.bin"), "rb").read()
+    back = fs.fft_g1(lag, inv=False)
+    assert_points_equal(back, setup_1337)
+    fs.close()
+
+
+# ------------------------------------------------------------------ FK20 (fk20_single_test.go, fk20_multi_test.go)
+def test_vector_C_da_using_fk20(kz):
+    fs = kz.FFTSettings(5)
+    setup = ko.generate_testing_setup_g1(S_TEST, 33)
+    ks = kz.KZGSettings(fs, setup)
+    fk = kz.FK20SingleSettings(ks, 32)
+    ofs = ko.FFTSettings(5)
+    ofk = ko.FK20SingleSettings(ko.KZGSettings(ofs, setup), 32)
+    assert_points_equal(fk.x_ext_fft(), ofk.x_ext_fft())
+    poly = ko.fr_from_ints(TEST_POLY)
+    proofs = fk.da_using_fk20(poly)
+    comp = ko.g1_compress(proofs)
+    v = DERIVED["C_da_using_fk20_scale5"]
+    assert hashlib.sha256(comp.tobytes()).hexdigest() == v["sha256"]
+    assert comp[18].tobytes().hex() == v["18"]             # position 9, fk20_single_test.go:30-41
+    assert_points_equal(proofs, ofk.da_using_fk20(poly))
+    ext = np.concatenate([poly, ko.fr_empty(16)])
+    assert_points_equal(fk.fk20_single_da_optimized(ext), ofk.fk20_single_da_optimized(ext))
+    bad = ext.copy()
+    bad[20] = poly[1]
+    with pytest.raises(kz.KzgPanic) as e:
+        fk.fk20_single_da_optimized(bad)
+    assert e.value.status == kz.ERR_UPPER_HALF
+    # FK20Single (no DA): 16 coefficients -> 16 proofs needs settings with n2 = 32
+    assert_points_equal(fk.fk20_single(poly), ofk.fk20_single(poly))
+    # ToeplitzPart2 / ToeplitzPart3 as public methods (fk20_single.go:59-87)
+    tc = ko.toeplitz_coeffs_step_strided(poly, 0, 1)
+    oks = ko.KZGSettings(ofs, setup)
+    h_ext = ks.toeplitz_part2(tc, ofk.x_ext_fft())
+    assert_points_equal(h_ext, oks.toeplitz_part2(tc, ofk.x_ext_fft()))
+    assert_points_equal(ks.toeplitz_part3(h_ext), oks.toeplitz_part3(h_ext))
+    fk.close(); ks.close(); fs.close()
+
+
+def fk20_multi_test_poly(chunk_count=32):
+    poly = []
+    for i in range(chunk_count):
+        vals = [1, 2, 3, 4 + i, 7, 8 + i * i, 9, 10, 13, 14, 1, 15, 0, 1000, 0, 33]
+        vals[12] = ko.R_MOD - 1
+        vals[14] = ko.R_MOD - 134
+        poly += vals
+    return poly
+
+
+def test_vectors_D_E_da_using_fk20_multi(kz):
+    chunk_len, chunk_count = 16, 32
+    n = chunk_len * chunk_count
+    fs = kz.FFTSettings(10)
+    setup = ko.generate_testing_setup_g1(S_TEST, 2 * n)
+    ks = kz.KZGSettings(fs, setup)
+    fk = kz.FK20MultiSettings(ks, 2 * n, chunk_len)
+    poly = ko.fr_from_ints(fk20_multi_test_poly())
+    assert comp_hex(ks.commit_to_poly(poly))[0] == DERIVED["D_commit_fk20_multi_poly"]
+    proofs = fk.da_using_fk20_multi(poly)
+    comp = ko.g1_compress(proofs)
+    v = DERIVED["E_da_using_fk20_multi_scale10_l16"]
+    assert hashlib.sha256(comp.tobytes()).hexdigest() == v["sha256"]
+    assert comp[0].tobytes().hex() == v["0"] and comp[63].tobytes().hex() == v["63"]
+    ofk = ko.FK20MultiSettings(ko.KZGSettings(ko.FFTSettings(10), setup), 2 * n, chunk_len)
+    assert_points_equal(proofs, ofk.da_using_fk20_multi(poly))
+    ext = np.concatenate([poly, ko.fr_empty(n)])
+    assert_points_equal(fk.fk20_multi_da_optimized(ext), ofk.fk20_multi_da_optimized(ext))
+    assert_points_equal(fk.fk20_multi(poly), ofk.fk20_multi(poly))
+    with pytest.raises(kz.KzgPanic):
+        kz.FK20MultiSettings(ks, 2 * n, 24)               # kzg.go:86-88
+    fk.close(); ks.close(); fs.close()
+
+
+def test_fk20_single_4096_config4a(kz, ks4096):
+    # BASELINE config 4a: DAUsingFK20 at scale 12, poly = blob(seed 4)[:2048], setup s = 1337 -> 4096 proofs,
+    # every proof checked against the pairing-free identity proof_i == [(p(s) - p(x_i)) / (s - x_i)] G1
+    fk = kz.FK20SingleSettings(ks4096, 4096)
+    poly = ko.synthetic_blob(4)[:2048]
+    proofs = fk.da_using_fk20(poly)
+    pfs = pyref.FFTSettings(12)
+    poly_i = ko.fr_to_ints(poly)
+    dl = pyref.bitrev(pyref.fk20_single_da_dlogs(pfs, poly_i, 1337))
+    # spot-check the dlog pipeline itself against the proof identity
+    for i in (0, 1, 2047, 4095):
+        x = pfs.expanded[pyref.rev_bits(i, 12)]
+        assert dl[i] == pyref.single_proof_dlog(poly_i, 1337, x)
+    want = ko.g1_empty(4096)
+    gen = ko.g1_generator()
+    ks_fr = ko.fr_from_ints(dl)
+    for i in range(4096):
+        want[i] = ko.g1_mul(gen, ks_fr[i])
+    assert_points_equal(proofs, want)
+    fk.close()

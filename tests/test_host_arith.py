@@ -1,0 +1,101 @@
+"""The device arithmetic headers (field.hpp / g1.hpp), compiled for the host, against the oracle. CPU only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import koracle as ko
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "host", "host_emul.cpp")
+OUT = os.path.join(HERE, "host", "_build", "libhost_emul.so")
+
+
+@pytest.fixture(scope="module")
+def he():
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    inc = os.path.join(ROOT, "go-kzg_amd", "csrc")
+    deps = [SRC, os.path.join(inc, "field.hpp"), os.path.join(inc, "g1.hpp")]
+    if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", inc, "-o", OUT, SRC])
+    return C.CDLL(OUT)
+
+
+def p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def rand_fr(rng, n):
+    return ko.fr_from_ints([int.from_bytes(rng.bytes(32), "little") % ko.R_MOD for _ in range(n)])
+
+
+def test_fr_ops(he):
+    rng = np.random.default_rng(1)
+    a, b = rand_fr(rng, 64), rand_fr(rng, 64)
+    edge = ko.fr_from_ints([0, 1, ko.R_MOD - 1, 2, ko.R_MOD - 2])
+    a[:5], b[5:10] = edge, edge
+    L = ko.lib()
+    for i in range(64):
+        for name in ("mul", "add", "sub"):
+            got, want = ko.fr_empty(1), ko.fr_empty(1)
+            getattr(he, "he_fr_" + name)(p(got), p(a[i]), p(b[i]))
+            getattr(L, "ko_fr_" + name)(p(want), p(a[i]), p(b[i]))
+            assert np.array_equal(got, want), (name, i)
+    for i in range(8):
+        got, want = ko.fr_empty(1), ko.fr_empty(1)
+        he.he_fr_inv(p(got), p(a[i]))
+        L.ko_fr_inv(p(want), p(a[i]))
+        assert np.array_equal(got, want)
+    got = ko.fr_empty(1)
+    he.he_fr_from_u64.argtypes = [C.c_void_p, C.c_uint64]
+    he.he_fr_from_u64(p(got), 2**64 - 5)
+    assert ko.fr_to_ints(got) == [2**64 - 5]
+
+
+def test_g1_group_law(he):
+    rng = np.random.default_rng(2)
+    gen = ko.g1_generator()
+    ks = rand_fr(rng, 6)
+    pts = [ko.g1_mul(gen, k) for k in ks]            # Jacobian, Z != 1
+    pts.append(ko.g1_zero()[0])                        # inf
+    pts.append(pts[0].copy())                          # P == P (same representation)
+    pts.append(ko.g1_affine(pts[0])[0])                # P == P (different representation)
+    pts.append(ko.g1_sub(ko.g1_zero()[0], pts[0]))     # -P
+    pts.append(gen)
+    pts = np.stack(pts)
+    L = ko.lib()
+    for i in range(len(pts)):
+        got, want = ko.g1_empty(1), ko.g1_empty(1)
+        he.he_g1_dbl(p(got), p(pts[i])); L.ko_g1_dbl(p(want), p(pts[i]))
+        assert np.array_equal(ko.g1_compress(got), ko.g1_compress(want))
+        he.he_g1_normalize(p(got), p(pts[i]))
+        assert np.array_equal(got, ko.g1_affine(pts[i]))   # bit-exact normalised image
+        for j in range(len(pts)):
+            for name in ("add", "sub"):
+                getattr(he, "he_g1_" + name)(p(got), p(pts[i]), p(pts[j]))
+                getattr(L, "ko_g1_" + name)(p(want), p(pts[i]), p(pts[j]))
+                assert np.array_equal(ko.g1_compress(got), ko.g1_compress(want)), (name, i, j)
+            qa = ko.g1_affine(pts[j])[0]
+            he.he_g1_madd(p(got), p(pts[i]), p(qa)); L.ko_g1_add(p(want), p(pts[i]), p(qa))
+            assert np.array_equal(ko.g1_compress(got), ko.g1_compress(want)), ("madd", i, j)
+
+
+def test_g1_scalar_mul(he):
+    rng = np.random.default_rng(3)
+    gen = ko.g1_generator()
+    base = ko.g1_mul(gen, rand_fr(rng, 1)[0])
+    scalars = list(rand_fr(rng, 6)) + list(ko.fr_from_ints([0, 1, 2, 15, 16, ko.R_MOD - 1, 2**64, (1 << 255) % ko.R_MOD]))
+    L = ko.lib()
+    for k in scalars:
+        for pt in (base, gen, ko.g1_zero()[0]):
+            got, want = ko.g1_empty(1), ko.g1_empty(1)
+            he.he_g1_mul(p(got), p(pt), p(k)); L.ko_g1_mul(p(want), p(pt), p(k))
+            assert np.array_equal(ko.g1_compress(got), ko.g1_compress(want))
+    he.he_g1_mul_small.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    for k in (0, 1, 2, 255, 4096, 2**32 - 1):
+        got = ko.g1_empty(1)
+        he.he_g1_mul_small(p(got), p(base), k)
+        assert ko.g1_equal(got[0], ko.g1_mul(base, ko.fr_from_ints([k])[0]))
