@@ -51,7 +51,7 @@ template <class Fn> __device__ __forceinline__ void for_each_digit(const fr &k, 
     uint32_t carry = 0;
     for (uint32_t w = 0; w < nwin; w++) {
         uint32_t raw = scalar_bits(k, w * c, c) + carry;
-        if (raw > nb) { carry = 1; f(w, (1u << c) - raw, 1u); }
+        if (raw > nb) { carry = 1; uint32_t mag = (1u << c) - raw; if (mag) f(w, mag, 1u); }   // raw == 2^c: digit 0, carry 1
         else { carry = 0; if (raw) f(w, raw, 0u); }
     }
 }
