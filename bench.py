@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the commitment / proof hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): KZGSettings.CommitToPoly on 4096-coefficient blobs against the 4096-point
+monomial setup of eth/trusted_setup.json (s = 1337; rebuilt from tests/golden/trusted_setup_g1.bin through the
+library's own FromCompressedG1).  One step = one pass of the hot path over one batch of `--batch` synthetic blobs
+(splitmix64 stream, blob b uses seed base + b) that are ALREADY resident in HBM; the step ends with the
+`batch` normalised commitments resident in HBM.  Blobs are independent, so ranks shard them with no data-path
+collective ("scaling": "weak"); value = commitments of all ranks / max-over-ranks time.
+
+Extra objects on the JSON line:
+  roofline      -- dominant kernel (msm_accumulate): algorithmic bytes per launch / HIP-event launch time vs 8 TB/s.
+  cpu_baseline  -- the oracle's restatement of bls.LinCombG1 (Kilic-style Pippenger) timed on one host core (rank 0, N = 1).
+  fk20          -- secondary metric: DAUsingFK20 (2048 coefficients -> 4096 proofs) all-proofs/s, own timed loop.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+R_MOD = 52435875175126190479447740508185965837690552500527637822603658699938581184513
+HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8.0 TB/s spec
+N_COEFF = 4096
+# algorithmic bytes of one commitment with the setup resident (scalars 131072 + 96 out), and the
+# setup itself (4096 affine points = 393216 B) counted once per launch.
+BYTES_PER_COMMIT = 131072 + 96
+BYTES_SETUP = 393216
+FK20_BYTES = 851968
+
+
+def splitmix_blobs(base_seed, batch, n=N_COEFF):
+    """SURVEY.md 8(d) synthetic scalars -> Montgomery images, shape (batch, n, 4) uint64 (host-side input synthesis)."""
+    out = np.empty((batch, n, 4), dtype=np.uint64)
+    mask = (1 << 64) - 1
+    rmont = (1 << 256) % R_MOD
+    for b in range(batch):
+        idx = np.arange(1, 4 * n + 1, dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            z = np.uint64((base_seed + b) & mask) + idx * np.uint64(0x9E3779B97F4A7C15)
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z = z ^ (z >> np.uint64(31))
+        limbs = z.reshape(n, 4)
+        raw = limbs.tobytes()
+        row = bytearray(n * 32)
+        for i in range(n):
+            v = int.from_bytes(raw[32 * i:32 * i + 32], "little") % R_MOD
+            row[32 * i:32 * i + 32] = (v * rmont % R_MOD).to_bytes(32, "little")
+        out[b] = np.frombuffer(bytes(row), dtype=np.uint64).reshape(n, 4)
+    return out
+
+
+def dist_env():
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    return rank, world, local
+
+
+def timed_steps(step_fn, steps, warmup, sync_fn, barrier_fn, max_over_ranks_fn):
+    """W untimed steps, then exactly K steps bracketed by barrier + device sync; returns max-over-ranks seconds.
+    Backend-agnostic so that tests/test_bench_dist.py can drive it with gloo on CPU."""
+    for _ in range(warmup):
+        step_fn()
+    sync_fn()
+    barrier_fn()
+    sync_fn()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    sync_fn()
+    barrier_fn()
+    t1 = time.perf_counter()
+    return max_over_ranks_fn(t1 - t0)
+
+
+def shard_units(total_units, world, rank):
+    """contiguous shard [lo, hi) of `total_units` for `rank` (used for strong-scaling workloads and FK20Multi positions)"""
+    base, rem = divmod(total_units, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def cpu_baseline(seconds_budget=12.0):
+    """oracle (kind 'port'): Kilic-style bls.LinCombG1 on 4096 points, single thread, bounded sample"""
+    from oracle import koracle as ko
+    raw = np.frombuffer(open(os.path.join(ROOT, "tests", "golden", "trusted_setup_g1.bin"), "rb").read(), dtype=np.uint8)
+    setup = ko.g1_decompress(raw)
+    blobs = [ko.synthetic_blob(1 + b) for b in range(4)]
+    ko.lincomb_g1(setup, blobs[0])
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds_budget:
+        ko.lincomb_g1(setup, blobs[n % 4])
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "commitments/s", "cores": 1, "kind": "port",
+            "sample": "%d x LinCombG1(n=4096) in %.1f s, oracle/kzg_oracle.c (Kilic-style Pippenger c=9), 1 thread" % (n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=512, help="blobs per step per GPU")
+    ap.add_argument("--fk20-batch", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fk20", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import gokzg_amd as kz
+
+    rank, world, local = dist_env()
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available() or kz.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: the HIP path is the only path")
+    torch.cuda.set_device(local)
+    use_dist = world > 1
+    if use_dist:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    lib = kz.lib()
+    fs = kz.FFTSettings(12, device=local)
+    raw = np.frombuffer(open(os.path.join(ROOT, "tests", "golden", "trusted_setup_g1.bin"), "rb").read(), dtype=np.uint8)
+    setup = fs.from_compressed_g1(raw)                      # 4096 x [1337^i]G1, decompressed on the device
+    ks = kz.KZGSettings(fs, setup)
+
+    B = args.batch
+    blobs_h = splitmix_blobs(1 + rank * B, B)               # rank r owns blobs [r B, (r + 1) B)
+    d_blobs = torch.from_numpy(blobs_h.view(np.int64)).cuda()
+    d_out = torch.zeros((B, 18), dtype=torch.int64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        st = lib.kzg_hip_commit_to_poly_batch_dev(ks.h, d_blobs.data_ptr(), N_COEFF, B, d_out.data_ptr(), stream)
+        if st:
+            raise RuntimeError("commit_to_poly_batch_dev status %d %s" % (st, lib.kzg_hip_last_error().decode()))
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+
+    def max_over_ranks(x):
+        if not use_dist:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # self-check of the timed path before timing it: blob 0 of rank 0 is SURVEY.md vector F
+    step()
+    torch.cuda.synchronize()
+    if rank == 0:
+        c0 = d_out[0].cpu().numpy().view(np.uint64).reshape(1, 3, 6)
+        hx = fs.to_compressed_g1(c0)[0].tobytes().hex()
+        exp = json.load(open(os.path.join(ROOT, "tests", "golden", "derived_vectors.json")))["F_blob_seed1"]["commit_monomial_s1337"]
+        if hx != exp:
+            raise SystemExit("bench self-check failed: commitment of blob(seed 1) = %s, expected %s" % (hx, exp))
+
+    lib.kzg_hip_prof_reset(fs.h, 0)
+    secs = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, barrier, max_over_ranks)
+    value = B * world * args.steps / secs
+
+    # roofline leg: HIP events around the dominant kernel on the launch stream, separate (un-timed) pass
+    lib.kzg_hip_prof_reset(fs.h, 1)
+    for _ in range(max(3, min(args.steps, 10))):
+        step()
+    torch.cuda.synchronize()
+    tot, cnt = C.c_double(0), C.c_uint64(0)
+    lib.kzg_hip_prof_read(fs.h, b"msm_accumulate", C.byref(tot), C.byref(cnt))
+    lib.kzg_hip_prof_reset(fs.h, 0)
+    roofline = None
+    if cnt.value:
+        avg_s = tot.value / cnt.value * 1e-3
+        alg_bytes = B * BYTES_PER_COMMIT + BYTES_SETUP
+        ach = alg_bytes / avg_s * 1e-9
+        roofline = {"bound": "hbm", "kernel": "k_msm_accumulate", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_s * 1e3,
+                    "algorithmic_bytes_per_launch": alg_bytes,
+                    "note": "integer-VALU-bound kernel: HBM fraction is reported as the contract asks; see DESIGN.md for the int-MAC model"}
+
+    fk20 = None
+    if not args.no_fk20:
+        fk = kz.FK20SingleSettings(ks, 4096)
+        FB = args.fk20_batch
+        polys_h = splitmix_blobs(4 + rank * FB, FB)[:, :2048, :].copy()
+        d_polys = torch.from_numpy(polys_h.view(np.int64)).cuda()
+        d_proofs = torch.zeros((FB, 4096, 18), dtype=torch.int64, device="cuda")
+
+        def fk_step():
+            st = lib.kzg_hip_da_using_fk20_batch_dev(fk.h, d_polys.data_ptr(), 2048, FB, d_proofs.data_ptr(), stream)
+            if st:
+                raise RuntimeError("da_using_fk20_batch_dev status %d" % st)
+
+        fsecs = timed_steps(fk_step, max(1, args.steps // 2), 1, torch.cuda.synchronize, barrier, max_over_ranks)
+        fk20 = {"metric": "FK20 all-proofs/s (DAUsingFK20, 2048 coeffs -> 4096 proofs, scale 12)",
+                "value": FB * world * max(1, args.steps // 2) / fsecs, "batch_per_gpu": FB,
+                "ms_per_all_proofs": fsecs / max(1, args.steps // 2) / FB * 1e3}
+        fk.close()
+
+    base = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        base = cpu_baseline()
+
+    if rank == 0:
+        print(json.dumps({
+            "metric": "KZG commitments/sec (CommitToPoly, 4096-element blob)", "value": value, "unit": "commitments/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": secs / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (381-bit F_p / 255-bit F_r Montgomery)",
+            "data": "synthetic",
+            "config": {"workload": "CommitToPoly, 4096-coeff blobs, eth/trusted_setup.json monomial setup (s=1337), %d blobs/step/GPU resident in HBM" % B,
+                       "global_batch": B * world, "parallelism": "dp%d (independent blobs, no data-path collective)" % world},
+            "roofline": roofline, "cpu_baseline": base, "fk20": fk20,
+        }))
+    if use_dist:
+        dist.destroy_process_group()
+    ks.close()
+    fs.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,77 @@
+"""bench.py's host logic on CPU: synthetic input synthesis matches SURVEY.md 8(d) (== the oracle's generator), and the
+N > 1 harness (barrier, max-over-ranks timing, unit sharding) runs with world_size 2 over gloo."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_splitmix_blobs_match_oracle_generator():
+    import bench
+    from oracle import koracle as ko
+    got = bench.splitmix_blobs(1, 2, n=64)
+    assert np.array_equal(got[0], ko.synthetic_blob(1, 64))
+    assert np.array_equal(got[1], ko.synthetic_blob(2, 64))
+
+
+def test_shard_units_cover_exactly():
+    import bench
+    for total in (0, 1, 7, 4096, 4097):
+        for world in (1, 2, 3, 8):
+            spans = [bench.shard_units(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, q):
+    import time
+    import torch
+    import torch.distributed as dist
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+
+    def step():
+        calls.append(1)
+        time.sleep(0.01 * (rank + 1))      # rank 1 is slower: the reported time must be the max over ranks
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    secs = bench.timed_steps(step, 5, 2, lambda: None, dist.barrier, max_over_ranks)
+    # all-gather of per-rank byte slices in rank order (the FK20Multi position sharding uses exactly this)
+    lo, hi = bench.shard_units(10, world, rank)
+    mine = torch.arange(lo, hi, dtype=torch.uint8)
+    sizes = [bench.shard_units(10, world, r) for r in range(world)]
+    bufs = [torch.zeros(h - l, dtype=torch.uint8) for l, h in sizes]
+    dist.all_gather(bufs, mine)
+    q.put((rank, len(calls), secs, torch.cat(bufs).tolist()))
+    dist.destroy_process_group()
+
+
+def test_timed_steps_world_size_2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [7, 7]                  # W + K steps on every rank
+    assert abs(res[0][2] - res[1][2]) < 1e-9             # both ranks report the same (max) time
+    assert res[0][2] >= 5 * 0.02 * 0.9                    # ... which is the slow rank's
+    assert res[0][3] == list(range(10)) == res[1][3]
