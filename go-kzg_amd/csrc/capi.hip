@@ -10,6 +10,7 @@
 #include <vector>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 using namespace kzg;
 
@@ -273,11 +274,11 @@ int kzg_hip_das_fft_extension(kzg_hip_fft *fs, void *vals_fr, uint64_t n) { retu
 // MSM
 // ---------------------------------------------------------------------------------------------------------
 static msm_plan classic_plan(uint64_t n) {
+    // Only window sizes that divide 256 keep the TOP window balanced (255 mod c == c - 1): with c = 9 the top window
+    // has 3 bits, 8 of its 256 buckets receive n / 8 points each and one wavefront per blob becomes a 20 ms tail.
     msm_plan p{};
-    int c = (int)ilog2(n) - 3;
-    if (c < 4) c = 4;
-    if (c > 12) c = 12;
-    p.c = (uint32_t)c; p.nwin = 255 / p.c + 1; p.nb = 1u << (p.c - 1); p.ngroups = p.nwin; p.fixed = 0; p.table_n = n;
+    p.c = n < 256 ? 4 : 8;
+    p.nwin = 255 / p.c + 1; p.nb = 1u << (p.c - 1); p.ngroups = p.nwin; p.fixed = 0; p.table_n = n;
     return p;
 }
 static void set_inf_image(void *out_g1) { g1j z = g1_inf(); memcpy(out_g1, &z, sizeof z); }
@@ -396,17 +397,44 @@ void kzg_hip_kzg_settings_free(kzg_hip_kzg *ks) {
     delete ks;
 }
 
+// Lazily builds the fixed-base table T[(w n + i) D + d - 1] = d 2^(c w) SecretG1[i] (k_msm.hip).  The window size is the
+// largest whose table fits the HBM budget (KZG_HIP_FB_BUDGET_GB, default 12 of the 288 GB): n = 4096 -> c = 11, 9.7 GB.
+static int ensure_fixed_table(kzg_hip_kzg *ks, hipStream_t s) {
+    if (ks->d_fixed || ks->fixed_plan.c == 0xffffffffu) return KZG_HIP_OK;
+    double budget_gb = 12.0;
+    if (const char *e = getenv("KZG_HIP_FB_BUDGET_GB")) budget_gb = atof(e);
+    uint32_t best = 0;
+    for (uint32_t c = 12; c >= 5; c--) {
+        double bytes = (double)(255 / c + 1) * (double)ks->n_setup * (double)(1u << (c - 1)) * sizeof(g1a);
+        if (bytes <= budget_gb * 1e9) { best = c; break; }
+    }
+    if (!best || ks->n_setup < 64) { ks->fixed_plan.c = 0xffffffffu; return KZG_HIP_OK; }   // classic path only
+    msm_plan p{};
+    p.c = best; p.nwin = 255 / best + 1; p.nb = 1u << (best - 1); p.ngroups = 1; p.fixed = 1; p.table_n = ks->n_setup;
+    size_t entries = (size_t)p.nwin * ks->n_setup * p.nb;
+    HIPCHK(hipMalloc((void **)&ks->d_fixed, entries * sizeof(g1a)));
+    launch_fb_build(s, ks->d_secret_a, ks->n_setup, p.c, p.nwin, ks->d_fixed);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    ks->fixed_plan = p;
+    return KZG_HIP_OK;
+}
+
 // MSM of `batch` resident scalar rows against SecretG1[:n]; out = batch normalised points (device)
 static int commit_rows(kzg_hip_kzg *ks, hipStream_t s, const fr *d_sc, uint64_t n, uint64_t batch, g1j *d_out) {
-    msm_plan p = classic_plan(n);
-    size_t need = msm_workspace_bytes(p, n, batch) + batch * sizeof(g1j);
+    CHK(ensure_fixed_table(ks, s));
+    bool fixed = ks->d_fixed != nullptr;
+    msm_plan p = fixed ? ks->fixed_plan : classic_plan(n);
+    size_t ws_main = fixed ? fb_partials_bytes(n, batch) : msm_workspace_bytes(p, n, batch);
+    size_t need = ws_main + batch * sizeof(g1j);
     if (need > ks->ws_bytes) {
         if (ks->d_ws) { HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipFree(ks->d_ws)); ks->d_ws = nullptr; }
         HIPCHK(hipMalloc(&ks->d_ws, need));
         ks->ws_bytes = need;
     }
-    g1j *d_raw = (g1j *)((uint8_t *)ks->d_ws + msm_workspace_bytes(p, n, batch));
-    launch_msm(s, p, ks->d_secret_a, d_sc, n, batch, ks->d_ws, d_raw);
+    g1j *d_raw = (g1j *)((uint8_t *)ks->d_ws + ws_main);
+    if (fixed) launch_fb_msm(s, ks->d_fixed, p.table_n, p.c, p.nwin, d_sc, n, batch, ks->d_ws, d_raw);
+    else launch_msm(s, p, ks->d_secret_a, d_sc, n, batch, ks->d_ws, d_raw);
     launch_g1_normalize(s, d_raw, d_out, batch);
     HIPCHK(hipGetLastError());
     return KZG_HIP_OK;

@@ -68,12 +68,21 @@ using fr = felem<FrP>;
 // ---------------------------------------------------------------------------------------------
 // limb helpers
 // ---------------------------------------------------------------------------------------------
-KZG_HD uint32_t addc(uint32_t a, uint32_t b, uint32_t &c) {   // a + b + c, carry out in c
+#if defined(__clang__)
+KZG_HD uint32_t addc(uint32_t a, uint32_t b, uint32_t &c) {   // a + b + c, carry out in c  (v_addc_co_u32 chain)
+    unsigned co; uint32_t r = __builtin_addc(a, b, c, &co); c = co; return r;
+}
+KZG_HD uint32_t subb(uint32_t a, uint32_t b, uint32_t &br) {  // a - b - br, borrow out in br  (v_subb_co_u32 chain)
+    unsigned bo; uint32_t r = __builtin_subc(a, b, br, &bo); br = bo; return r;
+}
+#else
+KZG_HD uint32_t addc(uint32_t a, uint32_t b, uint32_t &c) {
     uint64_t x = (uint64_t)a + b + c; c = (uint32_t)(x >> 32); return (uint32_t)x;
 }
-KZG_HD uint32_t subb(uint32_t a, uint32_t b, uint32_t &br) {  // a - b - br, borrow out in br
+KZG_HD uint32_t subb(uint32_t a, uint32_t b, uint32_t &br) {
     uint64_t x = (uint64_t)a - b - br; br = (uint32_t)(x >> 63); return (uint32_t)x;
 }
+#endif
 
 template <class F> KZG_HD bool is_zero(const felem<F> &a) {
     uint32_t v = 0;
@@ -166,10 +175,31 @@ template <class F> KZG_HD felem<F> mont_mul_inl(const felem<F> &a, const felem<F
     return o;
 }
 
-#if defined(KZG_FP_MUL_NOINLINE)
-// Out-of-line F_p product: keeps a Jacobian add at ~2 KB of code instead of ~100 KB (I-cache is 64 KB).
-KZG_HD_NOINLINE static fp fp_mul_call(fp a, fp b) { return mont_mul_inl<FpP>(a, b); }
-KZG_HD fp mul(const fp &a, const fp &b) { return fp_mul_call(a, b); }
+#if defined(KZG_FP_MUL_NOINLINE) && defined(__clang__)
+// Out-of-line F_p product: keeps a Jacobian add at ~2 KB of code instead of ~100 KB (the I-cache is 64 KB).
+// Operands and result travel as 12-wide vectors so the AMDGPU calling convention keeps all 24 + 12 dwords in
+// VGPRs; passing the `fp` structs by value spilled the second operand through scratch on every call.
+typedef uint32_t u32x12 __attribute__((ext_vector_type(12)));
+KZG_HD_NOINLINE static u32x12 fp_mul_call(u32x12 av, u32x12 bv) {
+    fp a, b;
+#pragma unroll
+    for (int i = 0; i < 12; i++) { a.l[i] = av[i]; b.l[i] = bv[i]; }
+    fp o = mont_mul_inl<FpP>(a, b);
+    u32x12 r;
+#pragma unroll
+    for (int i = 0; i < 12; i++) r[i] = o.l[i];
+    return r;
+}
+KZG_HD fp mul(const fp &a, const fp &b) {
+    u32x12 av, bv;
+#pragma unroll
+    for (int i = 0; i < 12; i++) { av[i] = a.l[i]; bv[i] = b.l[i]; }
+    u32x12 r = fp_mul_call(av, bv);
+    fp o;
+#pragma unroll
+    for (int i = 0; i < 12; i++) o.l[i] = r[i];
+    return o;
+}
 #else
 KZG_HD fp mul(const fp &a, const fp &b) { return mont_mul_inl<FpP>(a, b); }
 #endif

@@ -192,6 +192,142 @@ void launch_msm(hipStream_t s, const msm_plan &p, const g1a *table, const fr *sc
     hipLaunchKernelGGL(k_msm_combine, dim3((uint32_t)((batch + 63) / 64)), dim3(64), 0, s, ws, L.per_blob, L.gsum_off, p.c, p.ngroups, batch, out);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fixed-base MSM for the device-resident setup (CommitToPoly / ComputeProofSingle on KZGSettings.SecretG1).
+// HBM is 288 GB, so the table holds EVERY signed-digit multiple:  T[(w n + i) D + d - 1] = d * 2^(c w) * P_i,
+// d = 1..D = 2^(c-1), affine.  A commitment is then n * nwin mixed additions with no doublings, no buckets, no
+// sort, and exactly the same work on every lane (the bucket method's Poisson imbalance and reduce step vanish).
+// n = 4096, c = 11: 24 x 4096 x 1024 x 96 B = 9.7 GB, 98 304 mixed adds per commitment.
+// ---------------------------------------------------------------------------------------------------------
+#define FB_BLOCK 128
+
+// pass 1: lane (w, i) walks d = 1..D with mixed additions; X, Y go to the table slot, Z to ztmp
+__global__ __launch_bounds__(FB_BLOCK) void k_fb_build_pass1(const g1a *rows, uint64_t lanes, uint32_t D, g1a *table, fp *ztmp) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= lanes) return;
+    g1a b = rows[t];
+    g1j cur = to_jac(b);
+    g1a *dst = table + t * D; fp *zd = ztmp + t * D;
+#pragma nounroll
+    for (uint32_t d = 0; d < D; d++) {
+        g1a xy; xy.x = cur.x; xy.y = cur.y;
+        dst[d] = xy; zd[d] = cur.z;
+        cur = g1_madd(cur, b);
+    }
+}
+// pass 2: Montgomery batch inversion of the lane's D Z-values (prefix products in ptmp), then X/Z^2, Y/Z^3
+__global__ __launch_bounds__(FB_BLOCK) void k_fb_build_pass2(uint64_t lanes, uint32_t D, g1a *table, fp *ztmp, fp *ptmp) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= lanes) return;
+    g1a *dst = table + t * D; fp *zd = ztmp + t * D; fp *pd = ptmp + t * D;
+    fp acc = one<FpP>();
+#pragma nounroll
+    for (uint32_t d = 0; d < D; d++) {
+        pd[d] = acc;
+        fp z = zd[d];
+        if (!is_zero<FpP>(z)) acc = mul(acc, z);
+    }
+    fp inv_all = inv<FpP>(acc);
+#pragma nounroll
+    for (uint32_t d = D; d-- > 0;) {
+        fp z = zd[d];
+        if (is_zero<FpP>(z)) { dst[d] = g1a_inf(); continue; }
+        fp zi = mul(inv_all, pd[d]);
+        inv_all = mul(inv_all, z);
+        fp zi2 = sqr(zi);
+        g1a xy = dst[d];
+        xy.x = mul(xy.x, zi2); xy.y = mul(xy.y, mul(zi2, zi));
+        dst[d] = xy;
+    }
+}
+
+// main kernel: lane handles points i = lane, lane + L, ... of one blob; block tree-reduces through LDS
+__global__ __launch_bounds__(FB_BLOCK) void k_fb_accumulate(const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, uint32_t D, const fr *scalars,
+                                                            uint64_t n, uint32_t blocks_per_blob, g1j *partials) {
+    __shared__ g1j buf[FB_BLOCK];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t blob = blockIdx.x / blocks_per_blob; const uint32_t blk = blockIdx.x % blocks_per_blob;
+    const uint64_t L = (uint64_t)blocks_per_blob * FB_BLOCK;
+    const fr *sc = scalars + blob * n;
+    g1j acc = g1_inf();
+    for (uint64_t i = (uint64_t)blk * FB_BLOCK + tid; i < n; i += L) {
+        fr k = from_mont<FrP>(sc[i]);
+        uint32_t carry = 0;
+#pragma nounroll
+        for (uint32_t w = 0; w < nwin; w++) {
+            uint32_t raw = scalar_bits(k, w * c, c) + carry;
+            uint32_t mag, ng;
+            if (raw > D) { carry = 1; mag = (1u << c) - raw; ng = 1; } else { carry = 0; mag = raw; ng = 0; }
+            if (mag) {
+                g1a q = table[((uint64_t)w * table_n + i) * D + (mag - 1)];
+                if (ng) q.y = neg<FpP>(q.y);
+                acc = g1_madd(acc, q);
+            }
+        }
+    }
+    buf[tid] = acc;
+    __syncthreads();
+#pragma nounroll
+    for (uint32_t off = FB_BLOCK / 2; off >= 1; off >>= 1) {
+        if (tid < off) buf[tid] = g1_add(buf[tid], buf[tid + off]);
+        __syncthreads();
+    }
+    if (tid == 0) partials[blockIdx.x] = buf[0];
+}
+__global__ __launch_bounds__(64) void k_fb_finish(const g1j *partials, uint32_t blocks_per_blob, uint64_t batch, g1j *out) {
+    uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    g1j acc = g1_inf();
+#pragma nounroll
+    for (uint32_t j = 0; j < blocks_per_blob; j++) acc = g1_add(acc, partials[b * blocks_per_blob + j]);
+    out[b] = acc;
+}
+
+static uint32_t fb_blocks_per_blob(uint64_t n, uint64_t batch) {
+    uint64_t target = 262144 / FB_BLOCK;                 // ~4 waves per SIMD over 256 CUs
+    uint64_t bpb = target / (batch ? batch : 1);
+    uint64_t maxb = (n + FB_BLOCK - 1) / FB_BLOCK;
+    if (bpb > maxb) bpb = maxb;
+    if (bpb < 1) bpb = 1;
+    return (uint32_t)bpb;
+}
+size_t fb_partials_bytes(uint64_t n, uint64_t batch) { return (size_t)fb_blocks_per_blob(n, batch) * batch * sizeof(g1j); }
+
+void launch_fb_msm(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, uint64_t n, uint64_t batch,
+                   void *partials, g1j *out) {
+    if (!batch) return;
+    uint32_t bpb = fb_blocks_per_blob(n, batch);
+    prof_begin(s, "fb_accumulate");
+    hipLaunchKernelGGL(k_fb_accumulate, dim3((uint32_t)(batch * bpb)), dim3(FB_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars, n, bpb,
+                       (g1j *)partials);
+    prof_end(s, "fb_accumulate");
+    hipLaunchKernelGGL(k_fb_finish, dim3((uint32_t)((batch + 63) / 64)), dim3(64), 0, s, (const g1j *)partials, bpb, batch, out);
+}
+// builds the table for `n` affine points: rows (2^(c w) P_i) first, then all multiples window-slab by window-slab
+void launch_fb_build(hipStream_t s, const g1a *pts, uint64_t n, uint32_t c, uint32_t nwin, g1a *table) {
+    uint32_t D = 1u << (c - 1);
+    g1j *rows_j = nullptr; g1a *rows = nullptr; fp *ztmp = nullptr, *ptmp = nullptr;
+    uint64_t lanes_all = (uint64_t)nwin * n;
+    hipMallocAsync((void **)&rows_j, lanes_all * sizeof(g1j), s);
+    hipMallocAsync((void **)&rows, lanes_all * sizeof(g1a), s);
+    launch_msm_window_table(s, pts, n, c, nwin, rows_j, rows);
+    // slabs of windows bound the temporary Z / prefix storage to ~2 x 1 GiB
+    uint64_t per_win = n * D * sizeof(fp);
+    uint32_t slab = (uint32_t)((1ull << 30) / (per_win ? per_win : 1));
+    if (slab < 1) slab = 1;
+    if (slab > nwin) slab = nwin;
+    hipMallocAsync((void **)&ztmp, (uint64_t)slab * per_win, s);
+    hipMallocAsync((void **)&ptmp, (uint64_t)slab * per_win, s);
+    for (uint32_t w0 = 0; w0 < nwin; w0 += slab) {
+        uint32_t ws = (w0 + slab <= nwin) ? slab : nwin - w0;
+        uint64_t lanes = (uint64_t)ws * n;
+        dim3 g((uint32_t)((lanes + FB_BLOCK - 1) / FB_BLOCK)), b(FB_BLOCK);
+        hipLaunchKernelGGL(k_fb_build_pass1, g, b, 0, s, rows + (uint64_t)w0 * n, lanes, D, table + (uint64_t)w0 * n * D, ztmp);
+        hipLaunchKernelGGL(k_fb_build_pass2, g, b, 0, s, lanes, D, table + (uint64_t)w0 * n * D, ztmp, ptmp);
+    }
+    hipFreeAsync(rows_j, s); hipFreeAsync(rows, s); hipFreeAsync(ztmp, s); hipFreeAsync(ptmp, s);
+}
+
 // fixed-base table rows: tmp[w * n + i] = 2^(c w) * P_i (Jacobian), then normalised to affine by launch_g1_to_affine
 __global__ __launch_bounds__(MSM_ACC_BLOCK) void k_msm_window_rows(const g1a *pts, uint64_t n, uint32_t c, uint32_t nwin, g1j *tmp) {
     uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
