@@ -238,12 +238,13 @@ int kzg_hip_fft_g1(kzg_hip_fft *fs, const void *vals_g1, uint64_t n, int inv, vo
     dtmp<g1j> d_in(s), d_data(s);
     CHK(d_in.alloc(n)); CHK(d_data.alloc(n));
     HIPCHK(hipMemcpyAsync(d_in.p, vals_g1, n * sizeof(g1j), hipMemcpyHostToDevice, s));
+    launch_g1_from_kilic(s, d_in.p, n);
     g1_fft_rows(fs, s, d_in.p, n, n, d_data.p, n, 1, inv);
     if (inv) {   // fft_g1.go:72-85: every output times n^-1
         launch_g1_mul_vec(s, d_data.p, n, fs->d_inv_pow2 + ilog2(n), 0, n, d_in.p);
-        launch_g1_normalize(s, d_in.p, d_data.p, n);
+        launch_g1_normalize(s, d_in.p, d_data.p, n, true);
     } else {
-        launch_g1_normalize(s, d_data.p, d_in.p, n);
+        launch_g1_normalize(s, d_data.p, d_in.p, n, true);
         std::swap(d_in.p, d_data.p);
     }
     HIPCHK(hipGetLastError());
@@ -281,7 +282,7 @@ static msm_plan classic_plan(uint64_t n) {
     p.nwin = 255 / p.c + 1; p.nb = 1u << (p.c - 1); p.ngroups = p.nwin; p.fixed = 0; p.table_n = n;
     return p;
 }
-static void set_inf_image(void *out_g1) { g1j z = g1_inf(); memcpy(out_g1, &z, sizeof z); }
+static void set_inf_image(void *out_g1) { g1j z = g1_to_kilic(g1_inf()); memcpy(out_g1, &z, sizeof z); }   // Kilic Zero(): (0, R, 0)
 
 int kzg_hip_lincomb_g1(kzg_hip_fft *fs, const void *points_g1, const void *scalars_fr, uint64_t n, void *out_g1) {
     if (!fs || !out_g1) return KZG_HIP_ERR_BAD_ARG;
@@ -294,9 +295,10 @@ int kzg_hip_lincomb_g1(kzg_hip_fft *fs, const void *points_g1, const void *scala
     CHK(d_pts.alloc(n)); CHK(d_out.alloc(2)); CHK(d_tab.alloc(n)); CHK(d_sc.alloc(n)); CHK(d_ws.alloc(msm_workspace_bytes(p, n, 1)));
     HIPCHK(hipMemcpyAsync(d_pts.p, points_g1, n * sizeof(g1j), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_sc.p, scalars_fr, n * sizeof(fr), hipMemcpyHostToDevice, s));
+    launch_g1_from_kilic(s, d_pts.p, n);
     launch_g1_to_affine(s, d_pts.p, d_tab.p, n);
     launch_msm(s, p, d_tab.p, d_sc.p, n, 1, d_ws.p, d_out.p);
-    launch_g1_normalize(s, d_out.p, d_out.p + 1, 1);
+    launch_g1_normalize(s, d_out.p, d_out.p + 1, 1, true);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out_g1, d_out.p + 1, sizeof(g1j), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -311,6 +313,7 @@ int kzg_hip_g1_to_compressed(kzg_hip_fft *fs, const void *points_g1, uint64_t n,
     dtmp<g1j> d_pts(s); dtmp<uint8_t> d_out(s);
     CHK(d_pts.alloc(n)); CHK(d_out.alloc(48 * n));
     HIPCHK(hipMemcpyAsync(d_pts.p, points_g1, n * sizeof(g1j), hipMemcpyHostToDevice, s));
+    launch_g1_from_kilic(s, d_pts.p, n);
     launch_g1_compress(s, d_pts.p, d_out.p, n);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out48, d_out.p, 48 * n, hipMemcpyDeviceToHost, s));
@@ -343,8 +346,9 @@ int kzg_hip_g1_mul_vec(kzg_hip_fft *fs, const void *points_g1, const void *scala
     CHK(d_pts.alloc(n)); CHK(d_out.alloc(n)); CHK(d_sc.alloc(n));
     HIPCHK(hipMemcpyAsync(d_pts.p, points_g1, n * sizeof(g1j), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_sc.p, scalars_fr, n * sizeof(fr), hipMemcpyHostToDevice, s));
+    launch_g1_from_kilic(s, d_pts.p, n);
     launch_g1_mul_vec(s, d_pts.p, n, d_sc.p, 1, n, d_out.p);
-    launch_g1_normalize(s, d_out.p, d_pts.p, n);
+    launch_g1_normalize(s, d_out.p, d_pts.p, n, true);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out_g1, d_pts.p, n * sizeof(g1j), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -360,7 +364,7 @@ int kzg_hip_generate_testing_setup_g1(kzg_hip_fft *fs, const void *secret_fr, ui
     HIPCHK(hipMemcpyAsync(d_s.p, secret_fr, sizeof(fr), hipMemcpyHostToDevice, s));
     launch_fr_powers(s, d_s.p, n, d_pw.p);
     launch_g1_fixed_base_powers(s, d_pw.p, n, d_a.p);
-    launch_g1_normalize(s, d_a.p, d_b.p, n);
+    launch_g1_normalize(s, d_a.p, d_b.p, n, true);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out_g1, d_b.p, n * sizeof(g1j), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -383,6 +387,7 @@ int kzg_hip_kzg_settings_new(kzg_hip_fft *fs, const void *secret_g1, uint64_t n_
     HIPCHK(hipMalloc((void **)&ks->d_secret, n_setup * sizeof(g1j)));
     HIPCHK(hipMalloc((void **)&ks->d_secret_a, n_setup * sizeof(g1a)));
     HIPCHK(hipMemcpyAsync(d_raw.p, secret_g1, n_setup * sizeof(g1j), hipMemcpyHostToDevice, s));
+    launch_g1_from_kilic(s, d_raw.p, n_setup);
     launch_g1_normalize(s, d_raw.p, ks->d_secret, n_setup);
     launch_g1_to_affine(s, ks->d_secret, ks->d_secret_a, n_setup);
     HIPCHK(hipGetLastError());
@@ -435,7 +440,7 @@ static int commit_rows(kzg_hip_kzg *ks, hipStream_t s, const fr *d_sc, uint64_t 
     g1j *d_raw = (g1j *)((uint8_t *)ks->d_ws + ws_main);
     if (fixed) launch_fb_msm(s, ks->d_fixed, p.table_n, p.c, p.nwin, d_sc, n, batch, ks->d_ws, d_raw);
     else launch_msm(s, p, ks->d_secret_a, d_sc, n, batch, ks->d_ws, d_raw);
-    launch_g1_normalize(s, d_raw, d_out, batch);
+    launch_g1_normalize(s, d_raw, d_out, batch, true);
     HIPCHK(hipGetLastError());
     return KZG_HIP_OK;
 }
@@ -496,9 +501,10 @@ int kzg_hip_toeplitz_part2(kzg_hip_kzg *ks, const void *coeffs_fr, const void *x
     CHK(d_c.alloc(n)); CHK(d_cf.alloc(n)); CHK(d_x.alloc(n)); CHK(d_h.alloc(n));
     HIPCHK(hipMemcpyAsync(d_c.p, coeffs_fr, n * sizeof(fr), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_x.p, x_ext_fft_g1, n * sizeof(g1j), hipMemcpyHostToDevice, s));
+    launch_g1_from_kilic(s, d_x.p, n);
     fr_fft_rows(fs, s, d_c.p, n, n, d_cf.p, n, 1, 0);
     launch_g1_mul_vec(s, d_x.p, n, d_cf.p, 1, n, d_h.p);
-    launch_g1_normalize(s, d_h.p, d_x.p, n);
+    launch_g1_normalize(s, d_h.p, d_x.p, n, true);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out_g1, d_x.p, n * sizeof(g1j), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -563,8 +569,8 @@ static int fk20_finish(fk20_core *c, hipStream_t s, const g1j *d_hext, uint64_t 
     CHK(d_a.alloc(batch * k2)); CHK(d_b.alloc(batch * k2));
     g1_fft_rows(fs, s, d_hext, k2, k2, d_a.p, k2, batch, 1);          // ToeplitzPart3, fk20_single.go:80-87
     g1_fft_rows(fs, s, d_a.p, k2, k, d_b.p, on, batch, 0);            // fk20_single.go:163-167 / :129
-    if (bit_reverse) { launch_g1_bitrev_copy(s, d_b.p, on, on, d_a.p, on, batch); launch_g1_normalize(s, d_a.p, d_out, batch * on); }
-    else launch_g1_normalize(s, d_b.p, d_out, batch * on);
+    if (bit_reverse) { launch_g1_bitrev_copy(s, d_b.p, on, on, d_a.p, on, batch); launch_g1_normalize(s, d_a.p, d_out, batch * on, true); }
+    else launch_g1_normalize(s, d_b.p, d_out, batch * on, true);
     HIPCHK(hipGetLastError());
     return KZG_HIP_OK;
 }
@@ -618,8 +624,15 @@ void kzg_hip_fk20_single_settings_free(kzg_hip_fk20s *fk) {
 }
 int kzg_hip_fk20_single_x_ext_fft(const kzg_hip_fk20s *fk, void *out_g1) {
     if (!fk || !out_g1) return KZG_HIP_ERR_BAD_ARG;
-    dev_guard g(fk->c.ks->fs);
-    HIPCHK(hipMemcpy(out_g1, fk->c.d_files, fk->c.n2 * sizeof(g1j), hipMemcpyDeviceToHost));
+    kzg_hip_fft *fs = fk->c.ks->fs;
+    dev_guard g(fs);
+    hipStream_t s = fs->stream;
+    dtmp<g1j> d_tmp(s);
+    CHK(d_tmp.alloc(fk->c.n2));
+    launch_g1_normalize(s, fk->c.d_files, d_tmp.p, fk->c.n2, true);   // device-internal -> Kilic images
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_g1, d_tmp.p, fk->c.n2 * sizeof(g1j), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
     return KZG_HIP_OK;
 }
 int kzg_hip_fk20_single(kzg_hip_fk20s *fk, const void *poly_fr, uint64_t n, void *out_g1) {

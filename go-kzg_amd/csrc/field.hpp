@@ -26,21 +26,40 @@ namespace kzg {
 // field parameter packs.  mod(i) is written so that, after unrolling, every use folds to a literal.
 // ---------------------------------------------------------------------------------------------
 struct FpP {   // F_p, p = 0x1a0111ea...aaab (381 bit)
+    // DEVICE-INTERNAL Montgomery radix is R' = 2^390 (13 limbs of 30 bits, see mont_mul_fp30 below), NOT Kilic's
+    // 2^384: every G1 buffer that lives on the device is in the R' domain; the C ABI converts at the boundary
+    // (fp_from_kilic / fp_to_kilic).  Storage stays 12 x u32 saturated, values canonical (< p).
     static constexpr int N = 12;
-    static constexpr uint32_t INV = 0xfffcfffdu;   // -p^-1 mod 2^32
+    static constexpr uint32_t INV = 0xfffcfffdu;     // -p^-1 mod 2^32 (generic CIOS, unused for F_p on the device)
+    static constexpr uint32_t INV30 = 0x3ffcfffdu;   // -p^-1 mod 2^30
     KZG_HD static uint32_t mod(int i) {
         const uint32_t t[12] = {0xffffaaabu, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u,
                                 0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
         return t[i];
     }
-    KZG_HD static uint32_t one(int i) {   // R mod p
-        const uint32_t t[12] = {0x0002fffdu, 0x76090000u, 0xc40c0002u, 0xebf4000bu, 0x53c758bau, 0x5f489857u,
-                                0x70525745u, 0x77ce5853u, 0xa256ec6du, 0x5c071a97u, 0xfa80e493u, 0x15f65ec3u};
+    KZG_HD static uint32_t p30(int i) {   // p in 13 limbs of 30 bits
+        const uint32_t t[13] = {0x3fffaaabu, 0x27fbffffu, 0x153ffffbu, 0x2affffacu, 0x30f6241eu, 0x034a83dau, 0x112bf673u,
+                                0x12e13ce1u, 0x2cd76477u, 0x1ed90d2eu, 0x29a4b1bau, 0x3a8e5ff9u, 0x001a0111u};
         return t[i];
     }
-    KZG_HD static uint32_t r2(int i) {    // R^2 mod p
-        const uint32_t t[12] = {0x1c341746u, 0xf4df1f34u, 0x09d104f1u, 0x0a76e6a6u, 0x4c95b6d5u, 0x8de5476cu,
-                                0x939d83c0u, 0x67eb88a9u, 0xb519952du, 0x9a793e85u, 0x92cae3aau, 0x11988fe5u};
+    KZG_HD static uint32_t one(int i) {   // R' mod p = 2^390 mod p
+        const uint32_t t[12] = {0x00d1ff2eu, 0x46760000u, 0x9b4800acu, 0x84b80337u, 0xe882431cu, 0x0dd9a7e0u,
+                                0xb683dcf8u, 0xc26c26d0u, 0x63c4a5eeu, 0x29f14576u, 0x7f3e804bu, 0x015de996u};
+        return t[i];
+    }
+    KZG_HD static uint32_t r2(int i) {    // R'^2 mod p
+        const uint32_t t[12] = {0x4510070fu, 0xaec641c3u, 0xa0132243u, 0x6ea66ec3u, 0x1df507afu, 0x5efee07bu,
+                                0xeed21b14u, 0x41442921u, 0x2d32f70au, 0x97900177u, 0x4acd918cu, 0x0f696ee0u};
+        return t[i];
+    }
+    KZG_HD static uint32_t kilic_in(int i) {   // 2^396 mod p: mul(x_kilic, .) = x * 2^6 = R'-domain image
+        const uint32_t t[12] = {0x3480cb7fu, 0x6f830000u, 0xbe042b12u, 0xd1fccdeau, 0x3c7de4b4u, 0x40d78057u,
+                                0xc66805c5u, 0x6da3d19eu, 0x2746752au, 0x9afe6676u, 0x23205efbu, 0x09772fe1u};
+        return t[i];
+    }
+    KZG_HD static uint32_t kilic_one(int i) {  // 2^384 mod p: Kilic's Montgomery one; mul(x', .) = x' / 2^6 = Kilic image
+        const uint32_t t[12] = {0x0002fffdu, 0x76090000u, 0xc40c0002u, 0xebf4000bu, 0x53c758bau, 0x5f489857u,
+                                0x70525745u, 0x77ce5853u, 0xa256ec6du, 0x5c071a97u, 0xfa80e493u, 0x15f65ec3u};
         return t[i];
     }
 };
@@ -175,6 +194,63 @@ template <class F> KZG_HD felem<F> mont_mul_inl(const felem<F> &a, const felem<F
     return o;
 }
 
+// ---------------------------------------------------------------------------------------------
+// F_p Montgomery product with UNSATURATED 30-bit limbs (R' = 2^390).
+// Measured on gfx950 (tools/microbench.hip): v_mad_u64_u32, v_addc_co_u32 and v_lshl_add_u64 all issue at half rate,
+// so in a saturated 32-bit CIOS the carry handling costs as much as the 288 multiplies themselves.  With 13 limbs of
+// 30 bits every partial product (< 2^60) is accumulated by ONE v_mad_u64_u32 into a 64-bit column and columns never
+// carry into each other inside a round: 338 mads + ~130 cheap ops instead of 288 mads + ~900 carry/move ops.
+// A column holds at most 14 products between sweeps (14 * 2^60 < 2^64): one carry sweep after round 7 keeps it exact.
+// Inputs and output are canonical (< p) in 12 x u32 storage.
+// ---------------------------------------------------------------------------------------------
+KZG_HD void unpack30(uint32_t *o, const fp &a) {
+#pragma unroll
+    for (int k = 0; k < 13; k++) {
+        const int w = (30 * k) >> 5, sh = (30 * k) & 31;
+        uint64_t v = a.l[w];
+        if (w + 1 < 12) v |= (uint64_t)a.l[w + 1] << 32;
+        o[k] = (uint32_t)(v >> sh) & 0x3fffffffu;
+    }
+}
+KZG_HD fp mont_mul_fp30(const fp &a, const fp &b) {
+    uint32_t A[13], B[13];
+    unpack30(A, a); unpack30(B, b);
+    uint64_t acc[14];
+#pragma unroll
+    for (int j = 0; j < 14; j++) acc[j] = 0;
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+#pragma unroll
+        for (int j = 0; j < 13; j++) acc[j] += (uint64_t)A[j] * B[i];
+        uint32_t m = ((uint32_t)acc[0] * FpP::INV30) & 0x3fffffffu;
+#pragma unroll
+        for (int j = 0; j < 13; j++) acc[j] += (uint64_t)m * FpP::p30(j);
+        acc[1] += acc[0] >> 30;                       // low 30 bits of acc[0] are zero by construction of m
+#pragma unroll
+        for (int j = 0; j < 13; j++) acc[j] = acc[j + 1];
+        acc[13] = 0;
+        if (i == 6) {                                 // carry sweep: keeps every column below 2^64
+#pragma unroll
+            for (int j = 0; j < 12; j++) { acc[j + 1] += acc[j] >> 30; acc[j] &= 0x3fffffffull; }
+        }
+    }
+    uint32_t r[13]; uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 13; j++) { uint64_t x = acc[j] + c; r[j] = (uint32_t)x & 0x3fffffffu; c = x >> 30; }
+    // value = a b / R' + (multiple of p) < 2p < 2^382: fits 12 words; repack and subtract p once if needed
+    uint32_t t[12];
+#pragma unroll
+    for (int w = 0; w < 12; w++) {
+        const int k = (32 * w) / 30, o = (32 * w) % 30;
+        uint64_t v = (uint64_t)r[k] >> o;
+        v |= (uint64_t)r[k + 1] << (30 - o);
+        if (k + 2 < 13) v |= (uint64_t)r[k + 2] << (60 - o);
+        t[w] = (uint32_t)v;
+    }
+    fp out; reduce_once<FpP>(out, t);
+    return out;
+}
+
 #if defined(KZG_FP_MUL_NOINLINE) && defined(__clang__)
 // Out-of-line F_p product: keeps a Jacobian add at ~2 KB of code instead of ~100 KB (the I-cache is 64 KB).
 // Operands and result travel as 12-wide vectors so the AMDGPU calling convention keeps all 24 + 12 dwords in
@@ -184,7 +260,7 @@ KZG_HD_NOINLINE static u32x12 fp_mul_call(u32x12 av, u32x12 bv) {
     fp a, b;
 #pragma unroll
     for (int i = 0; i < 12; i++) { a.l[i] = av[i]; b.l[i] = bv[i]; }
-    fp o = mont_mul_inl<FpP>(a, b);
+    fp o = mont_mul_fp30(a, b);
     u32x12 r;
 #pragma unroll
     for (int i = 0; i < 12; i++) r[i] = o.l[i];
@@ -201,7 +277,7 @@ KZG_HD fp mul(const fp &a, const fp &b) {
     return o;
 }
 #else
-KZG_HD fp mul(const fp &a, const fp &b) { return mont_mul_inl<FpP>(a, b); }
+KZG_HD fp mul(const fp &a, const fp &b) { return mont_mul_fp30(a, b); }
 #endif
 KZG_HD fr mul(const fr &a, const fr &b) { return mont_mul_inl<FrP>(a, b); }
 KZG_HD fp sqr(const fp &a) { return mul(a, a); }
@@ -239,6 +315,26 @@ template <class F> KZG_HD felem<F> inv(const felem<F> &a) {
 KZG_HD fr fr_from_u64(uint64_t v) {   // bls.AsFr (bls/bignum_kilic.go:61-65)
     fr t = zero<FrP>(); t.l[0] = (uint32_t)v; t.l[1] = (uint32_t)(v >> 32);
     return to_mont<FrP>(t);
+}
+
+// Kilic memory image (R = 2^384) <-> device-internal image (R' = 2^390) of an F_p element
+KZG_HD fp fp_from_kilic(const fp &a) {
+    fp c;
+#pragma unroll
+    for (int i = 0; i < 12; i++) c.l[i] = FpP::kilic_in(i);
+    return mul(a, c);
+}
+KZG_HD fp fp_to_kilic(const fp &a) {
+    fp c;
+#pragma unroll
+    for (int i = 0; i < 12; i++) c.l[i] = FpP::kilic_one(i);
+    return mul(a, c);
+}
+KZG_HD fp fp_kilic_one() {
+    fp c;
+#pragma unroll
+    for (int i = 0; i < 12; i++) c.l[i] = FpP::kilic_one(i);
+    return c;
 }
 
 }  // namespace kzg

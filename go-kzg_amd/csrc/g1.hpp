@@ -138,4 +138,17 @@ KZG_HD g1j g1_mul_small(const g1j &p, uint32_t k) {
     return acc;
 }
 
+// Kilic image (bls.G1Point as the Go side holds it) <-> device-internal image; inf keeps Z == 0
+KZG_HD g1j g1_from_kilic(const g1j &p) {
+    if (is_zero<FpP>(p.z)) return g1_inf();
+    g1j o; o.x = fp_from_kilic(p.x); o.y = fp_from_kilic(p.y); o.z = fp_from_kilic(p.z);
+    return o;
+}
+KZG_HD g1j g1_to_kilic(const g1j &p) {
+    g1j o;
+    if (is_inf(p)) { o.x = zero<FpP>(); o.y = fp_kilic_one(); o.z = zero<FpP>(); return o; }   // Kilic Zero(): (0, 1, 0)
+    o.x = fp_to_kilic(p.x); o.y = fp_to_kilic(p.y); o.z = fp_to_kilic(p.z);
+    return o;
+}
+
 }  // namespace kzg

@@ -36,7 +36,9 @@ void launch_g1_file_msm(hipStream_t s, const g1j *files, const fr *scalars, uint
 void launch_g1_bitrev_copy(hipStream_t s, const g1j *in, uint64_t in_stride, uint64_t n_valid, g1j *out, uint64_t n, uint64_t batch);
 // one radix-2 DIT stage on bit-reversed data (replaces the loop of _fftG1, fft_g1.go:44-55)
 void launch_g1_fft_stage(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, uint64_t m, const fr *roots, uint64_t W);
-void launch_g1_normalize(hipStream_t s, const g1j *in, g1j *out, uint64_t n);
+// to_kilic: also leave the device-internal Montgomery domain (R' = 2^390) for Kilic's (2^384): every API output path ends here
+void launch_g1_normalize(hipStream_t s, const g1j *in, g1j *out, uint64_t n, bool to_kilic = false);
+void launch_g1_from_kilic(hipStream_t s, g1j *data, uint64_t n);   // in place: caller-supplied points enter the internal domain
 void launch_g1_to_affine(hipStream_t s, const g1j *in, g1a *out, uint64_t n);
 void launch_g1_compress(hipStream_t s, const g1j *in, uint8_t *out48, uint64_t n);
 void launch_g1_decompress(hipStream_t s, const uint8_t *in48, g1j *out, uint64_t n, uint32_t *bad_flag);

@@ -103,14 +103,24 @@ void launch_g1_fft_stage(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, u
     prof_end(s, "g1_fft_stage");
 }
 
-__global__ __launch_bounds__(G1_BLOCK) void k_g1_normalize(const g1j *in, g1j *out, uint64_t n) {
+__global__ __launch_bounds__(G1_BLOCK) void k_g1_normalize(const g1j *in, g1j *out, uint64_t n, int to_kilic) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= n) return;
-    out[t] = g1_normalize(in[t]);
+    g1j p = g1_normalize(in[t]);
+    out[t] = to_kilic ? g1_to_kilic(p) : p;
 }
-void launch_g1_normalize(hipStream_t s, const g1j *in, g1j *out, uint64_t n) {
+void launch_g1_normalize(hipStream_t s, const g1j *in, g1j *out, uint64_t n, bool to_kilic) {
     if (!n) return;
-    hipLaunchKernelGGL(k_g1_normalize, dim3((uint32_t)((n + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, in, out, n);
+    hipLaunchKernelGGL(k_g1_normalize, dim3((uint32_t)((n + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, in, out, n, to_kilic ? 1 : 0);
+}
+__global__ __launch_bounds__(G1_BLOCK) void k_g1_from_kilic(g1j *data, uint64_t n) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    data[t] = g1_from_kilic(data[t]);
+}
+void launch_g1_from_kilic(hipStream_t s, g1j *data, uint64_t n) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_g1_from_kilic, dim3((uint32_t)((n + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, data, n);
 }
 __global__ __launch_bounds__(G1_BLOCK) void k_g1_to_affine(const g1j *in, g1a *out, uint64_t n) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
@@ -168,12 +178,12 @@ __global__ __launch_bounds__(G1_BLOCK) void k_g1_decompress(const uint8_t *in48,
     if (t >= n) return;
     const uint8_t *b = in48 + 48 * t;
     uint8_t f = b[0];
-    if (!(f & 0x80)) { atomicOr(bad, 1u); out[t] = g1_inf(); return; }
+    if (!(f & 0x80)) { atomicOr(bad, 1u); out[t] = g1_to_kilic(g1_inf()); return; }
     if (f & 0x40) {
         uint32_t rest = f & 0x3f;
         for (int i = 1; i < 48; i++) rest |= b[i];
         if (rest) atomicOr(bad, 1u);
-        out[t] = g1_inf();
+        out[t] = g1_to_kilic(g1_inf());
         return;
     }
     fp x = zero<FpP>();
@@ -185,7 +195,7 @@ __global__ __launch_bounds__(G1_BLOCK) void k_g1_decompress(const uint8_t *in48,
     // x < p
     bool lt = false;
     for (int i = 11; i >= 0; i--) { uint32_t m = FpP::mod(i); if (x.l[i] < m) { lt = true; break; } if (x.l[i] > m) break; }
-    if (!lt) { atomicOr(bad, 1u); out[t] = g1_inf(); return; }
+    if (!lt) { atomicOr(bad, 1u); out[t] = g1_to_kilic(g1_inf()); return; }
     fp xm = to_mont<FpP>(x);
     fp four = one<FpP>(); four = add(four, four); four = add(four, four);
     fp y2 = add(mul(sqr(xm), xm), four);
@@ -197,10 +207,10 @@ __global__ __launch_bounds__(G1_BLOCK) void k_g1_decompress(const uint8_t *in48,
         uint32_t e = (lo >> 2) | (hi << 30);
         for (int bit = 31; bit >= 0; bit--) { acc = sqr(acc); if ((e >> bit) & 1u) acc = mul(acc, y2); }
     }
-    if (!equal<FpP>(sqr(acc), y2)) { atomicOr(bad, 1u); out[t] = g1_inf(); return; }
+    if (!equal<FpP>(sqr(acc), y2)) { atomicOr(bad, 1u); out[t] = g1_to_kilic(g1_inf()); return; }
     if (y_is_larger(from_mont<FpP>(acc)) != ((f & 0x20) != 0)) acc = neg<FpP>(acc);
     g1j o; o.x = xm; o.y = acc; o.z = one<FpP>();
-    out[t] = o;
+    out[t] = g1_to_kilic(o);   // API output: Kilic image
 }
 void launch_g1_decompress(hipStream_t s, const uint8_t *in48, g1j *out, uint64_t n, uint32_t *bad_flag) {
     if (!n) return;
@@ -211,10 +221,11 @@ void launch_g1_decompress(hipStream_t s, const uint8_t *in48, g1j *out, uint64_t
 __global__ __launch_bounds__(G1_BLOCK) void k_g1_fixed_base_powers(const fr *powers, uint64_t n, g1j *out) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= n) return;
-    const uint32_t gx[12] = {0xfd530c16u, 0x5cb38790u, 0x9976fff5u, 0x7817fc67u, 0x143ba1c1u, 0x154f95c7u,
-                             0xf3d0e747u, 0xf0ae6acdu, 0x21dbf440u, 0xedce6eccu, 0x9e0bfb75u, 0x12017741u};
-    const uint32_t gy[12] = {0x0ce72271u, 0xbaac93d5u, 0x7918fd8eu, 0x8c22631au, 0x570725ceu, 0xdd595f13u,
-                             0x50405194u, 0x51ac5829u, 0xad0059c0u, 0x0e1c8c3fu, 0x5008a26au, 0x0bbc3efcu};
+    // G1 generator (decimals in-tree at bls/bls_hbls.go:23-24) in the device-internal Montgomery domain (x * 2^390 mod p)
+    const uint32_t gx[12] = {0x54d1b01cu, 0x350de43fu, 0xe34ffd63u, 0xc06f1a1fu, 0xa87e2228u, 0x97813e1au,
+                             0x195a98dfu, 0xe719b8a3u, 0xe5fb5b36u, 0x8adadfb4u, 0xa1033af6u, 0x082ebc25u};
+    const uint32_t gy[12] = {0x39d1f18cu, 0x5340f543u, 0xe10f63b6u, 0xadc8c6c2u, 0xc66e87afu, 0x0d00bb3au,
+                             0x6d865848u, 0x6e09c7c9u, 0xe3cf8885u, 0x501cb7fbu, 0xb82b61a3u, 0x16f1c975u};
     g1j g;
     for (int i = 0; i < 12; i++) { g.x.l[i] = gx[i]; g.y.l[i] = gy[i]; }
     g.z = one<FpP>();

@@ -110,8 +110,9 @@ int kzg_hip_fk20_multi_da_optimized(kzg_hip_fk20m *fk, const void *poly_fr, uint
 int kzg_hip_da_using_fk20_multi(kzg_hip_fk20m *fk, const void *poly_fr, uint64_t n, void *out_g1 /* 2n / chunk_len */);
 int kzg_hip_da_using_fk20_multi_batch_dev(kzg_hip_fk20m *fk, const void *d_poly_fr, uint64_t n, uint64_t batch, void *d_out_g1, void *stream);
 /* Sharded form for one process per GPU: this rank computes hExtFFT for output positions
- * [j0, j0 + cnt) only and writes cnt normalised points; ranks all-gather the slices (RCCL, bytes) and call
- * kzg_hip_fk20_multi_finish on the gathered 2k points. */
+ * [j0, j0 + cnt) only and writes cnt points as OPAQUE 144-byte device-internal Jacobian images (not Kilic images: the
+ * device keeps F_p in Montgomery radix 2^390); ranks all-gather the slices (RCCL, bytes) and call
+ * kzg_hip_fk20_multi_finish_dev on the gathered 2k points, which returns normalised Kilic images. */
 int kzg_hip_fk20_multi_hext_slice_dev(kzg_hip_fk20m *fk, const void *d_poly_fr, uint64_t n, uint64_t j0, uint64_t cnt, void *d_out_g1, void *stream);
 int kzg_hip_fk20_multi_finish_dev(kzg_hip_fk20m *fk, const void *d_hext_g1, int bit_reverse, void *d_out_g1, void *stream);
 

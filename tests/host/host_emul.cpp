@@ -12,15 +12,18 @@ void he_fr_sub(fr *o, const fr *a, const fr *b) { *o = sub(*a, *b); }
 void he_fr_inv(fr *o, const fr *a) { *o = inv<FrP>(*a); }
 void he_fr_from_u64(fr *o, uint64_t v) { *o = fr_from_u64(v); }
 void he_fr_from_mont(fr *o, const fr *a) { *o = from_mont<FrP>(*a); }
-void he_g1_add(g1j *o, const g1j *a, const g1j *b) { *o = g1_add(*a, *b); }
-void he_g1_sub(g1j *o, const g1j *a, const g1j *b) { *o = g1_sub(*a, *b); }
-void he_g1_dbl(g1j *o, const g1j *a) { *o = g1_dbl(*a); }
+#define IN(p) g1_from_kilic(*(p))
+#define OUT(e) g1_to_kilic(e)
+void he_g1_add(g1j *o, const g1j *a, const g1j *b) { *o = OUT(g1_add(IN(a), IN(b))); }
+void he_g1_sub(g1j *o, const g1j *a, const g1j *b) { *o = OUT(g1_sub(IN(a), IN(b))); }
+void he_g1_dbl(g1j *o, const g1j *a) { *o = OUT(g1_dbl(IN(a))); }
 void he_g1_madd(g1j *o, const g1j *a, const g1j *b_affine_image) {   // b must have Z = R or be inf
-    g1a q; if (is_inf(*b_affine_image)) q = g1a_inf(); else { q.x = b_affine_image->x; q.y = b_affine_image->y; }
-    *o = g1_madd(*a, q);
+    g1j bi = IN(b_affine_image);
+    g1a q; if (is_inf(bi)) q = g1a_inf(); else { q.x = bi.x; q.y = bi.y; }
+    *o = OUT(g1_madd(IN(a), q));
 }
-void he_g1_mul(g1j *o, const g1j *a, const fr *k_mont) { g1j tbl[15]; *o = g1_mul_windowed(*a, from_mont<FrP>(*k_mont), tbl); }
-void he_g1_mul_small(g1j *o, const g1j *a, uint32_t k) { *o = g1_mul_small(*a, k); }
-void he_g1_normalize(g1j *o, const g1j *a) { *o = g1_normalize(*a); }
-int he_g1_equal(const g1j *a, const g1j *b) { return g1_equal(*a, *b); }
+void he_g1_mul(g1j *o, const g1j *a, const fr *k_mont) { g1j tbl[15]; *o = OUT(g1_mul_windowed(IN(a), from_mont<FrP>(*k_mont), tbl)); }
+void he_g1_mul_small(g1j *o, const g1j *a, uint32_t k) { *o = OUT(g1_mul_small(IN(a), k)); }
+void he_g1_normalize(g1j *o, const g1j *a) { *o = OUT(g1_normalize(IN(a))); }
+int he_g1_equal(const g1j *a, const g1j *b) { return g1_equal(IN(a), IN(b)); }
 }

@@ -5,14 +5,14 @@
 #include "../go-kzg_amd/csrc/field.hpp"
 using namespace kzg;
 
-template <int CH> __global__ __launch_bounds__(256) void k_mul(fp *io, int iters) {
+template <int CH, int V> __global__ __launch_bounds__(256) void k_mul(fp *io, int iters) {
     extern __shared__ uint32_t dummy[];
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     fp x[CH], y = io[t ^ 1];
     for (int c = 0; c < CH; c++) { x[c] = io[t]; x[c].l[0] += c; }
     for (int i = 0; i < iters; i++) {
 #pragma unroll
-        for (int c = 0; c < CH; c++) x[c] = mont_mul_inl<FpP>(x[c], y);
+        for (int c = 0; c < CH; c++) x[c] = V ? mont_mul_fp30(x[c], y) : mont_mul_inl<FpP>(x[c], y);
     }
     fp s = x[0];
     for (int c = 1; c < CH; c++) s = add(s, x[c]);
@@ -47,13 +47,13 @@ int main() {
         int blocks_per_cu = wps[w];                 // 256 threads = 4 waves = 1 wave per SIMD per block
         size_t sh = blocks_per_cu == 8 ? 0 : (160 * 1024) / blocks_per_cu - 1024;
         int blocks = cus * blocks_per_cu; int it = 128;
-        double s1 = time_kernel(k_mul<1>, dim3(blocks), dim3(256), sh, io, it);
-        double s2 = time_kernel(k_mul<2>, dim3(blocks), dim3(256), sh, io, it);
-        double s4 = time_kernel(k_mul<4>, dim3(blocks), dim3(256), sh, io, it);
+        double s1 = time_kernel(k_mul<1, 0>, dim3(blocks), dim3(256), sh, io, it);
+        double s2 = time_kernel(k_mul<1, 1>, dim3(blocks), dim3(256), sh, io, it);
+        double s4 = time_kernel(k_mul<2, 1>, dim3(blocks), dim3(256), sh, io, it);
         double sd = time_kernel(k_mad_dep, dim3(blocks), dim3(256), sh, o32, 1u, 256);
         double lanes = (double)blocks * 256;
-        printf("waves/SIMD %d: fp_mul 1-chain %6.2f G/s  2-chain %6.2f G/s  4-chain %6.2f G/s | dependent mad chain: %5.2f cycles/mad/wave\n", wps[w],
-               lanes * it / s1 * 1e-9, lanes * it * 2 / s2 * 1e-9, lanes * it * 4 / s4 * 1e-9, sd * 2.4e9 / (256.0 * 16) );
+        printf("waves/SIMD %d: CIOS32 %6.2f G/s | fp30 1-chain %6.2f G/s  2-chain %6.2f G/s | dependent mad chain: %5.2f cycles/mad/wave\n", wps[w],
+               lanes * it / s1 * 1e-9, lanes * it / s2 * 1e-9, lanes * it * 2 / s4 * 1e-9, sd * 2.4e9 / (256.0 * 16) );
     }
     return 0;
 }
