@@ -69,6 +69,7 @@ struct kzg_hip_fft {
     std::vector<fr> h_expanded, h_reversed;
     fr *d_expanded = nullptr, *d_reversed = nullptr;
     fr *d_inv_pow2 = nullptr;   // (2^k)^-1, k = 0..63 (Montgomery)
+    fr *d_glv_expanded = nullptr, *d_glv_reversed = nullptr;   // twiddles as GLV pairs for the G1 FFT (g1_mul_glv)
     std::mutex mu;
 };
 struct kzg_hip_kzg {
@@ -156,6 +157,15 @@ int kzg_hip_fft_settings_new(int device, unsigned max_scale, kzg_hip_fft **out) 
     HIPCHK(hipMalloc((void **)&fs->d_reversed, bytes));
     HIPCHK(hipMemcpy(fs->d_expanded, fs->h_expanded.data(), bytes, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(fs->d_reversed, fs->h_reversed.data(), bytes, hipMemcpyHostToDevice));
+    {   // G1-FFT twiddles leave Montgomery form (Kilic FromRed) and are split k = k2 lambda + k1 once, on the host
+        std::vector<fr> ge(fs->W + 1), gr(fs->W + 1);
+        for (uint64_t i = 0; i <= fs->W; i++) ge[i] = glv_decompose(from_mont<FrP>(fs->h_expanded[i]));
+        for (uint64_t i = 0; i <= fs->W; i++) gr[i] = ge[fs->W - i];
+        HIPCHK(hipMalloc((void **)&fs->d_glv_expanded, bytes));
+        HIPCHK(hipMalloc((void **)&fs->d_glv_reversed, bytes));
+        HIPCHK(hipMemcpy(fs->d_glv_expanded, ge.data(), bytes, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(fs->d_glv_reversed, gr.data(), bytes, hipMemcpyHostToDevice));
+    }
     fr invs[64]; fr half = inv<FrP>(fr_from_u64(2));
     invs[0] = one<FrP>();
     for (int i = 1; i < 64; i++) invs[i] = mul(invs[i - 1], half);
@@ -168,7 +178,7 @@ void kzg_hip_fft_settings_free(kzg_hip_fft *fs) {
     if (!fs) return;
     hipSetDevice(fs->device);
     hipStreamSynchronize(fs->stream);
-    hipFree(fs->d_expanded); hipFree(fs->d_reversed); hipFree(fs->d_inv_pow2);
+    hipFree(fs->d_expanded); hipFree(fs->d_reversed); hipFree(fs->d_inv_pow2); hipFree(fs->d_glv_expanded); hipFree(fs->d_glv_reversed);
     hipStreamDestroy(fs->stream);
     delete fs;
 }
@@ -224,7 +234,7 @@ int kzg_hip_fft_fr_batch(kzg_hip_fft *fs, const void *vals_fr, uint64_t n, uint6
 // NOT scaled by 1/n (callers fold the scale where it is cheapest).
 static void g1_fft_rows(kzg_hip_fft *fs, hipStream_t s, const g1j *d_in, uint64_t in_stride, uint64_t n_valid, g1j *d_data, uint64_t n, uint64_t batch, int inv) {
     launch_g1_bitrev_copy(s, d_in, in_stride, n_valid, d_data, n, batch);
-    const fr *roots = inv ? fs->d_reversed : fs->d_expanded;
+    const fr *roots = inv ? fs->d_glv_reversed : fs->d_glv_expanded;
     for (uint64_t m = 1; m < n; m <<= 1) launch_g1_fft_stage(s, d_data, n, batch, m, roots, fs->W);
 }
 

@@ -128,6 +128,50 @@ KZG_HD g1j g1_mul_windowed(const g1j &p, const fr &k, g1j *tbl) {
     return acc;
 }
 
+// ---------------------------------------------------------------------------------------------
+// GLV: phi(x, y) = (beta x, y) acts on G1 as multiplication by lambda = z^2 - 1 (z the BLS12-381 parameter),
+// and lambda^2 + lambda + 1 = r, so k = k2 lambda + k1 with k1 = k mod lambda, k2 = k div lambda both < 2^128 and
+// non-negative.  k P = k1 P + k2 phi(P) with SHARED doublings: 128 instead of 256.
+// `kk` holds k1 in limbs 0..3 and k2 in limbs 4..7 (standard form).  Same 15-entry table as g1_mul_windowed;
+// phi of a table entry costs one F_p product by beta at lookup time.
+// ---------------------------------------------------------------------------------------------
+KZG_HD fp glv_beta() {   // cube root of unity with phi(G) == lambda G (checked against oracle/pyref.py), radix-2^390 Montgomery
+    const uint32_t t[12] = {0x9c907181u, 0xef2f7921u, 0xb26574c3u, 0x1bcc91d7u, 0x191c3ebcu, 0x856e7b9au,
+                            0x67fd6ffau, 0xbd16b0d2u, 0xeb0c0550u, 0x18c86532u, 0x6567dd7du, 0x09c6d485u};
+    fp b;
+#pragma unroll
+    for (int i = 0; i < 12; i++) b.l[i] = t[i];
+    return b;
+}
+KZG_HD g1j g1_mul_glv(const g1j &p, const fr &kk, g1j *tbl) {
+    tbl[0] = p;
+    for (int i = 1; i < 15; i++) tbl[i] = (i & 1) ? g1_dbl(tbl[i >> 1]) : g1_add(tbl[i - 1], p);   // tbl[i] = (i+1) P
+    const fp beta = glv_beta();
+    g1j acc = g1_inf();
+    for (int w = 31; w >= 0; w--) {
+        acc = g1_dbl(g1_dbl(g1_dbl(g1_dbl(acc))));
+        uint32_t d1 = (kk.l[w >> 3] >> ((w & 7) * 4)) & 15u;
+        uint32_t d2 = (kk.l[4 + (w >> 3)] >> ((w & 7) * 4)) & 15u;
+        if (d1) acc = g1_add(acc, tbl[d1 - 1]);
+        if (d2) { g1j q = tbl[d2 - 1]; q.x = mul(q.x, beta); acc = g1_add(acc, q); }
+    }
+    return acc;
+}
+// host-side decomposition of a standard-form scalar: out = (k mod lambda, k div lambda)
+inline fr glv_decompose(const fr &k) {
+    typedef unsigned __int128 u128;
+    const u128 lam = ((u128)0xac45a4010001a402ull << 64) | 0x00000000ffffffffull;
+    u128 rem = 0, q = 0;
+    for (int b = 255; b >= 0; b--) {
+        bool top = (rem >> 127) & 1;
+        rem = (rem << 1) | ((k.l[b >> 5] >> (b & 31)) & 1u);
+        if (top || rem >= lam) { rem -= lam; q |= (b < 128) ? ((u128)1 << b) : 0; }
+    }
+    fr o;
+    for (int i = 0; i < 4; i++) { o.l[i] = (uint32_t)(rem >> (32 * i)); o.l[4 + i] = (uint32_t)(q >> (32 * i)); }
+    return o;
+}
+
 // Plain MSB-first double-and-add (no table); used where the scalar is short.
 KZG_HD g1j g1_mul_small(const g1j &p, uint32_t k) {
     g1j acc = g1_inf();

@@ -34,7 +34,8 @@ void launch_g1_file_msm(hipStream_t s, const g1j *files, const fr *scalars, uint
                         uint64_t batch, g1j *out);
 // out[b][rev(i)] = i < n_valid ? in[b][i] : inf     (bit-reversal + "h[:n] || inf" padding, fk20_single.go:163-166)
 void launch_g1_bitrev_copy(hipStream_t s, const g1j *in, uint64_t in_stride, uint64_t n_valid, g1j *out, uint64_t n, uint64_t batch);
-// one radix-2 DIT stage on bit-reversed data (replaces the loop of _fftG1, fft_g1.go:44-55)
+// one radix-2 DIT stage on bit-reversed data (replaces the loop of _fftG1, fft_g1.go:44-55); `roots` holds the twiddles as
+// GLV pairs (k mod lambda, k div lambda) in standard form, see g1_mul_glv
 void launch_g1_fft_stage(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, uint64_t m, const fr *roots, uint64_t W);
 // to_kilic: also leave the device-internal Montgomery domain (R' = 2^390) for Kilic's (2^384): every API output path ends here
 void launch_g1_normalize(hipStream_t s, const g1j *in, g1j *out, uint64_t n, bool to_kilic = false);
