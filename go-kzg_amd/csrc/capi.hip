@@ -85,6 +85,8 @@ struct fk20_core {
     kzg_hip_kzg *ks = nullptr;
     uint64_t n2 = 0, l = 1, k = 0;   // n2 = 2n, chunk length l, k = n / l
     g1j *d_files = nullptr;          // l x 2k points: xExtFFT (single) / xExtFFTFiles (multi)
+    g1a *d_files_fb = nullptr;       // fixed-base table over the l x 2k file points (k_fb_mul_vec); null -> double-and-add path
+    uint32_t fb_c = 0, fb_nwin = 0;
 };
 struct kzg_hip_fk20s { fk20_core c; };
 struct kzg_hip_fk20m { fk20_core c; };
@@ -552,6 +554,25 @@ static int fk20_core_new(kzg_hip_kzg *ks, uint64_t n2, uint64_t l, fk20_core *c)
     g1_fft_rows(fs, s, d_x.p, k, k, d_f.p, k2, l, 0);   // toeplitzPart1: FFTG1(x || inf^k), fk20_single.go:40-56
     launch_g1_normalize(s, d_f.p, c->d_files, l * k2);
     HIPCHK(hipGetLastError());
+    {   // fixed-base table over the file points, sized by KZG_HIP_FK20_FB_BUDGET_GB (default 8 GB of the 288)
+        double budget_gb = 8.0;
+        if (const char *e = getenv("KZG_HIP_FK20_FB_BUDGET_GB")) budget_gb = atof(e);
+        uint64_t npts = l * k2; uint32_t best = 0;
+        for (uint32_t cc = 11; cc >= 4; cc--) {
+            double bytes = (double)(255 / cc + 1) * (double)npts * (double)(1u << (cc - 1)) * sizeof(g1a);
+            if (bytes <= budget_gb * 1e9) { best = cc; break; }
+        }
+        if (best && npts >= 64) {
+            dtmp<g1a> d_fa(s);
+            CHK(d_fa.alloc(npts));
+            launch_g1_to_affine(s, c->d_files, d_fa.p, npts);
+            c->fb_c = best; c->fb_nwin = 255 / best + 1;
+            HIPCHK(hipMalloc((void **)&c->d_files_fb, (size_t)c->fb_nwin * npts * (1u << (best - 1)) * sizeof(g1a)));
+            launch_fb_build(s, d_fa.p, npts, c->fb_c, c->fb_nwin, c->d_files_fb);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(s));
+        }
+    }
     HIPCHK(hipStreamSynchronize(s));
     return KZG_HIP_OK;
 }
@@ -565,7 +586,15 @@ static int fk20_hext(fk20_core *c, hipStream_t s, const fr *d_poly, uint64_t pol
     CHK(d_tc.alloc(batch * l * k2)); CHK(d_cf.alloc(batch * l * k2));
     launch_toeplitz_coeffs(s, d_poly, poly_stride, n, l, batch, d_tc.p, fs->d_inv_pow2 + ilog2(k2));
     fr_fft_rows(fs, s, d_tc.p, k2, k2, d_cf.p, k2, batch * l, 0);
-    if (l == 1 && j0 == 0 && cnt == k2) launch_g1_mul_vec(s, c->d_files, k2, d_cf.p, 1, batch * k2, d_hext);
+    if (c->d_files_fb) {
+        if (l == 1) launch_fb_mul_vec(s, c->d_files_fb, l * k2, c->fb_c, c->fb_nwin, d_cf.p, k2, j0, cnt, batch, d_hext);
+        else {
+            dtmp<g1j> d_tmp(s);
+            CHK(d_tmp.alloc(batch * l * cnt));
+            launch_fb_mul_vec(s, c->d_files_fb, l * k2, c->fb_c, c->fb_nwin, d_cf.p, k2, j0, cnt, batch, d_tmp.p);
+            launch_g1_sum_files(s, d_tmp.p, l, cnt, batch, d_hext);
+        }
+    } else if (l == 1 && j0 == 0 && cnt == k2) launch_g1_mul_vec(s, c->d_files, k2, d_cf.p, 1, batch * k2, d_hext);
     else launch_g1_file_msm(s, c->d_files, d_cf.p, l, k2, j0, cnt, batch, d_hext);
     HIPCHK(hipGetLastError());
     return KZG_HIP_OK;
@@ -629,7 +658,7 @@ int kzg_hip_fk20_single_settings_new(kzg_hip_kzg *ks, uint64_t n2, kzg_hip_fk20s
 void kzg_hip_fk20_single_settings_free(kzg_hip_fk20s *fk) {
     if (!fk) return;
     hipSetDevice(fk->c.ks->fs->device);
-    hipFree(fk->c.d_files);
+    hipFree(fk->c.d_files); hipFree(fk->c.d_files_fb);
     delete fk;
 }
 int kzg_hip_fk20_single_x_ext_fft(const kzg_hip_fk20s *fk, void *out_g1) {
@@ -696,7 +725,7 @@ int kzg_hip_fk20_multi_settings_new(kzg_hip_kzg *ks, uint64_t n2, uint64_t chunk
 void kzg_hip_fk20_multi_settings_free(kzg_hip_fk20m *fk) {
     if (!fk) return;
     hipSetDevice(fk->c.ks->fs->device);
-    hipFree(fk->c.d_files);
+    hipFree(fk->c.d_files); hipFree(fk->c.d_files_fb);
     delete fk;
 }
 int kzg_hip_fk20_multi(kzg_hip_fk20m *fk, const void *poly_fr, uint64_t n, void *out_g1) {

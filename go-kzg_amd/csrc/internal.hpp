@@ -67,6 +67,11 @@ void launch_fb_build(hipStream_t s, const g1a *pts, uint64_t n, uint32_t c, uint
 void launch_fb_msm(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, uint64_t n, uint64_t batch,
                    void *partials, g1j *out);
 
+// out[(b, f, jj)] = scalars[b][f * row + j0 + jj] * P[f * row + j0 + jj] over a fixed-base table of table_n = nfiles * row points
+void launch_fb_mul_vec(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, uint64_t row, uint64_t j0,
+                       uint64_t cnt, uint64_t batch, g1j *out);
+void launch_g1_sum_files(hipStream_t s, const g1j *tmp, uint64_t nfiles, uint64_t cnt, uint64_t batch, g1j *out);
+
 // profiling hook (HIP events around the dominant kernel), see capi.hip
 struct prof_slot { const char *name; hipEvent_t e0, e1; };
 void prof_begin(hipStream_t s, const char *name);

@@ -51,6 +51,11 @@ __global__ __launch_bounds__(G1_BLOCK) void k_g1_sum_files(const g1j *tmp, uint6
     for (uint64_t f = 0; f < nfiles; f++) acc = g1_add(acc, tmp[(b * nfiles + f) * cnt + jj]);
     out[t] = acc;
 }
+void launch_g1_sum_files(hipStream_t s, const g1j *tmp, uint64_t nfiles, uint64_t cnt, uint64_t batch, g1j *out) {
+    uint64_t outs = batch * cnt;
+    if (!outs) return;
+    hipLaunchKernelGGL(k_g1_sum_files, dim3((uint32_t)((outs + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, tmp, nfiles, cnt, outs, out);
+}
 void launch_g1_file_msm(hipStream_t s, const g1j *files, const fr *scalars, uint64_t nfiles, uint64_t k2, uint64_t j0, uint64_t cnt, uint64_t batch,
                         g1j *out) {
     uint64_t total = batch * nfiles * cnt;

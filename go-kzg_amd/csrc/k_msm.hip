@@ -283,6 +283,42 @@ __global__ __launch_bounds__(64) void k_fb_finish(const g1j *partials, uint32_t 
     out[b] = acc;
 }
 
+// element-wise fixed-base products over the same table layout: out[b][i] = scalars[b][i] * P_i  (the FK20 Toeplitz stage,
+// ToeplitzPart2's loop fk20_single.go:72-74, where P = xExtFFT is fixed per settings): nwin mixed adds instead of a
+// 255-bit double-and-add per element.
+__global__ __launch_bounds__(FB_BLOCK) void k_fb_mul_vec(const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, uint32_t D, const fr *scalars,
+                                                         uint64_t i0, uint64_t cnt, uint64_t row, uint64_t total, g1j *out) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    // t enumerates (b, f, jj): point index i = f * k2 + j0 + jj is supplied through (row = k2, i0 = j0, cnt) by the caller
+    uint64_t jj = t % cnt, f = (t / cnt) % (table_n / row), b = t / (cnt * (table_n / row));
+    uint64_t i = f * row + i0 + jj;
+    fr k = from_mont<FrP>(scalars[b * table_n + i]);
+    g1j acc = g1_inf();
+    uint32_t carry = 0;
+#pragma nounroll
+    for (uint32_t w = 0; w < nwin; w++) {
+        uint32_t raw = scalar_bits(k, w * c, c) + carry;
+        uint32_t mag, ng;
+        if (raw > D) { carry = 1; mag = (1u << c) - raw; ng = 1; } else { carry = 0; mag = raw; ng = 0; }
+        if (mag) {
+            g1a q = table[((uint64_t)w * table_n + i) * D + (mag - 1)];
+            if (ng) q.y = neg<FpP>(q.y);
+            acc = g1_madd(acc, q);
+        }
+    }
+    out[t] = acc;
+}
+void launch_fb_mul_vec(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, uint64_t row, uint64_t j0,
+                       uint64_t cnt, uint64_t batch, g1j *out) {
+    uint64_t total = batch * (table_n / row) * cnt;
+    if (!total) return;
+    prof_begin(s, "fb_mul_vec");
+    hipLaunchKernelGGL(k_fb_mul_vec, dim3((uint32_t)((total + FB_BLOCK - 1) / FB_BLOCK)), dim3(FB_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars,
+                       j0, cnt, row, total, out);
+    prof_end(s, "fb_mul_vec");
+}
+
 static uint32_t fb_blocks_per_blob(uint64_t n, uint64_t batch) {
     uint64_t target = 262144 / FB_BLOCK;                 // ~4 waves per SIMD over 256 CUs
     uint64_t bpb = target / (batch ? batch : 1);

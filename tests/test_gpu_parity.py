@@ -433,3 +433,35 @@ def test_fk20_single_4096_config4a(kz, ks4096):
         want[i] = ko.g1_mul(gen, ks_fr[i])
     assert_points_equal(proofs, want)
     fk.close()
+
+
+# ------------------------------------------------------------------ BASELINE config 5: FK20Multi at scale 16
+def test_fk20_multi_scale16_config5(kz):
+    """FK20MultiDAOptimized / DAUsingFK20Multi, n2 = 65536, chunk length 16 (fk20_multi_test.go:13) -> 4096 coset proofs.
+    The oracle needs minutes for the settings alone at this size, so parity is established through the coset-proof
+    identity at sampled positions (pairing-free form of CheckProofMulti, fk20_multi_test.go:86) and through linearity
+    over ALL 4096 positions (a size-independent property)."""
+    l, n = 16, 32768
+    fs = kz.FFTSettings(16)
+    setup = fs.generate_testing_setup_g1(ko.fr_from_ints([S_TEST]), 65536)      # GenerateTestingSetup on the device
+    osetup = ko.generate_testing_setup_g1(S_TEST, 40)
+    assert np.array_equal(setup[:40], ko.g1_affine(osetup))
+    ks = kz.KZGSettings(fs, setup)
+    fk = kz.FK20MultiSettings(ks, 2 * n, l)
+    a, b = ko.synthetic_blob(5, n), ko.synthetic_blob(6, n)
+    ai, bi = ko.fr_to_ints(a), ko.fr_to_ints(b)
+    s = ko.fr_from_ints([(x + y) % ko.R_MOD for x, y in zip(ai, bi)])
+    pa, pb, ps = fk.da_using_fk20_multi(a), fk.da_using_fk20_multi(b), fk.da_using_fk20_multi(s)
+    assert pa.shape == (4096, 3, 6)
+    L = ko.lib()
+    tmp = ko.g1_empty(1)
+    for j in range(4096):                                                      # linearity, every position
+        L.ko_g1_add(tmp.ctypes.data, pa[j].ctypes.data, pb[j].ctypes.data)
+        assert L.ko_g1_equal(tmp.ctypes.data, ps[j].ctypes.data), j
+    w2n = pyref.root_of_unity(16)
+    gen = ko.g1_generator()
+    for pos in (0, 1, 2, 777, 2048, 4095):                                      # coset-proof identity
+        x = pow(w2n, pyref.rev_bits(pos, 12), ko.R_MOD)                         # domainStride = MaxWidth / n2 = 1
+        d = pyref.coset_proof_dlog(ai, S_TEST, x, l)
+        assert ko.g1_equal(pa[pos], ko.g1_mul(gen, ko.fr_from_ints([d])[0])), pos
+    fk.close(); ks.close(); fs.close()
