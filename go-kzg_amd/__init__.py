@@ -53,6 +53,13 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError("libkzg_hip.so is not built (run __graft_entry__.build()); there is no CPU fallback: " + LIB_PATH)
+    if os.environ.get("KZG_HIP_NO_TORCH_PRELOAD") != "1":
+        # PyTorch bundles its own libamdhip64; if this library initialises /opt/rocm's copy first, torch later reports
+        # "No HIP GPUs are available".  Importing torch first makes both resolve to ONE HIP runtime (same SONAME).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, u64, i32, u32 = C.c_void_p, C.c_uint64, C.c_int, C.c_uint
     pp = C.POINTER(C.c_void_p)

@@ -135,7 +135,7 @@ KZG_HD g1j g1_mul_windowed(const g1j &p, const fr &k, g1j *tbl) {
 // `kk` holds k1 in limbs 0..3 and k2 in limbs 4..7 (standard form).  Same 15-entry table as g1_mul_windowed;
 // phi of a table entry costs one F_p product by beta at lookup time.
 // ---------------------------------------------------------------------------------------------
-KZG_HD fp glv_beta() {   // cube root of unity with phi(G) == lambda G (checked against oracle/pyref.py), radix-2^390 Montgomery
+KZG_HD fp glv_beta() {   // cube root of unity with phi(G) == lambda G (checked in tests/test_host_arith.py), radix-2^390 Montgomery
     const uint32_t t[12] = {0x9c907181u, 0xef2f7921u, 0xb26574c3u, 0x1bcc91d7u, 0x191c3ebcu, 0x856e7b9au,
                             0x67fd6ffau, 0xbd16b0d2u, 0xeb0c0550u, 0x18c86532u, 0x6567dd7du, 0x09c6d485u};
     fp b;

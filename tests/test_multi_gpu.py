@@ -1,0 +1,107 @@
+"""The sharded FK20Multi orchestration (go-kzg_amd/multi_gpu.py): world_size 2 over gloo on CPU with the ORACLE standing
+in for the two device calls (test infrastructure only), against the unsharded oracle result; plus the real HIP backend
+at world size 1 on a GPU."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+S_TEST = 1927409816240961209460912649124
+
+
+class OracleBackend:
+    """CPU stand-in with the same two-call interface: hExtFFT slice, then IFFT / pad / FFT / bit-reverse"""
+
+    def __init__(self, n2, l):
+        from oracle import koracle as ko
+        self.ko, self.l, self.n2, self.k2 = ko, l, n2, n2 // l
+        self.fs = ko.FFTSettings(n2.bit_length() - 1)
+        self.ks = ko.KZGSettings(self.fs, ko.generate_testing_setup_g1(S_TEST, n2))
+        self.fk = ko.FK20MultiSettings(self.ks, n2, l)
+
+    def hext_slice(self, poly_t, n, j0, cnt):
+        import torch
+        ko = self.ko
+        poly = poly_t.numpy().view(np.uint64).reshape(n, 4)
+        acc = ko.g1_zero(self.k2)
+        for f in range(self.l):
+            tc = ko.toeplitz_coeffs_step_strided(poly, f, self.l)
+            part = self.ks.toeplitz_part2(tc, self.fk.file(f))
+            for j in range(j0, j0 + cnt):
+                acc[j] = ko.g1_add(acc[j], part[j])
+        return torch.from_numpy(acc[j0:j0 + cnt].reshape(cnt, 18).view(np.int64).copy())
+
+    def finish(self, hext_t, bit_reverse=True):
+        import torch
+        ko = self.ko
+        hext = hext_t.numpy().view(np.uint64).reshape(self.k2, 3, 6)
+        h = self.fs.fft_g1(hext, inv=True)
+        h[self.k2 // 2:] = ko.g1_zero(self.k2 // 2)
+        out = self.fs.fft_g1(h)
+        if bit_reverse:
+            out = ko.reverse_bit_order(out)
+        return torch.from_numpy(ko.g1_affine(out).reshape(self.k2, 18).view(np.int64).copy())
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    import gokzg_amd  # noqa: F401  (registers the package so the submodule import below resolves)
+    from gokzg_amd import multi_gpu
+    from oracle import koracle as ko
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n2, l = 128, 4
+    be = OracleBackend(n2, l)
+    poly = ko.synthetic_blob(77, n2 // 2)
+    got = multi_gpu.da_using_fk20_multi_sharded(be, torch.from_numpy(poly.view(np.int64).copy()), n2 // 2, be.k2)
+    want = ko.g1_affine(be.fk.da_using_fk20_multi(poly))
+    ok = np.array_equal(got.numpy().view(np.uint64).reshape(-1, 3, 6), want)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_sharded_fk20_multi_world2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
+
+
+@pytest.mark.gpu
+def test_sharded_fk20_multi_hip_backend_world1():
+    """the real device calls (slice + finish) compose to the unsharded DAUsingFK20Multi; also in two slices"""
+    import torch
+    import gokzg_amd as kz
+    from gokzg_amd import multi_gpu
+    from oracle import koracle as ko
+    n2, l = 1024, 16
+    fs = kz.FFTSettings(10)
+    setup = ko.generate_testing_setup_g1(S_TEST, n2)
+    ks = kz.KZGSettings(fs, setup)
+    fk = kz.FK20MultiSettings(ks, n2, l)
+    poly = ko.synthetic_blob(9, n2 // 2)
+    want = fk.da_using_fk20_multi(poly)
+    be = multi_gpu.HipFK20MultiBackend(fk)
+    d_poly = torch.from_numpy(poly.view(np.int64).copy()).cuda()
+    got = multi_gpu.da_using_fk20_multi_sharded(be, d_poly, n2 // 2, be.k2)
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy().view(np.uint64).reshape(-1, 3, 6), want)
+    a = be.hext_slice(d_poly, n2 // 2, 0, 20)
+    b = be.hext_slice(d_poly, n2 // 2, 20, be.k2 - 20)
+    got2 = be.finish(torch.cat([a, b]))
+    torch.cuda.synchronize()
+    assert np.array_equal(got2.cpu().numpy().view(np.uint64).reshape(-1, 3, 6), want)
+    fk.close(); ks.close(); fs.close()
