@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=512, help="blobs per step per GPU")
     ap.add_argument("--fk20-batch", type=int, default=64)
+    ap.add_argument("--fk20-multi-batch", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fk20", action="store_true")
     args = ap.parse_args()
@@ -223,6 +224,31 @@ def main():
                 "ms_per_all_proofs": fsecs / max(1, args.steps // 2) / FB * 1e3}
         fk.close()
 
+    fk20m = None
+    if not args.no_fk20 and args.fk20_multi_batch > 0:
+        # BASELINE config 5: FK20Multi, scale 16 (n2 = 65536, 32768 coefficients), chunk length 16 -> 4096 coset proofs per polynomial.
+        # Setup [s^i]G1 for the reference's test secret is generated on the device (GenerateTestingSetup).
+        s_test = 1927409816240961209460912649124
+        fs16 = kz.FFTSettings(16, device=local)
+        sec = np.frombuffer((s_test * ((1 << 256) % R_MOD) % R_MOD).to_bytes(32, "little"), dtype=np.uint64).reshape(1, 4)
+        ks16 = kz.KZGSettings(fs16, fs16.generate_testing_setup_g1(sec, 65536))
+        fkm = kz.FK20MultiSettings(ks16, 65536, 16)
+        MB = args.fk20_multi_batch
+        mp_h = splitmix_blobs(5 + rank * MB, MB, n=32768)
+        d_mp = torch.from_numpy(mp_h.view(np.int64)).cuda()
+        d_mproofs = torch.zeros((MB, 4096, 18), dtype=torch.int64, device="cuda")
+
+        def fkm_step():
+            st = lib.kzg_hip_da_using_fk20_multi_batch_dev(fkm.h, d_mp.data_ptr(), 32768, MB, d_mproofs.data_ptr(), stream)
+            if st:
+                raise RuntimeError("da_using_fk20_multi_batch_dev status %d" % st)
+
+        msteps = max(1, args.steps // 2)
+        msecs = timed_steps(fkm_step, msteps, 1, torch.cuda.synchronize, barrier, max_over_ranks)
+        fk20m = {"metric": "FK20Multi all-coset-proofs/s (DAUsingFK20Multi, scale 16, chunk 16: 32768 coeffs -> 4096 proofs)",
+                 "value": MB * world * msteps / msecs, "batch_per_gpu": MB, "ms_per_all_proofs": msecs / msteps / MB * 1e3}
+        fkm.close(); ks16.close(); fs16.close()
+
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base = cpu_baseline()
@@ -235,7 +261,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "CommitToPoly, 4096-coeff blobs, eth/trusted_setup.json monomial setup (s=1337), %d blobs/step/GPU resident in HBM" % B,
                        "global_batch": B * world, "parallelism": "dp%d (independent blobs, no data-path collective)" % world},
-            "roofline": roofline, "cpu_baseline": base, "fk20": fk20,
+            "roofline": roofline, "cpu_baseline": base, "fk20": fk20, "fk20_multi": fk20m,
         }))
     if use_dist:
         dist.destroy_process_group()
