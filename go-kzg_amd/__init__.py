@@ -88,6 +88,9 @@ def lib():
         "kzg_hip_da_using_fk20_multi_batch_dev": (i32, [vp, vp, u64, u64, vp, vp]),
         "kzg_hip_fk20_multi_hext_slice_dev": (i32, [vp, vp, u64, u64, u64, vp, vp]),
         "kzg_hip_fk20_multi_finish_dev": (i32, [vp, vp, i32, vp, vp]),
+        "kzg_hip_eth_settings_new": (i32, [vp, vp, u64, pp]), "kzg_hip_eth_settings_free": (None, [vp]),
+        "kzg_hip_eth_blob_to_kzg_commitment_batch": (i32, [vp, vp, u64, vp, vp]),
+        "kzg_hip_eth_compute_kzg_proof": (i32, [vp, vp, u64, vp, vp, vp]),
         "kzg_hip_prof_reset": (None, [vp, i32]), "kzg_hip_prof_read": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64)]),
     }
     for name, (res, args) in sig.items():
@@ -371,3 +374,42 @@ class FK20MultiSettings:
         out = g1_empty(2 * poly.shape[0] // self.chunk_len)
         _chk(lib().kzg_hip_da_using_fk20_multi(self.h, _p(poly), poly.shape[0], _p(out)))
         return out
+
+
+class EthSettings:
+    """eth/ package state (eth/globals.go:39-72): bit-reversed Lagrange setup + bit-reversed domain, device resident."""
+
+    def __init__(self, fs, setup_g1_lagrange):
+        lag = _g1(setup_g1_lagrange)
+        h = C.c_void_p()
+        _chk(lib().kzg_hip_eth_settings_new(fs.h, _p(lag), lag.shape[0], C.byref(h)))
+        self.h, self.fs, self.n = h, fs, lag.shape[0]
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().kzg_hip_eth_settings_free(self.h)
+            self.h = None
+
+    def blob_to_kzg_commitment_batch(self, blobs):
+        """eth.BlobToKZGCommitment (eth/eth.go:145-151) on (batch, n, 32) uint8 little-endian blobs -> ((batch, 48) uint8, ok flags)"""
+        blobs = np.ascontiguousarray(blobs, dtype=np.uint8).reshape(-1, self.n, 32)
+        b = blobs.shape[0]
+        out, ok = np.zeros((b, 48), dtype=np.uint8), np.zeros(b, dtype=np.uint8)
+        _chk(lib().kzg_hip_eth_blob_to_kzg_commitment_batch(self.h, _p(blobs), b, _p(out), _p(ok)))
+        return out, ok.astype(bool)
+
+    def blob_to_kzg_commitment(self, blob):
+        out, ok = self.blob_to_kzg_commitment_batch(np.asarray(blob, dtype=np.uint8).reshape(1, self.n, 32))
+        return out[0], bool(ok[0])
+
+    def compute_kzg_proof(self, polynomial, z):
+        """eth.ComputeKZGProof (eth/helpers.go:179-203): returns (proof48, y); raises KzgError like the reference's errors"""
+        poly, z = _fr(polynomial), _fr(z)
+        out, y = np.zeros(48, dtype=np.uint8), fr_empty(1)
+        st = lib().kzg_hip_eth_compute_kzg_proof(self.h, _p(poly), poly.shape[0], _p(z), _p(out), _p(y))
+        if st == ERR_LEN_MISMATCH:
+            raise KzgError(st, "polynomial has invalid length")
+        if st == ERR_BAD_ARG:
+            raise KzgError(st, "invalid z challenge")
+        _chk(st)
+        return out, y[0]

@@ -771,6 +771,118 @@ int kzg_hip_fk20_multi_finish_dev(kzg_hip_fk20m *fk, const void *d_hext_g1, int 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// eth/ byte-level prover path (row f1)
+// ---------------------------------------------------------------------------------------------------------
+struct kzg_hip_eth {
+    kzg_hip_fft *fs = nullptr;
+    kzg_hip_kzg *ks = nullptr;     // "SecretG1" = bit-reversed Lagrange setup (kzgSetupLagrange, eth/globals.go:48)
+    uint64_t n = 0;
+    fr *d_domain = nullptr;        // DomainFr: w^bitrev(i) (eth/globals.go:61-66)
+};
+
+int kzg_hip_eth_settings_new(kzg_hip_fft *fs, const void *lagrange_g1, uint64_t n, kzg_hip_eth **out) {
+    if (!fs || !lagrange_g1 || !out) return KZG_HIP_ERR_BAD_ARG;
+    *out = nullptr;
+    if (n == 0 || !is_pow2(n)) return KZG_HIP_ERR_NOT_POW2;
+    if (n > fs->W) return KZG_HIP_ERR_TOO_WIDE;
+    std::vector<g1j> br(n);
+    const g1j *src = (const g1j *)lagrange_g1;
+    uint32_t logn = ilog2(n);
+    for (uint64_t i = 0; i < n; i++) {   // bitReversalPermutation (eth/helpers.go, used at eth/globals.go:48)
+        uint64_t r = 0;
+        for (uint32_t b = 0; b < logn; b++) if (i & (1ull << b)) r |= 1ull << (logn - 1 - b);
+        br[i] = src[r];
+    }
+    kzg_hip_eth *eth = new kzg_hip_eth;
+    eth->fs = fs; eth->n = n;
+    // KZGSettings requires len(setup) >= MaxWidth (kzg.go:25-27); the eth setup is exactly its own width, so build it directly
+    {
+        dev_guard g(fs);
+        hipStream_t s = fs->stream;
+        kzg_hip_kzg *ks = new kzg_hip_kzg;
+        ks->fs = fs; ks->n_setup = n;
+        dtmp<g1j> d_raw(s);
+        CHK(d_raw.alloc(n));
+        HIPCHK(hipMalloc((void **)&ks->d_secret, n * sizeof(g1j)));
+        HIPCHK(hipMalloc((void **)&ks->d_secret_a, n * sizeof(g1a)));
+        HIPCHK(hipMemcpyAsync(d_raw.p, br.data(), n * sizeof(g1j), hipMemcpyHostToDevice, s));
+        launch_g1_from_kilic(s, d_raw.p, n);
+        launch_g1_normalize(s, d_raw.p, ks->d_secret, n);
+        launch_g1_to_affine(s, ks->d_secret, ks->d_secret_a, n);
+        HIPCHK(hipMalloc((void **)&eth->d_domain, n * sizeof(fr)));
+        // natural-order scale-log2(n) domain = every (W / n)-th expanded root; DomainFr[i] = domain[bitrev(i)]
+        std::vector<fr> dom(n);
+        for (uint64_t i = 0; i < n; i++) {
+            uint64_t r = 0;
+            for (uint32_t b = 0; b < logn; b++) if (i & (1ull << b)) r |= 1ull << (logn - 1 - b);
+            dom[i] = fs->h_expanded[r * (fs->W / n)];
+        }
+        HIPCHK(hipMemcpyAsync(eth->d_domain, dom.data(), n * sizeof(fr), hipMemcpyHostToDevice, s));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s));
+        eth->ks = ks;
+    }
+    *out = eth;
+    return KZG_HIP_OK;
+}
+void kzg_hip_eth_settings_free(kzg_hip_eth *eth) {
+    if (!eth) return;
+    hipSetDevice(eth->fs->device);
+    hipFree(eth->d_domain);
+    kzg_hip_kzg_settings_free(eth->ks);
+    delete eth;
+}
+int kzg_hip_eth_blob_to_kzg_commitment_batch(kzg_hip_eth *eth, const void *blobs_le32, uint64_t batch, void *out48, uint8_t *ok) {
+    if (!eth || !blobs_le32 || !out48 || !ok) return KZG_HIP_ERR_BAD_ARG;
+    if (!batch) return KZG_HIP_OK;
+    dev_guard g(eth->fs);
+    hipStream_t s = eth->fs->stream;
+    uint64_t n = eth->n;
+    dtmp<uint8_t> d_in(s), d_c(s); dtmp<fr> d_poly(s); dtmp<g1j> d_out(s); dtmp<uint32_t> d_bad(s);
+    CHK(d_in.alloc(batch * n * 32)); CHK(d_c.alloc(batch * 48)); CHK(d_poly.alloc(batch * n)); CHK(d_out.alloc(batch)); CHK(d_bad.alloc(batch));
+    HIPCHK(hipMemsetAsync(d_bad.p, 0, batch * 4, s));
+    HIPCHK(hipMemcpyAsync(d_in.p, blobs_le32, batch * n * 32, hipMemcpyHostToDevice, s));
+    launch_fr_from_le32(s, d_in.p, d_poly.p, n, batch, d_bad.p);                 // BlobToPolynomial, eth/helpers.go:264-273
+    CHK(commit_rows(eth->ks, s, d_poly.p, n, batch, d_out.p));                  // PolynomialToKZGCommitment, eth/helpers.go:98-103
+    launch_g1_from_kilic(s, d_out.p, batch);                                    // commit_rows leaves Kilic images; compress wants internal
+    launch_g1_compress(s, d_out.p, d_c.p, batch);
+    HIPCHK(hipGetLastError());
+    std::vector<uint32_t> bad(batch);
+    HIPCHK(hipMemcpyAsync(bad.data(), d_bad.p, batch * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out48, d_c.p, batch * 48, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (uint64_t b = 0; b < batch; b++) {
+        ok[b] = bad[b] ? 0 : 1;
+        if (bad[b]) memset((uint8_t *)out48 + 48 * b, 0, 48);
+    }
+    return KZG_HIP_OK;
+}
+int kzg_hip_eth_compute_kzg_proof(kzg_hip_eth *eth, const void *poly_fr, uint64_t n, const void *z_fr, void *out48, void *y_fr) {
+    if (!eth || !poly_fr || !z_fr || !out48) return KZG_HIP_ERR_BAD_ARG;
+    if (n != eth->n) return KZG_HIP_ERR_LEN_MISMATCH;                            // "polynomial has invalid length", eth/helpers.go:186-188
+    dev_guard g(eth->fs);
+    hipStream_t s = eth->fs->stream;
+    dtmp<fr> d_poly(s), d_q(s), d_z(s); dtmp<g1j> d_out(s); dtmp<uint8_t> d_c(s); dtmp<uint32_t> d_flag(s);
+    CHK(d_poly.alloc(n)); CHK(d_q.alloc(n)); CHK(d_z.alloc(2)); CHK(d_out.alloc(1)); CHK(d_c.alloc(48)); CHK(d_flag.alloc(1));
+    HIPCHK(hipMemsetAsync(d_flag.p, 0, 4, s));
+    HIPCHK(hipMemcpyAsync(d_poly.p, poly_fr, n * sizeof(fr), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_z.p, z_fr, sizeof(fr), hipMemcpyHostToDevice, s));
+    launch_eth_quotient(s, d_poly.p, eth->d_domain, n, d_z.p, eth->fs->d_inv_pow2 + ilog2(n), d_q.p, d_z.p + 1, d_flag.p);
+    uint32_t flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, d_flag.p, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (flag) return KZG_HIP_ERR_BAD_ARG;                                        // "invalid z challenge", eth/helpers.go:190-192
+    CHK(commit_rows(eth->ks, s, d_q.p, n, 1, d_out.p));                          // eth/helpers.go:199
+    launch_g1_from_kilic(s, d_out.p, 1);
+    launch_g1_compress(s, d_out.p, d_c.p, 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out48, d_c.p, 48, hipMemcpyDeviceToHost, s));
+    if (y_fr) HIPCHK(hipMemcpyAsync(y_fr, d_z.p + 1, sizeof(fr), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return KZG_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // instrumentation
 // ---------------------------------------------------------------------------------------------------------
 void kzg_hip_prof_reset(kzg_hip_fft *fs, int enable) {

@@ -287,4 +287,67 @@ void launch_fr_powers(hipStream_t s, const fr *base, uint64_t n, fr *out) {
     hipLaunchKernelGGL(k_fr_powers, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, base, n, out);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// eth/ byte-level path.
+// bytes_to_bls_field / bls.FrFrom32 (eth/helpers.go:105-109, bls/bignum_kilic.go:33-44, bls.ValidFr bls/bignum_all.go:12-35):
+// 32 little-endian bytes -> Montgomery image, rejected (flag of the blob set) unless the value is < r.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_fr_from_le32(const uint8_t *in, fr *out, uint64_t per_blob, uint64_t total, uint32_t *bad) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    fr v = *reinterpret_cast<const fr *>(in + 32 * t);      // little-endian host == little-endian limbs
+    bool lt = false;
+    for (int i = 7; i >= 0; i--) { uint32_t m = FrP::mod(i); if (v.l[i] < m) { lt = true; break; } if (v.l[i] > m) break; }
+    if (!lt) { atomicOr(&bad[t / per_blob], 1u); out[t] = zero<FrP>(); return; }
+    out[t] = to_mont<FrP>(v);
+}
+void launch_fr_from_le32(hipStream_t s, const uint8_t *in, fr *out, uint64_t per_blob, uint64_t batch, uint32_t *bad) {
+    uint64_t total = per_blob * batch;
+    if (!total) return;
+    hipLaunchKernelGGL(k_fr_from_le32, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, in, out, per_blob, total, bad);
+}
+__global__ void k_fr_bitrev_gather(const fr *in, fr *out, uint32_t logn, uint64_t n) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    out[t] = in[bitrev32((uint32_t)t, logn)];
+}
+void launch_fr_bitrev_gather(hipStream_t s, const fr *in, fr *out, uint64_t n) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_fr_bitrev_gather, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, in, out, ilog2(n), n);
+}
+// ComputeKZGProof's field part (eth/helpers.go:179-198) with bls.EvaluatePolyInEvaluationForm (bls/globals.go:106-153):
+//   y = (z^n - 1) / n * sum_i p_i w_i / (z - w_i);   q_i = (p_i - y) / (w_i - z).
+// One workgroup; every lane inverts its own denominators (Fermat), LDS tree for the sum.  flag |= 1 if z is in the domain.
+__global__ __launch_bounds__(1024) void k_eth_quotient(const fr *poly, const fr *domain, uint64_t n, const fr *zp, const fr *inv_n, fr *q, fr *y_out,
+                                                       uint32_t *flag) {
+    __shared__ fr red[1024];
+    const uint32_t tid = threadIdx.x;
+    const fr z = *zp;
+    fr part = zero<FrP>();
+    for (uint64_t i = tid; i < n; i += 1024) {
+        fr d = sub(z, domain[i]);
+        if (is_zero<FrP>(d)) { atomicOr(flag, 1u); continue; }
+        fr di = inv<FrP>(d);
+        q[i] = di;                                             // stash 1 / (z - w_i)
+        part = add(part, mul(mul(poly[i], domain[i]), di));
+    }
+    red[tid] = part;
+    __syncthreads();
+    for (uint32_t off = 512; off >= 1; off >>= 1) {
+        if (tid < off) red[tid] = add(red[tid], red[tid + off]);
+        __syncthreads();
+    }
+    fr zn = z;                                                  // z^n, n a power of two
+    for (uint64_t m = 1; m < n; m <<= 1) zn = sqr(zn);
+    fr y = mul(mul(red[0], sub(zn, one<FrP>())), *inv_n);
+    if (tid == 0) *y_out = y;
+    for (uint64_t i = tid; i < n; i += 1024) {
+        fr di = q[i];
+        q[i] = neg<FrP>(mul(sub(poly[i], y), di));              // (p_i - y) / (w_i - z)
+    }
+}
+void launch_eth_quotient(hipStream_t s, const fr *poly, const fr *domain, uint64_t n, const fr *z, const fr *inv_n, fr *q, fr *y_out, uint32_t *flag) {
+    hipLaunchKernelGGL(k_eth_quotient, dim3(1), dim3(1024), 0, s, poly, domain, n, z, inv_n, q, y_out, flag);
+}
+
 }  // namespace kzg

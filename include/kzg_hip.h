@@ -116,6 +116,19 @@ int kzg_hip_da_using_fk20_multi_batch_dev(kzg_hip_fk20m *fk, const void *d_poly_
 int kzg_hip_fk20_multi_hext_slice_dev(kzg_hip_fk20m *fk, const void *d_poly_fr, uint64_t n, uint64_t j0, uint64_t cnt, void *d_out_g1, void *stream);
 int kzg_hip_fk20_multi_finish_dev(kzg_hip_fk20m *fk, const void *d_hext_g1, int bit_reverse, void *d_out_g1, void *stream);
 
+/* ---- eth/ byte-level prover path: eth/globals.go:39-72, eth/eth.go:145-151, eth/helpers.go:98-103,179-203,264-273 ----
+ * kzg_hip_eth_settings_new takes setup_G1_lagrange in NATURAL order (as eth/trusted_setup.json stores it) and applies the
+ * bit-reversal permutation of eth/globals.go:48 itself; DomainFr is the bit-reversed scale-log2(n) domain (:61-66). */
+typedef struct kzg_hip_eth kzg_hip_eth;
+int kzg_hip_eth_settings_new(kzg_hip_fft *fs, const void *lagrange_g1, uint64_t n, kzg_hip_eth **out);
+void kzg_hip_eth_settings_free(kzg_hip_eth *eth);
+/* BlobToKZGCommitment over `batch` blobs of n x 32 little-endian bytes: out48[b] = commitment, ok[b] = 1, or ok[b] = 0 when a
+ * field element is >= r (the reference returns (KZGCommitment{}, false): out48[b] is zeroed). */
+int kzg_hip_eth_blob_to_kzg_commitment_batch(kzg_hip_eth *eth, const void *blobs_le32, uint64_t batch, void *out48, uint8_t *ok);
+/* ComputeKZGProof (eth/helpers.go:179-203): polynomial in evaluation form (n Fr), z; writes the 48-byte proof and (optionally) y.
+ * KZG_HIP_ERR_LEN_MISMATCH: "polynomial has invalid length"; KZG_HIP_ERR_BAD_ARG: "invalid z challenge" (z in the domain). */
+int kzg_hip_eth_compute_kzg_proof(kzg_hip_eth *eth, const void *poly_fr, uint64_t n, const void *z_fr, void *out48, void *y_fr);
+
 /* ---- instrumentation for bench.py: HIP-event time of the dominant kernel since the last reset (ms) and launch count ---- */
 void kzg_hip_prof_reset(kzg_hip_fft *fs, int enable);
 int kzg_hip_prof_read(kzg_hip_fft *fs, const char *kernel, double *total_ms, uint64_t *launches);

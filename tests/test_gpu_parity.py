@@ -465,3 +465,45 @@ def test_fk20_multi_scale16_config5(kz):
         d = pyref.coset_proof_dlog(ai, S_TEST, x, l)
         assert ko.g1_equal(pa[pos], ko.g1_mul(gen, ko.fr_from_ints([d])[0])), pos
     fk.close(); ks.close(); fs.close()
+
+
+# ------------------------------------------------------------------ eth/ byte-level path
+def test_eth_blob_to_kzg_commitment_and_compute_kzg_proof(kz):
+    fs = kz.FFTSettings(12)
+    lag = ko.g1_decompress(np.frombuffer(open(os.path.join(GOLDEN, "trusted_setup_g1_lagrange.bin"), "rb").read(), dtype=np.uint8))
+    eth = kz.EthSettings(fs, lag)                              # eth/globals.go:39-72 (applies the bit reversal itself)
+    blob_i = ko.fr_to_ints(ko.synthetic_blob(1))
+    blob = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in blob_i), dtype=np.uint8).reshape(4096, 32)
+    c, ok = eth.blob_to_kzg_commitment(blob)                   # eth/eth.go:145-151
+    assert ok and c.tobytes().hex() == DERIVED["F_blob_seed1"]["commit_eth_bitrev_lagrange"]
+    # batch with an invalid blob: one element == r (bls.ValidFr, bls/bignum_all.go:12-35) -> (KZGCommitment{}, false)
+    bad = blob.copy()
+    bad[77] = np.frombuffer(ko.R_MOD.to_bytes(32, "little"), dtype=np.uint8)
+    edge = blob.copy()
+    edge[5] = np.frombuffer((ko.R_MOD - 1).to_bytes(32, "little"), dtype=np.uint8)
+    outs, oks = eth.blob_to_kzg_commitment_batch(np.stack([blob, bad, edge]))
+    assert list(oks) == [True, False, True]
+    assert outs[0].tobytes() == c.tobytes() and not outs[1].any()
+    edge_i = list(blob_i)
+    edge_i[5] = ko.R_MOD - 1
+    lag_br = ko.reverse_bit_order(lag)
+    assert outs[2].tobytes().hex() == comp_hex(ko.lincomb_g1(lag_br, ko.fr_from_ints(edge_i)))[0]
+    # ComputeKZGProof (eth/helpers.go:179-203) against the same formulas evaluated with Python integers + the oracle's MSM
+    R = ko.R_MOD
+    pfs = pyref.FFTSettings(12)
+    dom = [pfs.expanded[pyref.rev_bits(i, 12)] for i in range(4096)]          # DomainFr, eth/globals.go:61-66
+    z = 0x1234567890abcdef1234567890abcdef % R
+    coeffs = pfs.fft(pyref.bitrev(blob_i), inv=True)                          # evaluations are in bit-reversed order
+    y_ref = pyref.eval_poly(coeffs, z)
+    q = [(p - y_ref) * pow(w - z, -1, R) % R for p, w in zip(blob_i, dom)]
+    proof_ref = comp_hex(ko.lincomb_g1(lag_br, ko.fr_from_ints(q)))[0]
+    proof, y = eth.compute_kzg_proof(ko.fr_from_ints(blob_i), ko.fr_from_ints([z]))
+    assert ko.fr_to_ints(y)[0] == y_ref
+    assert proof.tobytes().hex() == proof_ref
+    d = (pyref.eval_poly(coeffs, 1337) - y_ref) * pow(1337 - z, -1, R) % R    # pairing-free VerifyKZGProof: s = 1337
+    assert proof.tobytes().hex() == comp_hex(ko.g1_mul(ko.g1_generator(), ko.fr_from_ints([d])[0]))[0]
+    with pytest.raises(kz.KzgError, match="invalid z challenge"):
+        eth.compute_kzg_proof(ko.fr_from_ints(blob_i), ko.fr_from_ints([dom[9]]))
+    with pytest.raises(kz.KzgError, match="invalid length"):
+        eth.compute_kzg_proof(ko.fr_from_ints(blob_i[:2048]), ko.fr_from_ints([z]))
+    eth.close(); fs.close()
