@@ -415,13 +415,13 @@ void kzg_hip_kzg_settings_free(kzg_hip_kzg *ks) {
 }
 
 // Lazily builds the fixed-base table T[(w n + i) D + d - 1] = d 2^(c w) SecretG1[i] (k_msm.hip).  The window size is the
-// largest whose table fits the HBM budget (KZG_HIP_FB_BUDGET_GB, default 12 of the 288 GB): n = 4096 -> c = 11, 9.7 GB.
+// largest whose table fits the HBM budget (KZG_HIP_FB_BUDGET_GB, default 40 of the 288 GB): n = 4096 -> c = 13, 32 GB, 20 windows.
 static int ensure_fixed_table(kzg_hip_kzg *ks, hipStream_t s) {
     if (ks->d_fixed || ks->fixed_plan.c == 0xffffffffu) return KZG_HIP_OK;
-    double budget_gb = 12.0;
+    double budget_gb = 40.0;
     if (const char *e = getenv("KZG_HIP_FB_BUDGET_GB")) budget_gb = atof(e);
     uint32_t best = 0;
-    for (uint32_t c = 12; c >= 5; c--) {
+    for (uint32_t c = 14; c >= 5; c--) {
         double bytes = (double)(255 / c + 1) * (double)ks->n_setup * (double)(1u << (c - 1)) * sizeof(g1a);
         if (bytes <= budget_gb * 1e9) { best = c; break; }
     }
@@ -554,11 +554,11 @@ static int fk20_core_new(kzg_hip_kzg *ks, uint64_t n2, uint64_t l, fk20_core *c)
     g1_fft_rows(fs, s, d_x.p, k, k, d_f.p, k2, l, 0);   // toeplitzPart1: FFTG1(x || inf^k), fk20_single.go:40-56
     launch_g1_normalize(s, d_f.p, c->d_files, l * k2);
     HIPCHK(hipGetLastError());
-    {   // fixed-base table over the file points, sized by KZG_HIP_FK20_FB_BUDGET_GB (default 8 GB of the 288)
-        double budget_gb = 8.0;
+    {   // fixed-base table over the file points, sized by KZG_HIP_FK20_FB_BUDGET_GB (default 24 GB of the 288)
+        double budget_gb = 24.0;
         if (const char *e = getenv("KZG_HIP_FK20_FB_BUDGET_GB")) budget_gb = atof(e);
         uint64_t npts = l * k2; uint32_t best = 0;
-        for (uint32_t cc = 11; cc >= 4; cc--) {
+        for (uint32_t cc = 12; cc >= 4; cc--) {
             double bytes = (double)(255 / cc + 1) * (double)npts * (double)(1u << (cc - 1)) * sizeof(g1a);
             if (bytes <= budget_gb * 1e9) { best = cc; break; }
         }

@@ -132,8 +132,8 @@ KZG_HD g1j g1_mul_windowed(const g1j &p, const fr &k, g1j *tbl) {
 // GLV: phi(x, y) = (beta x, y) acts on G1 as multiplication by lambda = z^2 - 1 (z the BLS12-381 parameter),
 // and lambda^2 + lambda + 1 = r, so k = k2 lambda + k1 with k1 = k mod lambda, k2 = k div lambda both < 2^128 and
 // non-negative.  k P = k1 P + k2 phi(P) with SHARED doublings: 128 instead of 256.
-// `kk` holds k1 in limbs 0..3 and k2 in limbs 4..7 (standard form).  Same 15-entry table as g1_mul_windowed;
-// phi of a table entry costs one F_p product by beta at lookup time.
+// `kk` holds k1 in limbs 0..3 and k2 in limbs 4..7 (standard form); phi of a table entry costs one F_p product by beta
+// at lookup time.
 // ---------------------------------------------------------------------------------------------
 KZG_HD fp glv_beta() {   // cube root of unity with phi(G) == lambda G (checked in tests/test_host_arith.py), radix-2^390 Montgomery
     const uint32_t t[12] = {0x9c907181u, 0xef2f7921u, 0xb26574c3u, 0x1bcc91d7u, 0x191c3ebcu, 0x856e7b9au,
@@ -143,17 +143,32 @@ KZG_HD fp glv_beta() {   // cube root of unity with phi(G) == lambda G (checked 
     for (int i = 0; i < 12; i++) b.l[i] = t[i];
     return b;
 }
+// 5-bit signed digit j of the 128-bit value in limbs l[base .. base + 3] (plus the incoming carry): digits in [-16, 16]
+KZG_HD int glv_digit5(const fr &kk, int base, int j, uint32_t &carry) {
+    int bit = 5 * j, w = bit >> 5, sh = bit & 31;
+    uint64_t v = 0;
+    if (w < 4) v = kk.l[base + w];
+    if (w + 1 < 4) v |= (uint64_t)kk.l[base + w + 1] << 32;
+    uint32_t raw = ((uint32_t)(v >> sh) & 31u) + carry;
+    if (raw > 16u) { carry = 1; return (int)raw - 32; }
+    carry = 0; return (int)raw;
+}
+// Signed 5-bit windows on both halves: 26 windows (130 doublings) and at most 52 additions from ONE 16-entry table
+// (tbl[i] = (i + 1) P); a negative digit negates Y, the k2 half multiplies X by beta.  Digits are produced LSB first
+// (carry propagation) into two packed arrays, then consumed MSB first.
 KZG_HD g1j g1_mul_glv(const g1j &p, const fr &kk, g1j *tbl) {
     tbl[0] = p;
-    for (int i = 1; i < 15; i++) tbl[i] = (i & 1) ? g1_dbl(tbl[i >> 1]) : g1_add(tbl[i - 1], p);   // tbl[i] = (i+1) P
+    for (int i = 1; i < 16; i++) tbl[i] = (i & 1) ? g1_dbl(tbl[i >> 1]) : g1_add(tbl[i - 1], p);   // tbl[i] = (i+1) P
+    int8_t d1[27], d2[27];
+    uint32_t c1 = 0, c2 = 0;
+    for (int j = 0; j < 27; j++) { d1[j] = (int8_t)glv_digit5(kk, 0, j, c1); d2[j] = (int8_t)glv_digit5(kk, 4, j, c2); }
     const fp beta = glv_beta();
     g1j acc = g1_inf();
-    for (int w = 31; w >= 0; w--) {
-        acc = g1_dbl(g1_dbl(g1_dbl(g1_dbl(acc))));
-        uint32_t d1 = (kk.l[w >> 3] >> ((w & 7) * 4)) & 15u;
-        uint32_t d2 = (kk.l[4 + (w >> 3)] >> ((w & 7) * 4)) & 15u;
-        if (d1) acc = g1_add(acc, tbl[d1 - 1]);
-        if (d2) { g1j q = tbl[d2 - 1]; q.x = mul(q.x, beta); acc = g1_add(acc, q); }
+    for (int j = 26; j >= 0; j--) {
+        acc = g1_dbl(g1_dbl(g1_dbl(g1_dbl(g1_dbl(acc)))));
+        int a = d1[j], b = d2[j];
+        if (a) { g1j q = tbl[(a < 0 ? -a : a) - 1]; if (a < 0) q.y = neg<FpP>(q.y); acc = g1_add(acc, q); }
+        if (b) { g1j q = tbl[(b < 0 ? -b : b) - 1]; if (b < 0) q.y = neg<FpP>(q.y); q.x = mul(q.x, beta); acc = g1_add(acc, q); }
     }
     return acc;
 }

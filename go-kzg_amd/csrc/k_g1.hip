@@ -95,7 +95,7 @@ __global__ __launch_bounds__(G1_BLOCK) void k_g1_fft_stage(g1j *data, uint32_t l
     uint64_t j = bf & (m - 1);
     uint64_t i0 = ((bf - j) << 1) + j, i1 = i0 + m;
     g1j y = row[i1];
-    if (j && !is_inf(y)) { g1j tbl[15]; y = g1_mul_glv(y, roots[j * (W / (2 * m))], tbl); }   // roots: (k1, k2) GLV pairs
+    if (j && !is_inf(y)) { g1j tbl[16]; y = g1_mul_glv(y, roots[j * (W / (2 * m))], tbl); }   // roots: (k1, k2) GLV pairs
     g1j x = row[i0];
     row[i0] = g1_add(x, y);
     row[i1] = g1_add(x, g1_neg(y));
