@@ -507,3 +507,63 @@ def test_eth_blob_to_kzg_commitment_and_compute_kzg_proof(kz):
     with pytest.raises(kz.KzgError, match="invalid length"):
         eth.compute_kzg_proof(ko.fr_from_ints(blob_i[:2048]), ko.fr_from_ints([z]))
     eth.close(); fs.close()
+
+
+# ------------------------------------------------------------------ host-buffer batch APIs, concurrency, C-level misuse
+def test_da_using_fk20_batch_host_buffers(kz, ks4096):
+    fk = kz.FK20SingleSettings(ks4096, 4096)
+    polys = np.stack([ko.synthetic_blob(40 + b)[:2048] for b in range(3)])
+    got = fk.da_using_fk20_batch(polys)
+    assert got.shape == (3, 4096, 3, 6)
+    for b in (0, 2):
+        assert np.array_equal(got[b], fk.da_using_fk20(polys[b]))
+    fk.close()
+
+
+def test_concurrent_callers_share_a_handle(kz, ks4096, setup_1337):
+    """the reference's settings are read-only after construction (SURVEY.md 8b threading); the library serialises per handle"""
+    import threading
+    blobs = [ko.synthetic_blob(60 + i) for i in range(4)]
+    want = [ks4096.commit_to_poly(b) for b in blobs]
+    got, errs = [None] * 4, []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                got[i] = ks4096.commit_to_poly(blobs[i])
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs
+    for i in range(4):
+        assert np.array_equal(got[i], want[i])
+
+
+def test_c_abi_misuse_returns_status_codes(kz):
+    import ctypes as C
+    L = kz.lib()
+    fs = kz.FFTSettings(4)
+    buf = ko.fr_empty(16)
+    assert L.kzg_hip_fft_fr(None, buf.ctypes.data, 16, 0, buf.ctypes.data, None) == kz.ERR_BAD_ARG
+    assert L.kzg_hip_fft_fr(fs.h, None, 16, 0, buf.ctypes.data, None) == kz.ERR_BAD_ARG
+    assert L.kzg_hip_fft_g1(fs.h, buf.ctypes.data, 0, 0, buf.ctypes.data) == kz.ERR_BAD_ARG      # reference divides by zero (fft_g1.go:76)
+    assert L.kzg_hip_inplace_fft_fr(fs.h, buf.ctypes.data, buf.ctypes.data, 0, 0) == kz.OK       # IsPowerOfTwo(0) is true (bls/globals.go:72-74)
+    h = C.c_void_p()
+    assert L.kzg_hip_fft_settings_new(99, 4, C.byref(h)) == kz.ERR_NO_DEVICE
+    assert L.kzg_hip_fft_settings_new(0, 40, C.byref(h)) == kz.ERR_BAD_ARG
+    ks = kz.KZGSettings(fs, ko.generate_testing_setup_g1(S_TEST, 17))
+    out = ko.g1_empty(1)
+    assert L.kzg_hip_commit_to_poly(ks.h, buf.ctypes.data, 18, out.ctypes.data) == kz.ERR_LEN_MISMATCH   # SecretG1[:18] out of range
+    assert L.kzg_hip_compute_proof_single(ks.h, buf.ctypes.data, 1, 17, out.ctypes.data) == kz.ERR_BAD_ARG
+    with pytest.raises(kz.KzgPanic):
+        kz.FK20SingleSettings(ks, 64)                                                                  # kzg.go:44-46
+    with pytest.raises(kz.KzgPanic):
+        kz.FK20SingleSettings(ks, 12)                                                                  # kzg.go:47-49
+    fk = kz.FK20SingleSettings(ks, 16)
+    with pytest.raises(kz.KzgPanic) as e:
+        fk.da_using_fk20(ko.fr_from_ints(range(4)))                                                     # settings built for n2 = 16
+    assert e.value.status == kz.ERR_LEN_MISMATCH
+    fk.close(); ks.close(); fs.close()
