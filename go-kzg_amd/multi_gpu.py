@@ -65,3 +65,15 @@ def da_using_fk20_multi_sharded(backend, d_poly, n, k2, group=None):
             dist.all_gather(bufs, mine.contiguous(), group=group)
             hext = torch.cat(bufs)
     return backend.finish(hext, bit_reverse=True)
+
+
+def all_gather_proofs(d_proofs, group=None):
+    """Data-parallel FK20: every rank holds the proofs of ITS blobs (batch_r x m x 18 int64 = 144-byte points); one RCCL
+    all-gather of bytes over xGMI gives every rank the proofs of all blobs, rank-major.  (The "all-gather of proof points"
+    of the north star; 48-byte compressed form works the same way on uint8 tensors.)"""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return d_proofs
+    world = dist.get_world_size(group)
+    out = torch.empty((world * d_proofs.shape[0],) + tuple(d_proofs.shape[1:]), dtype=d_proofs.dtype, device=d_proofs.device)
+    dist.all_gather_into_tensor(out, d_proofs.contiguous(), group=group)
+    return out

@@ -567,3 +567,33 @@ def test_c_abi_misuse_returns_status_codes(kz):
         fk.da_using_fk20(ko.fr_from_ints(range(4)))                                                     # settings built for n2 = 16
     assert e.value.status == kz.ERR_LEN_MISMATCH
     fk.close(); ks.close(); fs.close()
+
+
+# ------------------------------------------------------------------ BASELINE config 4b: FK20Single, full 4096-coefficient blob
+def test_fk20_single_scale13_config4b(kz):
+    """FK20Single (fk20_single.go:122-134) on a full 4096-coefficient blob needs scale 13 and an 8192-point setup
+    (GenerateTestingSetup with the reference's test secret, generated on the device).  out[i] is the proof at w_4096^i."""
+    n = 4096
+    fs = kz.FFTSettings(13)
+    setup = fs.generate_testing_setup_g1(ko.fr_from_ints([S_TEST]), 8192)
+    ks = kz.KZGSettings(fs, setup)
+    fk = kz.FK20SingleSettings(ks, 2 * n)
+    blob = ko.synthetic_blob(1)
+    poly_i = ko.fr_to_ints(blob)
+    proofs = fk.fk20_single(blob)
+    assert proofs.shape == (n, 3, 6)
+    w = pyref.root_of_unity(12)
+    gen = ko.g1_generator()
+    for i in (0, 1, 2, 1234, 4095):
+        d = pyref.single_proof_dlog(poly_i, S_TEST, pow(w, i, ko.R_MOD))
+        assert ko.g1_equal(proofs[i], ko.g1_mul(gen, ko.fr_from_ints([d])[0])), i
+    # ... and equals ComputeProofSingle at an integer point as a cross-check of the same settings
+    assert ko.g1_equal(ks.compute_proof_single(blob, 17), ko.g1_mul(gen, ko.fr_from_ints([pyref.single_proof_dlog(poly_i, S_TEST, 17)])[0]))
+    # DA form on the same settings: 4096 coefficients -> 8192 proofs, sample + linearity
+    pa = fk.da_using_fk20(blob)
+    assert pa.shape == (2 * n, 3, 6)
+    w2 = pyref.root_of_unity(13)
+    for pos in (0, 3, 8191):
+        d = pyref.single_proof_dlog(poly_i, S_TEST, pow(w2, pyref.rev_bits(pos, 13), ko.R_MOD))
+        assert ko.g1_equal(pa[pos], ko.g1_mul(gen, ko.fr_from_ints([d])[0])), pos
+    fk.close(); ks.close(); fs.close()

@@ -61,6 +61,9 @@ def _worker(rank, world, port, q):
     got = multi_gpu.da_using_fk20_multi_sharded(be, torch.from_numpy(poly.view(np.int64).copy()), n2 // 2, be.k2)
     want = ko.g1_affine(be.fk.da_using_fk20_multi(poly))
     ok = np.array_equal(got.numpy().view(np.uint64).reshape(-1, 3, 6), want)
+    mine = torch.full((3, 2, 18), rank, dtype=torch.int64)
+    allp = multi_gpu.all_gather_proofs(mine)
+    ok = ok and allp.shape == (6, 2, 18) and bool((allp[:3] == 0).all()) and bool((allp[3:] == 1).all())
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
