@@ -77,6 +77,8 @@ def lib():
         "kzg_hip_commit_to_poly": (i32, [vp, vp, u64, vp]), "kzg_hip_commit_to_poly_batch": (i32, [vp, vp, u64, u64, vp]),
         "kzg_hip_commit_to_poly_batch_dev": (i32, [vp, vp, u64, u64, vp, vp]),
         "kzg_hip_compute_proof_single": (i32, [vp, vp, u64, u64, vp]),
+        "kzg_hip_compute_proof_multi": (i32, [vp, vp, u64, u64, u64, vp]),
+        "kzg_hip_check_proof_multi_interpolation": (i32, [vp, vp, u64, vp, vp, vp]),
         "kzg_hip_toeplitz_part2": (i32, [vp, vp, vp, u64, vp]), "kzg_hip_toeplitz_part3": (i32, [vp, vp, u64, vp]),
         "kzg_hip_fk20_single_settings_new": (i32, [vp, u64, pp]), "kzg_hip_fk20_single_settings_free": (None, [vp]),
         "kzg_hip_fk20_single_x_ext_fft": (i32, [vp, vp]), "kzg_hip_fk20_single": (i32, [vp, vp, u64, vp]),
@@ -284,6 +286,20 @@ class KZGSettings:
         out = g1_empty(1)
         _chk(lib().kzg_hip_compute_proof_single(self.h, _p(poly), poly.shape[0], x, _p(out)))
         return out[0]
+
+    def compute_proof_multi(self, poly, x, n):
+        """KZGSettings.ComputeProofMulti (kzg_multi_proofs.go:13-43), reference quirk (divisor X^n) included"""
+        poly = _fr(poly)
+        out = g1_empty(1)
+        _chk(lib().kzg_hip_compute_proof_multi(self.h, _p(poly), poly.shape[0], x, n, _p(out)))
+        return out[0]
+
+    def check_proof_multi_interpolation(self, ys, x):
+        """prover-side half of KZGSettings.CheckProofMulti (kzg_multi_proofs.go:47-75): ([I(s)]_1, x^n)"""
+        ys, x = _fr(ys), _fr(x)
+        out, xp = g1_empty(1), fr_empty(1)
+        _chk(lib().kzg_hip_check_proof_multi_interpolation(self.h, _p(ys), ys.shape[0], _p(x), _p(out), _p(xp)))
+        return out[0], xp[0]
 
     def toeplitz_part2(self, toeplitz_coeffs, x_ext_fft):
         toeplitz_coeffs, x_ext_fft = _fr(toeplitz_coeffs), _g1(x_ext_fft)

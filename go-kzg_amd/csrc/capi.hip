@@ -502,6 +502,33 @@ int kzg_hip_compute_proof_single(kzg_hip_kzg *ks, const void *poly_fr, uint64_t 
     return KZG_HIP_OK;
 }
 
+int kzg_hip_compute_proof_multi(kzg_hip_kzg *ks, const void *poly_fr, uint64_t len, uint64_t x, uint64_t n, void *out_g1) {
+    (void)x;   // the reference multiplies a zero-initialised xPowN by x n times (kzg_multi_proofs.go:20-24): it stays zero
+    if (!ks || !poly_fr || !out_g1 || len < n + 1) return KZG_HIP_ERR_BAD_ARG;
+    uint64_t nq = len - n;                                   // polyLongDiv by X^n: quotient = poly[n:] (poly.go:14-40)
+    if (nq > ks->n_setup) return KZG_HIP_ERR_LEN_MISMATCH;  // SecretG1[:len(quotient)], kzg_multi_proofs.go:42
+    return kzg_hip_commit_to_poly(ks, (const uint8_t *)poly_fr + n * sizeof(fr), nq, out_g1);
+}
+int kzg_hip_check_proof_multi_interpolation(kzg_hip_kzg *ks, const void *ys_fr, uint64_t n, const void *x_fr, void *out_is1_g1, void *out_xpow_fr) {
+    if (!ks || !ys_fr || !x_fr || !out_is1_g1 || n == 0) return KZG_HIP_ERR_BAD_ARG;
+    kzg_hip_fft *fs = ks->fs;
+    if (n > fs->W) return KZG_HIP_ERR_TOO_WIDE;              // "ys is bad, cannot compute FFT" panic, kzg_multi_proofs.go:50-53
+    uint64_t np = next_pow2(n);
+    if (np > ks->n_setup) return KZG_HIP_ERR_LEN_MISMATCH;
+    dev_guard g(fs);
+    hipStream_t s = fs->stream;
+    dtmp<fr> d_ys(s), d_ip(s), d_x(s); dtmp<g1j> d_out(s);
+    CHK(d_ys.alloc(n)); CHK(d_ip.alloc(np)); CHK(d_x.alloc(2)); CHK(d_out.alloc(1));
+    HIPCHK(hipMemcpyAsync(d_ys.p, ys_fr, n * sizeof(fr), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_x.p, x_fr, sizeof(fr), hipMemcpyHostToDevice, s));
+    fr_fft_rows(fs, s, d_ys.p, n, n, d_ip.p, np, 1, 1);
+    launch_fr_scale_by_inv_powers(s, d_ip.p, d_x.p, np, d_x.p + 1);
+    CHK(commit_rows(ks, s, d_ip.p, np, 1, d_out.p));
+    HIPCHK(hipMemcpyAsync(out_is1_g1, d_out.p, sizeof(g1j), hipMemcpyDeviceToHost, s));
+    if (out_xpow_fr) HIPCHK(hipMemcpyAsync(out_xpow_fr, d_x.p + 1, sizeof(fr), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return KZG_HIP_OK;
+}
 int kzg_hip_toeplitz_part2(kzg_hip_kzg *ks, const void *coeffs_fr, const void *x_ext_fft_g1, uint64_t n, void *out_g1) {
     if (!ks || !coeffs_fr || !x_ext_fft_g1 || !out_g1) return KZG_HIP_ERR_BAD_ARG;
     kzg_hip_fft *fs = ks->fs;

@@ -31,6 +31,8 @@ void launch_fr_from_le32(hipStream_t s, const uint8_t *in, fr *out, uint64_t per
 void launch_fr_bitrev_gather(hipStream_t s, const fr *in, fr *out, uint64_t n);
 void launch_eth_quotient(hipStream_t s, const fr *poly, const fr *domain, uint64_t n, const fr *z, const fr *inv_n, fr *q, fr *y_out, uint32_t *flag);
 
+void launch_fr_scale_by_inv_powers(hipStream_t s, fr *c, const fr *x, uint64_t n, fr *xpow_n);   // c_i /= x^i; *xpow_n = x^n
+
 // ---------------- k_g1.hip ----------------
 // out[i] = scalars[i * s_stride] * pts[(i % pts_mod)]   (element-wise bls.MulG1; scalars in Montgomery form)
 void launch_g1_mul_vec(hipStream_t s, const g1j *pts, uint64_t pts_mod, const fr *scalars, uint64_t s_stride, uint64_t n, g1j *out);

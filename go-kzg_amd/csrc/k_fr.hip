@@ -350,4 +350,23 @@ void launch_eth_quotient(hipStream_t s, const fr *poly, const fr *domain, uint64
     hipLaunchKernelGGL(k_eth_quotient, dim3(1), dim3(1024), 0, s, poly, domain, n, z, inv_n, q, y_out, flag);
 }
 
+// CheckProofMulti's coefficient scaling (kzg_multi_proofs.go:55-66): c_i <- c_i / x^i.  Lane i computes x^-i by
+// square-and-multiply on the once-inverted x (the reference inverts x^i afresh for every i).
+__global__ void k_fr_scale_by_inv_powers(fr *c, const fr *x, uint64_t n, fr *xpow_n) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    fr xi = inv<FrP>(*x), acc = one<FrP>(), pw = xi;
+    for (uint64_t e = t; e; e >>= 1) { if (e & 1) acc = mul(acc, pw); pw = sqr(pw); }
+    c[t] = mul(c[t], acc);
+    if (t == 0 && xpow_n) {
+        fr a = one<FrP>(), p2 = *x;
+        for (uint64_t e = n; e; e >>= 1) { if (e & 1) a = mul(a, p2); p2 = sqr(p2); }
+        *xpow_n = a;
+    }
+}
+void launch_fr_scale_by_inv_powers(hipStream_t s, fr *c, const fr *x, uint64_t n, fr *xpow_n) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_fr_scale_by_inv_powers, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, c, x, n, xpow_n);
+}
+
 }  // namespace kzg

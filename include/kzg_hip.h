@@ -91,6 +91,14 @@ int kzg_hip_compute_proof_single(kzg_hip_kzg *ks, const void *poly_fr, uint64_t 
 int kzg_hip_toeplitz_part2(kzg_hip_kzg *ks, const void *coeffs_fr, const void *x_ext_fft_g1, uint64_t n, void *out_g1);
 int kzg_hip_toeplitz_part3(kzg_hip_kzg *ks, const void *h_ext_fft_g1, uint64_t n, void *out_g1);
 
+/* ---- KZG multi proofs, prover side (kzg_multi_proofs.go) ----
+ * KZGSettings.ComputeProofMulti (kzg_multi_proofs.go:13-43).  The reference never initialises xPowN (:20-24), so its divisor is
+ * X^n rather than X^n - x^n and the quotient is poly[n:]; reproduced faithfully (the result is a valid proof while len <= 2n). */
+int kzg_hip_compute_proof_multi(kzg_hip_kzg *ks, const void *poly_fr, uint64_t len, uint64_t x, uint64_t n, void *out_g1);
+/* prover-side half of CheckProofMulti (kzg_multi_proofs.go:47-75): commitment to the interpolation polynomial on x * <w_n>
+ * ([I(s)]_1 = LinCombG1(SecretG1, IFFT(ys)_i / x^i)) and x^n; the pairing stays with the verifier's CPU backend. */
+int kzg_hip_check_proof_multi_interpolation(kzg_hip_kzg *ks, const void *ys_fr, uint64_t n, const void *x_fr, void *out_is1_g1, void *out_xpow_fr);
+
 /* ---- FK20 single (kzg.go:43-64; fk20_single.go:122-196) ---- */
 int kzg_hip_fk20_single_settings_new(kzg_hip_kzg *ks, uint64_t n2, kzg_hip_fk20s **out);
 void kzg_hip_fk20_single_settings_free(kzg_hip_fk20s *fk);

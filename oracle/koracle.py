@@ -55,6 +55,8 @@ def lib():
             "ko_commit_to_poly": (i32, [vp, u64, vp, u64, vp]),
             "ko_compute_proof_single": (i32, [vp, u64, vp, u64, u64, vp]),
             "ko_poly_quotient_linear": (None, [vp, u64, u64, vp]),
+            "ko_compute_proof_multi": (i32, [vp, u64, vp, u64, u64, u64, vp]),
+            "ko_check_proof_multi_interpolation": (i32, [vp, vp, u64, vp, u64, vp, vp, vp]),
             "ko_toeplitz_part2": (i32, [vp, vp, vp, u64, vp]), "ko_toeplitz_part3": (i32, [vp, vp, u64, vp]),
             "ko_toeplitz_coeffs_step_strided": (None, [vp, u64, u64, u64, vp]),
             "ko_fk20_single_new": (vp, [vp, vp, u64, u64, vp]), "ko_fk20_single_free": (None, [vp]),
@@ -302,6 +304,21 @@ class KZGSettings:
         o = g1_empty(1)
         _chk(lib().ko_compute_proof_single(_p(self.secret_g1), self.secret_g1.shape[0], _p(poly), poly.shape[0], x, _p(o)))
         return o[0]
+
+    def compute_proof_multi(self, poly, x, n):
+        """ComputeProofMulti (kzg_multi_proofs.go:13-43), including the reference's xPowN quirk"""
+        poly = np.ascontiguousarray(poly, dtype=np.uint64).reshape(-1, 4)
+        o = g1_empty(1)
+        _chk(lib().ko_compute_proof_multi(_p(self.secret_g1), self.secret_g1.shape[0], _p(poly), poly.shape[0], x, n, _p(o)))
+        return o[0]
+
+    def check_proof_multi_interpolation(self, ys, x):
+        """prover-side half of CheckProofMulti (kzg_multi_proofs.go:47-75): ([I(s)]_1, x^n)"""
+        ys = np.ascontiguousarray(ys, dtype=np.uint64).reshape(-1, 4)
+        x = np.ascontiguousarray(x, dtype=np.uint64).reshape(1, 4)
+        o, xp = g1_empty(1), fr_empty(1)
+        _chk(lib().ko_check_proof_multi_interpolation(self.fs.h, _p(self.secret_g1), self.secret_g1.shape[0], _p(ys), ys.shape[0], _p(x), _p(o), _p(xp)))
+        return o[0], xp[0]
 
     def toeplitz_part2(self, coeffs, x_ext_fft):
         coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)

@@ -554,6 +554,34 @@ API void ko_poly_quotient_linear(const fr_t *poly, u64 n, u64 x, fr_t *q_out) { 
     memcpy(q_out, q, nq * sizeof(fr_t)); free(q);
 }
 
+/* ComputeProofMulti (kzg_multi_proofs.go:13-43).  NOTE the reference never initialises xPowN to ONE (:20-24), so the loop
+ * leaves it at zero and the divisor is X^n, not X^n - x^n; restated faithfully. */
+API int ko_compute_proof_multi(const g1_t *secret_g1, u64 n_setup, const fr_t *poly, u64 len, u64 x, u64 n, g1_t *out) {
+    if (len < n + 1) return KO_ERR_BAD_ARG;
+    fr_t *divisor = calloc(n + 1, sizeof(fr_t));
+    fr_t xf, xpown, tmp, zero; memset(&zero, 0, sizeof zero); memset(&xpown, 0, sizeof xpown);
+    fr_from_u64(&xf, x);
+    for (u64 i = 0; i < n; i++) { fr_mul(&tmp, &xpown, &xf); xpown = tmp; }
+    fr_sub(&divisor[0], &zero, &xpown);
+    divisor[n] = FR_ONE;
+    u64 nq; fr_t *q = poly_long_div(poly, len, divisor, n + 1, &nq);
+    int s = nq > n_setup ? KO_ERR_LEN_MISMATCH : ko_lincomb_g1(out, secret_g1, q, nq);
+    free(q); free(divisor); return s;
+}
+/* prover-side part of CheckProofMulti (kzg_multi_proofs.go:47-75): interpolation polynomial on the coset x * <w_n>
+ * (IFFT of ys, coefficient i divided by x^i), its commitment [I(s)]_1, and x^n.  The pairing itself is out of scope. */
+API int ko_check_proof_multi_interpolation(const ko_fft_t *fs, const g1_t *secret_g1, u64 n_setup, const fr_t *ys, u64 n, const fr_t *x,
+                                           g1_t *is1, fr_t *xpow_out) {
+    fr_t *ip = malloc(next_pow2(n) * sizeof(fr_t)); u64 np;
+    int s = ko_fft_fr(fs, ys, n, 1, ip, &np);
+    if (s) { free(ip); return s; }
+    fr_t xpow = FR_ONE, tmp;
+    for (u64 i = 0; i < np; i++) { fr_inv(&tmp, &xpow); fr_mul(&ip[i], &ip[i], &tmp); fr_mul(&xpow, &xpow, x); }
+    if (xpow_out) *xpow_out = xpow;
+    s = np > n_setup ? KO_ERR_LEN_MISMATCH : ko_lincomb_g1(is1, secret_g1, ip, np);
+    free(ip); return s;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * FK20 (kzg.go:38-116, fk20_single.go, fk20_multi.go)
  * ---------------------------------------------------------------------------------------------- */

@@ -597,3 +597,30 @@ def test_fk20_single_scale13_config4b(kz):
         d = pyref.single_proof_dlog(poly_i, S_TEST, pow(w2, pyref.rev_bits(pos, 13), ko.R_MOD))
         assert ko.g1_equal(pa[pos], ko.g1_mul(gen, ko.fr_from_ints([d])[0])), pos
     fk.close(); ks.close(); fs.close()
+
+
+# ------------------------------------------------------------------ KZG multi proofs, prover side
+def test_compute_proof_multi_and_interpolation_commitment(kz):
+    fs = kz.FFTSettings(4)
+    setup = ko.generate_testing_setup_g1(S_TEST, 17)
+    ks, oks = kz.KZGSettings(fs, setup), ko.KZGSettings(ko.FFTSettings(4), setup)
+    poly = ko.fr_from_ints(TEST_POLY)
+    assert_points_equal(ks.compute_proof_multi(poly, 5431, 8), oks.compute_proof_multi(poly, 5431, 8))   # kzg_multi_proofs_test.go:46
+    fs3 = kz.FFTSettings(3)
+    setup9 = ko.generate_testing_setup_g1(S_TEST, 9)
+    ks8, oks8 = kz.KZGSettings(fs3, setup9), ko.KZGSettings(ko.FFTSettings(3), setup9)
+    w8 = pyref.root_of_unity(3)
+    ys = ko.fr_from_ints([pyref.eval_poly(TEST_POLY, 5431 * pow(w8, i, ko.R_MOD) % ko.R_MOD) for i in range(8)])
+    x = ko.fr_from_ints([5431])
+    is1, xpow = ks8.check_proof_multi_interpolation(ys, x)
+    o_is1, o_xpow = oks8.check_proof_multi_interpolation(ys, x[0])
+    assert_points_equal(is1, o_is1)
+    assert np.array_equal(xpow, o_xpow)
+    # full size: 4096 coefficients, coset of 16
+    fs12 = kz.FFTSettings(12)
+    raw = np.frombuffer(open(os.path.join(GOLDEN, "trusted_setup_g1.bin"), "rb").read(), dtype=np.uint8)
+    s1337 = ko.g1_decompress(raw)
+    ksb = kz.KZGSettings(fs12, s1337)
+    blob = ko.synthetic_blob(21)
+    assert_points_equal(ksb.compute_proof_multi(blob, 99, 16), ko.lincomb_g1(s1337[:4080], blob[16:]))
+    ksb.close(); ks8.close(); ks.close(); fs12.close(); fs3.close(); fs.close()

@@ -302,3 +302,29 @@ def test_error_codes():
     with pytest.raises(ko.OracleError) as e:
         fk.fk20_single_da_optimized(bad)  # fk20_single.go:150-154
     assert e.value.status == ko.ERR_UPPER_HALF
+
+
+def test_check_proof_multi_scenario():
+    """TestKZGSettings_CheckProofMulti (kzg_multi_proofs_test.go:12-51) with the pairing replaced by the dlog identity
+    (p(s) - I(s)) == pi * (s^n - x^n): holds for the reference's quirky ComputeProofMulti because len(poly) <= 2n."""
+    fs = ko.FFTSettings(4)
+    ks = ko.KZGSettings(fs, ko.generate_testing_setup_g1(S_TEST, 17))
+    poly = ko.fr_from_ints(TEST_POLY)
+    x, n = 5431, 8
+    proof = ks.compute_proof_multi(poly, x, n)
+    assert ko.g1_equal(proof, ko.lincomb_g1(ks.secret_g1[:8], poly[8:]))          # divisor X^n: quotient = poly[n:]
+    ks8 = ko.KZGSettings(ko.FFTSettings(3), ko.generate_testing_setup_g1(S_TEST, 9))
+    w8 = pyref.root_of_unity(3)
+    ys_i = [pyref.eval_poly(TEST_POLY, x * pow(w8, i, ko.R_MOD) % ko.R_MOD) for i in range(n)]
+    is1, xpow = ks8.check_proof_multi_interpolation(ko.fr_from_ints(ys_i), ko.fr_from_ints([x])[0])
+    assert ko.fr_to_ints(xpow.reshape(1, 4))[0] == pow(x, n, ko.R_MOD)
+    R = ko.R_MOD
+    xl = pow(x, n, R)
+    rem = list(TEST_POLY)
+    for i in range(15, n - 1, -1):
+        rem[i - n] = (rem[i - n] + rem[i] * xl) % R
+    i_s = pyref.eval_poly(rem[:n], S_TEST)
+    gen = ko.g1_generator()
+    assert ko.g1_equal(is1, ko.g1_mul(gen, ko.fr_from_ints([i_s])[0]))
+    pi = pyref.eval_poly(TEST_POLY[8:], S_TEST)
+    assert (pyref.eval_poly(TEST_POLY, S_TEST) - i_s) % R == pi * (pow(S_TEST, n, R) - xl) % R
