@@ -24,7 +24,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libkzg_hip.so")
 
-OK, ERR_TOO_WIDE, ERR_NOT_POW2, ERR_LEN_MISMATCH, ERR_UPPER_HALF, ERR_BAD_ARG, ERR_BAD_POINT, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED = range(10)
+OK, ERR_TOO_WIDE, ERR_NOT_POW2, ERR_LEN_MISMATCH, ERR_UPPER_HALF, ERR_BAD_ARG, ERR_BAD_POINT, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_RECOVERY = range(11)
 
 
 class KzgError(Exception):
@@ -93,6 +93,8 @@ def lib():
         "kzg_hip_eth_settings_new": (i32, [vp, vp, u64, pp]), "kzg_hip_eth_settings_free": (None, [vp]),
         "kzg_hip_eth_blob_to_kzg_commitment_batch": (i32, [vp, vp, u64, vp, vp]),
         "kzg_hip_eth_compute_kzg_proof": (i32, [vp, vp, u64, vp, vp, vp]),
+        "kzg_hip_zero_poly_via_multiplication": (i32, [vp, vp, u64, u64, vp, vp]),
+        "kzg_hip_recover_poly_from_samples": (i32, [vp, vp, vp, u64, vp]),
         "kzg_hip_prof_reset": (None, [vp, i32]), "kzg_hip_prof_read": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64)]),
     }
     for name, (res, args) in sig.items():
@@ -212,6 +214,24 @@ class FFTSettings:
         vals = np.ascontiguousarray(vals, dtype=np.uint64).copy()
         _chk(lib().kzg_hip_das_fft_extension_batch(self.h, _p(vals), vals.shape[1], vals.shape[0]))
         return vals
+
+    def zero_poly_via_multiplication(self, missing_indices, length):
+        """FFTSettings.ZeroPolyViaMultiplication (zero_poly.go:116-217): (zero_eval, zero_poly)"""
+        mi = np.ascontiguousarray(missing_indices, dtype=np.uint64)
+        ze, zp = fr_empty(length), fr_empty(length)
+        _chk(lib().kzg_hip_zero_poly_via_multiplication(self.h, _p(mi), mi.shape[0], length, _p(ze), _p(zp)))
+        return ze, zp
+
+    def recover_poly_from_samples(self, samples, present):
+        """FFTSettings.RecoverPolyFromSamples (recover_from_samples.go:42-109); present[i] False <=> samples[i] is nil"""
+        samples = _fr(samples)
+        present = np.ascontiguousarray(present, dtype=np.uint8)
+        out = fr_empty(samples.shape[0])
+        st = lib().kzg_hip_recover_poly_from_samples(self.h, _p(samples), _p(present), samples.shape[0], _p(out))
+        if st == ERR_RECOVERY:
+            raise KzgError(st, "failed to reconstruct data correctly")
+        _chk(st, error_ok=True)
+        return out
 
     # ---- bls.* batch helpers that need a device context ----
     def lin_comb_g1(self, numbers, factors):

@@ -33,6 +33,11 @@ void launch_eth_quotient(hipStream_t s, const fr *poly, const fr *domain, uint64
 
 void launch_fr_scale_by_inv_powers(hipStream_t s, fr *c, const fr *x, uint64_t n, fr *xpow_n);   // c_i /= x^i; *xpow_n = x^n
 
+// erasure recovery
+void launch_zero_eval_direct(hipStream_t s, const fr *expanded, uint64_t stride, const uint64_t *missing, uint64_t n_missing, uint64_t length, fr *zero_eval);
+void launch_fr_scale_by_powers(hipStream_t s, fr *poly, const fr *base, uint64_t n);
+void launch_fr_pointwise(hipStream_t s, const fr *a, const fr *b, const uint8_t *present, fr *out, uint64_t n, int mode, uint32_t *flag);
+
 // ---------------- k_g1.hip ----------------
 // out[i] = scalars[i * s_stride] * pts[(i % pts_mod)]   (element-wise bls.MulG1; scalars in Montgomery form)
 void launch_g1_mul_vec(hipStream_t s, const g1j *pts, uint64_t pts_mod, const fr *scalars, uint64_t s_stride, uint64_t n, g1j *out);

@@ -36,6 +36,7 @@ extern "C" {
 #define KZG_HIP_ERR_NO_DEVICE 7     /* no gfx950 device visible: the library has NO CPU fallback */
 #define KZG_HIP_ERR_HIP 8           /* HIP runtime error, see kzg_hip_last_error() */
 #define KZG_HIP_ERR_UNSUPPORTED 9
+#define KZG_HIP_ERR_RECOVERY 10      /* "failed to reconstruct data correctly" (recover_from_samples.go:103-107) */
 
 typedef struct kzg_hip_fft kzg_hip_fft;                 /* *kzg.FFTSettings         fft.go:34-42   */
 typedef struct kzg_hip_kzg kzg_hip_kzg;                 /* *kzg.KZGSettings         kzg.go:11-19   */
@@ -136,6 +137,16 @@ int kzg_hip_eth_blob_to_kzg_commitment_batch(kzg_hip_eth *eth, const void *blobs
 /* ComputeKZGProof (eth/helpers.go:179-203): polynomial in evaluation form (n Fr), z; writes the 48-byte proof and (optionally) y.
  * KZG_HIP_ERR_LEN_MISMATCH: "polynomial has invalid length"; KZG_HIP_ERR_BAD_ARG: "invalid z challenge" (z in the domain). */
 int kzg_hip_eth_compute_kzg_proof(kzg_hip_eth *eth, const void *poly_fr, uint64_t n, const void *z_fr, void *out48, void *y_fr);
+
+/* ---- erasure recovery ----
+ * FFTSettings.ZeroPolyViaMultiplication (zero_poly.go:116-217): vanishing polynomial of the missing indices of a size-`length`
+ * domain; writes `length` evaluations and `length` coefficients (zero-padded).  No missing index -> all zeros (:117-119). */
+int kzg_hip_zero_poly_via_multiplication(kzg_hip_fft *fs, const uint64_t *missing_indices, uint64_t n_missing, uint64_t length,
+                                         void *out_zero_eval_fr, void *out_zero_poly_fr);
+/* FFTSettings.RecoverPolyFromSamples (recover_from_samples.go:42-109) with ZeroPolyViaMultiplication as the zero-poly function:
+ * n samples, present[i] == 0 <=> samples[i] == nil; writes the n reconstructed values.  KZG_HIP_ERR_RECOVERY when a known
+ * sample is not reproduced (the reference's error). */
+int kzg_hip_recover_poly_from_samples(kzg_hip_fft *fs, const void *samples_fr, const uint8_t *present, uint64_t n, void *out_fr);
 
 /* ---- instrumentation for bench.py: HIP-event time of the dominant kernel since the last reset (ms) and launch count ---- */
 void kzg_hip_prof_reset(kzg_hip_fft *fs, int enable);

@@ -67,6 +67,8 @@ def lib():
             "ko_fk20_multi_file": (vp, [vp, u64]),
             "ko_fk20_multi": (i32, [vp, vp, u64, vp]), "ko_fk20_multi_da_optimized": (i32, [vp, vp, u64, vp]),
             "ko_da_using_fk20_multi": (i32, [vp, vp, u64, vp]),
+            "ko_zero_poly_via_multiplication": (i32, [vp, vp, u64, u64, vp, vp]),
+            "ko_recover_poly_from_samples": (i32, [vp, vp, vp, u64, vp]),
             "ko_synthetic_blob": (None, [u64, u64, vp]),
         }
         for name, (res, args) in sig.items():
@@ -275,6 +277,21 @@ class FFTSettings:
         vals = np.ascontiguousarray(vals, dtype=np.uint64).reshape(-1, 3, 6)
         out = g1_empty(vals.shape[0])
         _chk(lib().ko_fft_g1(self.h, _p(vals), vals.shape[0], int(inv), _p(out)))
+        return out
+
+    def zero_poly_via_multiplication(self, missing_indices, length):
+        """ZeroPolyViaMultiplication (zero_poly.go:116-217): (zero_eval, zero_poly), `length` entries each"""
+        mi = np.ascontiguousarray(missing_indices, dtype=np.uint64)
+        ze, zp = fr_empty(length), fr_empty(length)
+        _chk(lib().ko_zero_poly_via_multiplication(self.h, _p(mi), mi.shape[0], length, _p(ze), _p(zp)))
+        return ze, zp
+
+    def recover_poly_from_samples(self, samples, present):
+        """RecoverPolyFromSamples (recover_from_samples.go:42-109); present[i] False <=> samples[i] is nil"""
+        samples = np.ascontiguousarray(samples, dtype=np.uint64).reshape(-1, 4)
+        present = np.ascontiguousarray(present, dtype=np.uint8)
+        out = fr_empty(samples.shape[0])
+        _chk(lib().ko_recover_poly_from_samples(self.h, _p(samples), _p(present), samples.shape[0], _p(out)))
         return out
 
     def das_fft_extension(self, vals):

@@ -733,6 +733,118 @@ API int ko_da_using_fk20_multi(const ko_fk20m_t *fk, const fr_t *poly, u64 n, g1
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * Erasure recovery: zero_poly.go, recover_from_samples.go
+ * ---------------------------------------------------------------------------------------------- */
+/* makeZeroPolyMulLeaf (zero_poly.go:17-44) */
+static void zero_poly_leaf(const ko_fft_t *fs, fr_t *dst, u64 dst_len, const u64 *indices, u64 n_idx, u64 stride) {
+    fr_t zero; memset(&zero, 0, sizeof zero);
+    for (u64 i = n_idx + 1; i < dst_len; i++) dst[i] = zero;
+    dst[n_idx] = FR_ONE;
+    for (u64 i = 0; i < n_idx; i++) {
+        fr_t neg; fr_sub(&neg, &zero, &fs->expanded[indices[i] * stride]);
+        dst[i] = neg;
+        if (i > 0) {
+            fr_add(&dst[i], &dst[i], &dst[i - 1]);
+            for (u64 j = i - 1; j > 0; j--) { fr_mul(&dst[j], &dst[j], &neg); fr_add(&dst[j], &dst[j], &dst[j - 1]); }
+            fr_mul(&dst[0], &dst[0], &neg);
+        }
+    }
+}
+/* reduceLeaves (zero_poly.go:58-111): product of the polynomials ps[0..cnt) via FFT of size n = dst length */
+static u64 reduce_leaves(const ko_fft_t *fs, fr_t *scratch, fr_t *dst, u64 n, fr_t **ps, const u64 *lens, u64 cnt) {
+    u64 out_degree = 0;
+    for (u64 i = 0; i < cnt; i++) out_degree += lens[i] - 1;
+    fr_t *padded = scratch, *mul_eval = scratch + n, *p_eval = scratch + 2 * n;
+    u64 last = cnt - 1;
+    memset(padded, 0, n * sizeof(fr_t)); memcpy(padded, ps[last], lens[last] * sizeof(fr_t));
+    ko_inplace_fft(fs, padded, mul_eval, n, 0);
+    for (u64 i = 0; i < last; i++) {
+        /* the reference copies ps[i] over the previous padded buffer without clearing the tail (zero_poly.go:93-96); all leaves
+         * it multiplies have equal length except the last one, which it loads first, so the tail is already zero */
+        memset(padded, 0, n * sizeof(fr_t)); memcpy(padded, ps[i], lens[i] * sizeof(fr_t));
+        ko_inplace_fft(fs, padded, p_eval, n, 0);
+        for (u64 j = 0; j < n; j++) fr_mul(&mul_eval[j], &mul_eval[j], &p_eval[j]);
+    }
+    ko_inplace_fft(fs, mul_eval, dst, n, 1);
+    return out_degree + 1;
+}
+/* ZeroPolyViaMultiplication (zero_poly.go:116-217): zero_eval and zero_poly have `length` entries each */
+API int ko_zero_poly_via_multiplication(const ko_fft_t *fs, const u64 *missing, u64 n_missing, u64 length, fr_t *zero_eval, fr_t *zero_poly) {
+    memset(zero_eval, 0, length * sizeof(fr_t)); memset(zero_poly, 0, length * sizeof(fr_t));
+    if (n_missing == 0) return KO_OK;
+    if (length > fs->max_width) return KO_ERR_TOO_WIDE;
+    if (!is_pow2(length)) return KO_ERR_NOT_POW2;
+    u64 stride = fs->max_width / length, per_leaf_poly = 64, per_leaf = 63;
+    if (n_missing <= per_leaf) {
+        if (n_missing + 1 > length) return KO_ERR_BAD_ARG;
+        zero_poly_leaf(fs, zero_poly, n_missing + 1, missing, n_missing, stride);
+        return ko_inplace_fft(fs, zero_poly, zero_eval, length, 0);
+    }
+    u64 leaf_count = (n_missing + per_leaf - 1) / per_leaf;
+    u64 n = next_pow2(leaf_count * per_leaf_poly);
+    fr_t *out = calloc(n, sizeof(fr_t)), *scratch = calloc(3 * n, sizeof(fr_t));
+    fr_t **leaves = calloc(leaf_count, sizeof(fr_t *)); u64 *lens = calloc(leaf_count, sizeof(u64));
+    for (u64 i = 0, off = 0; i < leaf_count; i++, off += per_leaf) {
+        u64 end = off + per_leaf > n_missing ? n_missing : off + per_leaf;
+        leaves[i] = out + i * per_leaf_poly; lens[i] = per_leaf_poly;
+        zero_poly_leaf(fs, leaves[i], per_leaf_poly, missing + off, end - off, stride);
+    }
+    u64 nleaves = leaf_count;
+    fr_t *tmp = calloc(n, sizeof(fr_t));
+    while (nleaves > 1) {
+        u64 reduced = (nleaves + 3) / 4, leaf_size = next_pow2(lens[0]);
+        for (u64 i = 0; i < reduced; i++) {
+            u64 start = i * 4, end = start + 4, out_end = end * leaf_size;
+            if (out_end > n) out_end = n;
+            if (end > nleaves) end = nleaves;
+            fr_t *dst = out + start * leaf_size; u64 dst_n = out_end - start * leaf_size;
+            if (end > start + 1) {
+                /* inputs live inside dst: multiply into tmp, then copy back (the reference reads them before the final IFFT writes) */
+                u64 len = reduce_leaves(fs, scratch, tmp, dst_n, leaves + start, lens + start, end - start);
+                memcpy(dst, tmp, dst_n * sizeof(fr_t));
+                leaves[i] = dst; lens[i] = len;
+            } else { leaves[i] = dst; lens[i] = dst_n < lens[start] ? dst_n : lens[start]; if (leaves[start] != dst) memmove(dst, leaves[start], lens[i] * sizeof(fr_t)); }
+        }
+        nleaves = reduced;
+    }
+    int st = KO_OK;
+    if (lens[0] > length) st = KO_ERR_BAD_ARG;   /* "expected output smaller or equal to input length" */
+    else { memcpy(zero_poly, leaves[0], lens[0] * sizeof(fr_t)); st = ko_inplace_fft(fs, zero_poly, zero_eval, length, 0); }
+    free(out); free(scratch); free(leaves); free(lens); free(tmp);
+    return st;
+}
+/* ShiftPoly / UnshiftPoly (recover_from_samples.go:9-40): poly[i] *= 5^-i  /  5^i */
+static void shift_poly(fr_t *poly, u64 n, int unshift) {
+    fr_t f, pw = FR_ONE; fr_from_u64(&f, 5);
+    if (!unshift) fr_inv(&f, &f);
+    for (u64 i = 0; i < n; i++) { fr_mul(&poly[i], &poly[i], &pw); fr_mul(&pw, &pw, &f); }
+}
+/* RecoverPolyFromSamples (recover_from_samples.go:42-109) with ZeroPolyViaMultiplication; present[i] == 0 <=> samples[i] == nil */
+API int ko_recover_poly_from_samples(const ko_fft_t *fs, const fr_t *samples, const uint8_t *present, u64 n, fr_t *out) {
+    if (!is_pow2(n)) return KO_ERR_NOT_POW2;
+    if (n > fs->max_width) return KO_ERR_TOO_WIDE;
+    u64 *missing = malloc(n * sizeof(u64)), nm = 0;
+    for (u64 i = 0; i < n; i++) if (!present[i]) missing[nm++] = i;
+    fr_t *zeval = malloc(n * sizeof(fr_t)), *zpoly = malloc(n * sizeof(fr_t)), *e = calloc(n, sizeof(fr_t)), *a = malloc(n * sizeof(fr_t)),
+         *b = malloc(n * sizeof(fr_t)), *c = malloc(n * sizeof(fr_t));
+    int st = ko_zero_poly_via_multiplication(fs, missing, nm, n, zeval, zpoly);
+    if (!st) {
+        for (u64 i = 0; i < n; i++) if (present[i]) fr_mul(&e[i], &samples[i], &zeval[i]);
+        ko_inplace_fft(fs, e, a, n, 1);                  /* polyWithZero */
+        shift_poly(a, n, 0); shift_poly(zpoly, n, 0);
+        ko_inplace_fft(fs, a, b, n, 0);                  /* evalShiftedPolyWithZero */
+        ko_inplace_fft(fs, zpoly, c, n, 0);              /* evalShiftedZeroPoly */
+        for (u64 i = 0; i < n; i++) { fr_t inv; fr_inv(&inv, &c[i]); fr_mul(&b[i], &inv, &b[i]); }   /* DivModFr */
+        ko_inplace_fft(fs, b, a, n, 1);                  /* shiftedReconstructedPoly */
+        shift_poly(a, n, 1);
+        ko_inplace_fft(fs, a, out, n, 0);                /* reconstructedData */
+        for (u64 i = 0; i < n; i++) if (present[i] && !fr_eq(&out[i], &samples[i])) { st = KO_ERR_BAD_ARG; break; }
+    }
+    free(missing); free(zeval); free(zpoly); free(e); free(a); free(b); free(c);
+    return st;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * Synthetic inputs: splitmix64 stream -> uniform field elements, Montgomery form
  * ---------------------------------------------------------------------------------------------- */
 API void ko_synthetic_blob(u64 seed, u64 n, fr_t *out) {

@@ -57,6 +57,16 @@ def main():
     kats["test_point_compression"] = {"source": "bls/bls_test.go:11-23", "scalar": scalar,
                                       "expected_bytes": [int(v) for v in by.split(",")]}
     assert len(kats["test_point_compression"]["expected_bytes"]) == 48
+    # zero_poly_test.go:133-198 TestFFTSettings_ZeroPolyViaMultiplication_Python (16 + 16 decimals, scale 4)
+    zsrc = open(os.path.join(REF, "zero_poly_test.go")).read()
+    za = zsrc.index("func TestFFTSettings_ZeroPolyViaMultiplication_Python")
+    zb = zsrc.index("func testZeroPoly")
+    exists = re.search(r"exists := \[\]bool\{([^}]*)\}", zsrc[za:zb]).group(1)
+    allz = re.findall(r'bls\.ToFr\("(\d+)"\)', zsrc[za:zb])
+    kats["test_zero_poly_python"] = {"source": "zero_poly_test.go:133-198", "scale": 4,
+                                     "exists": [v.strip() == "true" for v in exists.split(",") if v.strip()],
+                                     "expected_eval": allz[:16], "expected_poly": allz[16:32]}
+    assert len(kats["test_zero_poly_python"]["exists"]) == 16 and len(allz) == 32
     # test secret / polynomial used all over the reference's tests
     kats["test_secret"] = {"source": "kzg_single_proofs_test.go:13", "value": "1927409816240961209460912649124"}
     kats["test_poly"] = {"source": "kzg_single_proofs_test.go:15", "values": [1, 2, 3, 4, 7, 7, 7, 7, 13, 13, 13, 13, 13, 13, 13, 13]}

@@ -624,3 +624,49 @@ def test_compute_proof_multi_and_interpolation_commitment(kz):
     blob = ko.synthetic_blob(21)
     assert_points_equal(ksb.compute_proof_multi(blob, 99, 16), ko.lincomb_g1(s1337[:4080], blob[16:]))
     ksb.close(); ks8.close(); ks.close(); fs12.close(); fs3.close(); fs.close()
+
+
+# ------------------------------------------------------------------ erasure recovery
+def test_zero_poly_python_kat_gpu(kz):
+    k = KATS["test_zero_poly_python"]                      # zero_poly_test.go:133-198
+    fs = kz.FFTSettings(k["scale"])
+    missing = [i for i, e in enumerate(k["exists"]) if not e]
+    ze, zp = fs.zero_poly_via_multiplication(missing, 16)
+    assert ko.fr_to_ints(ze) == [int(v) for v in k["expected_eval"]]
+    assert ko.fr_to_ints(zp) == [int(v) for v in k["expected_poly"]]
+    ze0, zp0 = fs.zero_poly_via_multiplication([], 16)     # zero_poly.go:117-119
+    assert not ze0.any() and not zp0.any()
+    with pytest.raises(kz.KzgPanic):
+        fs.zero_poly_via_multiplication([1], 32)           # domain too small
+    fs.close()
+
+
+@pytest.mark.parametrize("scale,frac", [(5, 2), (8, 2), (10, 3), (12, 2), (15, 2)])
+def test_zero_poly_and_recover_match_oracle(kz, scale, frac):
+    fs, ofs = kz.FFTSettings(scale), ko.FFTSettings(scale)
+    n = 1 << scale
+    rng = np.random.default_rng(scale)
+    missing = sorted(rng.choice(n, size=n // frac, replace=False).tolist())
+    ze, zp = fs.zero_poly_via_multiplication(missing, n)
+    oze, ozp = ofs.zero_poly_via_multiplication(missing, n)
+    assert np.array_equal(ze, oze) and np.array_equal(zp, ozp)
+    # recover_from_samples_test.go:62-137: half the coefficients zero, drop the `missing` samples, recover the data
+    poly = np.concatenate([rand_fr(rng, n // 2) if n <= 4096 else ko.synthetic_blob(scale, n // 2), ko.fr_empty(n // 2)])
+    data = ofs.fft(poly)
+    present = np.ones(n, dtype=np.uint8)
+    present[missing] = 0
+    samples = np.where(present[:, None].astype(bool), data, 0)
+    rec = fs.recover_poly_from_samples(samples, present)
+    assert np.array_equal(rec, data)
+    if scale <= 12:
+        assert np.array_equal(rec, ofs.recover_poly_from_samples(samples, present))
+    if scale == 5:   # a full-degree polynomial with half the samples missing: whatever the reference's algorithm yields, both agree
+        full = np.where(present[:, None].astype(bool), ofs.fft(rand_fr(rng, n)), 0)
+        try:
+            want = ofs.recover_poly_from_samples(full, present)
+        except ko.OracleError:
+            with pytest.raises(kz.KzgError, match="failed to reconstruct"):
+                fs.recover_poly_from_samples(full, present)
+        else:
+            assert np.array_equal(fs.recover_poly_from_samples(full, present), want)
+    fs.close()

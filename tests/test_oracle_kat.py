@@ -328,3 +328,48 @@ def test_check_proof_multi_scenario():
     assert ko.g1_equal(is1, ko.g1_mul(gen, ko.fr_from_ints([i_s])[0]))
     pi = pyref.eval_poly(TEST_POLY[8:], S_TEST)
     assert (pyref.eval_poly(TEST_POLY, S_TEST) - i_s) % R == pi * (pow(S_TEST, n, R) - xl) % R
+
+
+# ---------------------------------------------------------------- erasure recovery
+def test_zero_poly_python_kat():
+    k = KATS["test_zero_poly_python"]                      # zero_poly_test.go:133-198
+    fs = ko.FFTSettings(k["scale"])
+    missing = [i for i, e in enumerate(k["exists"]) if not e]
+    ze, zp = fs.zero_poly_via_multiplication(missing, 16)
+    assert ko.fr_to_ints(ze) == [int(v) for v in k["expected_eval"]]
+    assert ko.fr_to_ints(zp) == [int(v) for v in k["expected_poly"]]
+
+
+@pytest.mark.parametrize("scale,seed", [(5, 0), (8, 1), (10, 2), (12, 3)])
+def test_zero_poly_tree_matches_direct_product(scale, seed):
+    # zero_poly_test.go:83-131 (tree reduction == direct product), here against big-int products
+    fs = ko.FFTSettings(scale)
+    n = 1 << scale
+    rng = np.random.default_rng(seed)
+    missing = sorted(rng.choice(n, size=n // 2, replace=False).tolist())
+    ze, zp = fs.zero_poly_via_multiplication(missing, n)
+    w = pyref.root_of_unity(scale)
+    zp_i = ko.fr_to_ints(zp)
+    assert zp_i[len(missing)] == 1 and not any(zp_i[len(missing) + 1:])
+    ms = set(missing)
+    ze_i = ko.fr_to_ints(ze)
+    for k in list(range(0, n, max(1, n // 16))) + missing[:4]:
+        x = pow(w, k, ko.R_MOD)
+        assert ze_i[k] == pyref.eval_poly(zp_i, x)
+        assert (ze_i[k] == 0) == (k in ms)
+
+
+@pytest.mark.parametrize("scale", [2, 5, 10])
+def test_recover_poly_from_samples(scale):
+    # recover_from_samples_test.go:10-137: half the coefficients zero, drop up to half of the samples, recover
+    fs = ko.FFTSettings(scale)
+    n = 1 << scale
+    rng = np.random.default_rng(scale)
+    poly = np.concatenate([ko.fr_from_ints([int(v) for v in rng.integers(0, 2**63, size=n // 2)]), ko.fr_empty(n // 2)])
+    data = fs.fft(poly)
+    present = np.ones(n, dtype=np.uint8)
+    present[rng.choice(n, size=n // 2, replace=False)] = 0
+    if scale == 2:
+        present[:] = [1, 0, 0, 1]                           # TestFFTSettings_RecoverPolyFromSamples_Simple
+    rec = fs.recover_poly_from_samples(np.where(present[:, None].astype(bool), data, 0), present)
+    assert np.array_equal(rec, data)
