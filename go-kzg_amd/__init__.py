@@ -255,6 +255,18 @@ class FFTSettings:
         _chk(lib().kzg_hip_g1_from_compressed(self.h, _p(data), data.shape[0], _p(out)))
         return out
 
+    def g1_marshal_text(self, points):
+        """bls.G1Point.MarshalText over a slice (bls/bls_all.go:20-22): lower-case hex of the 48-byte compressed form"""
+        return [c.tobytes().hex() for c in self.to_compressed_g1(points)]
+
+    def g1_unmarshal_text(self, texts):
+        """bls.G1Point.UnmarshalText over a slice (bls/bls_all.go:24-39) -- e.g. the "setup_G1" / "setup_G1_lagrange" arrays of
+        eth/trusted_setup.json (eth/globals.go:33-49); decompression runs on the device"""
+        raw = np.frombuffer(b"".join(bytes.fromhex(t) for t in texts), dtype=np.uint8)
+        if raw.size != 48 * len(texts):
+            raise KzgPanic(ERR_BAD_POINT, "expected 48-byte compressed G1 points")
+        return self.from_compressed_g1(raw)
+
     def mul_g1_vec(self, points, scalars):
         points, scalars = _g1(points), _fr(scalars)
         out = g1_empty(points.shape[0])

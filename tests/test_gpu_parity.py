@@ -194,6 +194,17 @@ def test_compress_decompress_edge_cases(kz, fs16):
             fs16.from_compressed_g1(notoncurve)
 
 
+def test_g1_text_marshalling_roundtrip(kz, fs16):
+    # TestPointG1Marshalling (bls/bls_test.go:25-45) over a slice, plus the JSON-setup form (eth/globals.go:33-49)
+    pts = edge_points()
+    texts = fs16.g1_marshal_text(pts)
+    assert texts == comp_hex(pts)
+    assert_points_equal(fs16.g1_unmarshal_text(texts), pts)
+    raw = open(os.path.join(GOLDEN, "trusted_setup_g1.bin"), "rb").read()
+    hexes = [raw[48 * i:48 * i + 48].hex() for i in range(8)]          # first entries of "setup_G1"
+    assert_points_equal(fs16.g1_unmarshal_text(hexes), ko.generate_testing_setup_g1(1337, 8))
+
+
 def test_mul_g1_vec_matches_oracle(kz, fs16):
     pts = edge_points()
     rng = np.random.default_rng(4)
@@ -670,3 +681,54 @@ def test_zero_poly_and_recover_match_oracle(kz, scale, frac):
         else:
             assert np.array_equal(fs.recover_poly_from_samples(full, present), want)
     fs.close()
+
+
+# ------------------------------------------------------------------ end-to-end: the flow of TestFullDAS (integration_test.go:18-159)
+def test_full_das_flow(kz):
+    """random 31-byte data -> reverse-bit order -> DAS extension -> commitment -> FK20Multi coset proofs (l = 128) ->
+    every coset proof verified (pairing-free form of CheckProofMulti) -> up to half of the samples dropped -> recovery
+    -> original bytes.  Everything between the byte arrays runs on the device."""
+    scale, l = 10, 128
+    points = 1 << scale
+    rng = np.random.default_rng(1234)
+    data = rng.integers(0, 256, size=points * 31, dtype=np.uint8)
+    data[:100] = 0
+    even_i = [int.from_bytes(data[i * 31:(i + 1) * 31].tobytes() + b"\x00", "little") for i in range(points)]
+    even = ko.reverse_bit_order(ko.fr_from_ints(even_i))
+    fs = kz.FFTSettings(scale + 1)
+    odd = fs.das_fft_extension(even)                                       # integration_test.go:42
+    extended = np.empty((2 * points, 4), dtype=np.uint64)
+    extended[0::2], extended[1::2] = even, odd
+    setup = fs.generate_testing_setup_g1(ko.fr_from_ints([S_TEST]), 2 * points)
+    ks = kz.KZGSettings(fs, setup)
+    coeffs = fs.fft(extended, inv=True)
+    assert not coeffs[points:].any()                                       # the extension property
+    commit = ks.commit_to_poly(coeffs[:points])
+    coeffs_i = ko.fr_to_ints(coeffs[:points])
+    gen = ko.g1_generator()
+    assert ko.g1_equal(commit, ko.g1_mul(gen, ko.fr_from_ints([pyref.eval_poly(coeffs_i, S_TEST)])[0]))
+    fk = kz.FK20MultiSettings(ks, 2 * points, l)
+    proofs = fk.fk20_multi_da_optimized(coeffs)                            # integration_test.go:77 (natural order)
+    sample_count = 2 * points // l
+    ext_bro = ko.reverse_bit_order(extended)                               # integration_test.go:71
+    w = pyref.root_of_unity(scale + 1)
+    for i in range(sample_count):                                          # integration_test.go:98-111
+        pos = pyref.rev_bits(i, 4)
+        x = pow(w, pos, ko.R_MOD)                                          # domainStride = 1
+        d = pyref.coset_proof_dlog(coeffs_i, S_TEST, x, l)
+        assert ko.g1_equal(proofs[pos], ko.g1_mul(gen, ko.fr_from_ints([d])[0])), i
+        sub = pyref.bitrev(ko.fr_to_ints(ext_bro[i * l:(i + 1) * l]))      # sample i really is the coset's evaluations
+        wl = pow(w, (2 * points) // l, ko.R_MOD)
+        assert sub[:3] == [pyref.eval_poly(coeffs_i, x * pow(wl, j, ko.R_MOD) % ko.R_MOD) for j in range(3)]
+    present_samples = np.ones(sample_count, dtype=bool)
+    present_samples[rng.choice(sample_count, size=sample_count // 2, replace=False)] = False
+    present = np.repeat(present_samples, l)
+    partial = np.where(present[:, None], ext_bro, 0)
+    # undo the reverse-bit order (integration_test.go:132), recover on the device, redo it
+    present_nat = np.array(pyref.bitrev(present.astype(np.uint8).tolist()), dtype=np.uint8)
+    recovered = fs.recover_poly_from_samples(ko.reverse_bit_order(partial), present_nat)
+    recovered = ko.reverse_bit_order(recovered)
+    assert np.array_equal(recovered, ext_bro)
+    back = b"".join(v.to_bytes(32, "little")[:31] for v in ko.fr_to_ints(recovered[:points]))
+    assert back == data.tobytes()
+    fk.close(); ks.close(); fs.close()
