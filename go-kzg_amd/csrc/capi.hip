@@ -430,8 +430,7 @@ static int ensure_fixed_table(kzg_hip_kzg *ks, hipStream_t s) {
     p.c = best; p.nwin = 255 / best + 1; p.nb = 1u << (best - 1); p.ngroups = 1; p.fixed = 1; p.table_n = ks->n_setup;
     size_t entries = (size_t)p.nwin * ks->n_setup * p.nb;
     HIPCHK(hipMalloc((void **)&ks->d_fixed, entries * sizeof(g1a)));
-    launch_fb_build(s, ks->d_secret_a, ks->n_setup, p.c, p.nwin, ks->d_fixed);
-    HIPCHK(hipGetLastError());
+    HIPCHK(launch_fb_build(s, ks->d_secret_a, ks->n_setup, p.c, p.nwin, ks->d_fixed));
     HIPCHK(hipStreamSynchronize(s));
     ks->fixed_plan = p;
     return KZG_HIP_OK;
@@ -595,8 +594,7 @@ static int fk20_core_new(kzg_hip_kzg *ks, uint64_t n2, uint64_t l, fk20_core *c)
             launch_g1_to_affine(s, c->d_files, d_fa.p, npts);
             c->fb_c = best; c->fb_nwin = 255 / best + 1;
             HIPCHK(hipMalloc((void **)&c->d_files_fb, (size_t)c->fb_nwin * npts * (1u << (best - 1)) * sizeof(g1a)));
-            launch_fb_build(s, d_fa.p, npts, c->fb_c, c->fb_nwin, c->d_files_fb);
-            HIPCHK(hipGetLastError());
+            HIPCHK(launch_fb_build(s, d_fa.p, npts, c->fb_c, c->fb_nwin, c->d_files_fb));
             HIPCHK(hipStreamSynchronize(s));
         }
     }
@@ -622,7 +620,7 @@ static int fk20_hext(fk20_core *c, hipStream_t s, const fr *d_poly, uint64_t pol
             launch_g1_sum_files(s, d_tmp.p, l, cnt, batch, d_hext);
         }
     } else if (l == 1 && j0 == 0 && cnt == k2) launch_g1_mul_vec(s, c->d_files, k2, d_cf.p, 1, batch * k2, d_hext);
-    else launch_g1_file_msm(s, c->d_files, d_cf.p, l, k2, j0, cnt, batch, d_hext);
+    else HIPCHK(launch_g1_file_msm(s, c->d_files, d_cf.p, l, k2, j0, cnt, batch, d_hext));
     HIPCHK(hipGetLastError());
     return KZG_HIP_OK;
 }

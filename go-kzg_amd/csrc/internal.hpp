@@ -42,8 +42,8 @@ void launch_fr_pointwise(hipStream_t s, const fr *a, const fr *b, const uint8_t 
 // out[i] = scalars[i * s_stride] * pts[(i % pts_mod)]   (element-wise bls.MulG1; scalars in Montgomery form)
 void launch_g1_mul_vec(hipStream_t s, const g1j *pts, uint64_t pts_mod, const fr *scalars, uint64_t s_stride, uint64_t n, g1j *out);
 // acc[i] = sum over f < nfiles of scalars[b][f][j] * files[f][j]  -- the FK20-multi Toeplitz stage (fk20_multi.go:79-91)
-void launch_g1_file_msm(hipStream_t s, const g1j *files, const fr *scalars, uint64_t nfiles, uint64_t k2, uint64_t j0, uint64_t cnt,
-                        uint64_t batch, g1j *out);
+hipError_t launch_g1_file_msm(hipStream_t s, const g1j *files, const fr *scalars, uint64_t nfiles, uint64_t k2, uint64_t j0, uint64_t cnt,
+                              uint64_t batch, g1j *out);
 // out[b][rev(i)] = i < n_valid ? in[b][i] : inf     (bit-reversal + "h[:n] || inf" padding, fk20_single.go:163-166)
 void launch_g1_bitrev_copy(hipStream_t s, const g1j *in, uint64_t in_stride, uint64_t n_valid, g1j *out, uint64_t n, uint64_t batch);
 // one radix-2 DIT stage on bit-reversed data (replaces the loop of _fftG1, fft_g1.go:44-55); `roots` holds the twiddles as
@@ -75,7 +75,7 @@ void launch_msm_window_table(hipStream_t s, const g1a *pts, uint64_t n, uint32_t
 
 // fixed-base table MSM over the device-resident setup (see k_msm.hip)
 size_t fb_partials_bytes(uint64_t n, uint64_t batch);
-void launch_fb_build(hipStream_t s, const g1a *pts, uint64_t n, uint32_t c, uint32_t nwin, g1a *table);
+hipError_t launch_fb_build(hipStream_t s, const g1a *pts, uint64_t n, uint32_t c, uint32_t nwin, g1a *table);
 void launch_fb_msm(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, uint64_t n, uint64_t batch,
                    void *partials, g1j *out);
 
@@ -85,7 +85,6 @@ void launch_fb_mul_vec(hipStream_t s, const g1a *table, uint64_t table_n, uint32
 void launch_g1_sum_files(hipStream_t s, const g1j *tmp, uint64_t nfiles, uint64_t cnt, uint64_t batch, g1j *out);
 
 // profiling hook (HIP events around the dominant kernel), see capi.hip
-struct prof_slot { const char *name; hipEvent_t e0, e1; };
 void prof_begin(hipStream_t s, const char *name);
 void prof_end(hipStream_t s, const char *name);
 

@@ -107,23 +107,15 @@ void launch_fr_fft(hipStream_t s, const fr *in, uint64_t in_stride, uint64_t n_i
     if (n <= FR_TILE) {
         uint32_t T = (uint32_t)(n / 2 < 64 ? 64 : (n / 2 > 1024 ? 1024 : n / 2));
         size_t sh = (size_t)n * 32;
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fr_fft_tile<true>), hipFuncAttributeMaxDynamicSharedMemorySize, FR_TILE * 32);
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fr_fft_tile<false>), hipFuncAttributeMaxDynamicSharedMemorySize, FR_TILE * 32);
-            attr_set = true;
-        }
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fr_fft_tile<true>), hipFuncAttributeMaxDynamicSharedMemorySize, FR_TILE * 32);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fr_fft_tile<false>), hipFuncAttributeMaxDynamicSharedMemorySize, FR_TILE * 32);
         hipLaunchKernelGGL(k_fr_fft_tile<true>, dim3((uint32_t)batch), dim3(T), sh, s, in, in_stride, n_in, out, logn, (uint64_t)1, roots, W, scale);
         return;
     }
     // n > 4096: bit-reversal copy, 12 stages per 4096-tile in LDS, remaining stages through global memory
     uint64_t total = n * batch;
     hipLaunchKernelGGL(k_fr_bitrev_copy, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, in, in_stride, n_in, out, logn, total);
-    static bool attr_set2 = false;
-    if (!attr_set2) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fr_fft_tile<false>), hipFuncAttributeMaxDynamicSharedMemorySize, FR_TILE * 32);
-        attr_set2 = true;
-    }
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fr_fft_tile<false>), hipFuncAttributeMaxDynamicSharedMemorySize, FR_TILE * 32);
     uint64_t tiles_per_row = n / FR_TILE;
     hipLaunchKernelGGL(k_fr_fft_tile<false>, dim3((uint32_t)(tiles_per_row * batch)), dim3(1024), (size_t)FR_TILE * 32, s, (const fr *)nullptr,
                        (uint64_t)0, (uint64_t)0, out, FR_TILE_LOG, tiles_per_row, roots, W, (const fr *)nullptr);
@@ -193,11 +185,7 @@ void launch_das_ext(hipStream_t s, fr *vals, uint64_t n, uint64_t batch, const f
     (void)W;
     uint32_t logn = ilog2(n);
     if (n <= FR_TILE) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_das_ext_lds), hipFuncAttributeMaxDynamicSharedMemorySize, FR_TILE * 32);
-            attr_set = true;
-        }
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_das_ext_lds), hipFuncAttributeMaxDynamicSharedMemorySize, FR_TILE * 32);
         uint32_t T = (uint32_t)(n / 2 < 64 ? 64 : (n / 2 > 1024 ? 1024 : n / 2));
         hipLaunchKernelGGL(k_das_ext_lds, dim3((uint32_t)batch), dim3(T), (size_t)n * 32, s, vals, logn, expanded, reversed, inv_n);
         return;

@@ -56,18 +56,20 @@ void launch_g1_sum_files(hipStream_t s, const g1j *tmp, uint64_t nfiles, uint64_
     if (!outs) return;
     hipLaunchKernelGGL(k_g1_sum_files, dim3((uint32_t)((outs + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, tmp, nfiles, cnt, outs, out);
 }
-void launch_g1_file_msm(hipStream_t s, const g1j *files, const fr *scalars, uint64_t nfiles, uint64_t k2, uint64_t j0, uint64_t cnt, uint64_t batch,
-                        g1j *out) {
+hipError_t launch_g1_file_msm(hipStream_t s, const g1j *files, const fr *scalars, uint64_t nfiles, uint64_t k2, uint64_t j0, uint64_t cnt, uint64_t batch,
+                              g1j *out) {
     uint64_t total = batch * nfiles * cnt;
-    if (!total) return;
+    if (!total) return hipSuccess;
     g1j *tmp = nullptr;
-    hipMallocAsync((void **)&tmp, total * sizeof(g1j), s);
+    hipError_t e = hipMallocAsync((void **)&tmp, total * sizeof(g1j), s);
+    if (e != hipSuccess) return e;
     prof_begin(s, "g1_mul_vec");
     hipLaunchKernelGGL(k_g1_file_mul, dim3((uint32_t)((total + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, files, scalars, nfiles, k2, j0, cnt, total, tmp);
     prof_end(s, "g1_mul_vec");
     uint64_t outs = batch * cnt;
     hipLaunchKernelGGL(k_g1_sum_files, dim3((uint32_t)((outs + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, tmp, nfiles, cnt, outs, out);
     hipFreeAsync(tmp, s);
+    return hipGetLastError();
 }
 
 __global__ void k_g1_bitrev_copy(const g1j *in, uint64_t in_stride, uint64_t n_valid, g1j *out, uint32_t logn, uint64_t total) {

@@ -177,11 +177,7 @@ void launch_msm(hipStream_t s, const msm_plan &p, const g1a *table, const fr *sc
     uint8_t *ws = (uint8_t *)workspace;
     uint32_t K = (uint32_t)L.K;
     size_t sh = (size_t)(K + MSM_SORT_T) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_msm_sort), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_msm_sort), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(k_msm_sort, dim3((uint32_t)batch), dim3(MSM_SORT_T), sh, s, p, scalars, n, ws, L.per_blob, L.entries_off, L.offsets_off, K);
     uint64_t total = batch * L.K;
     prof_begin(s, "msm_accumulate");
@@ -340,20 +336,21 @@ void launch_fb_msm(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c
     hipLaunchKernelGGL(k_fb_finish, dim3((uint32_t)((batch + 63) / 64)), dim3(64), 0, s, (const g1j *)partials, bpb, batch, out);
 }
 // builds the table for `n` affine points: rows (2^(c w) P_i) first, then all multiples window-slab by window-slab
-void launch_fb_build(hipStream_t s, const g1a *pts, uint64_t n, uint32_t c, uint32_t nwin, g1a *table) {
+hipError_t launch_fb_build(hipStream_t s, const g1a *pts, uint64_t n, uint32_t c, uint32_t nwin, g1a *table) {
     uint32_t D = 1u << (c - 1);
     g1j *rows_j = nullptr; g1a *rows = nullptr; fp *ztmp = nullptr, *ptmp = nullptr;
     uint64_t lanes_all = (uint64_t)nwin * n;
-    hipMallocAsync((void **)&rows_j, lanes_all * sizeof(g1j), s);
-    hipMallocAsync((void **)&rows, lanes_all * sizeof(g1a), s);
+    hipError_t e;
+    if ((e = hipMallocAsync((void **)&rows_j, lanes_all * sizeof(g1j), s)) != hipSuccess) return e;
+    if ((e = hipMallocAsync((void **)&rows, lanes_all * sizeof(g1a), s)) != hipSuccess) { hipFreeAsync(rows_j, s); return e; }
     launch_msm_window_table(s, pts, n, c, nwin, rows_j, rows);
     // slabs of windows bound the temporary Z / prefix storage to ~2 x 1 GiB
     uint64_t per_win = n * D * sizeof(fp);
     uint32_t slab = (uint32_t)((1ull << 30) / (per_win ? per_win : 1));
     if (slab < 1) slab = 1;
     if (slab > nwin) slab = nwin;
-    hipMallocAsync((void **)&ztmp, (uint64_t)slab * per_win, s);
-    hipMallocAsync((void **)&ptmp, (uint64_t)slab * per_win, s);
+    if ((e = hipMallocAsync((void **)&ztmp, (uint64_t)slab * per_win, s)) != hipSuccess) { hipFreeAsync(rows_j, s); hipFreeAsync(rows, s); return e; }
+    if ((e = hipMallocAsync((void **)&ptmp, (uint64_t)slab * per_win, s)) != hipSuccess) { hipFreeAsync(rows_j, s); hipFreeAsync(rows, s); hipFreeAsync(ztmp, s); return e; }
     for (uint32_t w0 = 0; w0 < nwin; w0 += slab) {
         uint32_t ws = (w0 + slab <= nwin) ? slab : nwin - w0;
         uint64_t lanes = (uint64_t)ws * n;
@@ -362,6 +359,7 @@ void launch_fb_build(hipStream_t s, const g1a *pts, uint64_t n, uint32_t c, uint
         hipLaunchKernelGGL(k_fb_build_pass2, g, b, 0, s, lanes, D, table + (uint64_t)w0 * n * D, ztmp, ptmp);
     }
     hipFreeAsync(rows_j, s); hipFreeAsync(rows, s); hipFreeAsync(ztmp, s); hipFreeAsync(ptmp, s);
+    return hipGetLastError();
 }
 
 // fixed-base table rows: tmp[w * n + i] = 2^(c w) * P_i (Jacobian), then normalised to affine by launch_g1_to_affine
