@@ -249,6 +249,46 @@ def main():
                  "value": MB * world * msteps / msecs, "batch_per_gpu": MB, "ms_per_all_proofs": msecs / msteps / MB * 1e3}
         fkm.close(); ks16.close(); fs16.close()
 
+    ref_benches = None
+    if not args.no_fk20:
+        # The three transforms the reference publishes numbers for (BENCH.md, Kilic column, Ryzen 9 5950X, 1 thread), scale 12,
+        # device-resident batches: FFT over F_r (:43), FFT over G1 (:55), DAS FFT extension (:31).
+        def rate(fn, units, reps):
+            secs_ = timed_steps(fn, reps, 1, torch.cuda.synchronize, barrier, max_over_ranks)
+            return units * world * reps / secs_
+
+        FB = 1024
+        d_fr = torch.from_numpy(splitmix_blobs(12 + rank * 7, 8).view(np.int64)).cuda().repeat(FB // 8, 1, 1).contiguous()
+        d_fr_out = torch.empty_like(d_fr)
+
+        def fr_step():
+            st = lib.kzg_hip_fft_fr_batch_dev(fs.h, d_fr.data_ptr(), N_COEFF, FB, 0, d_fr_out.data_ptr(), stream)
+            if st:
+                raise RuntimeError("fft_fr_batch_dev status %d" % st)
+
+        d_das = d_fr[:, :2048, :].contiguous()
+
+        def das_step():
+            st = lib.kzg_hip_das_fft_extension_batch_dev(fs.h, d_das.data_ptr(), 2048, FB, stream)
+            if st:
+                raise RuntimeError("das_fft_extension_batch_dev status %d" % st)
+
+        GB = 32
+        d_g1 = torch.from_numpy(setup.view(np.int64).reshape(1, 4096, 18)).cuda().repeat(GB, 1, 1).contiguous()
+        d_g1_out = torch.empty_like(d_g1)
+
+        def g1_step():
+            st = lib.kzg_hip_fft_g1_batch_dev(fs.h, d_g1.data_ptr(), N_COEFF, GB, 0, d_g1_out.data_ptr(), stream)
+            if st:
+                raise RuntimeError("fft_g1_batch_dev status %d" % st)
+
+        r_fr, r_das, r_g1 = rate(fr_step, FB, 5), rate(das_step, FB, 5), rate(g1_step, GB, 2)
+        ref_benches = {
+            "fft_fr_scale12_per_s": {"value": r_fr, "reference_published": 1e9 / 1911871, "source": "BENCH.md:43 (Kilic, 5950X, 1 thread)", "batch": FB},
+            "das_fft_extension_scale12_per_s": {"value": r_das, "reference_published": 1e9 / 1169011, "source": "BENCH.md:31", "batch": FB},
+            "fft_g1_scale12_per_s": {"value": r_g1, "reference_published": 1e9 / 3745748396, "source": "BENCH.md:55", "batch": GB},
+        }
+
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base = cpu_baseline()
@@ -261,7 +301,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "CommitToPoly, 4096-coeff blobs, eth/trusted_setup.json monomial setup (s=1337), %d blobs/step/GPU resident in HBM" % B,
                        "global_batch": B * world, "parallelism": "dp%d (independent blobs, no data-path collective)" % world},
-            "roofline": roofline, "cpu_baseline": base, "fk20": fk20, "fk20_multi": fk20m,
+            "roofline": roofline, "cpu_baseline": base, "fk20": fk20, "fk20_multi": fk20m, "reference_benchmarks": ref_benches,
         }))
     if use_dist:
         dist.destroy_process_group()

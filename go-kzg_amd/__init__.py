@@ -70,6 +70,8 @@ def lib():
         "kzg_hip_fft_fr": (i32, [vp, vp, u64, i32, vp, C.POINTER(u64)]), "kzg_hip_inplace_fft_fr": (i32, [vp, vp, vp, u64, i32]),
         "kzg_hip_fft_fr_batch": (i32, [vp, vp, u64, u64, i32, vp]), "kzg_hip_fft_g1": (i32, [vp, vp, u64, i32, vp]),
         "kzg_hip_das_fft_extension": (i32, [vp, vp, u64]), "kzg_hip_das_fft_extension_batch": (i32, [vp, vp, u64, u64]),
+        "kzg_hip_fft_fr_batch_dev": (i32, [vp, vp, u64, u64, i32, vp, vp]), "kzg_hip_fft_g1_batch_dev": (i32, [vp, vp, u64, u64, i32, vp, vp]),
+        "kzg_hip_das_fft_extension_batch_dev": (i32, [vp, vp, u64, u64, vp]),
         "kzg_hip_lincomb_g1": (i32, [vp, vp, vp, u64, vp]), "kzg_hip_g1_to_compressed": (i32, [vp, vp, u64, vp]),
         "kzg_hip_g1_from_compressed": (i32, [vp, vp, u64, vp]), "kzg_hip_g1_mul_vec": (i32, [vp, vp, vp, u64, vp]),
         "kzg_hip_generate_testing_setup_g1": (i32, [vp, vp, u64, vp]),

@@ -281,6 +281,47 @@ int kzg_hip_das_fft_extension_batch(kzg_hip_fft *fs, void *vals_fr, uint64_t n, 
     HIPCHK(hipStreamSynchronize(s));
     return KZG_HIP_OK;
 }
+int kzg_hip_fft_fr_batch_dev(kzg_hip_fft *fs, const void *d_vals_fr, uint64_t n, uint64_t batch, int inv, void *d_out_fr, void *stream) {
+    if (!fs) return KZG_HIP_ERR_BAD_ARG;
+    if (n > fs->W) return KZG_HIP_ERR_TOO_WIDE;
+    if (!is_pow2(n)) return KZG_HIP_ERR_NOT_POW2;
+    if (n == 0 || batch == 0) return KZG_HIP_OK;
+    if (!d_vals_fr || !d_out_fr) return KZG_HIP_ERR_BAD_ARG;
+    dev_guard g(fs);
+    fr_fft_rows(fs, (hipStream_t)stream, (const fr *)d_vals_fr, n, n, (fr *)d_out_fr, n, batch, inv);
+    HIPCHK(hipGetLastError());
+    return KZG_HIP_OK;
+}
+int kzg_hip_fft_g1_batch_dev(kzg_hip_fft *fs, const void *d_vals_g1, uint64_t n, uint64_t batch, int inv, void *d_out_g1, void *stream) {
+    if (!fs) return KZG_HIP_ERR_BAD_ARG;
+    if (n > fs->W) return KZG_HIP_ERR_TOO_WIDE;
+    if (!is_pow2(n)) return KZG_HIP_ERR_NOT_POW2;
+    if (n == 0 || !d_vals_g1 || !d_out_g1) return KZG_HIP_ERR_BAD_ARG;
+    if (!batch) return KZG_HIP_OK;
+    dev_guard g(fs);
+    hipStream_t s = (hipStream_t)stream;
+    dtmp<g1j> d_in(s), d_data(s);
+    CHK(d_in.alloc(n * batch)); CHK(d_data.alloc(n * batch));
+    HIPCHK(hipMemcpyAsync(d_in.p, d_vals_g1, n * batch * sizeof(g1j), hipMemcpyDeviceToDevice, s));
+    launch_g1_from_kilic(s, d_in.p, n * batch);
+    g1_fft_rows(fs, s, d_in.p, n, n, d_data.p, n, batch, inv);
+    if (inv) {
+        launch_g1_mul_vec(s, d_data.p, n * batch, fs->d_inv_pow2 + ilog2(n), 0, n * batch, d_in.p);
+        launch_g1_normalize(s, d_in.p, (g1j *)d_out_g1, n * batch, true);
+    } else launch_g1_normalize(s, d_data.p, (g1j *)d_out_g1, n * batch, true);
+    HIPCHK(hipGetLastError());
+    return KZG_HIP_OK;
+}
+int kzg_hip_das_fft_extension_batch_dev(kzg_hip_fft *fs, void *d_vals_fr, uint64_t n, uint64_t batch, void *stream) {
+    if (!fs || !d_vals_fr) return KZG_HIP_ERR_BAD_ARG;
+    if (n * 2 > fs->W) return KZG_HIP_ERR_TOO_WIDE;
+    if (n < 2 || !is_pow2(n)) return KZG_HIP_ERR_BAD_ARG;
+    if (!batch) return KZG_HIP_OK;
+    dev_guard g(fs);
+    launch_das_ext((hipStream_t)stream, (fr *)d_vals_fr, n, batch, fs->d_expanded, fs->d_reversed, fs->W, fs->d_inv_pow2 + ilog2(n));
+    HIPCHK(hipGetLastError());
+    return KZG_HIP_OK;
+}
 int kzg_hip_das_fft_extension(kzg_hip_fft *fs, void *vals_fr, uint64_t n) { return kzg_hip_das_fft_extension_batch(fs, vals_fr, n, 1); }
 
 // ---------------------------------------------------------------------------------------------------------

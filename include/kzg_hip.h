@@ -67,6 +67,12 @@ int kzg_hip_fft_g1(kzg_hip_fft *fs, const void *vals_g1, uint64_t n, int inv, vo
 int kzg_hip_das_fft_extension(kzg_hip_fft *fs, void *vals_fr, uint64_t n);
 int kzg_hip_das_fft_extension_batch(kzg_hip_fft *fs, void *vals_fr, uint64_t n, uint64_t batch);
 
+/* device-resident batch forms of the three transforms the reference publishes benchmarks for (BENCH.md:31,43,55):
+ * `batch` rows of n values each, inputs and outputs in HBM, Kilic images for G1 (converted and normalised inside) */
+int kzg_hip_fft_fr_batch_dev(kzg_hip_fft *fs, const void *d_vals_fr, uint64_t n, uint64_t batch, int inv, void *d_out_fr, void *stream);
+int kzg_hip_fft_g1_batch_dev(kzg_hip_fft *fs, const void *d_vals_g1, uint64_t n, uint64_t batch, int inv, void *d_out_g1, void *stream);
+int kzg_hip_das_fft_extension_batch_dev(kzg_hip_fft *fs, void *d_vals_fr, uint64_t n, uint64_t batch, void *stream);
+
 /* ---- bls.LinCombG1 (bls/bls_kilic.go:132-150): Pippenger MSM; n == 0 -> infinity ---- */
 int kzg_hip_lincomb_g1(kzg_hip_fft *fs, const void *points_g1, const void *scalars_fr, uint64_t n, void *out_g1);
 /* bls.ToCompressedG1 over a slice (bls/bls_kilic.go:114-116): n points -> n x 48 B ZCash form */

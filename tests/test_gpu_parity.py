@@ -732,3 +732,30 @@ def test_full_das_flow(kz):
     back = b"".join(v.to_bytes(32, "little")[:31] for v in ko.fr_to_ints(recovered[:points]))
     assert back == data.tobytes()
     fk.close(); ks.close(); fs.close()
+
+
+def test_device_resident_batch_transforms(kz, setup_1337):
+    """the _dev forms bench.py times (inputs / outputs in HBM) equal the host-buffer forms"""
+    import torch
+    fs = kz.FFTSettings(12)
+    L = kz.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    blobs = np.stack([ko.synthetic_blob(70 + b) for b in range(3)])
+    d_in = torch.from_numpy(blobs.view(np.int64)).cuda()
+    d_out = torch.empty_like(d_in)
+    assert L.kzg_hip_fft_fr_batch_dev(fs.h, d_in.data_ptr(), 4096, 3, 0, d_out.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out.cpu().numpy().view(np.uint64), fs.fft_batch(blobs))
+    d_das = torch.from_numpy(blobs[:, :2048].copy().view(np.int64)).cuda()
+    assert L.kzg_hip_das_fft_extension_batch_dev(fs.h, d_das.data_ptr(), 2048, 3, st) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(d_das.cpu().numpy().view(np.uint64), fs.das_fft_extension_batch(blobs[:, :2048]))
+    pts = np.stack([setup_1337[:64], setup_1337[64:128]])
+    d_p = torch.from_numpy(pts.view(np.int64).reshape(2, 64, 18)).cuda()
+    d_q = torch.empty_like(d_p)
+    for inv in (0, 1):
+        assert L.kzg_hip_fft_g1_batch_dev(fs.h, d_p.data_ptr(), 64, 2, inv, d_q.data_ptr(), st) == 0
+        torch.cuda.synchronize()
+        got = d_q.cpu().numpy().view(np.uint64).reshape(2, 64, 3, 6)
+        assert np.array_equal(got[0], fs.fft_g1(pts[0], bool(inv))) and np.array_equal(got[1], fs.fft_g1(pts[1], bool(inv)))
+    fs.close()
