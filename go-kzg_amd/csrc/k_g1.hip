@@ -119,9 +119,46 @@ __global__ __launch_bounds__(G1_BLOCK) void k_g1_normalize(const g1j *in, g1j *o
     g1j p = g1_normalize(in[t]);
     out[t] = to_kilic ? g1_to_kilic(p) : p;
 }
+// Same result with ONE F_p inversion per NB points (Montgomery's trick inside a lane): a Fermat inversion is ~570 products,
+// so normalising the 4096 proofs of an FK20 run drops from ~575 to ~80 products per point.  Points are strided by `lanes`
+// so that the loads of a wavefront stay adjacent.  Z = 0 entries are skipped in the running product.
+#define NORM_NB 8
+__global__ __launch_bounds__(G1_BLOCK) void k_g1_normalize_batched(const g1j *in, g1j *out, uint64_t n, uint64_t lanes, int to_kilic) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= lanes) return;
+    fp pref[NORM_NB];
+    fp acc = one<FpP>();
+#pragma unroll
+    for (int k = 0; k < NORM_NB; k++) {
+        uint64_t i = t + (uint64_t)k * lanes;
+        pref[k] = acc;
+        if (i < n) { fp z = in[i].z; if (!is_zero<FpP>(z)) acc = mul(acc, z); }
+    }
+    fp inv_all = inv<FpP>(acc);
+#pragma unroll
+    for (int k = NORM_NB - 1; k >= 0; k--) {
+        uint64_t i = t + (uint64_t)k * lanes;
+        if (i >= n) continue;
+        g1j p = in[i];
+        g1j o;
+        if (is_inf(p)) o = g1_inf();
+        else {
+            fp zi = mul(inv_all, pref[k]);
+            inv_all = mul(inv_all, p.z);
+            fp zi2 = sqr(zi);
+            o.x = mul(p.x, zi2); o.y = mul(p.y, mul(zi2, zi)); o.z = one<FpP>();
+        }
+        out[i] = to_kilic ? g1_to_kilic(o) : o;
+    }
+}
 void launch_g1_normalize(hipStream_t s, const g1j *in, g1j *out, uint64_t n, bool to_kilic) {
     if (!n) return;
-    hipLaunchKernelGGL(k_g1_normalize, dim3((uint32_t)((n + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, in, out, n, to_kilic ? 1 : 0);
+    if (n < 1024 || in == out) {   // small outputs (one commitment) or in-place use: one inversion per point
+        hipLaunchKernelGGL(k_g1_normalize, dim3((uint32_t)((n + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, in, out, n, to_kilic ? 1 : 0);
+        return;
+    }
+    uint64_t lanes = (n + NORM_NB - 1) / NORM_NB;
+    hipLaunchKernelGGL(k_g1_normalize_batched, dim3((uint32_t)((lanes + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, in, out, n, lanes, to_kilic ? 1 : 0);
 }
 __global__ __launch_bounds__(G1_BLOCK) void k_g1_from_kilic(g1j *data, uint64_t n) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
