@@ -91,6 +91,42 @@ KZG_HD g1j g1_madd(const g1j &p, const g1a &q) {
     return o;
 }
 
+// ---------------------------------------------------------------------------------------------
+// XYZZ accumulator (x = X / ZZ, y = Y / ZZZ, ZZ^3 == ZZZ^2; inf <=> ZZ == 0) for loops that only ever add AFFINE points
+// (the fixed-base table walks): madd-2008-s costs 8M + 2S = 10 products against 7M + 4S = 11 for Jacobian + affine,
+// and this multiplier has no cheaper squaring.  Exceptional cases handled as everywhere else.
+// ---------------------------------------------------------------------------------------------
+struct g1x { fp x, y, zz, zzz; };
+KZG_HD g1x g1x_inf() { g1x o; o.x = zero<FpP>(); o.y = one<FpP>(); o.zz = zero<FpP>(); o.zzz = zero<FpP>(); return o; }
+KZG_HD bool is_inf(const g1x &p) { return is_zero<FpP>(p.zz); }
+KZG_HD g1x g1x_from_jac(const g1j &p) {
+    if (is_inf(p)) return g1x_inf();
+    g1x o; o.x = p.x; o.y = p.y; o.zz = sqr(p.z); o.zzz = mul(o.zz, p.z);
+    return o;
+}
+KZG_HD g1j g1x_to_jac(const g1x &p) {   // (X ZZ, Y ZZZ, ZZ) is a Jacobian image of the same point
+    if (is_inf(p)) return g1_inf();
+    g1j o; o.x = mul(p.x, p.zz); o.y = mul(p.y, p.zzz); o.z = p.zz;
+    return o;
+}
+KZG_HD g1x g1x_madd(const g1x &p, const g1a &q) {
+    if (is_inf(q)) return p;
+    if (is_inf(p)) { g1x o; o.x = q.x; o.y = q.y; o.zz = one<FpP>(); o.zzz = one<FpP>(); return o; }
+    fp u2 = mul(q.x, p.zz), s2 = mul(q.y, p.zzz);
+    if (equal<FpP>(u2, p.x)) {
+        if (equal<FpP>(s2, p.y)) return g1x_from_jac(g1_dbl(to_jac(q)));   // P == Q: double the affine operand
+        return g1x_inf();                                                    // P == -Q
+    }
+    fp pp_ = sub(u2, p.x), r = sub(s2, p.y);
+    fp pp = sqr(pp_), ppp = mul(pp_, pp), q_ = mul(p.x, pp);
+    g1x o;
+    o.x = sub(sub(sub(sqr(r), ppp), q_), q_);
+    o.y = sub(mul(r, sub(q_, o.x)), mul(p.y, ppp));
+    o.zz = mul(p.zz, pp);
+    o.zzz = mul(p.zzz, ppp);
+    return o;
+}
+
 KZG_HD g1j g1_sub(const g1j &p, const g1j &q) { return g1_add(p, g1_neg(q)); }
 
 // Projective equality (bls.EqualG1)

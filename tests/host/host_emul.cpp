@@ -22,6 +22,11 @@ void he_g1_madd(g1j *o, const g1j *a, const g1j *b_affine_image) {   // b must h
     g1a q; if (is_inf(bi)) q = g1a_inf(); else { q.x = bi.x; q.y = bi.y; }
     *o = OUT(g1_madd(IN(a), q));
 }
+void he_g1x_madd(g1j *o, const g1j *a, const g1j *b_affine_image) {   // XYZZ accumulator path of the table walks
+    g1j bi = IN(b_affine_image);
+    g1a q; if (is_inf(bi)) q = g1a_inf(); else { q.x = bi.x; q.y = bi.y; }
+    *o = OUT(g1x_to_jac(g1x_madd(g1x_from_jac(IN(a)), q)));
+}
 void he_g1_mul(g1j *o, const g1j *a, const fr *k_mont) { g1j tbl[15]; *o = OUT(g1_mul_windowed(IN(a), from_mont<FrP>(*k_mont), tbl)); }
 void he_g1_mul_small(g1j *o, const g1j *a, uint32_t k) { *o = OUT(g1_mul_small(IN(a), k)); }
 void he_g1_normalize(g1j *o, const g1j *a) { *o = OUT(g1_normalize(IN(a))); }

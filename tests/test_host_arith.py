@@ -81,6 +81,8 @@ def test_g1_group_law(he):
             qa = ko.g1_affine(pts[j])[0]
             he.he_g1_madd(p(got), p(pts[i]), p(qa)); L.ko_g1_add(p(want), p(pts[i]), p(qa))
             assert np.array_equal(ko.g1_compress(got), ko.g1_compress(want)), ("madd", i, j)
+            he.he_g1x_madd(p(got), p(pts[i]), p(qa))
+            assert np.array_equal(ko.g1_compress(got), ko.g1_compress(want)), ("xyzz madd", i, j)
 
 
 def test_g1_scalar_mul(he):
