@@ -114,7 +114,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=512, help="blobs per step per GPU")
     ap.add_argument("--fk20-batch", type=int, default=64)
-    ap.add_argument("--fk20-multi-batch", type=int, default=8)
+    ap.add_argument("--fk20-multi-batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fk20", action="store_true")
     args = ap.parse_args()
