@@ -212,9 +212,8 @@ KZG_HD void unpack30(uint32_t *o, const fp &a) {
         o[k] = (uint32_t)(v >> sh) & 0x3fffffffu;
     }
 }
-KZG_HD fp mont_mul_fp30(const fp &a, const fp &b) {
-    uint32_t A[13], B[13];
-    unpack30(A, a); unpack30(B, b);
+// core: r = A * B / 2^390 mod p on 13 x 30-bit limbs (limbs < 2^30), r normalised (limbs < 2^30), value < A B / 2^390 + p
+KZG_HD void mont_core30(uint32_t *r, const uint32_t *A, const uint32_t *B) {
     uint64_t acc[14];
 #pragma unroll
     for (int j = 0; j < 14; j++) acc[j] = 0;
@@ -234,11 +233,11 @@ KZG_HD fp mont_mul_fp30(const fp &a, const fp &b) {
             for (int j = 0; j < 12; j++) { acc[j + 1] += acc[j] >> 30; acc[j] &= 0x3fffffffull; }
         }
     }
-    uint32_t r[13]; uint64_t c = 0;
+    uint64_t c = 0;
 #pragma unroll
     for (int j = 0; j < 13; j++) { uint64_t x = acc[j] + c; r[j] = (uint32_t)x & 0x3fffffffu; c = x >> 30; }
-    // value = a b / R' + (multiple of p) < 2p < 2^382: fits 12 words; repack and subtract p once if needed
-    uint32_t t[12];
+}
+KZG_HD void pack30(uint32_t *t, const uint32_t *r) {   // 13 normalised limbs (value < 2^384) -> 12 words
 #pragma unroll
     for (int w = 0; w < 12; w++) {
         const int k = (32 * w) / 30, o = (32 * w) % 30;
@@ -247,6 +246,79 @@ KZG_HD fp mont_mul_fp30(const fp &a, const fp &b) {
         if (k + 2 < 13) v |= (uint64_t)r[k + 2] << (60 - o);
         t[w] = (uint32_t)v;
     }
+}
+KZG_HD fp mont_mul_fp30(const fp &a, const fp &b) {
+    uint32_t A[13], B[13], r[13];
+    unpack30(A, a); unpack30(B, b);
+    mont_core30(r, A, B);
+    // value = a b / R' + (multiple of p) < 2p < 2^382: fits 12 words; repack and subtract p once if needed
+    uint32_t t[12];
+    pack30(t, r);
+    fp out; reduce_once<FpP>(out, t);
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fq: UNPACKED, LAZILY REDUCED F_p element for hot loops (the fixed-base table walks).  13 limbs of 30 bits,
+// always normalised (limbs 0..11 < 2^30), value only bounded: v < B p with B tracked by hand at every use
+// (see g1x_madd_fast in g1.hpp).  Rules:
+//   mulq(a, b): needs Ba * Bb <= 600 (a b < 2^390 p), result B = 2.     No pack / unpack / final subtraction.
+//   addq(a, b): limb-wise add + carry sweep, B = Ba + Bb.
+//   subq<M>(a, b): a + M p - b with M p spread so that no limb goes negative (needs M >= Bb + 1), B = Ba + M.
+// ---------------------------------------------------------------------------------------------
+struct fq { uint32_t l[13]; };
+KZG_HD fq unpackq(const fp &a) { fq o; unpack30(o.l, a); return o; }
+KZG_HD void sweepq(fq &a) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) { uint32_t t = a.l[i] + c; a.l[i] = t & 0x3fffffffu; c = t >> 30; }
+    a.l[12] += c;
+}
+KZG_HD fq mulq(const fq &a, const fq &b) { fq o; mont_core30(o.l, a.l, b.l); return o; }
+KZG_HD fq addq(const fq &a, const fq &b) {
+    fq o;
+#pragma unroll
+    for (int i = 0; i < 13; i++) o.l[i] = a.l[i] + b.l[i];
+    sweepq(o);
+    return o;
+}
+// limb i of M * p in 30-bit limbs, spread so that every limb but the top is >= 2^30 - 1 (sum of the limbs is still M p)
+template <int M> KZG_HD uint32_t mp_spread(int i) {
+    uint64_t c = 0; uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k <= 12; k++) {
+        uint64_t t = (uint64_t)FpP::p30(k) * (uint32_t)M + c;
+        uint32_t limb = (k < 12) ? (uint32_t)(t & 0x3fffffffu) : (uint32_t)t;
+        c = (k < 12) ? (t >> 30) : 0;
+        if (k == i) v = limb;
+    }
+    if (i == 0) return v + (1u << 30);
+    if (i < 12) return v + (1u << 30) - 1u;
+    return v - 1u;
+}
+template <int M> KZG_HD fq subq(const fq &a, const fq &b) {
+    fq o;
+#pragma unroll
+    for (int i = 0; i < 13; i++) o.l[i] = a.l[i] + mp_spread<M>(i) - b.l[i];
+    sweepq(o);
+    return o;
+}
+// v ≡ 0 (mod p) for a normalised v < 2p, i.e. v in {0, p}
+KZG_HD bool is_zero_mod_p_q(const fq &a) {
+    uint32_t z = 0, e = 0;
+#pragma unroll
+    for (int i = 0; i < 13; i++) { z |= a.l[i]; e |= a.l[i] ^ FpP::p30(i); }
+    return z == 0 || e == 0;
+}
+// any bound B <= 600 -> canonical packed value
+KZG_HD fp packq(const fq &a) {
+    fq one_;
+#pragma unroll
+    for (int i = 0; i < 13; i++) one_.l[i] = 0;
+    fp o1 = one<FpP>(); unpack30(one_.l, o1);
+    fq r = mulq(a, one_);            // a * R' / R' = a, now < 2p
+    uint32_t t[12];
+    pack30(t, r.l);
     fp out; reduce_once<FpP>(out, t);
     return out;
 }

@@ -127,6 +127,46 @@ KZG_HD g1x g1x_madd(const g1x &p, const g1a &q) {
     return o;
 }
 
+// Fast path of g1x_madd on unpacked, lazily reduced coordinates (field.hpp: fq).  Bounds (value < B p) are a loop invariant:
+//   in : X <= 11, Y <= 5, ZZ <= 2, ZZZ <= 2   (the first point enters with all bounds 1)
+//   u2, s2 = 2;  P = u2 - X (M = 12) -> 14;  R = s2 - Y (M = 6) -> 8;  PP, PPP, Q = 2  (products 196, 28, 22 <= 600)
+//   X3 = R^2 - PPP - 2 Q : 2 + 3 + 3 + 3 = 11;  Q - X3 (M = 12) -> 14;  R (Q - X3): 8 * 14 = 112 <= 600
+//   Y3 = R (Q - X3) - Y PPP : 2 + 3 = 5;  ZZ3, ZZZ3 = 2                -> the invariant is reproduced.
+// Returns false (and leaves the accumulator untouched) when P == +-Q: the caller takes the generic path for those.
+struct g1xq { fq x, y, zz, zzz; };
+KZG_HD bool g1x_madd_fast(g1xq &p, const fq &x2, const fq &y2) {
+    fq u2 = mulq(x2, p.zz), s2 = mulq(y2, p.zzz);
+    fq pp_ = subq<12>(u2, p.x), r = subq<6>(s2, p.y);
+    fq pp = mulq(pp_, pp_);
+    if (is_zero_mod_p_q(pp)) return false;
+    fq ppp = mulq(pp_, pp), q_ = mulq(p.x, pp);
+    fq x3 = subq<3>(subq<3>(subq<3>(mulq(r, r), ppp), q_), q_);
+    fq y3 = subq<3>(mulq(r, subq<12>(q_, x3)), mulq(p.y, ppp));
+    p.zz = mulq(p.zz, pp);
+    p.zzz = mulq(p.zzz, ppp);
+    p.x = x3; p.y = y3;
+    return true;
+}
+KZG_HD g1xq g1xq_from_affine(const g1a &q) {
+    g1xq o; o.x = unpackq(q.x); o.y = unpackq(q.y); o.zz = unpackq(one<FpP>()); o.zzz = o.zz;
+    return o;
+}
+KZG_HD g1x g1xq_pack(const g1xq &p) { g1x o; o.x = packq(p.x); o.y = packq(p.y); o.zz = packq(p.zz); o.zzz = packq(p.zzz); return o; }
+KZG_HD g1xq g1xq_unpack(const g1x &p) { g1xq o; o.x = unpackq(p.x); o.y = unpackq(p.y); o.zz = unpackq(p.zz); o.zzz = unpackq(p.zzz); return o; }
+// accumulator with an explicit infinity flag; add() is what the table-walk kernels call per table entry
+struct g1x_acc {
+    g1xq v; bool inf;
+    KZG_HD void init() { inf = true; }
+    KZG_HD void add(const g1a &q) {
+        if (is_inf(q)) return;
+        if (inf) { v = g1xq_from_affine(q); inf = false; return; }
+        if (g1x_madd_fast(v, unpackq(q.x), unpackq(q.y))) return;
+        g1x s = g1x_madd(g1xq_pack(v), q);          // P == Q or P == -Q: generic, complete formulas
+        if (is_inf(s)) inf = true; else v = g1xq_unpack(s);
+    }
+    KZG_HD g1j to_jac() const { return inf ? g1_inf() : g1x_to_jac(g1xq_pack(v)); }
+};
+
 KZG_HD g1j g1_sub(const g1j &p, const g1j &q) { return g1_add(p, g1_neg(q)); }
 
 // Projective equality (bls.EqualG1)

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(FB_BLOCK) void k_fb_accumulate(const g1a *table, ui
     const uint64_t blob = blockIdx.x / blocks_per_blob; const uint32_t blk = blockIdx.x % blocks_per_blob;
     const uint64_t L = (uint64_t)blocks_per_blob * FB_BLOCK;
     const fr *sc = scalars + blob * n;
-    g1x acc = g1x_inf();   // XYZZ: 10 products per mixed addition instead of 11
+    g1x_acc acc; acc.init();   // XYZZ, unpacked lazy limbs: 10 products per mixed addition, no pack / reduce per product
     for (uint64_t i = (uint64_t)blk * FB_BLOCK + tid; i < n; i += L) {
         fr k = from_mont<FrP>(sc[i]);
         uint32_t carry = 0;
@@ -257,11 +257,11 @@ __global__ __launch_bounds__(FB_BLOCK) void k_fb_accumulate(const g1a *table, ui
             if (mag) {
                 g1a q = table[((uint64_t)w * table_n + i) * D + (mag - 1)];
                 if (ng) q.y = neg<FpP>(q.y);
-                acc = g1x_madd(acc, q);
+                acc.add(q);
             }
         }
     }
-    buf[tid] = g1x_to_jac(acc);
+    buf[tid] = acc.to_jac();
     __syncthreads();
 #pragma nounroll
     for (uint32_t off = FB_BLOCK / 2; off >= 1; off >>= 1) {
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(FB_BLOCK) void k_fb_mul_vec(const g1a *table, uint6
     uint64_t jj = t % cnt, f = (t / cnt) % (table_n / row), b = t / (cnt * (table_n / row));
     uint64_t i = f * row + i0 + jj;
     fr k = from_mont<FrP>(scalars[b * table_n + i]);
-    g1x acc = g1x_inf();
+    g1x_acc acc; acc.init();
     uint32_t carry = 0;
 #pragma nounroll
     for (uint32_t w = 0; w < nwin; w++) {
@@ -300,10 +300,10 @@ __global__ __launch_bounds__(FB_BLOCK) void k_fb_mul_vec(const g1a *table, uint6
         if (mag) {
             g1a q = table[((uint64_t)w * table_n + i) * D + (mag - 1)];
             if (ng) q.y = neg<FpP>(q.y);
-            acc = g1x_madd(acc, q);
+            acc.add(q);
         }
     }
-    out[t] = g1x_to_jac(acc);
+    out[t] = acc.to_jac();
 }
 void launch_fb_mul_vec(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, uint64_t row, uint64_t j0,
                        uint64_t cnt, uint64_t batch, g1j *out) {

@@ -27,6 +27,16 @@ void he_g1x_madd(g1j *o, const g1j *a, const g1j *b_affine_image) {   // XYZZ ac
     g1a q; if (is_inf(bi)) q = g1a_inf(); else { q.x = bi.x; q.y = bi.y; }
     *o = OUT(g1x_to_jac(g1x_madd(g1x_from_jac(IN(a)), q)));
 }
+// table-walk accumulator (unpacked lazy fast path + generic fallback): acc = sum of the n affine images in `pts` (Z = R or inf)
+void he_g1x_acc_sum(g1j *o, const g1j *pts, int n) {
+    g1x_acc a; a.init();
+    for (int i = 0; i < n; i++) {
+        g1j bi = IN(&pts[i]);
+        g1a q; if (is_inf(bi)) q = g1a_inf(); else { q.x = bi.x; q.y = bi.y; }
+        a.add(q);
+    }
+    *o = OUT(a.to_jac());
+}
 void he_g1_mul(g1j *o, const g1j *a, const fr *k_mont) { g1j tbl[15]; *o = OUT(g1_mul_windowed(IN(a), from_mont<FrP>(*k_mont), tbl)); }
 void he_g1_mul_small(g1j *o, const g1j *a, uint32_t k) { *o = OUT(g1_mul_small(IN(a), k)); }
 void he_g1_normalize(g1j *o, const g1j *a) { *o = OUT(g1_normalize(IN(a))); }

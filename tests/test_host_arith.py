@@ -103,3 +103,31 @@ def test_g1_scalar_mul(he):
         got = ko.g1_empty(1)
         he.he_g1_mul_small(p(got), p(base), k)
         assert ko.g1_equal(got[0], ko.g1_mul(base, ko.fr_from_ints([k])[0]))
+
+
+def test_table_walk_accumulator_fast_path(he):
+    """g1x_acc (unpacked lazy XYZZ mixed additions, generic fallback for P == +-Q) over long chains and edge patterns"""
+    rng = np.random.default_rng(9)
+    gen = ko.g1_generator()
+    he.he_g1x_acc_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    base = [ko.g1_affine(ko.g1_mul(gen, k))[0] for k in rand_fr(rng, 24)]
+    inf = ko.g1_zero()[0]
+    neg0 = ko.g1_affine(ko.g1_sub(inf, base[0]))[0]
+    patterns = {
+        "random chain": base * 12,                                    # 288 additions: the bounds invariant must hold forever
+        "with infinities": [inf, base[0], inf, base[1], inf],
+        "P + P": [base[0], base[0], base[1]],
+        "P - P then more": [base[0], neg0, base[2], base[3]],
+        "sum hits a later operand": [base[0], base[1], ko.g1_affine(ko.g1_add(base[0], base[1]))[0], base[4]],
+        "sum hits minus a later operand": [base[0], base[1], ko.g1_affine(ko.g1_sub(inf, ko.g1_add(base[0], base[1])))[0], base[5]],
+        "only infinity": [inf, inf],
+        "empty": [],
+    }
+    for name, pts in patterns.items():
+        arr = np.stack(pts) if pts else ko.g1_empty(1)
+        got = ko.g1_empty(1)
+        he.he_g1x_acc_sum(p(got), p(arr), len(pts))
+        want = inf
+        for q in pts:
+            want = ko.g1_add(want, q)
+        assert np.array_equal(ko.g1_compress(got), ko.g1_compress(want)), name
