@@ -274,7 +274,33 @@ KZG_HD void sweepq(fq &a) {
     for (int i = 0; i < 12; i++) { uint32_t t = a.l[i] + c; a.l[i] = t & 0x3fffffffu; c = t >> 30; }
     a.l[12] += c;
 }
+#if defined(KZG_MULQ_NOINLINE) && defined(__clang__)
+// out-of-line form for kernels with many call sites (the G1 FFT stage has ~65: inlined they are ~240 KB of code against a
+// 64 KB instruction cache); operands travel as 13-wide vectors in VGPRs
+typedef uint32_t u32x13 __attribute__((ext_vector_type(13)));
+KZG_HD_NOINLINE static u32x13 mulq_call(u32x13 av, u32x13 bv) {
+    uint32_t A[13], B[13], r[13];
+#pragma unroll
+    for (int i = 0; i < 13; i++) { A[i] = av[i]; B[i] = bv[i]; }
+    mont_core30(r, A, B);
+    u32x13 o;
+#pragma unroll
+    for (int i = 0; i < 13; i++) o[i] = r[i];
+    return o;
+}
+KZG_HD fq mulq(const fq &a, const fq &b) {
+    u32x13 av, bv;
+#pragma unroll
+    for (int i = 0; i < 13; i++) { av[i] = a.l[i]; bv[i] = b.l[i]; }
+    u32x13 r = mulq_call(av, bv);
+    fq o;
+#pragma unroll
+    for (int i = 0; i < 13; i++) o.l[i] = r[i];
+    return o;
+}
+#else
 KZG_HD fq mulq(const fq &a, const fq &b) { fq o; mont_core30(o.l, a.l, b.l); return o; }
+#endif
 KZG_HD fq addq(const fq &a, const fq &b) {
     fq o;
 #pragma unroll

@@ -263,6 +263,96 @@ inline fr glv_decompose(const fr &k) {
     return o;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Jacobian arithmetic on unpacked, lazily reduced coordinates (fq) for the GLV scalar multiplication of the G1 FFT.
+// Bound invariant (value < B p): every point that lives in the loop has (X, Y, Z) <= (19, 20, 4).
+//   dbl (dbl-2009-l with D = 4 X Y^2 instead of 2((X + Y^2)^2 - X^2 - Y^4): same 3M + 4S, no subtractions in D):
+//     A = X^2, B = Y^2, C = B^2, S = X B : 2 each (products <= 20^2 = 400 <= 600)
+//     D = 4 S : 8;  E = 3 A : 6;  F = E^2 : 2;  X3 = F - 2 D (M = 17) : 19
+//     Y3 = E (D - X3) - 8 C : D - X3 (M = 20) : 28, 6 * 28 = 168, then 2 - 16 (M = 17) : 19;  Z3 = 2 Y Z : 4 (20 * 4 = 80)
+//   add (add-2007-bl, Z3 = 2 Z1 Z2 H), P1 <= (19, 20, 4), P2 <= (19, 20, 4):
+//     Z1Z1, Z2Z2, U1, U2, S1, S2 : 2 (largest product 20 * 4 = 80);  H = U2 - U1 (M = 3) : 5;  I = (2 H)^2 : 2 (100)
+//     J = H I : 2;  r = 2 (S2 - S1) : 10;  V = U1 I : 2;  X3 = r^2 - J - 2 V : 2 + 3 + 3 + 3 = 11
+//     Y3 = r (V - X3) - 2 S1 J : (M = 12) 14, 10 * 14 = 140, 2 - 4 (M = 5) : 7;  Z3 = 2 (Z1 Z2) H : 4
+//   negation: Y -> 20 p - Y (M = 20 >= 19 + 1) : 20;  phi: X -> beta X : 2.
+// add returns false when H == 0 (P1 == +-P2); the caller then uses the generic complete formulas.
+// Inputs are assumed to lie in G1 (as the reference assumes): Y == 0 cannot occur.
+// ---------------------------------------------------------------------------------------------
+struct g1jq { fq x, y, z; };
+KZG_HD g1jq g1jq_unpack(const g1j &p) { g1jq o; o.x = unpackq(p.x); o.y = unpackq(p.y); o.z = unpackq(p.z); return o; }
+KZG_HD g1j g1jq_pack(const g1jq &p) { g1j o; o.x = packq(p.x); o.y = packq(p.y); o.z = packq(p.z); return o; }
+KZG_HD g1jq g1jq_dbl(const g1jq &p) {
+    fq a = mulq(p.x, p.x), b = mulq(p.y, p.y), c = mulq(b, b), s_ = mulq(p.x, b);
+    fq d = addq(s_, s_); d = addq(d, d);                   // 4 X Y^2 : 8
+    fq e = addq(addq(a, a), a);                            // 6
+    fq f = mulq(e, e);
+    g1jq o;
+    o.x = subq<17>(f, addq(d, d));                         // 19
+    fq c8 = addq(c, c); c8 = addq(c8, c8); c8 = addq(c8, c8);   // 16
+    o.y = subq<17>(mulq(e, subq<20>(d, o.x)), c8);         // 19
+    fq yz = mulq(p.y, p.z);
+    o.z = addq(yz, yz);                                    // 4
+    return o;
+}
+KZG_HD bool g1jq_add(g1jq &o, const g1jq &p, const g1jq &q) {
+    fq z1z1 = mulq(p.z, p.z), z2z2 = mulq(q.z, q.z);
+    fq u1 = mulq(p.x, z2z2), u2 = mulq(q.x, z1z1);
+    fq s1 = mulq(mulq(p.y, q.z), z2z2), s2 = mulq(mulq(q.y, p.z), z1z1);
+    fq h = subq<3>(u2, u1);
+    fq h2 = addq(h, h);
+    fq i = mulq(h2, h2);
+    if (is_zero_mod_p_q(i)) return false;
+    fq j = mulq(h, i);
+    fq r = subq<3>(s2, s1); r = addq(r, r);
+    fq v = mulq(u1, i);
+    fq x3 = subq<3>(subq<3>(subq<3>(mulq(r, r), j), v), v);
+    fq sj = mulq(s1, j);
+    fq y3 = subq<5>(mulq(r, subq<12>(v, x3)), addq(sj, sj));
+    fq zz = mulq(mulq(p.z, q.z), h);
+    o.x = x3; o.y = y3; o.z = addq(zz, zz);
+    return true;
+}
+// accumulator of the scalar multiplication: unpacked point + explicit infinity flag
+struct g1jq_acc {
+    g1jq v; bool inf;
+    KZG_HD void dbl() { if (!inf) v = g1jq_dbl(v); }
+    KZG_HD void add(const g1jq &q) {
+        if (inf) { v = q; inf = false; return; }
+        g1jq o;
+        if (g1jq_add(o, v, q)) { v = o; return; }
+        g1j s = g1_add(g1jq_pack(v), g1jq_pack(q));       // P == +-Q: generic complete formulas
+        if (is_inf(s)) inf = true; else v = g1jq_unpack(s);
+    }
+};
+// k P via GLV with signed 5-bit windows, all group arithmetic on unpacked lazy coordinates; p must not be inf.
+// `tbl` (16 entries, (i + 1) P) lives in the lane's private scratch.
+KZG_HD g1j g1_mul_glv_fast(const g1j &p, const fr &kk, g1jq *tbl) {
+    tbl[0] = g1jq_unpack(p);
+    for (int i = 1; i < 16; i++) {
+        if (i & 1) tbl[i] = g1jq_dbl(tbl[i >> 1]);
+        else {
+            g1jq o;
+            if (!g1jq_add(o, tbl[i - 1], tbl[0])) o = g1jq_unpack(g1_add(g1jq_pack(tbl[i - 1]), p));   // cannot happen for points of G1
+            tbl[i] = o;
+        }
+    }
+    int8_t d1[27], d2[27];
+    uint32_t c1 = 0, c2 = 0;
+    for (int j = 0; j < 27; j++) { d1[j] = (int8_t)glv_digit5(kk, 0, j, c1); d2[j] = (int8_t)glv_digit5(kk, 4, j, c2); }
+    const fq beta = unpackq(glv_beta());
+    fq zero_q;
+#pragma unroll
+    for (int i = 0; i < 13; i++) zero_q.l[i] = 0;
+    g1jq_acc acc; acc.inf = true;
+    for (int j = 26; j >= 0; j--) {
+        for (int t = 0; t < 5; t++) acc.dbl();
+        int a = d1[j], b = d2[j];
+        if (a) { g1jq q = tbl[(a < 0 ? -a : a) - 1]; if (a < 0) q.y = subq<20>(zero_q, q.y); acc.add(q); }
+        if (b) { g1jq q = tbl[(b < 0 ? -b : b) - 1]; if (b < 0) q.y = subq<20>(zero_q, q.y); q.x = mulq(q.x, beta); acc.add(q); }
+    }
+    return acc.inf ? g1_inf() : g1jq_pack(acc.v);
+}
+
 // Plain MSB-first double-and-add (no table); used where the scalar is short.
 KZG_HD g1j g1_mul_small(const g1j &p, uint32_t k) {
     g1j acc = g1_inf();

@@ -1,6 +1,7 @@
 // k_g1.hip -- G1 kernels, one point per lane: element-wise scalar multiplication, the radix-2 G1 FFT stages,
 // normalisation (Jacobian -> Z = R), ZCash (de)compression.  Replaces the loops of fft_g1.go:33-94,
 // fk20_single.go:72-74 (ToeplitzPart2), fk20_multi.go:86-89 and bls.To/FromCompressedG1 (bls/bls_kilic.go:114-121).
+#define KZG_MULQ_NOINLINE 1   // many mulq call sites in this translation unit: keep the product out of line (I-cache)
 #include "internal.hpp"
 
 namespace kzg {
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(G1_BLOCK) void k_g1_fft_stage(g1j *data, uint32_t l
     g1j *row = data + (b << logn);
     uint64_t i0 = g * 2 * m + j, i1 = i0 + m;
     g1j y = row[i1];
-    if (j && !is_inf(y)) { g1j tbl[16]; y = g1_mul_glv(y, roots[j * (W / (2 * m))], tbl); }   // roots: (k1, k2) GLV pairs
+    if (j && !is_inf(y)) { g1jq tbl[16]; y = g1_mul_glv_fast(y, roots[j * (W / (2 * m))], tbl); }   // roots: (k1, k2) GLV pairs
     g1j x = row[i0];
     row[i0] = g1_add(x, y);
     row[i1] = g1_add(x, g1_neg(y));

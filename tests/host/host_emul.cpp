@@ -41,5 +41,10 @@ void he_g1_mul(g1j *o, const g1j *a, const fr *k_mont) { g1j tbl[15]; *o = OUT(g
 void he_g1_mul_small(g1j *o, const g1j *a, uint32_t k) { *o = OUT(g1_mul_small(IN(a), k)); }
 void he_g1_normalize(g1j *o, const g1j *a) { *o = OUT(g1_normalize(IN(a))); }
 void he_g1_mul_glv(g1j *o, const g1j *a, const fr *k_mont) { g1j tbl[16]; *o = OUT(g1_mul_glv(IN(a), glv_decompose(from_mont<FrP>(*k_mont)), tbl)); }
+void he_g1_mul_glv_fast(g1j *o, const g1j *a, const fr *k_mont) {
+    g1j pi = IN(a);
+    if (is_inf(pi)) { *o = OUT(g1_inf()); return; }
+    g1jq tbl[16]; *o = OUT(g1_mul_glv_fast(pi, glv_decompose(from_mont<FrP>(*k_mont)), tbl));
+}
 int he_g1_equal(const g1j *a, const g1j *b) { return g1_equal(IN(a), IN(b)); }
 }
