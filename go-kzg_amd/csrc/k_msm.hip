@@ -111,15 +111,15 @@ __global__ __launch_bounds__(MSM_ACC_BLOCK) void k_msm_accumulate(const g1a *tab
     const uint32_t *offsets = (const uint32_t *)(ws + b * per_blob + offsets_off);
     g1j *buckets = (g1j *)(ws + b * per_blob + buckets_off);
     uint32_t s = offsets[key], e = offsets[key + 1];
-    g1j acc = g1_inf();
+    g1x_acc acc; acc.init();
 #pragma nounroll
     for (uint32_t i = s; i < e; i++) {
         uint32_t en = entries[i];
         g1a q = table[en >> 1];
         if (en & 1u) q.y = neg<FpP>(q.y);
-        acc = g1_madd(acc, q);
+        acc.add(q);
     }
-    buckets[key] = acc;
+    buckets[key] = acc.to_jac();
 }
 
 // sum_{k=1..nb} k * B_k for one (blob, group): 64 lanes x segments of m = nb / 64 buckets
