@@ -12,9 +12,12 @@ library's own FromCompressedG1).  One step = one pass of the hot path over one b
 collective ("scaling": "weak"); value = commitments of all ranks / max-over-ranks time.
 
 Extra objects on the JSON line:
-  roofline      -- dominant kernel (msm_accumulate): algorithmic bytes per launch / HIP-event launch time vs 8 TB/s.
+  roofline      -- dominant kernel (k_fb_accumulate, the fixed-base table walk): algorithmic bytes per launch / HIP-event launch
+                   time vs 8 TB/s, plus the PMC traffic of the committed rocprofv3 passes (profiles/r01_pmc_traffic.json).
   cpu_baseline  -- the oracle's restatement of bls.LinCombG1 (Kilic-style Pippenger) timed on one host core (rank 0, N = 1).
   fk20          -- secondary metric: DAUsingFK20 (2048 coefficients -> 4096 proofs) all-proofs/s, own timed loop.
+  fk20_multi    -- BASELINE config 5: DAUsingFK20Multi at scale 16, chunk 16 (32768 coefficients -> 4096 coset proofs).
+  reference_benchmarks -- FFT_Fr / DAS extension / FFT_G1 at scale 12 beside the reference's published BENCH.md numbers.
 """
 import argparse
 import ctypes as C
@@ -297,7 +300,7 @@ def main():
         print(json.dumps({
             "metric": "KZG commitments/sec (CommitToPoly, 4096-element blob)", "value": value, "unit": "commitments/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": secs / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (381-bit F_p / 255-bit F_r Montgomery)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "dtype_note": "30/32-bit limbs in u32 lanes, 64-bit accumulators (v_mad_u64_u32): 381-bit F_p and 255-bit F_r Montgomery arithmetic",
             "data": "synthetic",
             "config": {"workload": "CommitToPoly, 4096-coeff blobs, eth/trusted_setup.json monomial setup (s=1337), %d blobs/step/GPU resident in HBM" % B,
                        "global_batch": B * world, "parallelism": "dp%d (independent blobs, no data-path collective)" % world},
