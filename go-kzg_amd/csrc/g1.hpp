@@ -137,10 +137,10 @@ struct g1xq { fq x, y, zz, zzz; };
 KZG_HD bool g1x_madd_fast(g1xq &p, const fq &x2, const fq &y2) {
     fq u2 = mulq(x2, p.zz), s2 = mulq(y2, p.zzz);
     fq pp_ = subq<12>(u2, p.x), r = subq<6>(s2, p.y);
-    fq pp = mulq(pp_, pp_);
+    fq pp = sqrq(pp_);
     if (is_zero_mod_p_q(pp)) return false;
     fq ppp = mulq(pp_, pp), q_ = mulq(p.x, pp);
-    fq x3 = subq<3>(subq<3>(subq<3>(mulq(r, r), ppp), q_), q_);
+    fq x3 = subq<3>(subq<3>(subq<3>(sqrq(r), ppp), q_), q_);
     fq y3 = subq<3>(mulq(r, subq<12>(q_, x3)), mulq(p.y, ppp));
     p.zz = mulq(p.zz, pp);
     p.zzz = mulq(p.zzz, ppp);
@@ -282,10 +282,10 @@ struct g1jq { fq x, y, z; };
 KZG_HD g1jq g1jq_unpack(const g1j &p) { g1jq o; o.x = unpackq(p.x); o.y = unpackq(p.y); o.z = unpackq(p.z); return o; }
 KZG_HD g1j g1jq_pack(const g1jq &p) { g1j o; o.x = packq(p.x); o.y = packq(p.y); o.z = packq(p.z); return o; }
 KZG_HD g1jq g1jq_dbl(const g1jq &p) {
-    fq a = mulq(p.x, p.x), b = mulq(p.y, p.y), c = mulq(b, b), s_ = mulq(p.x, b);
+    fq a = sqrq(p.x), b = sqrq(p.y), c = sqrq(b), s_ = mulq(p.x, b);
     fq d = addq(s_, s_); d = addq(d, d);                   // 4 X Y^2 : 8
     fq e = addq(addq(a, a), a);                            // 6
-    fq f = mulq(e, e);
+    fq f = sqrq(e);
     g1jq o;
     o.x = subq<17>(f, addq(d, d));                         // 19
     fq c8 = addq(c, c); c8 = addq(c8, c8); c8 = addq(c8, c8);   // 16
@@ -295,17 +295,17 @@ KZG_HD g1jq g1jq_dbl(const g1jq &p) {
     return o;
 }
 KZG_HD bool g1jq_add(g1jq &o, const g1jq &p, const g1jq &q) {
-    fq z1z1 = mulq(p.z, p.z), z2z2 = mulq(q.z, q.z);
+    fq z1z1 = sqrq(p.z), z2z2 = sqrq(q.z);
     fq u1 = mulq(p.x, z2z2), u2 = mulq(q.x, z1z1);
     fq s1 = mulq(mulq(p.y, q.z), z2z2), s2 = mulq(mulq(q.y, p.z), z1z1);
     fq h = subq<3>(u2, u1);
     fq h2 = addq(h, h);
-    fq i = mulq(h2, h2);
+    fq i = sqrq(h2);
     if (is_zero_mod_p_q(i)) return false;
     fq j = mulq(h, i);
     fq r = subq<3>(s2, s1); r = addq(r, r);
     fq v = mulq(u1, i);
-    fq x3 = subq<3>(subq<3>(subq<3>(mulq(r, r), j), v), v);
+    fq x3 = subq<3>(subq<3>(subq<3>(sqrq(r), j), v), v);
     fq sj = mulq(s1, j);
     fq y3 = subq<5>(mulq(r, subq<12>(v, x3)), addq(sj, sj));
     fq zz = mulq(mulq(p.z, q.z), h);
