@@ -116,7 +116,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=512, help="blobs per step per GPU")
-    ap.add_argument("--fk20-batch", type=int, default=64)
+    ap.add_argument("--fk20-batch", type=int, default=128)
     ap.add_argument("--fk20-multi-batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fk20", action="store_true")
@@ -276,7 +276,7 @@ def main():
             if st:
                 raise RuntimeError("das_fft_extension_batch_dev status %d" % st)
 
-        GB = 32
+        GB = 64
         d_g1 = torch.from_numpy(setup.view(np.int64).reshape(1, 4096, 18)).cuda().repeat(GB, 1, 1).contiguous()
         d_g1_out = torch.empty_like(d_g1)
 

@@ -18,7 +18,7 @@ __device__ __forceinline__ g1j g1_mul_fr(const g1j &p, const fr &k_mont) {
     return g1_mul_windowed(p, from_mont<FrP>(k_mont), tbl);
 }
 
-__global__ __launch_bounds__(G1_BLOCK) void k_g1_mul_vec(const g1j *pts, uint64_t pts_mod, const fr *scalars, uint64_t s_stride, uint64_t n,
+__global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_mul_vec(const g1j *pts, uint64_t pts_mod, const fr *scalars, uint64_t s_stride, uint64_t n,
                                                          g1j *out) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= n) return;
@@ -35,7 +35,7 @@ void launch_g1_mul_vec(hipStream_t s, const g1j *pts, uint64_t pts_mod, const fr
 
 // FK20-multi Toeplitz stage (fk20_multi.go:79-91): hExtFFT[j] = sum_f C_f[j] * X_f[j].
 // tmp[b][f][jj] = scalars[b][f][j0 + jj] * files[f][j0 + jj], then summed over f.
-__global__ __launch_bounds__(G1_BLOCK) void k_g1_file_mul(const g1j *files, const fr *scalars, uint64_t nfiles, uint64_t k2, uint64_t j0, uint64_t cnt,
+__global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_file_mul(const g1j *files, const fr *scalars, uint64_t nfiles, uint64_t k2, uint64_t j0, uint64_t cnt,
                                                           uint64_t total, g1j *tmp) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= total) return;
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(G1_BLOCK) void k_g1_file_mul(const g1j *files, cons
     fr k = scalars[(b * nfiles + f) * k2 + j0 + jj];
     tmp[t] = g1_mul_fr(p, k);
 }
-__global__ __launch_bounds__(G1_BLOCK) void k_g1_sum_files(const g1j *tmp, uint64_t nfiles, uint64_t cnt, uint64_t total, g1j *out) {
+__global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_sum_files(const g1j *tmp, uint64_t nfiles, uint64_t cnt, uint64_t total, g1j *out) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= total) return;
     uint64_t jj = t % cnt, b = t / cnt;
@@ -90,7 +90,7 @@ void launch_g1_bitrev_copy(hipStream_t s, const g1j *in, uint64_t in_stride, uin
 // One DIT stage with half-size m on bit-reversed data: (x, y) -> (x + w y, x - w y), w = roots[j * W / (2m)].
 // This is the butterfly loop of _fftG1 (fft_g1.go:44-55); the recursion's 4-point leaves (simpleFTG1, :11-31) are
 // the same linear map, so outputs are identical as group elements.
-__global__ __launch_bounds__(G1_BLOCK) void k_g1_fft_stage(g1j *data, uint32_t logn, uint64_t m, const fr *roots, uint64_t W, uint64_t total, uint64_t batch) {
+__global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_fft_stage(g1j *data, uint32_t logn, uint64_t m, const fr *roots, uint64_t W, uint64_t total, uint64_t batch) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= total) return;
     // Twiddle-major lane order: t -> (j, b, g).  All lanes of a wavefront then share ONE twiddle, so (i) the waves with j == 0
@@ -114,7 +114,7 @@ void launch_g1_fft_stage(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, u
     prof_end(s, "g1_fft_stage");
 }
 
-__global__ __launch_bounds__(G1_BLOCK) void k_g1_normalize(const g1j *in, g1j *out, uint64_t n, int to_kilic) {
+__global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_normalize(const g1j *in, g1j *out, uint64_t n, int to_kilic) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= n) return;
     g1j p = g1_normalize(in[t]);
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(G1_BLOCK) void k_g1_normalize(const g1j *in, g1j *o
 // so normalising the 4096 proofs of an FK20 run drops from ~575 to ~80 products per point.  Points are strided by `lanes`
 // so that the loads of a wavefront stay adjacent.  Z = 0 entries are skipped in the running product.
 #define NORM_NB 8
-__global__ __launch_bounds__(G1_BLOCK) void k_g1_normalize_batched(const g1j *in, g1j *out, uint64_t n, uint64_t lanes, int to_kilic) {
+__global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_normalize_batched(const g1j *in, g1j *out, uint64_t n, uint64_t lanes, int to_kilic) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= lanes) return;
     fp pref[NORM_NB];
@@ -161,7 +161,7 @@ void launch_g1_normalize(hipStream_t s, const g1j *in, g1j *out, uint64_t n, boo
     uint64_t lanes = (n + NORM_NB - 1) / NORM_NB;
     hipLaunchKernelGGL(k_g1_normalize_batched, dim3((uint32_t)((lanes + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, in, out, n, lanes, to_kilic ? 1 : 0);
 }
-__global__ __launch_bounds__(G1_BLOCK) void k_g1_from_kilic(g1j *data, uint64_t n) {
+__global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_from_kilic(g1j *data, uint64_t n) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= n) return;
     data[t] = g1_from_kilic(data[t]);
@@ -170,7 +170,7 @@ void launch_g1_from_kilic(hipStream_t s, g1j *data, uint64_t n) {
     if (!n) return;
     hipLaunchKernelGGL(k_g1_from_kilic, dim3((uint32_t)((n + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, data, n);
 }
-__global__ __launch_bounds__(G1_BLOCK) void k_g1_to_affine(const g1j *in, g1a *out, uint64_t n) {
+__global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_to_affine(const g1j *in, g1a *out, uint64_t n) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= n) return;
     g1j p = in[t];
@@ -202,7 +202,7 @@ __device__ __forceinline__ bool y_is_larger(const fp &y_std) {   // y > (p - 1) 
     return false;
 }
 // ZCash compressed form: big-endian x, bit7 compressed, bit6 inf, bit5 y > (p-1)/2
-__global__ __launch_bounds__(G1_BLOCK) void k_g1_compress(const g1j *in, uint8_t *out48, uint64_t n) {
+__global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_compress(const g1j *in, uint8_t *out48, uint64_t n) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= n) return;
     g1j p = in[t];
@@ -221,7 +221,7 @@ void launch_g1_compress(hipStream_t s, const g1j *in, uint8_t *out48, uint64_t n
     if (!n) return;
     hipLaunchKernelGGL(k_g1_compress, dim3((uint32_t)((n + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, in, out48, n);
 }
-__global__ __launch_bounds__(G1_BLOCK) void k_g1_decompress(const uint8_t *in48, g1j *out, uint64_t n, uint32_t *bad) {
+__global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_decompress(const uint8_t *in48, g1j *out, uint64_t n, uint32_t *bad) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= n) return;
     const uint8_t *b = in48 + 48 * t;
@@ -266,7 +266,7 @@ void launch_g1_decompress(hipStream_t s, const uint8_t *in48, g1j *out, uint64_t
 }
 
 // GenerateTestingSetup's G1 loop (setup.go:18-24): out[i] = powers[i] * G
-__global__ __launch_bounds__(G1_BLOCK) void k_g1_fixed_base_powers(const fr *powers, uint64_t n, g1j *out) {
+__global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_fixed_base_powers(const fr *powers, uint64_t n, g1j *out) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= n) return;
     // G1 generator (decimals in-tree at bls/bls_hbls.go:23-24) in the device-internal Montgomery domain (x * 2^390 mod p)

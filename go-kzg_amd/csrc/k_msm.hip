@@ -102,7 +102,7 @@ __global__ __launch_bounds__(MSM_SORT_T) void k_msm_sort(msm_plan p, const fr *s
     }
 }
 
-__global__ __launch_bounds__(MSM_ACC_BLOCK) void k_msm_accumulate(const g1a *table, uint8_t *ws, size_t per_blob, size_t entries_off, size_t offsets_off,
+__global__ __launch_bounds__(MSM_ACC_BLOCK, 2) void k_msm_accumulate(const g1a *table, uint8_t *ws, size_t per_blob, size_t entries_off, size_t offsets_off,
                                                                   size_t buckets_off, uint32_t K, uint64_t total) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= total) return;
@@ -198,7 +198,7 @@ void launch_msm(hipStream_t s, const msm_plan &p, const g1a *table, const fr *sc
 #define FB_BLOCK 128
 
 // pass 1: lane (w, i) walks d = 1..D with mixed additions; X, Y go to the table slot, Z to ztmp
-__global__ __launch_bounds__(FB_BLOCK) void k_fb_build_pass1(const g1a *rows, uint64_t lanes, uint32_t D, g1a *table, fp *ztmp) {
+__global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_build_pass1(const g1a *rows, uint64_t lanes, uint32_t D, g1a *table, fp *ztmp) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= lanes) return;
     g1a b = rows[t];
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(FB_BLOCK) void k_fb_build_pass1(const g1a *rows, ui
     }
 }
 // pass 2: Montgomery batch inversion of the lane's D Z-values (prefix products in ptmp), then X/Z^2, Y/Z^3
-__global__ __launch_bounds__(FB_BLOCK) void k_fb_build_pass2(uint64_t lanes, uint32_t D, g1a *table, fp *ztmp, fp *ptmp) {
+__global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_build_pass2(uint64_t lanes, uint32_t D, g1a *table, fp *ztmp, fp *ptmp) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= lanes) return;
     g1a *dst = table + t * D; fp *zd = ztmp + t * D; fp *pd = ptmp + t * D;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(FB_BLOCK) void k_fb_build_pass2(uint64_t lanes, uin
 }
 
 // main kernel: lane handles points i = lane, lane + L, ... of one blob; block tree-reduces through LDS
-__global__ __launch_bounds__(FB_BLOCK) void k_fb_accumulate(const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, uint32_t D, const fr *scalars,
+__global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_accumulate(const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, uint32_t D, const fr *scalars,
                                                             uint64_t n, uint32_t blocks_per_blob, g1j *partials) {
     __shared__ g1j buf[FB_BLOCK];
     const uint32_t tid = threadIdx.x;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(64) void k_fb_finish(const g1j *partials, uint32_t 
 // element-wise fixed-base products over the same table layout: out[b][i] = scalars[b][i] * P_i  (the FK20 Toeplitz stage,
 // ToeplitzPart2's loop fk20_single.go:72-74, where P = xExtFFT is fixed per settings): nwin mixed adds instead of a
 // 255-bit double-and-add per element.
-__global__ __launch_bounds__(FB_BLOCK) void k_fb_mul_vec(const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, uint32_t D, const fr *scalars,
+__global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_mul_vec(const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, uint32_t D, const fr *scalars,
                                                          uint64_t i0, uint64_t cnt, uint64_t row, uint64_t total, g1j *out) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= total) return;
@@ -363,7 +363,7 @@ hipError_t launch_fb_build(hipStream_t s, const g1a *pts, uint64_t n, uint32_t c
 }
 
 // fixed-base table rows: tmp[w * n + i] = 2^(c w) * P_i (Jacobian), then normalised to affine by launch_g1_to_affine
-__global__ __launch_bounds__(MSM_ACC_BLOCK) void k_msm_window_rows(const g1a *pts, uint64_t n, uint32_t c, uint32_t nwin, g1j *tmp) {
+__global__ __launch_bounds__(MSM_ACC_BLOCK, 2) void k_msm_window_rows(const g1a *pts, uint64_t n, uint32_t c, uint32_t nwin, g1j *tmp) {
     uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     g1j q = to_jac(pts[i]);
