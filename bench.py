@@ -63,6 +63,39 @@ def splitmix_blobs(base_seed, batch, n=N_COEFF):
     return out
 
 
+_R_LIMBS = [(R_MOD >> (64 * i)) & ((1 << 64) - 1) for i in range(4)]
+
+
+def splitmix_blobs_le32(base_seed, batch, n=N_COEFF):
+    """The same scalars as splitmix_blobs, in STANDARD form as 32 little-endian bytes each (batch, n, 32) uint8, fully
+    vectorised (the 256-bit value is < 2^256 < 3 r: at most two conditional subtractions of r).  The Montgomery conversion
+    is then done on the device with kzg_hip_fr_from_le32 (bls.FrFrom32 over a slice)."""
+    seeds = (np.uint64(base_seed & ((1 << 64) - 1)) + np.arange(batch, dtype=np.uint64))[:, None]
+    idx = np.arange(1, 4 * n + 1, dtype=np.uint64)[None, :]
+    with np.errstate(over="ignore"):
+        z = seeds + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+        v = z.reshape(batch, n, 4)
+        r = np.array(_R_LIMBS, dtype=np.uint64)
+        for _ in range(2):
+            ge = np.ones(v.shape[:2], dtype=bool)          # v >= r, lexicographic from the top limb
+            decided = np.zeros(v.shape[:2], dtype=bool)
+            for k in (3, 2, 1, 0):
+                gt, lt = v[..., k] > r[k], v[..., k] < r[k]
+                ge = np.where(~decided & lt, False, ge)
+                decided |= gt | lt
+            borrow = np.zeros(v.shape[:2], dtype=np.uint64)
+            out = v.copy()
+            for k in range(4):
+                d = v[..., k] - r[k] - borrow
+                borrow = ((v[..., k] < r[k] + borrow) | ((r[k] + borrow) < r[k])).astype(np.uint64)
+                out[..., k] = d
+            v = np.where(ge[..., None], out, v)
+    return np.ascontiguousarray(v).view(np.uint8).reshape(batch, n, 32)
+
+
 def dist_env():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,7 +150,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=512, help="blobs per step per GPU")
     ap.add_argument("--fk20-batch", type=int, default=128)
-    ap.add_argument("--fk20-multi-batch", type=int, default=64)
+    ap.add_argument("--fk20-multi-batch", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fk20", action="store_true")
     args = ap.parse_args()
@@ -143,8 +176,15 @@ def main():
     setup = fs.from_compressed_g1(raw)                      # 4096 x [1337^i]G1, decompressed on the device
     ks = kz.KZGSettings(fs, setup)
 
+    def mont_blobs(seed, batch, n=N_COEFF):
+        """synthetic scalars as Montgomery images: vectorised splitmix + mod r on the host, FrFrom32 on the device"""
+        std = splitmix_blobs_le32(seed, batch, n)
+        out, ok = fs.fr_from_32(std.reshape(-1, 32))
+        assert ok
+        return out.reshape(batch, n, 4)
+
     B = args.batch
-    blobs_h = splitmix_blobs(1 + rank * B, B)               # rank r owns blobs [r B, (r + 1) B)
+    blobs_h = mont_blobs(1 + rank * B, B)                   # rank r owns blobs [r B, (r + 1) B)
     d_blobs = torch.from_numpy(blobs_h.view(np.int64)).cuda()
     d_out = torch.zeros((B, 18), dtype=torch.int64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
@@ -212,7 +252,7 @@ def main():
     if not args.no_fk20:
         fk = kz.FK20SingleSettings(ks, 4096)
         FB = args.fk20_batch
-        polys_h = splitmix_blobs(4 + rank * FB, FB)[:, :2048, :].copy()
+        polys_h = mont_blobs(4 + rank * FB, FB)[:, :2048, :].copy()
         d_polys = torch.from_numpy(polys_h.view(np.int64)).cuda()
         d_proofs = torch.zeros((FB, 4096, 18), dtype=torch.int64, device="cuda")
 
@@ -237,7 +277,7 @@ def main():
         ks16 = kz.KZGSettings(fs16, fs16.generate_testing_setup_g1(sec, 65536))
         fkm = kz.FK20MultiSettings(ks16, 65536, 16)
         MB = args.fk20_multi_batch
-        mp_h = splitmix_blobs(5 + rank * MB, MB, n=32768)
+        mp_h = mont_blobs(5 + rank * MB, MB, n=32768)
         d_mp = torch.from_numpy(mp_h.view(np.int64)).cuda()
         d_mproofs = torch.zeros((MB, 4096, 18), dtype=torch.int64, device="cuda")
 
@@ -261,7 +301,7 @@ def main():
             return units * world * reps / secs_
 
         FB = 1024
-        d_fr = torch.from_numpy(splitmix_blobs(12 + rank * 7, 8).view(np.int64)).cuda().repeat(FB // 8, 1, 1).contiguous()
+        d_fr = torch.from_numpy(mont_blobs(12 + rank * FB, FB).view(np.int64)).cuda()
         d_fr_out = torch.empty_like(d_fr)
 
         def fr_step():

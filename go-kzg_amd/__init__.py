@@ -72,6 +72,7 @@ def lib():
         "kzg_hip_das_fft_extension": (i32, [vp, vp, u64]), "kzg_hip_das_fft_extension_batch": (i32, [vp, vp, u64, u64]),
         "kzg_hip_fft_fr_batch_dev": (i32, [vp, vp, u64, u64, i32, vp, vp]), "kzg_hip_fft_g1_batch_dev": (i32, [vp, vp, u64, u64, i32, vp, vp]),
         "kzg_hip_das_fft_extension_batch_dev": (i32, [vp, vp, u64, u64, vp]),
+        "kzg_hip_fr_from_le32": (i32, [vp, vp, u64, vp, C.POINTER(i32)]), "kzg_hip_fr_to_le32": (i32, [vp, vp, u64, vp]),
         "kzg_hip_lincomb_g1": (i32, [vp, vp, vp, u64, vp]), "kzg_hip_g1_to_compressed": (i32, [vp, vp, u64, vp]),
         "kzg_hip_g1_from_compressed": (i32, [vp, vp, u64, vp]), "kzg_hip_g1_mul_vec": (i32, [vp, vp, vp, u64, vp]),
         "kzg_hip_generate_testing_setup_g1": (i32, [vp, vp, u64, vp]),
@@ -216,6 +217,20 @@ class FFTSettings:
         vals = np.ascontiguousarray(vals, dtype=np.uint64).copy()
         _chk(lib().kzg_hip_das_fft_extension_batch(self.h, _p(vals), vals.shape[1], vals.shape[0]))
         return vals
+
+    def fr_from_32(self, data):
+        """bls.FrFrom32 over a slice (bls/bignum_kilic.go:33-44): (n, 32) LE bytes -> ((n, 4) images, all_ok)"""
+        data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1, 32)
+        out, ok = fr_empty(data.shape[0]), C.c_int(1)
+        _chk(lib().kzg_hip_fr_from_le32(self.h, _p(data), data.shape[0], _p(out), C.byref(ok)))
+        return out, bool(ok.value)
+
+    def fr_to_32(self, vals):
+        """bls.FrTo32 over a slice (bls/bignum_kilic.go:46-55)"""
+        vals = _fr(vals)
+        out = np.zeros((vals.shape[0], 32), dtype=np.uint8)
+        _chk(lib().kzg_hip_fr_to_le32(self.h, _p(vals), vals.shape[0], _p(out)))
+        return out
 
     def zero_poly_via_multiplication(self, missing_indices, length):
         """FFTSettings.ZeroPolyViaMultiplication (zero_poly.go:116-217): (zero_eval, zero_poly)"""

@@ -358,6 +358,39 @@ int kzg_hip_lincomb_g1(kzg_hip_fft *fs, const void *points_g1, const void *scala
     return KZG_HIP_OK;
 }
 
+int kzg_hip_fr_from_le32(kzg_hip_fft *fs, const void *in_le32, uint64_t n, void *out_fr, int *all_ok) {
+    if (!fs || (n && (!in_le32 || !out_fr))) return KZG_HIP_ERR_BAD_ARG;
+    if (all_ok) *all_ok = 1;
+    if (!n) return KZG_HIP_OK;
+    dev_guard g(fs);
+    hipStream_t s = fs->stream;
+    dtmp<uint8_t> d_in(s); dtmp<fr> d_out(s); dtmp<uint32_t> d_bad(s);
+    CHK(d_in.alloc(32 * n)); CHK(d_out.alloc(n)); CHK(d_bad.alloc(1));
+    HIPCHK(hipMemsetAsync(d_bad.p, 0, 4, s));
+    HIPCHK(hipMemcpyAsync(d_in.p, in_le32, 32 * n, hipMemcpyHostToDevice, s));
+    launch_fr_from_le32(s, d_in.p, d_out.p, n, 1, d_bad.p);
+    HIPCHK(hipGetLastError());
+    uint32_t bad = 0;
+    HIPCHK(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out_fr, d_out.p, n * sizeof(fr), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (all_ok) *all_ok = bad ? 0 : 1;
+    return KZG_HIP_OK;
+}
+int kzg_hip_fr_to_le32(kzg_hip_fft *fs, const void *in_fr, uint64_t n, void *out_le32) {
+    if (!fs || (n && (!in_fr || !out_le32))) return KZG_HIP_ERR_BAD_ARG;
+    if (!n) return KZG_HIP_OK;
+    dev_guard g(fs);
+    hipStream_t s = fs->stream;
+    dtmp<uint8_t> d_out(s); dtmp<fr> d_in(s);
+    CHK(d_in.alloc(n)); CHK(d_out.alloc(32 * n));
+    HIPCHK(hipMemcpyAsync(d_in.p, in_fr, n * sizeof(fr), hipMemcpyHostToDevice, s));
+    launch_fr_to_le32(s, d_in.p, d_out.p, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_le32, d_out.p, 32 * n, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return KZG_HIP_OK;
+}
 int kzg_hip_g1_to_compressed(kzg_hip_fft *fs, const void *points_g1, uint64_t n, void *out48) {
     if (!fs || (n && (!points_g1 || !out48))) return KZG_HIP_ERR_BAD_ARG;
     if (!n) return KZG_HIP_OK;

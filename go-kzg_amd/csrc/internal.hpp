@@ -28,6 +28,7 @@ void launch_fr_powers(hipStream_t s, const fr *base, uint64_t n, fr *out);   // 
 
 // eth/ byte-level path
 void launch_fr_from_le32(hipStream_t s, const uint8_t *in, fr *out, uint64_t per_blob, uint64_t batch, uint32_t *bad);
+void launch_fr_to_le32(hipStream_t s, const fr *in, uint8_t *out, uint64_t n);
 void launch_fr_bitrev_gather(hipStream_t s, const fr *in, fr *out, uint64_t n);
 void launch_eth_quotient(hipStream_t s, const fr *poly, const fr *domain, uint64_t n, const fr *z, const fr *inv_n, fr *q, fr *y_out, uint32_t *flag);
 

@@ -402,4 +402,14 @@ void launch_fr_pointwise(hipStream_t s, const fr *a, const fr *b, const uint8_t 
     hipLaunchKernelGGL(k_fr_pointwise, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, a, b, present, out, n, mode, flag);
 }
 
+__global__ void k_fr_to_le32(const fr *in, uint8_t *out, uint64_t n) {   // bls.FrTo32 (bls/bignum_kilic.go:46-55)
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    *reinterpret_cast<fr *>(out + 32 * t) = from_mont<FrP>(in[t]);
+}
+void launch_fr_to_le32(hipStream_t s, const fr *in, uint8_t *out, uint64_t n) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_fr_to_le32, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
+}
+
 }  // namespace kzg

@@ -73,6 +73,11 @@ int kzg_hip_fft_fr_batch_dev(kzg_hip_fft *fs, const void *d_vals_fr, uint64_t n,
 int kzg_hip_fft_g1_batch_dev(kzg_hip_fft *fs, const void *d_vals_g1, uint64_t n, uint64_t batch, int inv, void *d_out_g1, void *stream);
 int kzg_hip_das_fft_extension_batch_dev(kzg_hip_fft *fs, void *d_vals_fr, uint64_t n, uint64_t batch, void *stream);
 
+/* bls.FrFrom32 / bls.FrTo32 over a slice (bls/bignum_kilic.go:33-55; range rule bls.ValidFr, bls/bignum_all.go:12-35):
+ * n x 32 little-endian bytes <-> Montgomery images.  from: *all_ok = 0 if any value is >= r (those become 0). */
+int kzg_hip_fr_from_le32(kzg_hip_fft *fs, const void *in_le32, uint64_t n, void *out_fr, int *all_ok);
+int kzg_hip_fr_to_le32(kzg_hip_fft *fs, const void *in_fr, uint64_t n, void *out_le32);
+
 /* ---- bls.LinCombG1 (bls/bls_kilic.go:132-150): Pippenger MSM; n == 0 -> infinity ---- */
 int kzg_hip_lincomb_g1(kzg_hip_fft *fs, const void *points_g1, const void *scalars_fr, uint64_t n, void *out_g1);
 /* bls.ToCompressedG1 over a slice (bls/bls_kilic.go:114-116): n points -> n x 48 B ZCash form */

@@ -18,6 +18,15 @@ def test_splitmix_blobs_match_oracle_generator():
     assert np.array_equal(got[1], ko.synthetic_blob(2, 64))
 
 
+def test_splitmix_blobs_le32_vectorised_matches_oracle_generator():
+    import bench
+    from oracle import koracle as ko
+    got = bench.splitmix_blobs_le32(7, 2, n=128)
+    for b in range(2):
+        want = ko.fr_to_ints(ko.synthetic_blob(7 + b, 128))
+        assert [int.from_bytes(got[b, i].tobytes(), "little") for i in range(128)] == want
+
+
 def test_shard_units_cover_exactly():
     import bench
     for total in (0, 1, 7, 4096, 4097):

@@ -194,6 +194,19 @@ def test_compress_decompress_edge_cases(kz, fs16):
             fs16.from_compressed_g1(notoncurve)
 
 
+def test_fr_from_32_to_32(kz, fs16):
+    # bls.FrFrom32 / FrTo32 (bls/bignum_kilic.go:33-55) over a slice, incl. the range rule (TestValidFr, bls/bignum_test.go:91)
+    vals = [0, 1, 5, ko.R_MOD - 1, 2**255 % ko.R_MOD, 123456789 << 200]
+    raw = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in vals), dtype=np.uint8).reshape(-1, 32)
+    imgs, ok = fs16.fr_from_32(raw)
+    assert ok and np.array_equal(imgs, ko.fr_from_ints(vals))
+    assert np.array_equal(fs16.fr_to_32(imgs), raw)
+    bad = raw.copy()
+    bad[2] = np.frombuffer(ko.R_MOD.to_bytes(32, "little"), dtype=np.uint8)
+    _, ok = fs16.fr_from_32(bad)
+    assert not ok
+
+
 def test_g1_text_marshalling_roundtrip(kz, fs16):
     # TestPointG1Marshalling (bls/bls_test.go:25-45) over a slice, plus the JSON-setup form (eth/globals.go:33-49)
     pts = edge_points()
