@@ -488,20 +488,39 @@ void kzg_hip_kzg_settings_free(kzg_hip_kzg *ks) {
     delete ks;
 }
 
+// number of signed c-bit windows of a canonical scalar (< r < 2^255): ceil(255 / c), plus one only if the top window's
+// digit (top bits of r - 1, plus the incoming carry) can exceed 2^(c-1) and carry out (c = 15: 17 windows, c = 16: 16)
+// table budget in GB: the environment override, else min(cap, free HBM - headroom)
+static double table_budget_gb(const char *env, double cap_gb, double headroom_gb) {
+    if (const char *e = getenv(env)) return atof(e);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0.0;
+    double g = (double)free_b / 1e9 - headroom_gb;
+    return g > cap_gb ? cap_gb : (g > 0.0 ? g : 0.0);
+}
+static uint32_t fb_windows(uint32_t c) {
+    uint32_t nw = (255 + c - 1) / c, sh = c * (nw - 1);
+    uint64_t top = (0x73eda753299d7d48ull >> (sh - 192)) + 1;
+    return top > (1ull << (c - 1)) ? nw + 1 : nw;
+}
+
 // Lazily builds the fixed-base table T[(w n + i) D + d - 1] = d 2^(c w) SecretG1[i] (k_msm.hip).  The window size is the
-// largest whose table fits the HBM budget (KZG_HIP_FB_BUDGET_GB, default 70 of the 288 GB): n = 4096 -> c = 14, 61 GB, 19 windows (measured: c = 13 43.4k, c = 14 46.8k, c = 15 46.2k commitments/s).
+// largest whose table fits the HBM budget: KZG_HIP_FB_BUDGET_GB if set, else what is free on the device minus 40 GB of
+// headroom for the FK20 tables and workspaces, capped at 210 GB.  On an otherwise empty 288 GB MI355X, n = 4096 gets
+// c = 16: 16 windows, 206 GB (measured: c = 13 20 windows 55k, c = 14 19 windows 60.2k, c = 15 17 windows 57.9k,
+// c = 16 16 windows 68.7k commitments/s); a second settings object built while the first is alive gets a smaller table.
 static int ensure_fixed_table(kzg_hip_kzg *ks, hipStream_t s) {
     if (ks->d_fixed || ks->fixed_plan.c == 0xffffffffu) return KZG_HIP_OK;
-    double budget_gb = 70.0;
-    if (const char *e = getenv("KZG_HIP_FB_BUDGET_GB")) budget_gb = atof(e);
+    double budget_gb = table_budget_gb("KZG_HIP_FB_BUDGET_GB", 210.0, 40.0);
     uint32_t best = 0;
-    for (uint32_t c = 14; c >= 5; c--) {
-        double bytes = (double)(255 / c + 1) * (double)ks->n_setup * (double)(1u << (c - 1)) * sizeof(g1a);
+    for (uint32_t c = 16; c >= 5; c--) {
+        if (c == 15) continue;                               // measured slower than c = 14 despite 17 windows (gather stride)
+        double bytes = (double)fb_windows(c) * (double)ks->n_setup * (double)(1u << (c - 1)) * sizeof(g1a);
         if (bytes <= budget_gb * 1e9) { best = c; break; }
     }
     if (!best || ks->n_setup < 64) { ks->fixed_plan.c = 0xffffffffu; return KZG_HIP_OK; }   // classic path only
     msm_plan p{};
-    p.c = best; p.nwin = 255 / best + 1; p.nb = 1u << (best - 1); p.ngroups = 1; p.fixed = 1; p.table_n = ks->n_setup;
+    p.c = best; p.nwin = fb_windows(best); p.nb = 1u << (best - 1); p.ngroups = 1; p.fixed = 1; p.table_n = ks->n_setup;
     size_t entries = (size_t)p.nwin * ks->n_setup * p.nb;
     HIPCHK(hipMalloc((void **)&ks->d_fixed, entries * sizeof(g1a)));
     HIPCHK(launch_fb_build(s, ks->d_secret_a, ks->n_setup, p.c, p.nwin, ks->d_fixed));
@@ -655,18 +674,17 @@ static int fk20_core_new(kzg_hip_kzg *ks, uint64_t n2, uint64_t l, fk20_core *c)
     launch_g1_normalize(s, d_f.p, c->d_files, l * k2);
     HIPCHK(hipGetLastError());
     {   // fixed-base table over the file points, sized by KZG_HIP_FK20_FB_BUDGET_GB (default 24 GB of the 288)
-        double budget_gb = 24.0;
-        if (const char *e = getenv("KZG_HIP_FK20_FB_BUDGET_GB")) budget_gb = atof(e);
+        double budget_gb = table_budget_gb("KZG_HIP_FK20_FB_BUDGET_GB", 24.0, 12.0);
         uint64_t npts = l * k2; uint32_t best = 0;
         for (uint32_t cc = 12; cc >= 4; cc--) {
-            double bytes = (double)(255 / cc + 1) * (double)npts * (double)(1u << (cc - 1)) * sizeof(g1a);
+            double bytes = (double)fb_windows(cc) * (double)npts * (double)(1u << (cc - 1)) * sizeof(g1a);
             if (bytes <= budget_gb * 1e9) { best = cc; break; }
         }
         if (best && npts >= 64) {
             dtmp<g1a> d_fa(s);
             CHK(d_fa.alloc(npts));
             launch_g1_to_affine(s, c->d_files, d_fa.p, npts);
-            c->fb_c = best; c->fb_nwin = 255 / best + 1;
+            c->fb_c = best; c->fb_nwin = fb_windows(best);
             HIPCHK(hipMalloc((void **)&c->d_files_fb, (size_t)c->fb_nwin * npts * (1u << (best - 1)) * sizeof(g1a)));
             HIPCHK(launch_fb_build(s, d_fa.p, npts, c->fb_c, c->fb_nwin, c->d_files_fb));
             HIPCHK(hipStreamSynchronize(s));

@@ -197,35 +197,47 @@ void launch_msm(hipStream_t s, const msm_plan &p, const g1a *table, const fr *sc
 // ---------------------------------------------------------------------------------------------------------
 #define FB_BLOCK 128
 
-// pass 1: lane (w, i) walks d = 1..D with mixed additions; X, Y go to the table slot, Z to ztmp
-__global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_build_pass1(const g1a *rows, uint64_t lanes, uint32_t D, g1a *table, fp *ztmp) {
+// pass 1: lane (w, i, seg) walks d = seg S + 1 .. (seg + 1) S with mixed additions from (seg S + 1) b (a short double-and-add);
+// X, Y go to the table slot, Z to ztmp.  S = D / segs keeps >= 4 waves per SIMD busy even for the 65 536-row n = 4096 tables.
+__global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_build_pass1(const g1a *rows, uint64_t lanes, uint32_t D, uint32_t S, g1a *table, fp *ztmp) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    if (t >= lanes) return;
-    g1a b = rows[t];
+    const uint32_t segs = D / S;
+    if (t >= lanes * segs) return;
+    const uint64_t row = t / segs; const uint32_t seg = (uint32_t)(t % segs);
+    g1a b = rows[row];
     g1j cur = to_jac(b);
-    g1a *dst = table + t * D; fp *zd = ztmp + t * D;
+    uint32_t k = seg * S + 1;
+    if (k > 1) {
+        cur = g1_inf();
 #pragma nounroll
-    for (uint32_t d = 0; d < D; d++) {
+        for (int bit = 31 - __builtin_clz(k); bit >= 0; bit--) {
+            cur = g1_dbl(cur);
+            if ((k >> bit) & 1u) cur = g1_madd(cur, b);
+        }
+    }
+    g1a *dst = table + row * D + (uint64_t)seg * S; fp *zd = ztmp + row * D + (uint64_t)seg * S;
+#pragma nounroll
+    for (uint32_t d = 0; d < S; d++) {
         g1a xy; xy.x = cur.x; xy.y = cur.y;
         dst[d] = xy; zd[d] = cur.z;
         cur = g1_madd(cur, b);
     }
 }
-// pass 2: Montgomery batch inversion of the lane's D Z-values (prefix products in ptmp), then X/Z^2, Y/Z^3
-__global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_build_pass2(uint64_t lanes, uint32_t D, g1a *table, fp *ztmp, fp *ptmp) {
+// pass 2: Montgomery batch inversion of the lane's S Z-values (prefix products in ptmp), then X/Z^2, Y/Z^3
+__global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_build_pass2(uint64_t lanes, uint32_t D, uint32_t S, g1a *table, fp *ztmp, fp *ptmp) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    if (t >= lanes) return;
-    g1a *dst = table + t * D; fp *zd = ztmp + t * D; fp *pd = ptmp + t * D;
+    if (t >= lanes * (D / S)) return;
+    g1a *dst = table + t * S; fp *zd = ztmp + t * S; fp *pd = ptmp + t * S;   // (row, seg) slots are contiguous: row D + seg S = t S
     fp acc = one<FpP>();
 #pragma nounroll
-    for (uint32_t d = 0; d < D; d++) {
+    for (uint32_t d = 0; d < S; d++) {
         pd[d] = acc;
         fp z = zd[d];
         if (!is_zero<FpP>(z)) acc = mul(acc, z);
     }
     fp inv_all = inv<FpP>(acc);
 #pragma nounroll
-    for (uint32_t d = D; d-- > 0;) {
+    for (uint32_t d = S; d-- > 0;) {
         fp z = zd[d];
         if (is_zero<FpP>(z)) { dst[d] = g1a_inf(); continue; }
         fp zi = mul(inv_all, pd[d]);
@@ -354,9 +366,11 @@ hipError_t launch_fb_build(hipStream_t s, const g1a *pts, uint64_t n, uint32_t c
     for (uint32_t w0 = 0; w0 < nwin; w0 += slab) {
         uint32_t ws = (w0 + slab <= nwin) ? slab : nwin - w0;
         uint64_t lanes = (uint64_t)ws * n;
-        dim3 g((uint32_t)((lanes + FB_BLOCK - 1) / FB_BLOCK)), b(FB_BLOCK);
-        hipLaunchKernelGGL(k_fb_build_pass1, g, b, 0, s, rows + (uint64_t)w0 * n, lanes, D, table + (uint64_t)w0 * n * D, ztmp);
-        hipLaunchKernelGGL(k_fb_build_pass2, g, b, 0, s, lanes, D, table + (uint64_t)w0 * n * D, ztmp, ptmp);
+        uint32_t S = D;                                      // segment length: split rows until the slab has >= 2^20 lanes, S >= 64
+        while (S > 64 && lanes * (D / S) < (1ull << 20)) S >>= 1;
+        dim3 g((uint32_t)((lanes * (D / S) + FB_BLOCK - 1) / FB_BLOCK)), b(FB_BLOCK);
+        hipLaunchKernelGGL(k_fb_build_pass1, g, b, 0, s, rows + (uint64_t)w0 * n, lanes, D, S, table + (uint64_t)w0 * n * D, ztmp);
+        hipLaunchKernelGGL(k_fb_build_pass2, g, b, 0, s, lanes, D, S, table + (uint64_t)w0 * n * D, ztmp, ptmp);
     }
     hipFreeAsync(rows_j, s); hipFreeAsync(rows, s); hipFreeAsync(ztmp, s); hipFreeAsync(ptmp, s);
     return hipGetLastError();
