@@ -236,17 +236,28 @@ def main():
         avg_s = tot.value / cnt.value * 1e-3
         alg_bytes = B * BYTES_PER_COMMIT + BYTES_SETUP
         ach = alg_bytes / avg_s * 1e-9
+        tab_c, tab_w, tab_bytes = ks.table_info()
         traffic = None
         try:   # HBM bytes per launch from the committed PMC passes (profiles/), only when the workload matches that measurement
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if pm["kernel"] == "k_" + dominant.decode() and pm["batch"] == B and pm["n"] == N_COEFF:
+            if pm["kernel"] == "k_" + dominant.decode() and pm["batch"] == B and pm["n"] == N_COEFF and pm["table_c"] == tab_c:
                 traffic = pm["fetch_bytes_per_launch"] + pm["write_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
         roofline = {"bound": "hbm", "kernel": "k_" + dominant.decode(), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_s * 1e3,
                     "algorithmic_bytes_per_launch": alg_bytes,
+                    "table": {"window_bits": tab_c, "windows": tab_w, "GB": tab_bytes / 1e9},
                     "note": "integer-VALU-bound kernel; traffic (PMC, profiles/r01_pmc_traffic.json) exceeds the algorithmic bytes by design: fixed-base table gathers trade HBM bandwidth for integer work (DESIGN.md 4)"}
+
+        if tab_w:
+            # what actually bounds the walk: v_mad_u64_u32 issue (half rate: 8 lanes/clk/SIMD, tools/mulbench.hip).  One XYZZ mixed
+            # addition = 8 products (338 mads) + 2 squarings (260 mads); a launch does B * n * windows of them (zero digits: < 2^-13).
+            mads = B * N_COEFF * tab_w * (8 * 338 + 2 * 260)
+            peak = 256 * 4 * 8 * 2.4e9
+            roofline["valu"] = {"bound": "v_mad_u64_u32 issue", "mads_per_launch": mads, "achieved_Tmad_s": mads / avg_s * 1e-12,
+                                "peak_Tmad_s": peak * 1e-12, "frac": mads / avg_s / peak,
+                                "note": "peak at the 2.4 GHz nominal clock; the kernel runs power-limited at ~2.0-2.1 GHz (DESIGN.md 4)"}
 
     fk20 = None
     if not args.no_fk20:

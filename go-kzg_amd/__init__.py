@@ -98,6 +98,7 @@ def lib():
         "kzg_hip_eth_compute_kzg_proof": (i32, [vp, vp, u64, vp, vp, vp]),
         "kzg_hip_zero_poly_via_multiplication": (i32, [vp, vp, u64, u64, vp, vp]),
         "kzg_hip_recover_poly_from_samples": (i32, [vp, vp, vp, u64, vp]),
+        "kzg_hip_kzg_table_info": (i32, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(u64)]),
         "kzg_hip_prof_reset": (None, [vp, i32]), "kzg_hip_prof_read": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64)]),
     }
     for name, (res, args) in sig.items():
@@ -316,6 +317,12 @@ class KZGSettings:
         if getattr(self, "h", None):
             lib().kzg_hip_kzg_settings_free(self.h)
             self.h = None
+
+    def table_info(self):
+        """(window bits, windows, bytes) of the fixed-base table the commitments walk; zeros before the first commitment"""
+        c, w, b = C.c_uint32(0), C.c_uint32(0), C.c_uint64(0)
+        _chk(lib().kzg_hip_kzg_table_info(self.h, C.byref(c), C.byref(w), C.byref(b)))
+        return c.value, w.value, b.value
 
     def commit_to_poly(self, coeffs):
         coeffs = _fr(coeffs)

@@ -1073,6 +1073,13 @@ int kzg_hip_eth_compute_kzg_proof(kzg_hip_eth *eth, const void *poly_fr, uint64_
 // ---------------------------------------------------------------------------------------------------------
 // instrumentation
 // ---------------------------------------------------------------------------------------------------------
+int kzg_hip_kzg_table_info(kzg_hip_kzg *ks, uint32_t *window_bits, uint32_t *windows, uint64_t *table_bytes) {
+    if (!ks || !window_bits || !windows || !table_bytes) return KZG_HIP_ERR_BAD_ARG;
+    bool have = ks->d_fixed != nullptr;
+    *window_bits = have ? ks->fixed_plan.c : 0; *windows = have ? ks->fixed_plan.nwin : 0;
+    *table_bytes = have ? (uint64_t)ks->fixed_plan.nwin * ks->fixed_plan.table_n * ks->fixed_plan.nb * sizeof(g1a) : 0;
+    return KZG_HIP_OK;
+}
 void kzg_hip_prof_reset(kzg_hip_fft *fs, int enable) {
     (void)fs;
     std::lock_guard<std::mutex> lk(g_prof_mu);

@@ -162,6 +162,9 @@ int kzg_hip_recover_poly_from_samples(kzg_hip_fft *fs, const void *samples_fr, c
 /* ---- instrumentation for bench.py: HIP-event time of the dominant kernel since the last reset (ms) and launch count ---- */
 void kzg_hip_prof_reset(kzg_hip_fft *fs, int enable);
 int kzg_hip_prof_read(kzg_hip_fft *fs, const char *kernel, double *total_ms, uint64_t *launches);
+/* shape of the fixed-base table CommitToPoly walks (built lazily by the first commitment): signed window bits c, window count and
+ * bytes of HBM; all zero before the first commitment or when the setup is too small for a table (classic bucket path) */
+int kzg_hip_kzg_table_info(kzg_hip_kzg *ks, uint32_t *window_bits, uint32_t *windows, uint64_t *table_bytes);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -5,11 +5,37 @@
 #include "g1.hpp"
 #include <string.h>
 using namespace kzg;
+// n pseudo-random (and bit-pattern-structured) elements: inv(x) * x == one and inv(x) == inv_fermat(x) on every 16th; returns mismatches
+template <class F> static uint64_t inv_stress(uint64_t n, uint64_t seed) {
+    uint64_t bad = 0, st = seed;
+    auto next = [&]() { st += 0x9e3779b97f4a7c15ull; uint64_t z = st; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; return z ^ (z >> 31); };
+    for (uint64_t i = 0; i < n; i++) {
+        felem<F> x;
+        uint64_t mode = next() % 4;
+        for (int w = 0; w < F::N; w++) {
+            uint64_t r = next();
+            x.l[w] = mode == 0 ? (uint32_t)r : mode == 1 ? (uint32_t)(r & (r >> 32)) & (uint32_t)next() : mode == 2 ? ((r & 7) ? 0u : (uint32_t)(r >> 8)) : ~((uint32_t)(r & (r >> 32)) & (uint32_t)next());
+        }
+        x.l[F::N - 1] &= (1u << ((F::BITS - 1) % 32)) - 1;           // below the modulus
+        if (next() % 8 == 0) for (int w = (int)(next() % F::N); w < F::N; w++) x.l[w] = 0;   // short values
+        felem<F> y = inv<F>(x);
+        if (is_zero<F>(x)) { bad += !is_zero<F>(y); continue; }
+        if (!equal<F>(mul(x, y), one<F>())) bad++;
+        if (i % 16 == 0 && !equal<F>(y, inv_fermat<F>(x))) bad++;
+    }
+    return bad;
+}
+
 extern "C" {
 void he_fr_mul(fr *o, const fr *a, const fr *b) { *o = mul(*a, *b); }
 void he_fr_add(fr *o, const fr *a, const fr *b) { *o = add(*a, *b); }
 void he_fr_sub(fr *o, const fr *a, const fr *b) { *o = sub(*a, *b); }
 void he_fr_inv(fr *o, const fr *a) { *o = inv<FrP>(*a); }
+void he_fr_inv_fermat(fr *o, const fr *a) { *o = inv_fermat<FrP>(*a); }
+void he_fp_inv(fp *o, const fp *a) { *o = inv<FpP>(*a); }
+void he_fp_inv_fermat(fp *o, const fp *a) { *o = inv_fermat<FpP>(*a); }
+uint64_t he_fr_inv_stress(uint64_t n, uint64_t seed) { return inv_stress<FrP>(n, seed); }
+uint64_t he_fp_inv_stress(uint64_t n, uint64_t seed) { return inv_stress<FpP>(n, seed); }
 void he_fr_from_u64(fr *o, uint64_t v) { *o = fr_from_u64(v); }
 void he_fr_from_mont(fr *o, const fr *a) { *o = from_mont<FrP>(*a); }
 #define IN(p) g1_from_kilic(*(p))

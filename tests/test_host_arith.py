@@ -55,6 +55,36 @@ def test_fr_ops(he):
     assert ko.fr_to_ints(got) == [2**64 - 5]
 
 
+P_MOD = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+
+
+def test_binary_gcd_inversion_matches_fermat_and_bigint(he):
+    # inv() (binary GCD on 30-bit limbs) == inv_fermat() == pow(x, -1, m) in the Montgomery domain, F_r (R = 2^256) and F_p (R' = 2^390)
+    rng = np.random.default_rng(11)
+    for name, mod, words, rbits in (("fr", ko.R_MOD, 8, 256), ("fp", P_MOD, 12, 390)):
+        edge = [0, 1, 2, 3, mod - 1, mod - 2, (mod + 1) // 2, (mod - 1) // 2, 2**30, 2**30 - 1, 2**60, 2**64 - 1, 2**64, 2**65 + 1,
+                2**90, 2**(mod.bit_length() - 1), 2**(mod.bit_length() - 1) - 1, mod - 2**30, mod - 2**64, 0x3fffffff << 30,
+                (1 << 200) - 1, 1 << 200, (1 << 120) + 1, 3**100 % mod, 5**150 % mod]
+        edge += [pow(2, -k, mod) for k in (1, 30, 31, 255, 381, 390)] + [(mod >> k) for k in (1, 2, 29, 30, 31, 64, 100, 300)]
+        vals = edge + [int.from_bytes(rng.bytes(48), "little") % mod for _ in range(400)]
+        vals += [int.from_bytes(rng.bytes(48), "little") % mod >> int(rng.integers(0, mod.bit_length())) for _ in range(400)]
+        R = pow(2, rbits, mod)
+        for x in vals:
+            img = np.frombuffer(((x * R) % mod).to_bytes(4 * words, "little"), dtype=np.uint32).copy()
+            got, ferm = np.zeros(words, dtype=np.uint32), np.zeros(words, dtype=np.uint32)
+            getattr(he, "he_%s_inv" % name)(p(got), p(img))
+            getattr(he, "he_%s_inv_fermat" % name)(p(ferm), p(img))
+            want = (pow(x, -1, mod) * R) % mod if x else 0
+            assert int.from_bytes(got.tobytes(), "little") == want, (name, hex(x))
+            assert np.array_equal(got, ferm), (name, hex(x))
+
+
+def test_binary_gcd_inversion_stress(he):
+    for f in (he.he_fr_inv_stress, he.he_fp_inv_stress):
+        f.restype, f.argtypes = C.c_uint64, [C.c_uint64, C.c_uint64]
+        assert f(60000, 12345) == 0
+
+
 def test_g1_group_law(he):
     rng = np.random.default_rng(2)
     gen = ko.g1_generator()
