@@ -220,7 +220,14 @@ KZG_HD void unpack30(uint32_t *o, const fp &a) {
     }
 }
 // core: r = A * B / 2^390 mod p on 13 x 30-bit limbs (limbs < 2^30), r normalised (limbs < 2^30), value < A B / 2^390 + p
+#ifdef KZG_COUNT_OPS
+static uint64_t g_count_mul = 0, g_count_sqr = 0;          // host-only instrumentation (tests/host): products per group operation
+#define KZG_COUNT(x) (++(x))
+#else
+#define KZG_COUNT(x)
+#endif
 KZG_HD void mont_core30(uint32_t *r, const uint32_t *A, const uint32_t *B) {
+    KZG_COUNT(g_count_mul);
     uint64_t acc[14];
 #pragma unroll
     for (int j = 0; j < 14; j++) acc[j] = 0;
@@ -248,6 +255,7 @@ KZG_HD void mont_core30(uint32_t *r, const uint32_t *A, const uint32_t *B) {
 // most 6 of them + one square: < 2^64), all 26 columns are swept, then the 13 reduction rounds add at most 13 products of
 // 2^60 per column.  91 + 169 = 260 multiplies instead of 338.
 KZG_HD void mont_sqr_core30(uint32_t *r, const uint32_t *A) {
+    KZG_COUNT(g_count_sqr);
     uint64_t T[26];
     uint32_t A2[13];
 #pragma unroll

@@ -353,6 +353,148 @@ KZG_HD g1j g1_mul_glv_fast(const g1j &p, const fr &kk, g1jq *tbl) {
     return acc.inf ? g1_inf() : g1jq_pack(acc.v);
 }
 
+// ---- width-5 NAF variant: what the G1 FFT stages run ------------------------------------------------------------------------
+// The twiddle of a butterfly is wave-uniform (k_g1_fft_stage orders lanes twiddle-major), so an irregular digit schedule costs no
+// divergence: each 128-bit GLV half is recoded into a width-5 NAF (odd digits +-1..+-15, on average one non-zero in six), the
+// table holds the 8 odd multiples with Z^2 and Z^3 cached, and the loop runs ~128 doublings + ~43 additions instead of
+// 135 + ~54 with a 16-entry table.
+KZG_HD int glv_wnaf5(const fr &kk, int base, int8_t *d, int stride) {   // LSB first into d[i * stride], returns the digit count (<= 130)
+    uint32_t w0 = kk.l[base], w1 = kk.l[base + 1], w2 = kk.l[base + 2], w3 = kk.l[base + 3], w4 = 0;
+    int len = 0;
+#pragma nounroll
+    for (int i = 0; i < 130; i++) {
+        int dig = 0;
+        if (w0 & 1u) {
+            dig = (int)(w0 & 31u);
+            w0 &= ~31u;
+            if (dig >= 16) {                                // k - (dig - 32) = (k with the low 5 bits cleared) + 32
+                dig -= 32;
+                uint32_t t = w0 + 32u, c = t < 32u ? 1u : 0u; w0 = t;
+                t = w1 + c; c = t < c ? 1u : 0u; w1 = t;
+                t = w2 + c; c = t < c ? 1u : 0u; w2 = t;
+                t = w3 + c; c = t < c ? 1u : 0u; w3 = t;
+                w4 += c;
+            }
+            len = i + 1;
+        }
+        d[i * stride] = (int8_t)dig;
+        w0 = (w0 >> 1) | (w1 << 31); w1 = (w1 >> 1) | (w2 << 31); w2 = (w2 >> 1) | (w3 << 31); w3 = (w3 >> 1) | (w4 << 31); w4 >>= 1;
+    }
+    return len;
+}
+struct g1jq_t { fq x, y, z, zz, zzz; };                     // table entry: Jacobian point with Z^2, Z^3 cached (bounds 19, 20, 4, 2, 2)
+KZG_HD void g1jq_t_make(g1jq_t *o, const g1jq &p) { o->x = p.x; o->y = p.y; o->z = p.z; o->zz = sqrq(p.z); o->zzz = mulq(o->zz, p.z); }
+// acc += (+-) (phi?) *t : add-2007-bl with the table entry's Z^2, Z^3 cached (11M + 3S, + 1M for phi).  The entry is read field by
+// field where it is used and the sign is applied to S2, so the operand never sits in registers as a whole; beta is materialised
+// inside the phi branch (literals) instead of living in 13 registers across the whole loop.  Bounds as in g1jq_add, with
+// S2 <= 3 when negated: r <= 12, r (V - X3) <= 12 * 14.  Returns false when H == 0 (P == +-Q).
+KZG_HD bool g1jq_add_entry(g1jq &acc, const g1jq_t *t, bool ng, bool phi) {
+    fq z1z1 = sqrq(acc.z);
+    fq u2 = phi ? mulq(mulq(t->x, unpackq(glv_beta())), z1z1) : mulq(t->x, z1z1);
+    fq u1 = mulq(acc.x, t->zz);
+    fq h = subq<3>(u2, u1);
+    fq s2 = mulq(mulq(t->y, acc.z), z1z1);
+    if (ng) { fq zero_q;
+#pragma unroll
+        for (int i = 0; i < 13; i++) zero_q.l[i] = 0;
+        s2 = subq<3>(zero_q, s2); }
+    fq s1 = mulq(acc.y, t->zzz);
+    fq r = subq<3>(s2, s1); r = addq(r, r);
+    fq h2 = addq(h, h);
+    fq i = sqrq(h2);
+    if (is_zero_mod_p_q(i)) return false;
+    fq zz = mulq(mulq(acc.z, t->z), h);
+    fq j = mulq(h, i);
+    fq v = mulq(u1, i);
+    fq x3 = subq<3>(subq<3>(subq<3>(sqrq(r), j), v), v);
+    fq sj = mulq(s1, j);
+    acc.y = subq<5>(mulq(r, subq<12>(v, x3)), addq(sj, sj));
+    acc.x = x3; acc.z = addq(zz, zz);
+    return true;
+}
+// the entry as a plain point, sign and phi applied (first addition into an empty accumulator, and the P == +-Q fallback)
+KZG_HD g1jq g1jq_entry_point(const g1jq_t *t, bool ng, bool phi) {
+    g1jq q; q.x = phi ? mulq(t->x, unpackq(glv_beta())) : t->x; q.z = t->z;
+    if (ng) { fq zero_q;
+#pragma unroll
+        for (int i = 0; i < 13; i++) zero_q.l[i] = 0;
+        q.y = subq<20>(zero_q, t->y); } else q.y = t->y;
+    return q;
+}
+// P == +-Q (never for the points and digit schedules of the FFT, kept for completeness): generic complete formulas, out of line
+// so that the cold path costs the hot loop neither registers nor scratch.  Returns true when the sum is the point at infinity.
+KZG_HD_NOINLINE static bool g1jq_add_slow(g1jq *acc, const g1jq *q) {
+    g1j sgen = g1_add(g1jq_pack(*acc), g1jq_pack(*q));
+    if (is_inf(sgen)) return true;
+    *acc = g1jq_unpack(sgen);
+    return false;
+}
+// callers hand over COPIES so that their accumulator never has its address taken (it must stay in registers)
+KZG_HD bool g1jq_add_slow_copy(g1jq &acc, const g1jq_t *t, bool ng, bool phi);
+KZG_HD_NOINLINE static void g1_mul_glv_cold(g1j *o, const g1j *p, const fr *kk) { g1j gt[16]; *o = g1_mul_glv(*p, *kk, gt); }
+KZG_HD bool g1jq_add_slow_copy(g1jq &acc, const g1jq_t *t, bool ng, bool phi) {
+    g1jq a2 = acc, q2 = g1jq_entry_point(t, ng, phi);
+    bool inf = g1jq_add_slow(&a2, &q2);
+    acc = a2;
+    return inf;
+}
+// p must not be inf.  `tbl` (8 entries, (2 i + 1) P) lives in the lane's private scratch; the digit arrays d1 / d2 (132 entries
+// each, element i at [i * stride]) are caller storage (private arrays; an LDS byte column per lane was measured: the 33 KB per
+// workgroup cost more in multi-round launches than the scratch reads it saved).
+// Loop shape: the accumulator starts from the top non-zero digit (no infinity flag in the loop), runs of zero digits become a
+// tight doubling loop, and an addition happens once per non-zero digit.  If an addition ever meets P == +-Q and the sum is the
+// point at infinity, the whole product is redone by the generic g1_mul_glv (cold).
+KZG_HD g1j g1_mul_glv_wnaf(const g1j &p, const fr &kk, g1jq_t *tbl, int8_t *d1, int8_t *d2, int stride) {
+    {
+        g1jq cur = g1jq_unpack(p);
+        g1jq_t_make(&tbl[0], cur);
+        g1jq_t p2;
+        g1jq_t_make(&p2, g1jq_dbl(cur));
+#pragma nounroll
+        for (int i = 1; i < 8; i++) {
+            if (!g1jq_add_entry(cur, &p2, false, false)) g1jq_add_slow_copy(cur, &p2, false, false);   // cannot happen for points of G1
+            g1jq_t_make(&tbl[i], cur);
+        }
+    }
+    const int n1 = glv_wnaf5(kk, 0, d1, stride), n2 = glv_wnaf5(kk, 4, d2, stride);
+    int j = (n1 > n2 ? n1 : n2) - 1;
+    if (j < 0) return g1_inf();                            // k == 0
+    g1jq acc;
+    bool degenerate = false;
+    {   // top position: at least one of the two digits is non-zero there
+        const int a = d1[j * stride], b = d2[j * stride];
+        if (a) {
+            acc = g1jq_entry_point(&tbl[((a < 0 ? -a : a) - 1) >> 1], a < 0, false);
+            if (b) {
+                const g1jq_t *t = &tbl[((b < 0 ? -b : b) - 1) >> 1];
+                if (!g1jq_add_entry(acc, t, b < 0, true)) degenerate = g1jq_add_slow_copy(acc, t, b < 0, true);
+            }
+        } else acc = g1jq_entry_point(&tbl[((b < 0 ? -b : b) - 1) >> 1], b < 0, true);
+        j--;
+    }
+    int pend = 0;
+#pragma nounroll
+    for (; j >= 0 && !degenerate; j--) {
+        const int a = d1[j * stride], b = d2[j * stride];
+        pend++;
+        if (!(a | b)) continue;
+#pragma nounroll
+        for (; pend > 0; pend--) acc = g1jq_dbl(acc);
+#pragma nounroll
+        for (int half = 0; half < 2; half++) {
+            const int dg = half ? b : a;
+            if (!dg || degenerate) continue;
+            const g1jq_t *t = &tbl[((dg < 0 ? -dg : dg) - 1) >> 1];
+            if (g1jq_add_entry(acc, t, dg < 0, half != 0)) continue;
+            degenerate = g1jq_add_slow_copy(acc, t, dg < 0, half != 0);
+        }
+    }
+    if (degenerate) { g1j o, pc = p; fr kc = kk; g1_mul_glv_cold(&o, &pc, &kc); return o; }
+#pragma nounroll
+    for (; pend > 0; pend--) acc = g1jq_dbl(acc);
+    return g1jq_pack(acc);
+}
+
 // Plain MSB-first double-and-add (no table); used where the scalar is short.
 KZG_HD g1j g1_mul_small(const g1j &p, uint32_t k) {
     g1j acc = g1_inf();

@@ -90,18 +90,26 @@ void launch_g1_bitrev_copy(hipStream_t s, const g1j *in, uint64_t in_stride, uin
 // One DIT stage with half-size m on bit-reversed data: (x, y) -> (x + w y, x - w y), w = roots[j * W / (2m)].
 // This is the butterfly loop of _fftG1 (fft_g1.go:44-55); the recursion's 4-point leaves (simpleFTG1, :11-31) are
 // the same linear map, so outputs are identical as group elements.
-__global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_fft_stage(g1j *data, uint32_t logn, uint64_t m, const fr *roots, uint64_t W, uint64_t total, uint64_t batch) {
+template <int MODE> __global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_fft_stage(g1j *data, uint32_t logn, uint64_t m, const fr *roots, uint64_t W, uint64_t total, uint64_t batch) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= total) return;
     // Twiddle-major lane order: t -> (j, b, g).  All lanes of a wavefront then share ONE twiddle, so (i) the waves with j == 0
     // (1/2, 1/4, 1/8 ... of the early stages) skip the scalar multiplication entirely instead of idling beside their
-    // neighbours, and (ii) the signed-digit schedule of g1_mul_glv is wave-uniform.
+    // neighbours, and (ii) the irregular width-5 NAF digit schedule of g1_mul_glv_wnaf is wave-uniform: no divergence.
+    // MODE 0 keeps the regular signed-window variant (g1_mul_glv_fast) selectable for A/B runs (KZG_HIP_G1_MUL=fast, tools/ab_g1mul.sh).
     const uint64_t half = 1ull << (logn - 1), groups = half / m;
     const uint64_t j = t / (groups * batch), rem = t % (groups * batch), b = rem / groups, g = rem % groups;
     g1j *row = data + (b << logn);
     uint64_t i0 = g * 2 * m + j, i1 = i0 + m;
     g1j y = row[i1];
-    if (j && !is_inf(y)) { g1jq tbl[16]; y = g1_mul_glv_fast(y, roots[j * (W / (2 * m))], tbl); }   // roots: (k1, k2) GLV pairs
+    if (MODE == 1) {
+        if (j && !is_inf(y)) {                                 // roots: (k1, k2) GLV pairs
+            g1jq_t tbl[8]; int8_t dg1[132], dg2[132];
+            y = g1_mul_glv_wnaf(y, roots[j * (W / (2 * m))], tbl, dg1, dg2, 1);
+        }
+    } else {
+        if (j && !is_inf(y)) { g1jq tbl[16]; y = g1_mul_glv_fast(y, roots[j * (W / (2 * m))], tbl); }
+    }
     g1j x = row[i0];
     row[i0] = g1_add(x, y);
     row[i1] = g1_add(x, g1_neg(y));
@@ -110,7 +118,10 @@ void launch_g1_fft_stage(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, u
     uint64_t total = n / 2 * batch;
     if (!total) return;
     prof_begin(s, "g1_fft_stage");
-    hipLaunchKernelGGL(k_g1_fft_stage, dim3((uint32_t)((total + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, data, ilog2g(n), m, roots, W, total, batch);
+    static int mode = -1;
+    if (mode < 0) { const char *e = getenv("KZG_HIP_G1_MUL"); mode = (e && e[0] == 'f') ? 0 : 1; }
+    if (mode == 1) hipLaunchKernelGGL(k_g1_fft_stage<1>, dim3((uint32_t)((total + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, data, ilog2g(n), m, roots, W, total, batch);
+    else hipLaunchKernelGGL(k_g1_fft_stage<0>, dim3((uint32_t)((total + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, data, ilog2g(n), m, roots, W, total, batch);
     prof_end(s, "g1_fft_stage");
 }
 

@@ -72,5 +72,10 @@ void he_g1_mul_glv_fast(g1j *o, const g1j *a, const fr *k_mont) {
     if (is_inf(pi)) { *o = OUT(g1_inf()); return; }
     g1jq tbl[16]; *o = OUT(g1_mul_glv_fast(pi, glv_decompose(from_mont<FrP>(*k_mont)), tbl));
 }
+void he_g1_mul_glv_wnaf(g1j *o, const g1j *a, const fr *k_mont) {
+    g1j pi = IN(a);
+    if (is_inf(pi)) { *o = OUT(g1_inf()); return; }
+    g1jq_t tbl[8]; int8_t d1[132], d2[132]; *o = OUT(g1_mul_glv_wnaf(pi, glv_decompose(from_mont<FrP>(*k_mont)), tbl, d1, d2, 1));
+}
 int he_g1_equal(const g1j *a, const g1j *b) { return g1_equal(IN(a), IN(b)); }
 }
