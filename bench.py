@@ -237,11 +237,12 @@ def main():
         alg_bytes = B * BYTES_PER_COMMIT + BYTES_SETUP
         ach = alg_bytes / avg_s * 1e-9
         tab_c, tab_w, tab_bytes = ks.table_info()
-        traffic = None
+        traffic, pm, pm_ok = None, {}, False
         try:   # HBM bytes per launch from the committed PMC passes (profiles/), only when the workload matches that measurement
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             if pm["kernel"] == "k_" + dominant.decode() and pm["batch"] == B and pm["n"] == N_COEFF and pm["table_c"] == tab_c:
                 traffic = pm["fetch_bytes_per_launch"] + pm["write_bytes_per_launch"]
+                pm_ok = True
         except (OSError, KeyError, ValueError):
             pass
         roofline = {"bound": "hbm", "kernel": "k_" + dominant.decode(), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -251,13 +252,18 @@ def main():
                     "note": "integer-VALU-bound kernel; traffic (PMC, profiles/r01_pmc_traffic.json) exceeds the algorithmic bytes by design: fixed-base table gathers trade HBM bandwidth for integer work (DESIGN.md 4)"}
 
         if tab_w:
-            # what actually bounds the walk: v_mad_u64_u32 issue (half rate: 8 lanes/clk/SIMD, tools/mulbench.hip).  One XYZZ mixed
-            # addition = 8 products (338 mads) + 2 squarings (260 mads); a launch does B * n * windows of them (zero digits: < 2^-13).
+            # What actually bounds the walk is VALU issue: one wave64 instruction per 4 cycles per SIMD, v_mad_u64_u32 included (the
+            # PMC passes show the G1 kernels at 4.1-4.9 cycles per VALU instruction).  Instructions per launch come
+            # from the committed SQ_INSTS_VALU pass of this workload; the multiply count is derived: one XYZZ mixed addition =
+            # 8 products (338 mads) + 2 squarings (260 mads), B * n * windows of them per launch (zero digits: < 2^-15).
             mads = B * N_COEFF * tab_w * (8 * 338 + 2 * 260)
-            peak = 256 * 4 * 8 * 2.4e9
-            roofline["valu"] = {"bound": "v_mad_u64_u32 issue", "mads_per_launch": mads, "achieved_Tmad_s": mads / avg_s * 1e-12,
-                                "peak_Tmad_s": peak * 1e-12, "frac": mads / avg_s / peak,
-                                "note": "peak at the 2.4 GHz nominal clock; the kernel runs power-limited at ~2.0-2.1 GHz (DESIGN.md 4)"}
+            peak = 256 * 4 * 2.4e9 / 4
+            valu = {"bound": "VALU issue (1 wave64 instruction / 4 cycles / SIMD, 1024 SIMDs, 2.4 GHz nominal)", "peak_Ginst_s": peak * 1e-9,
+                    "mads_per_launch": mads}
+            if pm_ok and "valu_insts_per_launch" in pm:
+                valu.update({"insts_per_launch": pm["valu_insts_per_launch"], "achieved_Ginst_s": pm["valu_insts_per_launch"] / avg_s * 1e-9,
+                             "frac": pm["valu_insts_per_launch"] / avg_s / peak, "mad_share": mads / 64 / pm["valu_insts_per_launch"]})
+            roofline["valu"] = valu
 
     fk20 = None
     if not args.no_fk20:

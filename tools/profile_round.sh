@@ -1,5 +1,6 @@
 #!/bin/bash
-# rocprofv3 passes behind profiles/*: kernel trace + stats of the whole bench, then FETCH_SIZE / WRITE_SIZE of the commitment step
+# rocprofv3 passes behind profiles/*: kernel trace + stats of the whole bench, then FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU /
+# GRBM_GUI_ACTIVE of the commitment step
 # (counter passes are separate and carry no other trace domain).  usage (GPU box): bash tools/profile_round.sh <tag>
 tag=${1:-vX}
 R=$(pwd); out=$R/gpurun_out/prof_$tag; mkdir -p $out
@@ -7,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $out/trace -o $tag -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/trace_bench.json 2> $out/trace_err.txt
 db=$(find $out/trace -name "*.db" | head -1)
 python $R/tools/rocprof_summary.py $db $out/kernel_stats.md > /dev/null
-for ctr in FETCH_SIZE WRITE_SIZE; do
+for ctr in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU GRBM_GUI_ACTIVE; do
   rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_$ctr -o $tag -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fk20 > /dev/null 2> $out/pmc_${ctr}_err.txt
   f=$(find $out/pmc_$ctr -name "*counter_collection.csv" | head -1)
   python - "$f" $ctr <<'PY' | tee -a $out/pmc_summary.txt
