@@ -282,202 +282,6 @@ __global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_accumulate(const g1a *table,
     }
     if (tid == 0) partials[blockIdx.x] = buf[0];
 }
-// ---------------------------------------------------------------------------------------------------------
-// Batch-affine variant of the walk.  The 16 table entries of one point are summed pairwise in AFFINE coordinates,
-// level by level (16 -> 8 -> 4 -> 2 sums per point), with ONE field inversion per lane and level (Montgomery's trick over
-// all pairs of the lane: forward pass = running product of the x differences, stored; backward pass = per-pair inverse,
-// slope, sum).  An affine addition is 5 products + 1 squaring + its share of the inversion (~30 k instructions over 64 / 32 /
-// 16 pairs) against 8 + 2 for the XYZZ mixed addition, and only 2 sums per point are left for the XYZZ accumulator:
-// ~530 k instead of ~706 k VALU instructions per lane.  The price is HBM traffic (prefix products and level outputs live in
-// a per-lane workspace, limb-plane layout so that every access is a coalesced dword stream; the entries are gathered
-// twice): ~4x the plain walk, still well under the roofline.
-// Values stay unpacked and lazily reduced (fq); bounds of (x, y): level inputs (1,1) / (6,4) / (16,7), outputs (6,4) /
-// (16,7) / (36,10) - see ba_pair.  Infinity (zero digit, or a point beyond n) is the all-zero (x, y): a lazily reduced
-// coordinate of a real sum is never all-zero because every subq adds a positive multiple of p.
-// P == +-Q cannot occur inside one point's windows for non-zero digits, but the code does not rely on it: a pair with
-// dx == 0 (mod p) zeroes the lane's running product, the inversion returns 0, and the lane then falls back to pushing
-// ALL inputs of that level through the complete XYZZ accumulator instead.
-// ---------------------------------------------------------------------------------------------------------
-struct ba_pt { fq x, y; };
-// workspace slot of element q of lane T: 16 dwords (13 limbs + 3 of padding) at (q LT + T) * 16, moved as 4 x dwordx4: a
-// wavefront reads or writes 4 KB of contiguous HBM per element (limb planes - 13 separate 256-byte streams 1 MB apart - were
-// measured ~10 % slower: DRAM row locality)
-__device__ __forceinline__ fq ba_ld(const uint32_t *ws, uint64_t q, uint64_t LT, uint64_t T) {
-    const uint4 *p = reinterpret_cast<const uint4 *>(ws + (q * LT + T) * 16);
-    uint4 a = p[0], b = p[1], c = p[2], d = p[3];
-    fq o;
-    o.l[0] = a.x; o.l[1] = a.y; o.l[2] = a.z; o.l[3] = a.w; o.l[4] = b.x; o.l[5] = b.y; o.l[6] = b.z; o.l[7] = b.w;
-    o.l[8] = c.x; o.l[9] = c.y; o.l[10] = c.z; o.l[11] = c.w; o.l[12] = d.x;
-    return o;
-}
-__device__ __forceinline__ void ba_st(uint32_t *ws, uint64_t q, uint64_t LT, uint64_t T, const fq &v) {
-    uint4 *p = reinterpret_cast<uint4 *>(ws + (q * LT + T) * 16);
-    p[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]); p[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
-    p[2] = make_uint4(v.l[8], v.l[9], v.l[10], v.l[11]); p[3] = make_uint4(v.l[12], 0u, 0u, 0u);
-}
-__device__ __forceinline__ bool ba_is_inf(const fq &x) {
-    uint32_t z = 0;
-#pragma unroll
-    for (int k = 0; k < 13; k++) z |= x.l[k];
-    return z == 0;
-}
-__device__ __forceinline__ fq ba_zero() {
-    fq o;
-#pragma unroll
-    for (int k = 0; k < 13; k++) o.l[k] = 0;
-    return o;
-}
-// A + B for two finite points with distinct x; t = 1 / (xB - xA).  Input bounds (BX, BY) -> output (2 BX + 4, BY + 3).
-template <int BX, int BY> __device__ __forceinline__ ba_pt ba_pair(const ba_pt &A, const ba_pt &B, const fq &t) {
-    fq dy = subq<BY + 1>(B.y, A.y);                       // 2 BY + 1
-    fq lam = mulq(dy, t);
-    fq l2 = sqrq(lam);
-    ba_pt o;
-    o.x = subq<BX + 1>(subq<BX + 1>(l2, A.x), B.x);       // 2 + 2 (BX + 1)
-    o.y = subq<BY + 1>(mulq(lam, subq<2 * BX + 5>(A.x, o.x)), A.y);   // (3 BX + 5) * 2 <= 600; result 2 + BY + 1
-    return o;
-}
-// XYZZ accumulator fed with lazily reduced affine coordinates (bounds up to (76, 13): products 152, 26 <= 600)
-__device__ __forceinline__ void ba_acc_add(g1x_acc &acc, const ba_pt &q) {
-    if (ba_is_inf(q.x)) return;
-    if (acc.inf) {
-        const fq one_q = unpackq(one<FpP>());
-        acc.v.x = mulq(q.x, one_q); acc.v.y = mulq(q.y, one_q); acc.v.zz = one_q; acc.v.zzz = one_q;   // same values, bound 2
-        acc.inf = false;
-        return;
-    }
-    if (g1x_madd_fast(acc.v, q.x, q.y)) return;
-    g1a qa; qa.x = packq(q.x); qa.y = packq(q.y);
-    g1x sgen = g1x_madd(g1xq_pack(acc.v), qa);            // P == +-Q: generic, complete formulas
-    if (is_inf(sgen)) acc.inf = true; else acc.v = g1xq_unpack(sgen);
-}
-// running product -> its inverse (unpacked); false when the product was 0 mod p
-__device__ __forceinline__ bool ba_invert(const fq &run, fq &inv_out) {
-    fp ri = inv<FpP>(packq(run));
-    inv_out = unpackq(ri);
-    return !is_zero<FpP>(ri);
-}
-// one level on workspace points: pairs (2 j, 2 j + 1) of `in` -> `out[j]`, or into the accumulator when LAST
-template <int BX, int BY, bool LAST>
-__device__ __forceinline__ bool ba_level(const uint32_t *in, uint32_t *out, uint32_t *prefix, uint32_t npairs, uint64_t LT, uint64_t T, g1x_acc &acc) {
-    fq run = unpackq(one<FpP>());
-#pragma nounroll
-    for (uint32_t j = 0; j < npairs; j++) {
-        fq xa = ba_ld(in, 4 * j, LT, T), xb = ba_ld(in, 4 * j + 2, LT, T);
-        if (ba_is_inf(xa) || ba_is_inf(xb)) continue;
-        ba_st(prefix, j, LT, T, run);
-        run = mulq(run, subq<BX + 1>(xb, xa));
-    }
-    fq I;
-    if (!ba_invert(run, I)) {                             // some dx == 0: complete formulas for every input of this level
-#pragma nounroll
-        for (uint32_t e = 0; e < 2 * npairs; e++) { ba_pt q; q.x = ba_ld(in, 2 * e, LT, T); q.y = ba_ld(in, 2 * e + 1, LT, T); ba_acc_add(acc, q); }
-        return false;
-    }
-#pragma nounroll
-    for (uint32_t j = npairs; j-- > 0;) {
-        ba_pt A, B, o;
-        A.x = ba_ld(in, 4 * j, LT, T); B.x = ba_ld(in, 4 * j + 2, LT, T);
-        const bool ia = ba_is_inf(A.x), ib = ba_is_inf(B.x);
-        if (!ia && !ib) {
-            A.y = ba_ld(in, 4 * j + 1, LT, T); B.y = ba_ld(in, 4 * j + 3, LT, T);
-            fq t = mulq(I, ba_ld(prefix, j, LT, T));
-            I = mulq(I, subq<BX + 1>(B.x, A.x));
-            o = ba_pair<BX, BY>(A, B, t);
-        } else if (!ia) { o.x = A.x; o.y = ba_ld(in, 4 * j + 1, LT, T); }
-        else if (!ib) { o.x = B.x; o.y = ba_ld(in, 4 * j + 3, LT, T); }
-        else { o.x = ba_zero(); o.y = o.x; }
-        if (LAST) ba_acc_add(acc, o);
-        else { ba_st(out, 2 * j, LT, T, o.x); ba_st(out, 2 * j + 1, LT, T, o.y); }
-    }
-    return true;
-}
-// carries of the signed-digit recoding as a bit mask: bit w = carry INTO window w
-__device__ __forceinline__ uint64_t ba_carry_mask(const fr &k, uint32_t c, uint32_t nwin, uint32_t D) {
-    uint64_t cm = 0; uint32_t carry = 0;
-#pragma nounroll
-    for (uint32_t w = 0; w + 1 < nwin; w++) {
-        carry = (scalar_bits(k, w * c, c) + carry > D) ? 1u : 0u;
-        cm |= (uint64_t)carry << (w + 1);
-    }
-    return cm;
-}
-__device__ __forceinline__ void ba_digit(const fr &k, uint64_t cm, uint32_t w, uint32_t c, uint32_t nwin, uint32_t D, uint32_t &mag, uint32_t &ng) {
-    if (w >= nwin) { mag = 0; ng = 0; return; }
-    uint32_t raw = scalar_bits(k, w * c, c) + (uint32_t)((cm >> w) & 1u);
-    if (raw > D) { mag = (1u << c) - raw; ng = 1; } else { mag = raw; ng = 0; }
-}
-__global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_accumulate_ba(const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, uint32_t D, const fr *scalars,
-                                                               uint64_t n, uint32_t blocks_per_blob, g1j *partials, uint32_t *ws_prefix, uint32_t *ws_l1,
-                                                               uint32_t *ws_l2) {
-    __shared__ g1j buf[FB_BLOCK];
-    const uint32_t tid = threadIdx.x;
-    const uint64_t blob = blockIdx.x / blocks_per_blob; const uint32_t blk = blockIdx.x % blocks_per_blob;
-    const uint64_t L = (uint64_t)blocks_per_blob * FB_BLOCK;
-    const uint64_t T = (uint64_t)blockIdx.x * FB_BLOCK + tid, LT = (uint64_t)gridDim.x * FB_BLOCK;
-    const fr *sc = scalars + blob * n;
-    const uint32_t P = (uint32_t)((n + L - 1) / L);        // points per lane
-    const uint32_t halfw = ((nwin + 7) & ~7u) / 2;         // window pairs per point (windows padded to a multiple of 8 with inf)
-    const uint32_t N1 = P * halfw;
-    g1x_acc acc; acc.init();
-    bool ok = true;
-    {   // ---- level 1: table entries -> ws_l1 ----
-        fq run = unpackq(one<FpP>());
-#pragma nounroll
-        for (uint32_t s_ = 0; s_ < P; s_++) {
-            const uint64_t i = (uint64_t)blk * FB_BLOCK + tid + (uint64_t)s_ * L;
-            if (i >= n) continue;
-            const fr k = from_mont<FrP>(sc[i]);
-            const uint64_t cm = ba_carry_mask(k, c, nwin, D);
-#pragma nounroll
-            for (uint32_t v = 0; v < halfw; v++) {
-                uint32_t m0, n0, m1, n1;
-                ba_digit(k, cm, 2 * v, c, nwin, D, m0, n0); ba_digit(k, cm, 2 * v + 1, c, nwin, D, m1, n1);
-                if (!m0 || !m1) continue;
-                fq xa = unpackq(table[((uint64_t)(2 * v) * table_n + i) * D + (m0 - 1)].x);
-                fq xb = unpackq(table[((uint64_t)(2 * v + 1) * table_n + i) * D + (m1 - 1)].x);
-                ba_st(ws_prefix, s_ * halfw + v, LT, T, run);
-                run = mulq(run, subq<2>(xb, xa));
-            }
-        }
-        fq I;
-        ok = ba_invert(run, I);
-#pragma nounroll
-        for (uint32_t s_ = P; s_-- > 0;) {
-            const uint64_t i = (uint64_t)blk * FB_BLOCK + tid + (uint64_t)s_ * L;
-            const bool valid = i < n;
-            fr k; uint64_t cm = 0;
-            if (valid) { k = from_mont<FrP>(sc[i]); cm = ba_carry_mask(k, c, nwin, D); }
-#pragma nounroll
-            for (uint32_t v = halfw; v-- > 0;) {
-                const uint32_t j = s_ * halfw + v;
-                uint32_t m0 = 0, n0 = 0, m1 = 0, n1 = 0;
-                if (valid) { ba_digit(k, cm, 2 * v, c, nwin, D, m0, n0); ba_digit(k, cm, 2 * v + 1, c, nwin, D, m1, n1); }
-                ba_pt A, B, o;
-                A.x = ba_zero(); A.y = A.x; B = A;
-                if (m0) { g1a q = table[((uint64_t)(2 * v) * table_n + i) * D + (m0 - 1)]; if (n0) q.y = neg<FpP>(q.y); A.x = unpackq(q.x); A.y = unpackq(q.y); }
-                if (m1) { g1a q = table[((uint64_t)(2 * v + 1) * table_n + i) * D + (m1 - 1)]; if (n1) q.y = neg<FpP>(q.y); B.x = unpackq(q.x); B.y = unpackq(q.y); }
-                if (!ok) { ba_acc_add(acc, A); ba_acc_add(acc, B); continue; }   // fallback: complete formulas on every entry
-                if (m0 && m1) {
-                    fq t = mulq(I, ba_ld(ws_prefix, j, LT, T));
-                    I = mulq(I, subq<2>(B.x, A.x));
-                    o = ba_pair<1, 1>(A, B, t);
-                } else o = m0 ? A : B;                      // B is the all-zero infinity when both digits are zero
-                ba_st(ws_l1, 2 * j, LT, T, o.x); ba_st(ws_l1, 2 * j + 1, LT, T, o.y);
-            }
-        }
-    }
-    if (ok) ok = ba_level<6, 4, false>(ws_l1, ws_l2, ws_prefix, N1 / 2, LT, T, acc);
-    if (ok) ba_level<16, 7, true>(ws_l2, nullptr, ws_prefix, N1 / 4, LT, T, acc);
-    buf[tid] = acc.to_jac();
-    __syncthreads();
-#pragma nounroll
-    for (uint32_t off = FB_BLOCK / 2; off >= 1; off >>= 1) {
-        if (tid < off) buf[tid] = g1_add(buf[tid], buf[tid + off]);
-        __syncthreads();
-    }
-    if (tid == 0) partials[blockIdx.x] = buf[0];
-}
 __global__ __launch_bounds__(64) void k_fb_finish(const g1j *partials, uint32_t blocks_per_blob, uint64_t batch, g1j *out) {
     uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (b >= batch) return;
@@ -524,49 +328,26 @@ void launch_fb_mul_vec(hipStream_t s, const g1a *table, uint64_t table_n, uint32
 }
 
 static uint32_t fb_blocks_per_blob(uint64_t n, uint64_t batch) {
+    // 131072 lanes = 2048 wavefronts = exactly the resident capacity at 2 waves per SIMD: ONE round.  Measured (512 blobs):
+    // 131072 lanes 5.7 ms, 262144 lanes (two rounds) 6.4 ms, 98304 / 65536 lanes 10.4 ms.  KZG_HIP_FB_LANES overrides.
     static uint64_t lanes = 0;
-    if (!lanes) { const char *e = getenv("KZG_HIP_FB_LANES"); lanes = e ? strtoull(e, nullptr, 10) : 262144; if (lanes < FB_BLOCK) lanes = FB_BLOCK; }
-    uint64_t target = lanes / FB_BLOCK;                  // 262144 lanes = 2 rounds of 2 waves per SIMD over 256 CUs
+    if (!lanes) { const char *e = getenv("KZG_HIP_FB_LANES"); lanes = e ? strtoull(e, nullptr, 10) : 131072; if (lanes < FB_BLOCK) lanes = FB_BLOCK; }
+    uint64_t target = lanes / FB_BLOCK;
     uint64_t bpb = target / (batch ? batch : 1);
     uint64_t maxb = (n + FB_BLOCK - 1) / FB_BLOCK;
     if (bpb > maxb) bpb = maxb;
     if (bpb < 1) bpb = 1;
     return (uint32_t)bpb;
 }
-static bool fb_batch_affine() {                           // KZG_HIP_FB_MODE=xyzz selects the plain XYZZ walk (A/B runs)
-    static int mode = -1;
-    if (mode < 0) { const char *e = getenv("KZG_HIP_FB_MODE"); mode = (e && e[0] == 'x') ? 0 : 1; }
-    return mode == 1;
-}
-// partial sums, then (batch-affine walk) per lane: prefix products (N1 fq), level-1 sums (N1 points), level-2 sums (N1 / 2 points)
-static size_t fb_ba_words(uint64_t n, uint64_t batch, uint32_t nwin, size_t &prefix_w, size_t &l1_w, size_t &l2_w) {
-    uint32_t bpb = fb_blocks_per_blob(n, batch);
-    uint64_t LT = (uint64_t)bpb * batch * FB_BLOCK, L = (uint64_t)bpb * FB_BLOCK;
-    uint64_t P = (n + L - 1) / L, N1 = P * (((nwin + 7) & ~7u) / 2);
-    prefix_w = N1 * 16 * LT; l1_w = N1 * 32 * LT; l2_w = (N1 / 2) * 32 * LT;
-    return prefix_w + l1_w + l2_w;
-}
-size_t fb_partials_bytes(uint64_t n, uint64_t batch, uint32_t nwin) {
-    size_t part = ((size_t)fb_blocks_per_blob(n, batch) * batch * sizeof(g1j) + 255) & ~(size_t)255;
-    if (!fb_batch_affine()) return part;
-    size_t a, b, c_;
-    return part + fb_ba_words(n, batch, nwin, a, b, c_) * sizeof(uint32_t);
-}
+size_t fb_partials_bytes(uint64_t n, uint64_t batch) { return (size_t)fb_blocks_per_blob(n, batch) * batch * sizeof(g1j); }
 
 void launch_fb_msm(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, uint64_t n, uint64_t batch,
                    void *partials, g1j *out) {
     if (!batch) return;
     uint32_t bpb = fb_blocks_per_blob(n, batch);
     prof_begin(s, "fb_accumulate");
-    if (fb_batch_affine()) {
-        size_t part = ((size_t)bpb * batch * sizeof(g1j) + 255) & ~(size_t)255, pw, l1w, l2w;
-        fb_ba_words(n, batch, nwin, pw, l1w, l2w);
-        uint32_t *wp = (uint32_t *)((uint8_t *)partials + part);
-        hipLaunchKernelGGL(k_fb_accumulate_ba, dim3((uint32_t)(batch * bpb)), dim3(FB_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars, n, bpb,
-                           (g1j *)partials, wp, wp + pw, wp + pw + l1w);
-    } else
-        hipLaunchKernelGGL(k_fb_accumulate, dim3((uint32_t)(batch * bpb)), dim3(FB_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars, n, bpb,
-                           (g1j *)partials);
+    hipLaunchKernelGGL(k_fb_accumulate, dim3((uint32_t)(batch * bpb)), dim3(FB_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars, n, bpb,
+                       (g1j *)partials);
     prof_end(s, "fb_accumulate");
     hipLaunchKernelGGL(k_fb_finish, dim3((uint32_t)((batch + 63) / 64)), dim3(64), 0, s, (const g1j *)partials, bpb, batch, out);
 }
