@@ -489,7 +489,7 @@ void kzg_hip_kzg_settings_free(kzg_hip_kzg *ks) {
 }
 
 // number of signed c-bit windows of a canonical scalar (< r < 2^255): ceil(255 / c), plus one only if the top window's
-// digit (top bits of r - 1, plus the incoming carry) can exceed 2^(c-1) and carry out (c = 15: 17 windows, c = 16: 16)
+// digit (top bits of r - 1, plus the incoming carry) can exceed 2^(c-1) and carry out (c = 15 carries: 18 windows, c = 16 does not: 16)
 // table budget in GB: the environment override, else min(cap, free HBM - headroom)
 static double table_budget_gb(const char *env, double cap_gb, double headroom_gb) {
     if (const char *e = getenv(env)) return atof(e);
@@ -507,14 +507,14 @@ static uint32_t fb_windows(uint32_t c) {
 // Lazily builds the fixed-base table T[(w n + i) D + d - 1] = d 2^(c w) SecretG1[i] (k_msm.hip).  The window size is the
 // largest whose table fits the HBM budget: KZG_HIP_FB_BUDGET_GB if set, else what is free on the device minus 40 GB of
 // headroom for the FK20 tables and workspaces, capped at 210 GB.  On an otherwise empty 288 GB MI355X, n = 4096 gets
-// c = 16: 16 windows, 206 GB (measured: c = 13 20 windows 55k, c = 14 19 windows 60.2k, c = 15 17 windows 57.9k,
+// c = 16: 16 windows, 206 GB (measured: c = 13 20 windows 55k, c = 14 19 windows 60.2k, c = 15 18 windows 57.9k,
 // c = 16 16 windows 68.7k commitments/s); a second settings object built while the first is alive gets a smaller table.
 static int ensure_fixed_table(kzg_hip_kzg *ks, hipStream_t s) {
     if (ks->d_fixed || ks->fixed_plan.c == 0xffffffffu) return KZG_HIP_OK;
     double budget_gb = table_budget_gb("KZG_HIP_FB_BUDGET_GB", 210.0, 40.0);
     uint32_t best = 0;
     for (uint32_t c = 16; c >= 5; c--) {
-        if (c == 15) continue;                               // measured slower than c = 14 despite 17 windows (gather stride)
+        if (c == 15) continue;                               // measured slower than c = 14 (18 windows, 116 GB)
         double bytes = (double)fb_windows(c) * (double)ks->n_setup * (double)(1u << (c - 1)) * sizeof(g1a);
         if (bytes <= budget_gb * 1e9) { best = c; break; }
     }

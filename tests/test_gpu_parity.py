@@ -331,6 +331,26 @@ def test_vector_F_and_batch_commit_4096(kz, ks4096, setup_1337):
     assert comp_hex(c)[0] == DERIVED["F_blob_seed1"]["commit_eth_bitrev_lagrange"]
 
 
+@pytest.mark.parametrize("budget_gb,want_c", [(0.05, 0), (0.4, 5), (1.0, 7), (6.0, 10), (20.0, 12), (70.0, 14), (120.0, 14)])
+def test_commit_with_every_table_size(kz, setup_1337, budget_gb, want_c, monkeypatch):
+    # the fixed-base table adapts to the HBM budget: every window size must give the same commitments (incl. edge scalars:
+    # zero digits, digits that carry through several windows, r - 1); 0.05 GB fits no table (bucket path), 120 GB would fit
+    # c = 15, which the sizing rule skips
+    monkeypatch.setenv("KZG_HIP_FB_BUDGET_GB", str(budget_gb))
+    fs = kz.FFTSettings(12)
+    ks = kz.KZGSettings(fs, setup_1337)
+    try:
+        edge = [0, 1, 2**14, 2**15, 2**16 - 1, 2**16, (1 << 255) % ko.R_MOD, ko.R_MOD - 1, ko.R_MOD - 2**15, 0x8000800080008000, int("7fff" * 15, 16), int("8000" * 15, 16)]
+        blob = ko.synthetic_blob(77)[:256].copy()
+        blob[:len(edge)] = ko.fr_from_ints(edge)
+        got = ks.commit_to_poly(blob)
+        assert ks.table_info()[0] == want_c
+        assert_points_equal(got, ko.lincomb_g1(setup_1337[:256], blob))
+    finally:
+        ks.close()
+        fs.close()
+
+
 def test_commit_linearity_full_size(kz, ks4096):
     # size-independent property at full size: commit(a) + commit(b) == commit(a + b)
     a, b = ko.synthetic_blob(101), ko.synthetic_blob(102)
