@@ -534,7 +534,7 @@ static int commit_rows(kzg_hip_kzg *ks, hipStream_t s, const fr *d_sc, uint64_t 
     CHK(ensure_fixed_table(ks, s));
     bool fixed = ks->d_fixed != nullptr;
     msm_plan p = fixed ? ks->fixed_plan : classic_plan(n);
-    size_t ws_main = fixed ? fb_partials_bytes(n, batch, p.nwin) : msm_workspace_bytes(p, n, batch);
+    size_t ws_main = fixed ? fb_partials_bytes(n, batch) : msm_workspace_bytes(p, n, batch);
     size_t need = ws_main + batch * sizeof(g1j);
     if (need > ks->ws_bytes) {
         if (ks->d_ws) { HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipFree(ks->d_ws)); ks->d_ws = nullptr; }

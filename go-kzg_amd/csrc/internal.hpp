@@ -75,7 +75,7 @@ void launch_msm(hipStream_t s, const msm_plan &p, const g1a *table, const fr *sc
 void launch_msm_window_table(hipStream_t s, const g1a *pts, uint64_t n, uint32_t c, uint32_t nwin, g1j *tmp, g1a *out);
 
 // fixed-base table MSM over the device-resident setup (see k_msm.hip)
-size_t fb_partials_bytes(uint64_t n, uint64_t batch, uint32_t nwin);
+size_t fb_partials_bytes(uint64_t n, uint64_t batch);
 hipError_t launch_fb_build(hipStream_t s, const g1a *pts, uint64_t n, uint32_t c, uint32_t nwin, g1a *table);
 void launch_fb_msm(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, uint64_t n, uint64_t batch,
                    void *partials, g1j *out);

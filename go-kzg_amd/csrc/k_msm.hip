@@ -282,240 +282,6 @@ __global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_accumulate(const g1a *table,
     }
     if (tid == 0) partials[blockIdx.x] = buf[0];
 }
-// ---------------------------------------------------------------------------------------------------------
-// Batch-affine variant of the walk (KZG_HIP_FB_MODE=ba; the XYZZ walk above is the default).  The 16 table entries of a
-// point are first summed pairwise in AFFINE coordinates over two levels (16 -> 8 -> 4 sums per point) with ONE field
-// inversion per lane and level (Montgomery's trick over all pairs of the lane: the forward pass keeps a running product of
-// the x differences and stores its prefixes, the backward pass turns the inverse of the total into per-pair inverses);
-// only the 4 sums per point go through the XYZZ accumulator.  An affine addition is 5 products + 1 squaring + its share of
-// the inversion (~31 k instructions over 128 / 64 pairs at 16 points per lane) against 8 + 2 for the mixed addition.
-//   * level-1 backward and level-2 forward are fused (the x difference of two consecutive level-1 sums feeds the level-2
-//     running product as soon as both exist), so level 2 has no forward pass over memory;
-//   * gathers are issued one pair (backward) or four pairs (forward) ahead of their use;
-//   * values stay unpacked and lazily reduced (fq); bounds of (x, y): table (1,1) -> level 1 (6,4) -> level 2 (16,7);
-//   * infinity (zero digit, point beyond n) is the all-zero (x, y): a lazily reduced coordinate of a real sum is never
-//     all-zero because every subq adds a positive multiple of p;
-//   * P == +-Q: a pair with dx == 0 (mod p) zeroes the lane's running product, the inversion returns 0, and the lane
-//     falls back to the plain XYZZ walk over its table entries.
-// Workspace: limb planes, word k of element q of lane T at ((q W + k) LT + T): every access is a coalesced dword stream.
-// ---------------------------------------------------------------------------------------------------------
-struct ba_pt { fq x, y; };
-__device__ __forceinline__ fq ba_ld(const uint32_t *ws, uint64_t q, uint32_t W, uint32_t k0, uint64_t LT, uint64_t T) {
-    fq o;
-#pragma unroll
-    for (int k = 0; k < 13; k++) o.l[k] = ws[(q * W + k0 + k) * LT + T];
-    return o;
-}
-__device__ __forceinline__ void ba_st(uint32_t *ws, uint64_t q, uint32_t W, uint32_t k0, uint64_t LT, uint64_t T, const fq &v) {
-#pragma unroll
-    for (int k = 0; k < 13; k++) ws[(q * W + k0 + k) * LT + T] = v.l[k];
-}
-__device__ __forceinline__ bool ba_is_inf(const fq &x) {
-    uint32_t z = 0;
-#pragma unroll
-    for (int k = 0; k < 13; k++) z |= x.l[k];
-    return z == 0;
-}
-__device__ __forceinline__ fq ba_zero() {
-    fq o;
-#pragma unroll
-    for (int k = 0; k < 13; k++) o.l[k] = 0;
-    return o;
-}
-// A + B for two finite points with distinct x; t = 1 / (xB - xA).  Input bounds (BX, BY) -> output (2 BX + 4, BY + 3).
-template <int BX, int BY> __device__ __forceinline__ ba_pt ba_pair(const ba_pt &A, const ba_pt &B, const fq &t) {
-    fq dy = subq<BY + 1>(B.y, A.y);                       // 2 BY + 1
-    fq lam = mulq(dy, t);
-    fq l2 = sqrq(lam);
-    ba_pt o;
-    o.x = subq<BX + 1>(subq<BX + 1>(l2, A.x), B.x);       // 2 + 2 (BX + 1)
-    o.y = subq<BY + 1>(mulq(lam, subq<2 * BX + 5>(A.x, o.x)), A.y);   // (3 BX + 5) * 2 <= 600; result 2 + BY + 1
-    return o;
-}
-// XYZZ accumulator fed with lazily reduced affine coordinates (bounds (16, 7): products 32, 14 <= 600)
-__device__ __forceinline__ void ba_acc_add(g1x_acc &acc, const ba_pt &q) {
-    if (ba_is_inf(q.x)) return;
-    if (acc.inf) {
-        const fq one_q = unpackq(one<FpP>());
-        acc.v.x = mulq(q.x, one_q); acc.v.y = mulq(q.y, one_q); acc.v.zz = one_q; acc.v.zzz = one_q;   // same values, bound 2
-        acc.inf = false;
-        return;
-    }
-    if (g1x_madd_fast(acc.v, q.x, q.y)) return;
-    g1a qa; qa.x = packq(q.x); qa.y = packq(q.y);
-    g1x sgen = g1x_madd(g1xq_pack(acc.v), qa);            // P == +-Q: generic, complete formulas
-    if (is_inf(sgen)) acc.inf = true; else acc.v = g1xq_unpack(sgen);
-}
-// running product -> its inverse (unpacked); false when the product was 0 mod p
-__device__ __forceinline__ bool ba_invert(const fq &run, fq &inv_out) {
-    fp ri = inv<FpP>(packq(run));
-    inv_out = unpackq(ri);
-    return !is_zero<FpP>(ri);
-}
-// carries of the signed-digit recoding as a bit mask: bit w = carry INTO window w
-__device__ __forceinline__ uint64_t ba_carry_mask(const fr &k, uint32_t c, uint32_t nwin, uint32_t D) {
-    uint64_t cm = 0; uint32_t carry = 0;
-#pragma nounroll
-    for (uint32_t w = 0; w + 1 < nwin; w++) {
-        carry = (scalar_bits(k, w * c, c) + carry > D) ? 1u : 0u;
-        cm |= (uint64_t)carry << (w + 1);
-    }
-    return cm;
-}
-__device__ __forceinline__ void ba_digit(const fr &k, uint64_t cm, uint32_t w, uint32_t c, uint32_t nwin, uint32_t D, uint32_t &mag, uint32_t &ng) {
-    if (w >= nwin) { mag = 0; ng = 0; return; }
-    uint32_t raw = scalar_bits(k, w * c, c) + (uint32_t)((cm >> w) & 1u);
-    if (raw > D) { mag = (1u << c) - raw; ng = 1; } else { mag = raw; ng = 0; }
-}
-// table entry of window w (clamped to the padded range), point i, magnitude mag; mag == 0 reads entry 1 (valid memory, unused)
-__device__ __forceinline__ const g1a *ba_entry(const g1a *table, uint64_t table_n, uint32_t D, uint32_t nwin, uint32_t w, uint64_t i, uint32_t mag) {
-    const uint32_t ww = w < nwin ? w : nwin - 1;
-    return table + ((uint64_t)ww * table_n + i) * D + (mag ? mag - 1 : 0);
-}
-__global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_accumulate_ba(const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, uint32_t D, const fr *scalars,
-                                                               uint64_t n, uint32_t blocks_per_blob, g1j *partials, uint32_t *ws_pa, uint32_t *ws_pb,
-                                                               uint32_t *ws_l1, uint32_t *ws_l2) {
-    __shared__ g1j buf[FB_BLOCK];
-    const uint32_t tid = threadIdx.x;
-    const uint64_t blob = blockIdx.x / blocks_per_blob; const uint32_t blk = blockIdx.x % blocks_per_blob;
-    const uint64_t L = (uint64_t)blocks_per_blob * FB_BLOCK;
-    const uint64_t T = (uint64_t)blockIdx.x * FB_BLOCK + tid, LT = (uint64_t)gridDim.x * FB_BLOCK;
-    const fr *sc = scalars + blob * n;
-    const uint32_t P = (uint32_t)((n + L - 1) / L);        // points per lane
-    const uint32_t halfw = ((nwin + 7) & ~7u) / 2;         // window pairs per point (windows padded to a multiple of 8 with inf)
-    const uint32_t N1 = P * halfw;
-    const uint64_t i_base = (uint64_t)blk * FB_BLOCK + tid;
-    bool ok = true;
-    {   // ---- level 1 forward: running product of the x differences, four pairs of gathers in flight ----
-        fq run = unpackq(one<FpP>());
-#pragma nounroll
-        for (uint32_t s_ = 0; s_ < P; s_++) {
-            const uint64_t i = i_base + (uint64_t)s_ * L;
-            if (i >= n) continue;
-            const fr k = from_mont<FrP>(sc[i]);
-            const uint64_t cm = ba_carry_mask(k, c, nwin, D);
-#pragma nounroll
-            for (uint32_t v0 = 0; v0 < halfw; v0 += 4) {
-                uint32_t m0[4], m1[4], sg;
-                fp xa[4], xb[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    ba_digit(k, cm, 2 * (v0 + q), c, nwin, D, m0[q], sg); ba_digit(k, cm, 2 * (v0 + q) + 1, c, nwin, D, m1[q], sg);
-                    xa[q] = ba_entry(table, table_n, D, nwin, 2 * (v0 + q), i, m0[q])->x;
-                    xb[q] = ba_entry(table, table_n, D, nwin, 2 * (v0 + q) + 1, i, m1[q])->x;
-                }
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    if (!m0[q] || !m1[q]) continue;
-                    ba_st(ws_pa, s_ * halfw + v0 + q, 13, 0, LT, T, run);
-                    run = mulq(run, subq<2>(unpackq(xb[q]), unpackq(xa[q])));
-                }
-            }
-        }
-        fq I;
-        ok = ba_invert(run, I);
-        // ---- level 1 backward (descending) fused with level 2 forward: sums to ws_l1, level-2 prefixes to ws_pb ----
-        fq run2 = unpackq(one<FpP>());
-        fq prev_x = ba_zero();
-#pragma nounroll
-        for (uint32_t s_ = P; s_-- > 0;) {
-            const uint64_t i = i_base + (uint64_t)s_ * L;
-            const bool valid = i < n;
-            fr k; uint64_t cm = 0;
-            if (valid) { k = from_mont<FrP>(sc[i]); cm = ba_carry_mask(k, c, nwin, D); }
-            uint32_t nm0 = 0, nn0 = 0, nm1 = 0, nn1 = 0;
-            g1a nA, nB;
-            if (valid) {
-                ba_digit(k, cm, 2 * (halfw - 1), c, nwin, D, nm0, nn0); ba_digit(k, cm, 2 * (halfw - 1) + 1, c, nwin, D, nm1, nn1);
-                nA = *ba_entry(table, table_n, D, nwin, 2 * (halfw - 1), i, nm0); nB = *ba_entry(table, table_n, D, nwin, 2 * (halfw - 1) + 1, i, nm1);
-            }
-#pragma nounroll
-            for (uint32_t v = halfw; v-- > 0;) {
-                const uint32_t j = s_ * halfw + v;
-                const uint32_t m0 = nm0, n0 = nn0, m1 = nm1, n1 = nn1;
-                g1a qa = nA, qb = nB;
-                if (valid && v > 0) {                      // gathers of the next pair, one addition ahead
-                    ba_digit(k, cm, 2 * (v - 1), c, nwin, D, nm0, nn0); ba_digit(k, cm, 2 * (v - 1) + 1, c, nwin, D, nm1, nn1);
-                    nA = *ba_entry(table, table_n, D, nwin, 2 * (v - 1), i, nm0); nB = *ba_entry(table, table_n, D, nwin, 2 * (v - 1) + 1, i, nm1);
-                }
-                ba_pt A, B, o;
-                A.x = ba_zero(); A.y = A.x; B = A;
-                if (m0) { if (n0) qa.y = neg<FpP>(qa.y); A.x = unpackq(qa.x); A.y = unpackq(qa.y); }
-                if (m1) { if (n1) qb.y = neg<FpP>(qb.y); B.x = unpackq(qb.x); B.y = unpackq(qb.y); }
-                if (m0 && m1) {
-                    fq t = mulq(I, ba_ld(ws_pa, j, 13, 0, LT, T));
-                    I = mulq(I, subq<2>(B.x, A.x));
-                    o = ba_pair<1, 1>(A, B, t);
-                } else o = m0 ? A : B;                      // B is the all-zero infinity when both digits are zero
-                ba_st(ws_l1, j, 26, 0, LT, T, o.x); ba_st(ws_l1, j, 26, 13, LT, T, o.y);
-                if (v & 1) prev_x = o.x;                    // level-2 pair (j - 1, j): x difference = x_j - x_(j-1)
-                else if (!ba_is_inf(o.x) && !ba_is_inf(prev_x)) {
-                    ba_st(ws_pb, j >> 1, 13, 0, LT, T, run2);
-                    run2 = mulq(run2, subq<7>(prev_x, o.x));
-                }
-            }
-        }
-        // ---- level 2 backward (ascending: the reverse of its forward order) ----
-        fq I2;
-        const bool ok2 = ba_invert(run2, I2);
-        ok = ok && ok2;
-        const uint32_t N2 = N1 / 2;
-        ba_pt nA2, nB2;
-        nA2.x = ba_ld(ws_l1, 0, 26, 0, LT, T); nA2.y = ba_ld(ws_l1, 0, 26, 13, LT, T);
-        nB2.x = ba_ld(ws_l1, 1, 26, 0, LT, T); nB2.y = ba_ld(ws_l1, 1, 26, 13, LT, T);
-#pragma nounroll
-        for (uint32_t j2 = 0; j2 < N2; j2++) {
-            ba_pt A = nA2, B = nB2, o;
-            if (j2 + 1 < N2) {
-                nA2.x = ba_ld(ws_l1, 2 * j2 + 2, 26, 0, LT, T); nA2.y = ba_ld(ws_l1, 2 * j2 + 2, 26, 13, LT, T);
-                nB2.x = ba_ld(ws_l1, 2 * j2 + 3, 26, 0, LT, T); nB2.y = ba_ld(ws_l1, 2 * j2 + 3, 26, 13, LT, T);
-            }
-            const bool ia = ba_is_inf(A.x), ib = ba_is_inf(B.x);
-            if (!ia && !ib) {
-                fq t = mulq(I2, ba_ld(ws_pb, j2, 13, 0, LT, T));
-                I2 = mulq(I2, subq<7>(B.x, A.x));
-                o = ba_pair<6, 4>(A, B, t);
-            } else o = ia ? B : A;
-            ba_st(ws_l2, j2, 26, 0, LT, T, o.x); ba_st(ws_l2, j2, 26, 13, LT, T, o.y);
-        }
-    }
-    g1x_acc acc; acc.init();
-    if (ok) {   // ---- the 4 sums per point through the XYZZ accumulator ----
-        const uint32_t N2 = N1 / 2;
-        ba_pt nx; nx.x = ba_ld(ws_l2, 0, 26, 0, LT, T); nx.y = ba_ld(ws_l2, 0, 26, 13, LT, T);
-#pragma nounroll
-        for (uint32_t j2 = 0; j2 < N2; j2++) {
-            ba_pt q = nx;
-            if (j2 + 1 < N2) { nx.x = ba_ld(ws_l2, j2 + 1, 26, 0, LT, T); nx.y = ba_ld(ws_l2, j2 + 1, 26, 13, LT, T); }
-            ba_acc_add(acc, q);
-        }
-    } else {    // ---- some dx was 0 mod p in this lane: plain walk over its table entries ----
-#pragma nounroll
-        for (uint32_t s_ = 0; s_ < P; s_++) {
-            const uint64_t i = i_base + (uint64_t)s_ * L;
-            if (i >= n) continue;
-            const fr k = from_mont<FrP>(sc[i]);
-            const uint64_t cm = ba_carry_mask(k, c, nwin, D);
-#pragma nounroll
-            for (uint32_t w = 0; w < nwin; w++) {
-                uint32_t mag, ng;
-                ba_digit(k, cm, w, c, nwin, D, mag, ng);
-                if (!mag) continue;
-                g1a q = *ba_entry(table, table_n, D, nwin, w, i, mag);
-                if (ng) q.y = neg<FpP>(q.y);
-                acc.add(q);
-            }
-        }
-    }
-    buf[tid] = acc.to_jac();
-    __syncthreads();
-#pragma nounroll
-    for (uint32_t off = FB_BLOCK / 2; off >= 1; off >>= 1) {
-        if (tid < off) buf[tid] = g1_add(buf[tid], buf[tid + off]);
-        __syncthreads();
-    }
-    if (tid == 0) partials[blockIdx.x] = buf[0];
-}
 __global__ __launch_bounds__(64) void k_fb_finish(const g1j *partials, uint32_t blocks_per_blob, uint64_t batch, g1j *out) {
     uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (b >= batch) return;
@@ -573,39 +339,15 @@ static uint32_t fb_blocks_per_blob(uint64_t n, uint64_t batch) {
     if (bpb < 1) bpb = 1;
     return (uint32_t)bpb;
 }
-static bool fb_batch_affine() {                           // read per call so that tests can switch it
-    const char *e = getenv("KZG_HIP_FB_MODE");
-    return e && e[0] == 'b';
-}
-// per lane: level-1 prefixes (N1 fq), level-2 prefixes (N1 / 2 fq), level-1 sums (N1 points), level-2 sums (N1 / 2 points)
-static size_t fb_ba_words(uint64_t n, uint64_t batch, uint32_t nwin, size_t w[4]) {
-    uint32_t bpb = fb_blocks_per_blob(n, batch);
-    uint64_t LT = (uint64_t)bpb * batch * FB_BLOCK, L = (uint64_t)bpb * FB_BLOCK;
-    uint64_t P = (n + L - 1) / L, N1 = P * (((nwin + 7) & ~7u) / 2);
-    w[0] = N1 * 13 * LT; w[1] = (N1 / 2) * 13 * LT; w[2] = N1 * 26 * LT; w[3] = (N1 / 2) * 26 * LT;
-    return w[0] + w[1] + w[2] + w[3];
-}
-size_t fb_partials_bytes(uint64_t n, uint64_t batch, uint32_t nwin) {
-    size_t part = ((size_t)fb_blocks_per_blob(n, batch) * batch * sizeof(g1j) + 255) & ~(size_t)255;
-    if (!fb_batch_affine()) return part;
-    size_t w[4];
-    return part + fb_ba_words(n, batch, nwin, w) * sizeof(uint32_t);
-}
+size_t fb_partials_bytes(uint64_t n, uint64_t batch) { return (size_t)fb_blocks_per_blob(n, batch) * batch * sizeof(g1j); }
 
 void launch_fb_msm(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, uint64_t n, uint64_t batch,
                    void *partials, g1j *out) {
     if (!batch) return;
     uint32_t bpb = fb_blocks_per_blob(n, batch);
     prof_begin(s, "fb_accumulate");
-    if (fb_batch_affine()) {
-        size_t part = ((size_t)bpb * batch * sizeof(g1j) + 255) & ~(size_t)255, w[4];
-        fb_ba_words(n, batch, nwin, w);
-        uint32_t *wp = (uint32_t *)((uint8_t *)partials + part);
-        hipLaunchKernelGGL(k_fb_accumulate_ba, dim3((uint32_t)(batch * bpb)), dim3(FB_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars, n, bpb,
-                           (g1j *)partials, wp, wp + w[0], wp + w[0] + w[1], wp + w[0] + w[1] + w[2]);
-    } else
-        hipLaunchKernelGGL(k_fb_accumulate, dim3((uint32_t)(batch * bpb)), dim3(FB_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars, n, bpb,
-                           (g1j *)partials);
+    hipLaunchKernelGGL(k_fb_accumulate, dim3((uint32_t)(batch * bpb)), dim3(FB_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars, n, bpb,
+                       (g1j *)partials);
     prof_end(s, "fb_accumulate");
     hipLaunchKernelGGL(k_fb_finish, dim3((uint32_t)((batch + 63) / 64)), dim3(64), 0, s, (const g1j *)partials, bpb, batch, out);
 }

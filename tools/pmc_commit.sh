@@ -1,7 +1,7 @@
 #!/bin/bash
 # instruction / stall counters of k_fb_accumulate (commitment step, 512 blobs), one counter group per pass
 R=$(pwd); cd /tmp && export TMPDIR=/tmp
-for grp in "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_SALU SQ_INST_CYCLES_VMEM SQ_WAIT_ANY"; do
+for grp in "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
   out=$R/gpurun_out/pmcc; rm -rf $out
   rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out -o t -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fk20 > /dev/null 2>&1
   f=$(find $out -name "*counter_collection.csv" | head -1)
