@@ -673,10 +673,11 @@ static int fk20_core_new(kzg_hip_kzg *ks, uint64_t n2, uint64_t l, fk20_core *c)
     g1_fft_rows(fs, s, d_x.p, k, k, d_f.p, k2, l, 0);   // toeplitzPart1: FFTG1(x || inf^k), fk20_single.go:40-56
     launch_g1_normalize(s, d_f.p, c->d_files, l * k2);
     HIPCHK(hipGetLastError());
-    {   // fixed-base table over the file points, sized by KZG_HIP_FK20_FB_BUDGET_GB (default 24 GB of the 288)
-        double budget_gb = table_budget_gb("KZG_HIP_FK20_FB_BUDGET_GB", 24.0, 12.0);
+    {   // fixed-base table over the file points, sized by KZG_HIP_FK20_FB_BUDGET_GB (default: min(48 GB, free HBM - 12 GB)):
+        // scale 12, l = 1: c = 13, 20 windows, 32 GB;  scale 16, l = 16 (65 536 file points): c = 9, 29 windows, 47 GB
+        double budget_gb = table_budget_gb("KZG_HIP_FK20_FB_BUDGET_GB", 48.0, 12.0);
         uint64_t npts = l * k2; uint32_t best = 0;
-        for (uint32_t cc = 12; cc >= 4; cc--) {
+        for (uint32_t cc = 14; cc >= 4; cc--) {
             double bytes = (double)fb_windows(cc) * (double)npts * (double)(1u << (cc - 1)) * sizeof(g1a);
             if (bytes <= budget_gb * 1e9) { best = cc; break; }
         }
