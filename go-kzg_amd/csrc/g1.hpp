@@ -131,7 +131,8 @@ KZG_HD g1x g1x_madd(const g1x &p, const g1a &q) {
 //   in : X <= 11, Y <= 5, ZZ <= 2, ZZZ <= 2   (the first point enters with all bounds 1)
 //   u2, s2 = 2;  P = u2 - X (M = 12) -> 14;  R = s2 - Y (M = 6) -> 8;  PP, PPP, Q = 2  (products 196, 28, 22 <= 600)
 //   X3 = R^2 - PPP - 2 Q : 2 + 3 + 3 + 3 = 11;  Q - X3 (M = 12) -> 14;  R (Q - X3): 8 * 14 = 112 <= 600
-//   Y3 = R (Q - X3) - Y PPP : 2 + 3 = 5;  ZZ3, ZZZ3 = 2                -> the invariant is reproduced.
+//   Y3 = R (Q - X3) + (6 p - Y) PPP in ONE reduction (dot2q: 8 * 14 + 11 * 2 = 134 <= 600) : 2;  ZZ3, ZZZ3 = 2
+//                                                                        -> the invariant is reproduced.
 // Returns false (and leaves the accumulator untouched) when P == +-Q: the caller takes the generic path for those.
 struct g1xq { fq x, y, zz, zzz; };
 KZG_HD bool g1x_madd_fast(g1xq &p, const fq &x2, const fq &y2) {
@@ -141,7 +142,10 @@ KZG_HD bool g1x_madd_fast(g1xq &p, const fq &x2, const fq &y2) {
     if (is_zero_mod_p_q(pp)) return false;
     fq ppp = mulq(pp_, pp), q_ = mulq(p.x, pp);
     fq x3 = subq<3>(subq<3>(subq<3>(sqrq(r), ppp), q_), q_);
-    fq y3 = subq<3>(mulq(r, subq<12>(q_, x3)), mulq(p.y, ppp));
+    fq zero_q;
+#pragma unroll
+    for (int i = 0; i < 13; i++) zero_q.l[i] = 0;
+    fq y3 = dot2q_inl(r, subq<12>(q_, x3), subq<6>(zero_q, p.y), ppp);
     p.zz = mulq(p.zz, pp);
     p.zzz = mulq(p.zzz, ppp);
     p.x = x3; p.y = y3;
@@ -296,16 +300,20 @@ KZG_HD g1jq g1jq_dbl(const g1jq &p) {
 }
 // the same doubling with the seven products inlined (3.3 k instructions): used by the tight doubling loop of g1_mul_glv_wnaf
 KZG_HD g1jq g1jq_dbl_inl(const g1jq &p) {
-    fq a = sqrq_inl(p.x), b = sqrq_inl(p.y), c = sqrq_inl(b), s_ = mulq_inl(p.x, b);
-    fq d = addq(s_, s_); d = addq(d, d);
-    fq e = addq(addq(a, a), a);
+    fq a = sqrq_inl(p.x), b = sqrq_inl(p.y), s_ = mulq_inl(p.x, b);
+    fq d = addq(s_, s_); d = addq(d, d);                   // 8
+    fq e = addq(addq(a, a), a);                            // 6
     fq f = sqrq_inl(e);
     g1jq o;
-    o.x = subq<17>(f, addq(d, d));
-    fq c8 = addq(c, c); c8 = addq(c8, c8); c8 = addq(c8, c8);
-    o.y = subq<17>(mulq_inl(e, subq<20>(d, o.x)), c8);
+    o.x = subq<17>(f, addq(d, d));                         // 19
+    // Y3 = E (D - X3) - 8 B^2 as ONE reduction: E (D - X3) + (17 p - 8 B) B  (6 * 28 + 33 * 2 = 234 <= 600) : 2
+    fq b8 = addq(b, b); b8 = addq(b8, b8); b8 = addq(b8, b8);   // 16
+    fq zero_q;
+#pragma unroll
+    for (int i = 0; i < 13; i++) zero_q.l[i] = 0;
+    o.y = dot2q_inl(e, subq<20>(d, o.x), subq<17>(zero_q, b8), b);
     fq yz = mulq_inl(p.y, p.z);
-    o.z = addq(yz, yz);
+    o.z = addq(yz, yz);                                    // 4
     return o;
 }
 KZG_HD bool g1jq_add(g1jq &o, const g1jq &p, const g1jq &q) {
@@ -423,8 +431,15 @@ template <bool INL = false> KZG_HD bool g1jq_add_entry(g1jq &acc, const g1jq_t *
     fq j = MQ(h, i);
     fq v = MQ(u1, i);
     fq x3 = subq<3>(subq<3>(subq<3>(SQ(r), j), v), v);
-    fq sj = MQ(s1, j);
-    acc.y = subq<5>(MQ(r, subq<12>(v, x3)), addq(sj, sj));
+    if (INL) {                                             // Y3 = r (V - X3) + (5 p - 2 S1) J in ONE reduction (12 * 14 + 9 * 2 <= 600) : 2
+        fq zq;
+#pragma unroll
+        for (int ii = 0; ii < 13; ii++) zq.l[ii] = 0;
+        acc.y = dot2q_inl(r, subq<12>(v, x3), subq<5>(zq, addq(s1, s1)), j);
+    } else {
+        fq sj = MQ(s1, j);
+        acc.y = subq<5>(MQ(r, subq<12>(v, x3)), addq(sj, sj));
+    }
     acc.x = x3; acc.z = addq(zz, zz);
     return true;
 }

@@ -77,5 +77,10 @@ void he_g1_mul_glv_wnaf(g1j *o, const g1j *a, const fr *k_mont) {
     if (is_inf(pi)) { *o = OUT(g1_inf()); return; }
     g1jq_t tbl[8]; int8_t d1[132], d2[132]; *o = OUT(g1_mul_glv_wnaf(pi, glv_decompose(from_mont<FrP>(*k_mont)), tbl, d1, d2, 1));
 }
+void he_g1_mul_glv_wnaf_inl(g1j *o, const g1j *a, const fr *k_mont) {   // the instantiation the G1 FFT stages run (all products inlined, dot2)
+    g1j pi = IN(a);
+    if (is_inf(pi)) { *o = OUT(g1_inf()); return; }
+    g1jq_t tbl[8]; int8_t d1[132], d2[132]; *o = OUT((g1_mul_glv_wnaf<true, true>(pi, glv_decompose(from_mont<FrP>(*k_mont)), tbl, d1, d2, 1)));
+}
 int he_g1_equal(const g1j *a, const g1j *b) { return g1_equal(IN(a), IN(b)); }
 }

@@ -119,7 +119,7 @@ def test_g1_scalar_mul(he):
     rng = np.random.default_rng(3)
     gen = ko.g1_generator()
     base = ko.g1_mul(gen, rand_fr(rng, 1)[0])
-    scalars = list(rand_fr(rng, 6)) + list(ko.fr_from_ints([0, 1, 2, 3, 15, 16, 17, 31, 32, 33, 1023, 1024, ko.R_MOD - 1, 2**64, (1 << 255) % ko.R_MOD, 0xac45a4010001a40200000000ffffffff, 0xac45a4010001a40200000000fffffffe, 0xac45a4010001a40200000000ffffffff * 5 + 3]))
+    scalars = list(rand_fr(rng, 10)) + list(ko.fr_from_ints([0, 1, 2, 3, 15, 16, 17, 31, 32, 33, 1023, 1024, ko.R_MOD - 1, 2**64, (1 << 255) % ko.R_MOD, 0xac45a4010001a40200000000ffffffff, 0xac45a4010001a40200000000fffffffe, 0xac45a4010001a40200000000ffffffff * 5 + 3]))
     L = ko.lib()
     for k in scalars:
         for pt in (base, gen, ko.g1_zero()[0]):
@@ -130,7 +130,9 @@ def test_g1_scalar_mul(he):
             assert np.array_equal(ko.g1_compress(got), ko.g1_compress(want))
             he.he_g1_mul_glv_fast(p(got), p(pt), p(k))  # GLV on unpacked lazy coordinates, signed 5-bit windows
             assert np.array_equal(ko.g1_compress(got), ko.g1_compress(want))
-            he.he_g1_mul_glv_wnaf(p(got), p(pt), p(k))  # width-5 NAF, 8 odd multiples: what the G1 FFT stages run
+            he.he_g1_mul_glv_wnaf(p(got), p(pt), p(k))  # width-5 NAF, 8 odd multiples, every product a call
+            assert np.array_equal(ko.g1_compress(got), ko.g1_compress(want))
+            he.he_g1_mul_glv_wnaf_inl(p(got), p(pt), p(k))  # the instantiation the G1 FFT stages run: inlined products, merged reductions
             assert np.array_equal(ko.g1_compress(got), ko.g1_compress(want))
     he.he_g1_mul_small.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     for k in (0, 1, 2, 255, 4096, 2**32 - 1):
