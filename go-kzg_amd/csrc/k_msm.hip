@@ -260,15 +260,21 @@ __global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_accumulate(const g1a *table,
     g1x_acc acc; acc.init();   // XYZZ, unpacked lazy limbs: 10 products per mixed addition, no pack / reduce per product
     for (uint64_t i = (uint64_t)blk * FB_BLOCK + tid; i < n; i += L) {
         fr k = from_mont<FrP>(sc[i]);
-        uint32_t carry = 0;
+        // software pipeline: the gather of window w + 1 is issued before the addition of window w (+1.3 % measured)
+        uint32_t raw = scalar_bits(k, 0, c), carry, mag, ng;
+        if (raw > D) { carry = 1; mag = (1u << c) - raw; ng = 1; } else { carry = 0; mag = raw; ng = 0; }
+        g1a qn = table[((uint64_t)0 * table_n + i) * D + (mag ? mag - 1 : 0)];
 #pragma nounroll
         for (uint32_t w = 0; w < nwin; w++) {
-            uint32_t raw = scalar_bits(k, w * c, c) + carry;
-            uint32_t mag, ng;
-            if (raw > D) { carry = 1; mag = (1u << c) - raw; ng = 1; } else { carry = 0; mag = raw; ng = 0; }
-            if (mag) {
-                g1a q = table[((uint64_t)w * table_n + i) * D + (mag - 1)];
-                if (ng) q.y = neg<FpP>(q.y);
+            g1a q = qn;
+            const uint32_t cmag = mag, cng = ng;
+            if (w + 1 < nwin) {
+                raw = scalar_bits(k, (w + 1) * c, c) + carry;
+                if (raw > D) { carry = 1; mag = (1u << c) - raw; ng = 1; } else { carry = 0; mag = raw; ng = 0; }
+                qn = table[((uint64_t)(w + 1) * table_n + i) * D + (mag ? mag - 1 : 0)];
+            }
+            if (cmag) {
+                if (cng) q.y = neg<FpP>(q.y);
                 acc.add(q);
             }
         }
@@ -303,15 +309,21 @@ __global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_mul_vec(const g1a *table, ui
     uint64_t i = f * row + i0 + jj;
     fr k = from_mont<FrP>(scalars[b * table_n + i]);
     g1x_acc acc; acc.init();
-    uint32_t carry = 0;
+    // same software pipeline as k_fb_accumulate: gather of window w + 1 before the addition of window w
+    uint32_t raw = scalar_bits(k, 0, c), carry, mag, ng;
+    if (raw > D) { carry = 1; mag = (1u << c) - raw; ng = 1; } else { carry = 0; mag = raw; ng = 0; }
+    g1a qn = table[((uint64_t)0 * table_n + i) * D + (mag ? mag - 1 : 0)];
 #pragma nounroll
     for (uint32_t w = 0; w < nwin; w++) {
-        uint32_t raw = scalar_bits(k, w * c, c) + carry;
-        uint32_t mag, ng;
-        if (raw > D) { carry = 1; mag = (1u << c) - raw; ng = 1; } else { carry = 0; mag = raw; ng = 0; }
-        if (mag) {
-            g1a q = table[((uint64_t)w * table_n + i) * D + (mag - 1)];
-            if (ng) q.y = neg<FpP>(q.y);
+        g1a q = qn;
+        const uint32_t cmag = mag, cng = ng;
+        if (w + 1 < nwin) {
+            raw = scalar_bits(k, (w + 1) * c, c) + carry;
+            if (raw > D) { carry = 1; mag = (1u << c) - raw; ng = 1; } else { carry = 0; mag = raw; ng = 0; }
+            qn = table[((uint64_t)(w + 1) * table_n + i) * D + (mag ? mag - 1 : 0)];
+        }
+        if (cmag) {
+            if (cng) q.y = neg<FpP>(q.y);
             acc.add(q);
         }
     }
