@@ -542,9 +542,8 @@ static int commit_rows(kzg_hip_kzg *ks, hipStream_t s, const fr *d_sc, uint64_t 
         ks->ws_bytes = need;
     }
     g1j *d_raw = (g1j *)((uint8_t *)ks->d_ws + ws_main);
-    if (fixed) launch_fb_msm(s, ks->d_fixed, p.table_n, p.c, p.nwin, d_sc, n, batch, ks->d_ws, d_raw);
-    else launch_msm(s, p, ks->d_secret_a, d_sc, n, batch, ks->d_ws, d_raw);
-    launch_g1_normalize(s, d_raw, d_out, batch, true);
+    if (fixed) launch_fb_msm(s, ks->d_fixed, p.table_n, p.c, p.nwin, d_sc, n, batch, ks->d_ws, d_out, true);   // sums, normalises, converts
+    else { launch_msm(s, p, ks->d_secret_a, d_sc, n, batch, ks->d_ws, d_raw); launch_g1_normalize(s, d_raw, d_out, batch, true); }
     HIPCHK(hipGetLastError());
     return KZG_HIP_OK;
 }

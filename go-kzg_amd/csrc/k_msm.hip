@@ -288,13 +288,14 @@ __global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_accumulate(const g1a *table,
     }
     if (tid == 0) partials[blockIdx.x] = buf[0];
 }
-__global__ __launch_bounds__(64) void k_fb_finish(const g1j *partials, uint32_t blocks_per_blob, uint64_t batch, g1j *out) {
+__global__ __launch_bounds__(64) void k_fb_finish(const g1j *partials, uint32_t blocks_per_blob, uint64_t batch, g1j *out, int to_kilic) {
     uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (b >= batch) return;
     g1j acc = g1_inf();
 #pragma nounroll
     for (uint32_t j = 0; j < blocks_per_blob; j++) acc = g1_add(acc, partials[b * blocks_per_blob + j]);
-    out[b] = acc;
+    acc = g1_normalize(acc);
+    out[b] = to_kilic ? g1_to_kilic(acc) : acc;
 }
 
 // element-wise fixed-base products over the same table layout: out[b][i] = scalars[b][i] * P_i  (the FK20 Toeplitz stage,
@@ -353,15 +354,17 @@ static uint32_t fb_blocks_per_blob(uint64_t n, uint64_t batch) {
 }
 size_t fb_partials_bytes(uint64_t n, uint64_t batch) { return (size_t)fb_blocks_per_blob(n, batch) * batch * sizeof(g1j); }
 
+// out[b] = the NORMALISED sum (Z = one), as Kilic images when to_kilic: the per-blob partial sums are added and inverted in one
+// latency-bound kernel instead of two
 void launch_fb_msm(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, uint64_t n, uint64_t batch,
-                   void *partials, g1j *out) {
+                   void *partials, g1j *out, bool to_kilic) {
     if (!batch) return;
     uint32_t bpb = fb_blocks_per_blob(n, batch);
     prof_begin(s, "fb_accumulate");
     hipLaunchKernelGGL(k_fb_accumulate, dim3((uint32_t)(batch * bpb)), dim3(FB_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars, n, bpb,
                        (g1j *)partials);
     prof_end(s, "fb_accumulate");
-    hipLaunchKernelGGL(k_fb_finish, dim3((uint32_t)((batch + 63) / 64)), dim3(64), 0, s, (const g1j *)partials, bpb, batch, out);
+    hipLaunchKernelGGL(k_fb_finish, dim3((uint32_t)((batch + 63) / 64)), dim3(64), 0, s, (const g1j *)partials, bpb, batch, out, to_kilic ? 1 : 0);
 }
 // builds the table for `n` affine points: rows (2^(c w) P_i) first, then all multiples window-slab by window-slab
 hipError_t launch_fb_build(hipStream_t s, const g1a *pts, uint64_t n, uint32_t c, uint32_t nwin, g1a *table) {
