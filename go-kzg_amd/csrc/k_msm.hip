@@ -344,7 +344,16 @@ static uint32_t fb_blocks_per_blob(uint64_t n, uint64_t batch) {
     // 131072 lanes = 2048 wavefronts = exactly the resident capacity at 2 waves per SIMD: ONE round.  Measured (512 blobs):
     // 131072 lanes 5.7 ms, 262144 lanes (two rounds) 6.4 ms, 98304 / 65536 lanes 10.4 ms.  KZG_HIP_FB_LANES overrides.
     static uint64_t lanes = 0;
-    if (!lanes) { const char *e = getenv("KZG_HIP_FB_LANES"); lanes = e ? strtoull(e, nullptr, 10) : 131072; if (lanes < FB_BLOCK) lanes = FB_BLOCK; }
+    if (!lanes) {
+        const char *e = getenv("KZG_HIP_FB_LANES");
+        if (e) lanes = strtoull(e, nullptr, 10);
+        else {                                               // CUs x 4 SIMDs x 2 resident waves x 64 lanes (256 CUs: 131072)
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            lanes = (uint64_t)(cus > 0 ? cus : 256) * 4 * 2 * 64;
+        }
+        if (lanes < FB_BLOCK) lanes = FB_BLOCK;
+    }
     uint64_t target = lanes / FB_BLOCK;
     uint64_t bpb = target / (batch ? batch : 1);
     uint64_t maxb = (n + FB_BLOCK - 1) / FB_BLOCK;
