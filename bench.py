@@ -149,8 +149,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=512, help="blobs per step per GPU")
-    ap.add_argument("--fk20-batch", type=int, default=128)
-    ap.add_argument("--fk20-multi-batch", type=int, default=128)
+    ap.add_argument("--fk20-batch", type=int, default=512)
+    ap.add_argument("--fk20-multi-batch", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fk20", action="store_true")
     args = ap.parse_args()
