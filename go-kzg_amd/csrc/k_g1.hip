@@ -96,23 +96,47 @@ template <int MODE> __global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_fft_stag
     // Twiddle-major lane order: t -> (j, b, g).  All lanes of a wavefront then share ONE twiddle, so (i) the waves with j == 0
     // (1/2, 1/4, 1/8 ... of the early stages) skip the scalar multiplication entirely instead of idling beside their
     // neighbours, and (ii) the irregular width-5 NAF digit schedule of g1_mul_glv_wnaf is wave-uniform: no divergence.
-    // MODE 3 (default): width-5 NAF with the products of the doubling loop and of the additions inlined; 2: only the doublings
-    // inlined; 1: every product a call; 0: the regular signed-window variant (g1_mul_glv_fast).  KZG_HIP_G1_MUL = fast / wnaf / inl
-    // selects 0 / 1 / 2 for A/B runs (tools/ab_g1mul.sh): measured FK20 814 / 865 / 886 / 888 per second for modes 0..3.
+    // MODE 4 (default): width-5 NAF, products of the doubling loop and of the additions inlined, (x + w y, x - w y) by the shared
+    // lazy formulas; 3: generic butterfly additions; 2: only the doublings inlined; 1: every product a call; 0: the regular
+    // signed-window variant (g1_mul_glv_fast).  KZG_HIP_G1_MUL = fast / wnaf / inl / all selects 0 / 1 / 2 / 3 for A/B runs
+    // (tools/ab_g1mul.sh): measured FK20 814 / 865 / 886 / 888 per second for modes 0..3 at batch 128.
     const uint64_t half = 1ull << (logn - 1), groups = half / m;
     const uint64_t j = t / (groups * batch), rem = t % (groups * batch), b = rem / groups, g = rem % groups;
     g1j *row = data + (b << logn);
     uint64_t i0 = g * 2 * m + j, i1 = i0 + m;
     g1j y = row[i1];
-    if (MODE >= 1) {
+    g1j x = row[i0];
+    if (MODE == 4) {
+        // y <- w y unpacked, then (x + y, x - y) with the shared formulas; anything exceptional (an infinite operand, x == +-y, a
+        // degenerate addition inside the product) takes the generic complete path below
+        g1jq yq; int st = is_inf(y) ? 0 : 1;
+        if (st == 1) {
+            if (j) {
+                g1jq_t tbl[8]; int8_t dg1[132], dg2[132]; g1j packed;
+                st = g1_mul_glv_wnaf_q<true, true>(y, roots[j * (W / (2 * m))], tbl, dg1, dg2, 1, yq, packed);   // roots: (k1, k2) GLV pairs
+                if (st == 2) y = packed; else if (st == 0) y = g1_inf();
+            } else yq = g1jq_unpack(y);
+        }
+        if (st == 1 && !is_inf(x)) {
+            g1jq sum, dif;
+            if (g1jq_addsub(g1jq_unpack(x), yq, sum, dif)) {
+                fp z3 = packq(sum.z);
+                g1j o0, o1;
+                o0.x = packq(sum.x); o0.y = packq(sum.y); o0.z = z3;
+                o1.x = packq(dif.x); o1.y = packq(dif.y); o1.z = z3;
+                row[i0] = o0; row[i1] = o1;
+                return;
+            }
+        }
+        if (st == 1) y = g1jq_pack(yq);
+    } else if (MODE >= 1) {
         if (j && !is_inf(y)) {                                 // roots: (k1, k2) GLV pairs
             g1jq_t tbl[8]; int8_t dg1[132], dg2[132];
-            y = g1_mul_glv_wnaf<MODE >= 2, MODE == 3>(y, roots[j * (W / (2 * m))], tbl, dg1, dg2, 1);
+            y = g1_mul_glv_wnaf<MODE >= 2, MODE >= 3>(y, roots[j * (W / (2 * m))], tbl, dg1, dg2, 1);
         }
     } else {
         if (j && !is_inf(y)) { g1jq tbl[16]; y = g1_mul_glv_fast(y, roots[j * (W / (2 * m))], tbl); }
     }
-    g1j x = row[i0];
     row[i0] = g1_add(x, y);
     row[i1] = g1_add(x, g1_neg(y));
 }
@@ -121,7 +145,9 @@ void launch_g1_fft_stage(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, u
     if (!total) return;
     prof_begin(s, "g1_fft_stage");
     static int mode = -1;
-    if (mode < 0) { const char *e = getenv("KZG_HIP_G1_MUL"); mode = (e && e[0] == 'f') ? 0 : (e && e[0] == 'w') ? 1 : (e && e[0] == 'i') ? 2 : 3; }
+    if (mode < 0) { const char *e = getenv("KZG_HIP_G1_MUL"); mode = (e && e[0] == 'f') ? 0 : (e && e[0] == 'w') ? 1 : (e && e[0] == 'i') ? 2 : (e && e[0] == 'a') ? 3 : 4; }
+    if (mode == 4) hipLaunchKernelGGL(k_g1_fft_stage<4>, dim3((uint32_t)((total + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, data, ilog2g(n), m, roots, W, total, batch);
+    else
     if (mode == 3) hipLaunchKernelGGL(k_g1_fft_stage<3>, dim3((uint32_t)((total + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, data, ilog2g(n), m, roots, W, total, batch);
     else
     if (mode == 2) hipLaunchKernelGGL(k_g1_fft_stage<2>, dim3((uint32_t)((total + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, data, ilog2g(n), m, roots, W, total, batch);

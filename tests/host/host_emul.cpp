@@ -82,5 +82,17 @@ void he_g1_mul_glv_wnaf_inl(g1j *o, const g1j *a, const fr *k_mont) {   // the i
     if (is_inf(pi)) { *o = OUT(g1_inf()); return; }
     g1jq_t tbl[8]; int8_t d1[132], d2[132]; *o = OUT((g1_mul_glv_wnaf<true, true>(pi, glv_decompose(from_mont<FrP>(*k_mont)), tbl, d1, d2, 1)));
 }
+// (a + k b, a - k b) through the butterfly's shared lazy formulas; returns 0 when they decline (a == +-k b or an infinite operand)
+int he_g1_butterfly(g1j *o_sum, g1j *o_dif, const g1j *a, const g1j *b, const fr *k_mont) {
+    g1j x = IN(a), y = IN(b);
+    if (is_inf(x) || is_inf(y)) return 0;
+    g1jq_t tbl[8]; int8_t d1[132], d2[132]; g1jq yq; g1j packed;
+    int st = g1_mul_glv_wnaf_q<true, true>(y, glv_decompose(from_mont<FrP>(*k_mont)), tbl, d1, d2, 1, yq, packed);
+    if (st != 1) return 0;
+    g1jq sum, dif;
+    if (!g1jq_addsub(g1jq_unpack(x), yq, sum, dif)) return 0;
+    *o_sum = OUT(g1jq_pack(sum)); *o_dif = OUT(g1jq_pack(dif));
+    return 1;
+}
 int he_g1_equal(const g1j *a, const g1j *b) { return g1_equal(IN(a), IN(b)); }
 }

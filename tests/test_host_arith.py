@@ -141,6 +141,27 @@ def test_g1_scalar_mul(he):
         assert ko.g1_equal(got[0], ko.g1_mul(base, ko.fr_from_ints([k])[0]))
 
 
+def test_fft_butterfly_shared_add_sub(he):
+    # (x + w y, x - w y) of k_g1_fft_stage: shared lazy formulas == oracle; they decline (return 0) when x == +-w y
+    rng = np.random.default_rng(5)
+    gen = ko.g1_generator()
+    L = ko.lib()
+    for trial in range(6):
+        kx, ky, w = rand_fr(rng, 3)
+        x, y = ko.g1_mul(gen, kx), ko.g1_mul(gen, ky)
+        wy = ko.g1_mul(y, w)
+        s_, d_ = ko.g1_empty(1), ko.g1_empty(1)
+        assert he.he_g1_butterfly(p(s_), p(d_), p(x), p(y), p(w)) == 1
+        assert ko.g1_equal(s_[0], ko.g1_add(x, wy)) and ko.g1_equal(d_[0], ko.g1_sub(x, wy))
+    w = rand_fr(rng, 1)[0]
+    y = ko.g1_mul(gen, rand_fr(rng, 1)[0])
+    wy = ko.g1_mul(y, w)
+    s_, d_ = ko.g1_empty(1), ko.g1_empty(1)
+    assert he.he_g1_butterfly(p(s_), p(d_), p(wy), p(y), p(w)) == 0                    # x == w y: doubling, generic path
+    assert he.he_g1_butterfly(p(s_), p(d_), p(ko.g1_sub(ko.g1_zero()[0], wy)), p(y), p(w)) == 0   # x == -w y
+    assert he.he_g1_butterfly(p(s_), p(d_), p(ko.g1_zero()[0]), p(y), p(w)) == 0
+
+
 def test_table_walk_accumulator_fast_path(he):
     """g1x_acc (unpacked lazy XYZZ mixed additions, generic fallback for P == +-Q) over long chains and edge patterns"""
     rng = np.random.default_rng(9)
