@@ -80,6 +80,8 @@ struct kzg_hip_kzg {
     g1a *d_fixed = nullptr;      // fixed-base window table (lazily built)
     msm_plan fixed_plan{};
     void *d_ws = nullptr; size_t ws_bytes = 0;
+    hipStream_t copy_stream = nullptr;   // uploads of the host-buffer batch entry point, overlapped with the walk of the previous chunk
+    hipEvent_t copy_done[2] = {nullptr, nullptr};
 };
 struct fk20_core {
     kzg_hip_kzg *ks = nullptr;
@@ -485,6 +487,8 @@ void kzg_hip_kzg_settings_free(kzg_hip_kzg *ks) {
     if (!ks) return;
     hipSetDevice(ks->fs->device);
     hipFree(ks->d_secret); hipFree(ks->d_secret_a); hipFree(ks->d_fixed); hipFree(ks->d_ws);
+    if (ks->copy_stream) hipStreamDestroy(ks->copy_stream);
+    for (int i = 0; i < 2; i++) if (ks->copy_done[i]) hipEventDestroy(ks->copy_done[i]);
     delete ks;
 }
 
@@ -566,8 +570,28 @@ int kzg_hip_commit_to_poly_batch(kzg_hip_kzg *ks, const void *coeffs_fr, uint64_
     hipStream_t s = ks->fs->stream;
     dtmp<fr> d_sc(s); dtmp<g1j> d_out(s);
     CHK(d_sc.alloc(n * batch)); CHK(d_out.alloc(batch));
-    HIPCHK(hipMemcpyAsync(d_sc.p, coeffs_fr, n * batch * sizeof(fr), hipMemcpyHostToDevice, s));
-    CHK(commit_rows(ks, s, d_sc.p, n, batch, d_out.p));
+    // Large batches are uploaded in chunks on a second stream: the copy of chunk i + 1 (from pageable host memory it occupies the
+    // calling thread) runs while the GPU walks chunk i.  Chunks keep >= 256 blobs so that a walk still fills one round of waves.
+    uint64_t chunk = batch >= 1024 ? 512 : (batch >= 512 ? 256 : batch);
+    if (chunk < batch && n * sizeof(fr) >= (64u << 10)) {
+        if (!ks->copy_stream) {
+            HIPCHK(hipStreamCreateWithFlags(&ks->copy_stream, hipStreamNonBlocking));
+            for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&ks->copy_done[i], hipEventDisableTiming));
+        }
+        CHK(ensure_fixed_table(ks, s));
+        HIPCHK(hipStreamSynchronize(s));                     // d_sc was allocated in order on s: make it visible to the copy stream
+        int slot = 0;
+        for (uint64_t b0 = 0; b0 < batch; b0 += chunk, slot ^= 1) {
+            uint64_t cnt = batch - b0 < chunk ? batch - b0 : chunk;
+            HIPCHK(hipMemcpyAsync(d_sc.p + b0 * n, (const fr *)coeffs_fr + b0 * n, n * cnt * sizeof(fr), hipMemcpyHostToDevice, ks->copy_stream));
+            HIPCHK(hipEventRecord(ks->copy_done[slot], ks->copy_stream));
+            HIPCHK(hipStreamWaitEvent(s, ks->copy_done[slot], 0));
+            CHK(commit_rows(ks, s, d_sc.p + b0 * n, n, cnt, d_out.p + b0));
+        }
+    } else {
+        HIPCHK(hipMemcpyAsync(d_sc.p, coeffs_fr, n * batch * sizeof(fr), hipMemcpyHostToDevice, s));
+        CHK(commit_rows(ks, s, d_sc.p, n, batch, d_out.p));
+    }
     HIPCHK(hipMemcpyAsync(out_g1, d_out.p, batch * sizeof(g1j), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return KZG_HIP_OK;
