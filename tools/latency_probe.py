@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Single-call latencies of the host-buffer entry points (one blob per call), for the table in DESIGN.md 5."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import gokzg_amd as kz  # noqa: E402
+
+
+def timeit(fn, reps):
+    fn()
+    t0 = time.time()
+    for _ in range(reps):
+        fn()
+    return (time.time() - t0) / reps * 1e3
+
+
+fs = kz.FFTSettings(12)
+raw = np.frombuffer(open(os.path.join(ROOT, "tests", "golden", "trusted_setup_g1.bin"), "rb").read(), dtype=np.uint8)
+setup = fs.from_compressed_g1(raw)
+ks = kz.KZGSettings(fs, setup)
+blob, _ = fs.fr_from_32(bench.splitmix_blobs_le32(1, 1, 4096).reshape(-1, 32))
+print("CommitToPoly(4096)            %.3f ms" % timeit(lambda: ks.commit_to_poly(blob), 50))
+print("ComputeProofSingle(4096)      %.3f ms" % timeit(lambda: ks.compute_proof_single(blob, 17), 50))
+print("FFT_Fr(4096)                  %.3f ms" % timeit(lambda: fs.fft(blob, False), 100))
+print("DASFFTExtension(2048)         %.3f ms" % timeit(lambda: fs.das_fft_extension(blob[:2048].copy()), 100))
+print("FFTG1(4096)                   %.3f ms" % timeit(lambda: fs.fft_g1(setup, False), 5))
+fk = kz.FK20SingleSettings(ks, 4096)
+print("DAUsingFK20(2048 -> 4096)     %.3f ms" % timeit(lambda: fk.da_using_fk20(blob[:2048].copy()), 5))
