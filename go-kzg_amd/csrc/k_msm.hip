@@ -288,14 +288,29 @@ __global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_accumulate(const g1a *table,
     }
     if (tid == 0) partials[blockIdx.x] = buf[0];
 }
+// one wavefront per blob: the blob's partial sums are added by a tree through LDS (a lone commitment has 32 of them: 5 levels
+// instead of 31 serial additions), then lane 0 normalises and converts
 __global__ __launch_bounds__(64) void k_fb_finish(const g1j *partials, uint32_t blocks_per_blob, uint64_t batch, g1j *out, int to_kilic) {
-    uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    if (b >= batch) return;
+    __shared__ g1j buf[64];
+    const uint64_t b = blockIdx.x;
+    const uint32_t tid = threadIdx.x;
     g1j acc = g1_inf();
 #pragma nounroll
-    for (uint32_t j = 0; j < blocks_per_blob; j++) acc = g1_add(acc, partials[b * blocks_per_blob + j]);
-    acc = g1_normalize(acc);
-    out[b] = to_kilic ? g1_to_kilic(acc) : acc;
+    for (uint32_t j = tid; j < blocks_per_blob; j += 64) acc = g1_add(acc, partials[b * blocks_per_blob + j]);
+    buf[tid] = acc;
+    __syncthreads();
+    const uint32_t live = blocks_per_blob < 64 ? blocks_per_blob : 64;
+    uint32_t off = 1;
+    while (off * 2 < live) off *= 2;                      // largest power of two below `live`
+#pragma nounroll
+    for (; off >= 1; off >>= 1) {
+        if (tid < off && tid + off < live) buf[tid] = g1_add(buf[tid], buf[tid + off]);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        g1j r = g1_normalize(buf[0]);
+        out[b] = to_kilic ? g1_to_kilic(r) : r;
+    }
 }
 
 // element-wise fixed-base products over the same table layout: out[b][i] = scalars[b][i] * P_i  (the FK20 Toeplitz stage,
@@ -373,7 +388,7 @@ void launch_fb_msm(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c
     hipLaunchKernelGGL(k_fb_accumulate, dim3((uint32_t)(batch * bpb)), dim3(FB_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars, n, bpb,
                        (g1j *)partials);
     prof_end(s, "fb_accumulate");
-    hipLaunchKernelGGL(k_fb_finish, dim3((uint32_t)((batch + 63) / 64)), dim3(64), 0, s, (const g1j *)partials, bpb, batch, out, to_kilic ? 1 : 0);
+    hipLaunchKernelGGL(k_fb_finish, dim3((uint32_t)batch), dim3(64), 0, s, (const g1j *)partials, bpb, batch, out, to_kilic ? 1 : 0);
 }
 // builds the table for `n` affine points: rows (2^(c w) P_i) first, then all multiples window-slab by window-slab
 hipError_t launch_fb_build(hipStream_t s, const g1a *pts, uint64_t n, uint32_t c, uint32_t nwin, g1a *table) {
