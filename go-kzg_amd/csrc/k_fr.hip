@@ -222,7 +222,7 @@ void launch_toeplitz_coeffs(hipStream_t s, const fr *poly, uint64_t poly_stride,
 // ---------------------------------------------------------------------------------------------------------
 // q = p / (X - x): q[nq-1] = p[n-1], q[i] = p[i+1] + x q[i+1]  (what polyLongDiv computes for the monic linear
 // divisor, poly.go:14-40; the reference spends one InvModFr per step on the constant 1).  Blocked Horner:
-// 256 lanes each run a contiguous segment with carry-in 0, one lane chains the 256 segment carries, then every
+// 256 lanes each run a contiguous segment with carry-in 0, a suffix scan composes the 256 segment maps, then every
 // lane adds x^(distance) * carry.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_quotient_linear(const fr *poly, uint64_t n, const fr *xp, fr *q) {
@@ -235,12 +235,22 @@ __global__ __launch_bounds__(256) void k_quotient_linear(const fr *poly, uint64_
     if (lo < nq) {
         for (uint64_t i = hi; i-- > lo;) { acc = add(poly[i + 1], mul(x, acc)); q[i] = acc; pw = mul(pw, x); }
     }
-    head[t] = acc; xpow[t] = pw; cin[t] = zero<FrP>();
+    // segment s maps its carry-in c to head[s] + xpow[s] c; the carry into segment s is the composition of the maps of segments
+    // s + 1 .. 255 applied to 0.  Suffix scan of affine maps (Kogge-Stone, 8 steps of two products) instead of a 256-step chain:
+    // (H, P)[s] <- (H[s] + P[s] H[s + d], P[s] P[s + d]).
+    head[t] = acc; xpow[t] = pw;
     __syncthreads();
-    if (t == 0) {
-        fr c = zero<FrP>();
-        for (int s = 255; s >= 0; s--) { cin[s] = c; c = add(head[s], mul(xpow[s], c)); }
+#pragma nounroll
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        fr h = head[t], pq = xpow[t];
+        const bool has = t + d < 256;
+        fr h2, p2;
+        if (has) { h2 = head[t + d]; p2 = xpow[t + d]; }
+        __syncthreads();
+        if (has) { head[t] = add(h, mul(pq, h2)); xpow[t] = mul(pq, p2); }
+        __syncthreads();
     }
+    cin[t] = t + 1 < 256 ? head[t + 1] : zero<FrP>();
     __syncthreads();
     if (lo < nq) {
         fr c = cin[t];
