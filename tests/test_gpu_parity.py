@@ -351,6 +351,23 @@ def test_commit_with_every_table_size(kz, setup_1337, budget_gb, want_c, monkeyp
         fs.close()
 
 
+def test_commit_batch_shapes_fuzz(kz, ks4096, setup_1337):
+    # batch sizes that exercise every launch shape (blocks per blob 32 .. 1, the chunked upload of the host-buffer form at >= 512
+    # blobs, ragged last chunk) and ragged polynomial lengths; the first five rows are random (oracle MSM each), the others are
+    # (b + 1) times one of them, so every commitment of the batch is checked at the cost of one oracle scalar multiplication
+    rng = np.random.default_rng(2024)
+    for batch, n in ((1, 4096), (3, 4095), (7, 1), (33, 130), (257, 4096), (600, 2048)):
+        ints = [[int.from_bytes(rng.bytes(32), "little") % ko.R_MOD for _ in range(n)] for _ in range(min(batch, 5))]
+        rows = [ints[b % len(ints)] if b < len(ints) else [(v * (b + 1)) % ko.R_MOD for v in ints[b % len(ints)]] for b in range(batch)]
+        blobs = np.stack([ko.fr_from_ints(r) for r in rows])
+        got = ks4096.commit_to_poly_batch(blobs)
+        # rows beyond the first five are (b + 1) times one of them: their commitments must be (b + 1) times that commitment
+        base = [ko.lincomb_g1(setup_1337[:n], blobs[b]) for b in range(len(ints))]
+        for b in range(batch):
+            want = base[b] if b < len(ints) else ko.g1_mul(base[b % len(ints)], ko.fr_from_ints([b + 1])[0])
+            assert ko.g1_equal(got[b], want), (batch, n, b)
+
+
 def test_commit_linearity_full_size(kz, ks4096):
     # size-independent property at full size: commit(a) + commit(b) == commit(a + b)
     a, b = ko.synthetic_blob(101), ko.synthetic_blob(102)
