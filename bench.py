@@ -152,6 +152,7 @@ def main():
     ap.add_argument("--fk20-batch", type=int, default=512)
     ap.add_argument("--fk20-multi-batch", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sharded-fk20-multi", action="store_true", help="also time ONE FK20Multi through the sharded driver at world size 1")
     ap.add_argument("--no-fk20", action="store_true")
     args = ap.parse_args()
 
@@ -307,6 +308,26 @@ def main():
         msecs = timed_steps(fkm_step, msteps, 1, torch.cuda.synchronize, barrier, max_over_ranks)
         fk20m = {"metric": "FK20Multi all-coset-proofs/s (DAUsingFK20Multi, scale 16, chunk 16: 32768 coeffs -> 4096 proofs)",
                  "value": MB * world * msteps / msecs, "batch_per_gpu": MB, "ms_per_all_proofs": msecs / msteps / MB * 1e3}
+        if use_dist or args.sharded_fk20_multi:
+            # ONE FK20Multi with its Toeplitz stage sharded over the ranks and an RCCL all-gather of the 144-byte point slices
+            # (BASELINE config 5, go-kzg_amd/multi_gpu.py).  A latency figure, reported beside the throughput numbers; a failure
+            # here must not cost the bench line.
+            try:
+                from gokzg_amd import multi_gpu as mg
+                be = mg.HipFK20MultiBackend(fkm)
+                if use_dist:                                 # every rank works on rank 0's polynomial
+                    dist.broadcast(d_mp[0], src=0)
+                one = d_mp[0].contiguous()
+                ref = torch.empty((4096, 18), dtype=torch.int64, device="cuda")
+                st = lib.kzg_hip_da_using_fk20_multi_batch_dev(fkm.h, one.data_ptr(), 32768, 1, ref.data_ptr(), stream)
+                got = mg.da_using_fk20_multi_sharded(be, one, 32768, 4096)
+                torch.cuda.synchronize()
+                same = bool(st == 0 and torch.equal(got, ref))
+                ssecs = timed_steps(lambda: mg.da_using_fk20_multi_sharded(be, one, 32768, 4096), 3, 1, torch.cuda.synchronize, barrier, max_over_ranks)
+                fk20m["sharded_one_polynomial"] = {"ms": ssecs / 3 * 1e3, "ranks": world, "matches_unsharded": same,
+                                                   "collective": "all_gather of 4096 x 144 B point slices (RCCL)" if use_dist else "none (1 rank)"}
+            except Exception as e:                           # noqa: BLE001
+                fk20m["sharded_one_polynomial"] = {"error": "%s: %s" % (type(e).__name__, e)}
         fkm.close(); ks16.close(); fs16.close()
 
     ref_benches = None
