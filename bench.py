@@ -283,6 +283,19 @@ def main():
         fk20 = {"metric": "FK20 all-proofs/s (DAUsingFK20, 2048 coeffs -> 4096 proofs, scale 12)",
                 "value": FB * world * max(1, args.steps // 2) / fsecs, "batch_per_gpu": FB,
                 "ms_per_all_proofs": fsecs / max(1, args.steps // 2) / FB * 1e3}
+        if use_dist:
+            # the north star's "RCCL all-gather of proof points over xGMI": every rank ends up with the proofs of 32 blobs of every
+            # rank (32 x 4096 x 144 B = 18.9 MB per rank).  Reported beside the throughput; a failure must not cost the bench line.
+            try:
+                from gokzg_amd import multi_gpu as mg
+                part = d_proofs[:32].contiguous()
+                gsecs = timed_steps(lambda: mg.all_gather_proofs(part), 5, 1, torch.cuda.synchronize, barrier, max_over_ranks)
+                gathered = mg.all_gather_proofs(part)
+                ok_ = bool(torch.equal(gathered[rank * 32:(rank + 1) * 32], part))
+                fk20["all_gather_proofs"] = {"ms": gsecs / 5 * 1e3, "bytes_per_rank": int(part.numel() * 8), "ranks": world,
+                                             "GB_s_out_per_rank": part.numel() * 8 * (world - 1) / (gsecs / 5) * 1e-9, "own_slice_intact": ok_}
+            except Exception as e:                           # noqa: BLE001
+                fk20["all_gather_proofs"] = {"error": "%s: %s" % (type(e).__name__, e)}
         fk.close()
 
     fk20m = None
