@@ -164,12 +164,17 @@ def main():
         raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available() or kz.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: the HIP path is the only path")
+    local = local % max(1, torch.cuda.device_count())        # (test hook: several ranks on one GPU with KZG_BENCH_BACKEND=gloo)
     torch.cuda.set_device(local)
     use_dist = world > 1
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        backend = os.environ.get("KZG_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; gloo only to smoke-test N > 1 on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     lib = kz.lib()
     fs = kz.FFTSettings(12, device=local)
@@ -285,13 +290,14 @@ def main():
                 "ms_per_all_proofs": fsecs / max(1, args.steps // 2) / FB * 1e3}
         if use_dist:
             # the north star's "RCCL all-gather of proof points over xGMI": every rank ends up with the proofs of 32 blobs of every
-            # rank (32 x 4096 x 144 B = 18.9 MB per rank).  Reported beside the throughput; a failure must not cost the bench line.
+            # rank (up to 32 x 4096 x 144 B = 18.9 MB per rank).  Reported beside the throughput; a failure must not cost the bench line.
             try:
                 from gokzg_amd import multi_gpu as mg
                 part = d_proofs[:32].contiguous()
                 gsecs = timed_steps(lambda: mg.all_gather_proofs(part), 5, 1, torch.cuda.synchronize, barrier, max_over_ranks)
                 gathered = mg.all_gather_proofs(part)
-                ok_ = bool(torch.equal(gathered[rank * 32:(rank + 1) * 32], part))
+                cnt_ = part.shape[0]
+                ok_ = bool(gathered.shape[0] == world * cnt_ and torch.equal(gathered[rank * cnt_:(rank + 1) * cnt_], part))
                 fk20["all_gather_proofs"] = {"ms": gsecs / 5 * 1e3, "bytes_per_rank": int(part.numel() * 8), "ranks": world,
                                              "GB_s_out_per_rank": part.numel() * 8 * (world - 1) / (gsecs / 5) * 1e-9, "own_slice_intact": ok_}
             except Exception as e:                           # noqa: BLE001
