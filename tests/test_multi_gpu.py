@@ -108,3 +108,52 @@ def test_sharded_fk20_multi_hip_backend_world1():
     torch.cuda.synchronize()
     assert np.array_equal(got2.cpu().numpy().view(np.uint64).reshape(-1, 3, 6), want)
     fk.close(); ks.close(); fs.close()
+
+
+def _gpu_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    import gokzg_amd as kz
+    from gokzg_amd import multi_gpu
+    from oracle import koracle as ko
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["KZG_HIP_FB_BUDGET_GB"] = "1"
+    os.environ["KZG_HIP_FK20_FB_BUDGET_GB"] = "1"
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # both ranks share the one GPU: RCCL refuses that, gloo moves the bytes
+    n2, l = 1024, 16
+    fs = kz.FFTSettings(10)
+    ks = kz.KZGSettings(fs, ko.generate_testing_setup_g1(S_TEST, n2))
+    fk = kz.FK20MultiSettings(ks, n2, l)
+    poly = ko.synthetic_blob(9, n2 // 2)
+    want = fk.da_using_fk20_multi(poly)
+    be = multi_gpu.HipFK20MultiBackend(fk)
+    d_poly = torch.from_numpy(poly.view(np.int64).copy()).cuda()
+    got = multi_gpu.da_using_fk20_multi_sharded(be, d_poly, n2 // 2, be.k2)
+    torch.cuda.synchronize()
+    ok = np.array_equal(got.cpu().numpy().view(np.uint64).reshape(-1, 3, 6), want)
+    mine = torch.full((3, 2, 18), rank, dtype=torch.int64, device="cuda")
+    allp = multi_gpu.all_gather_proofs(mine).cpu()
+    ok = ok and allp.shape == (6, 2, 18) and bool((allp[:3] == 0).all()) and bool((allp[3:] == 1).all())
+    q.put((rank, bool(ok)))
+    fk.close(); ks.close(); fs.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_fk20_multi_hip_backend_two_ranks_one_gpu():
+    """world size 2 with the REAL device calls on both ranks (each computes half of the Toeplitz stage on the GPU, the 144-byte
+    slices cross a real all-gather, each finishes with the two G1 FFTs): bit-identical to the unsharded result on both ranks"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
