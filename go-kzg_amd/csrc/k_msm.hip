@@ -161,14 +161,16 @@ __global__ __launch_bounds__(64) void k_msm_combine(uint8_t *ws, size_t per_blob
     uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (b >= batch) return;
     const g1j *gsum = (const g1j *)(ws + b * per_blob + gsum_off);
-    g1j acc = g1_inf();
+    // ~250 doublings on the critical path of ONE lane: lazy unpacked coordinates (8.5 us per doubling instead of 15)
+    g1jq_acc acc; acc.inf = true;
 #pragma nounroll
     for (uint32_t g = ngroups; g-- > 0;) {
 #pragma nounroll
-        for (uint32_t j = 0; j < c; j++) acc = g1_dbl(acc);
-        acc = g1_add(acc, gsum[g]);
+        for (uint32_t j = 0; j < c; j++) acc.dbl();
+        g1j w = gsum[g];
+        if (!is_inf(w)) acc.add(g1jq_unpack(w));
     }
-    out[b] = acc;
+    out[b] = acc.inf ? g1_inf() : g1jq_pack(acc.v);
 }
 
 void launch_msm(hipStream_t s, const msm_plan &p, const g1a *table, const fr *scalars, uint64_t n, uint64_t batch, void *workspace, g1j *out) {

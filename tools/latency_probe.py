@@ -30,5 +30,6 @@ print("ComputeProofSingle(4096)      %.3f ms" % timeit(lambda: ks.compute_proof_
 print("FFT_Fr(4096)                  %.3f ms" % timeit(lambda: fs.fft(blob, False), 100))
 print("DASFFTExtension(2048)         %.3f ms" % timeit(lambda: fs.das_fft_extension(blob[:2048].copy()), 100))
 print("FFTG1(4096)                   %.3f ms" % timeit(lambda: fs.fft_g1(setup, False), 5))
+print("LinCombG1(4096 caller points) %.3f ms" % timeit(lambda: fs.lin_comb_g1(setup, blob), 20))
 fk = kz.FK20SingleSettings(ks, 4096)
 print("DAUsingFK20(2048 -> 4096)     %.3f ms" % timeit(lambda: fk.da_using_fk20(blob[:2048].copy()), 5))
