@@ -22,7 +22,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkzg_hip.so")
+LIB_PATH = os.environ.get("KZG_HIP_LIB") or os.path.join(_HERE, "libkzg_hip.so")   # KZG_HIP_LIB: another build of the same library (A/B runs)
 
 OK, ERR_TOO_WIDE, ERR_NOT_POW2, ERR_LEN_MISMATCH, ERR_UPPER_HALF, ERR_BAD_ARG, ERR_BAD_POINT, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_RECOVERY = range(11)
 
