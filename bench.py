@@ -225,6 +225,22 @@ def main():
     secs = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, barrier, max_over_ranks)
     value = B * world * args.steps / secs
 
+    # SURVEY.md 8(d) config 2 also names the batch sizes 1, 64 and 1024: the same step at those sizes (secondary figures)
+    batch_sweep = {}
+    if not args.no_fk20:
+        big = mont_blobs(1 + rank * 1024, 1024)
+        d_big = torch.from_numpy(big.view(np.int64)).cuda()
+        d_big_out = torch.zeros((1024, 18), dtype=torch.int64, device="cuda")
+        for bs in (1, 64, 1024):
+            def sweep_step(bs=bs):
+                st = lib.kzg_hip_commit_to_poly_batch_dev(ks.h, d_big.data_ptr(), N_COEFF, bs, d_big_out.data_ptr(), stream)
+                if st:
+                    raise RuntimeError("commit_to_poly_batch_dev status %d" % st)
+            reps = 20 if bs < 1024 else 5
+            ssecs = timed_steps(sweep_step, reps, 2, torch.cuda.synchronize, barrier, max_over_ranks)
+            batch_sweep[str(bs)] = {"commitments_per_s": bs * world * reps / ssecs, "ms_per_step": ssecs / reps * 1e3}
+        del d_big, d_big_out
+
     # roofline leg: HIP events around the dominant kernel on the launch stream, separate (un-timed) pass
     lib.kzg_hip_prof_reset(fs.h, 1)
     for _ in range(max(3, min(args.steps, 10))):
@@ -401,7 +417,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "CommitToPoly, 4096-coeff blobs, eth/trusted_setup.json monomial setup (s=1337), %d blobs/step/GPU resident in HBM" % B,
                        "global_batch": B * world, "parallelism": "dp%d (independent blobs, no data-path collective)" % world},
-            "roofline": roofline, "cpu_baseline": base, "fk20": fk20, "fk20_multi": fk20m, "reference_benchmarks": ref_benches,
+            "roofline": roofline, "cpu_baseline": base, "batch_sweep": batch_sweep, "fk20": fk20, "fk20_multi": fk20m, "reference_benchmarks": ref_benches,
         }))
     if use_dist:
         dist.destroy_process_group()
