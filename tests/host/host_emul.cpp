@@ -94,5 +94,15 @@ int he_g1_butterfly(g1j *o_sum, g1j *o_dif, const g1j *a, const g1j *b, const fr
     *o_sum = OUT(g1jq_pack(sum)); *o_dif = OUT(g1jq_pack(dif));
     return 1;
 }
+// the P == +-Q handling of the width-5 NAF loop: acc (= a) += sign * b through g1jq_add_entry, falling back to g1jq_add_slow_copy when
+// it declines.  Returns 1 when the fast formulas were used, 0 when the slow path ran; *o = the sum (infinity allowed).
+int he_g1jq_add_entry(g1j *o, const g1j *a, const g1j *b, int negate) {
+    g1jq acc = g1jq_unpack(IN(a));
+    g1jq_t t; g1jq_t_make(&t, g1jq_unpack(IN(b)));
+    if (g1jq_add_entry<true>(acc, &t, negate != 0, false)) { *o = OUT(g1jq_pack(acc)); return 1; }
+    bool inf = g1jq_add_slow_copy(acc, &t, negate != 0, false);
+    *o = OUT(inf ? g1_inf() : g1jq_pack(acc));
+    return 0;
+}
 int he_g1_equal(const g1j *a, const g1j *b) { return g1_equal(IN(a), IN(b)); }
 }

@@ -141,6 +141,22 @@ def test_g1_scalar_mul(he):
         assert ko.g1_equal(got[0], ko.g1_mul(base, ko.fr_from_ints([k])[0]))
 
 
+def test_wnaf_loop_exceptional_additions(he):
+    # acc += +-entry inside g1_mul_glv_wnaf: distinct points use the fast formulas; acc == entry (doubling) and acc == -entry
+    # (infinity) are declined by them and handled by the complete formulas
+    rng = np.random.default_rng(6)
+    gen = ko.g1_generator()
+    a = ko.g1_mul(gen, rand_fr(rng, 1)[0])
+    b = ko.g1_mul(gen, rand_fr(rng, 1)[0])
+    out = ko.g1_empty(1)
+    assert he.he_g1jq_add_entry(p(out), p(a), p(b), 0) == 1 and ko.g1_equal(out[0], ko.g1_add(a, b))
+    assert he.he_g1jq_add_entry(p(out), p(a), p(b), 1) == 1 and ko.g1_equal(out[0], ko.g1_sub(a, b))
+    assert he.he_g1jq_add_entry(p(out), p(a), p(a), 0) == 0 and ko.g1_equal(out[0], ko.g1_add(a, a))
+    assert he.he_g1jq_add_entry(p(out), p(a), p(a), 1) == 0 and ko.g1_equal(out[0], ko.g1_zero()[0])
+    a2 = ko.g1_add(a, a)                                   # same point, different Jacobian representation (Z != 1)
+    assert he.he_g1jq_add_entry(p(out), p(a2), p(ko.g1_add(a, a)), 0) == 0 and ko.g1_equal(out[0], ko.g1_add(a2, a2))
+
+
 def test_fft_butterfly_shared_add_sub(he):
     # (x + w y, x - w y) of k_g1_fft_stage: shared lazy formulas == oracle; they decline (return 0) when x == +-w y
     rng = np.random.default_rng(5)
