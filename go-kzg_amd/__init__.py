@@ -76,6 +76,9 @@ def lib():
         "kzg_hip_lincomb_g1": (i32, [vp, vp, vp, u64, vp]), "kzg_hip_g1_to_compressed": (i32, [vp, vp, u64, vp]),
         "kzg_hip_g1_from_compressed": (i32, [vp, vp, u64, vp]), "kzg_hip_g1_mul_vec": (i32, [vp, vp, vp, u64, vp]),
         "kzg_hip_generate_testing_setup_g1": (i32, [vp, vp, u64, vp]),
+        "kzg_hip_g1_marshal_text": (i32, [vp, vp, u64, vp]), "kzg_hip_g1_unmarshal_text": (i32, [vp, C.c_char_p, u64, vp]),
+        "kzg_hip_trusted_setup_from_json": (i32, [vp, C.c_char_p, u64, vp, vp, u64, C.POINTER(u64), C.POINTER(u64)]),
+        "kzg_hip_kzg_set_table_budget_gb": (i32, [vp, C.c_double]),
         "kzg_hip_kzg_settings_new": (i32, [vp, vp, u64, pp]), "kzg_hip_kzg_settings_free": (None, [vp]),
         "kzg_hip_commit_to_poly": (i32, [vp, vp, u64, vp]), "kzg_hip_commit_to_poly_batch": (i32, [vp, vp, u64, u64, vp]),
         "kzg_hip_commit_to_poly_batch_dev": (i32, [vp, vp, u64, u64, vp, vp]),
@@ -275,15 +278,31 @@ class FFTSettings:
 
     def g1_marshal_text(self, points):
         """bls.G1Point.MarshalText over a slice (bls/bls_all.go:20-22): lower-case hex of the 48-byte compressed form"""
-        return [c.tobytes().hex() for c in self.to_compressed_g1(points)]
+        points = _g1(points)
+        n = points.shape[0]
+        buf = C.create_string_buffer(96 * n + 1)
+        _chk(lib().kzg_hip_g1_marshal_text(self.h, _p(points), n, buf))
+        txt = buf.raw[:96 * n].decode("ascii")
+        return [txt[96 * i:96 * i + 96] for i in range(n)]
 
     def g1_unmarshal_text(self, texts):
-        """bls.G1Point.UnmarshalText over a slice (bls/bls_all.go:24-39) -- e.g. the "setup_G1" / "setup_G1_lagrange" arrays of
-        eth/trusted_setup.json (eth/globals.go:33-49); decompression runs on the device"""
-        raw = np.frombuffer(b"".join(bytes.fromhex(t) for t in texts), dtype=np.uint8)
-        if raw.size != 48 * len(texts):
+        """bls.G1Point.UnmarshalText over a slice (bls/bls_all.go:24-39); hex decoding in the library, decompression on the device"""
+        texts = list(texts)
+        if any(len(t) != 96 for t in texts):
             raise KzgPanic(ERR_BAD_POINT, "expected 48-byte compressed G1 points")
-        return self.from_compressed_g1(raw)
+        out = g1_empty(len(texts))
+        _chk(lib().kzg_hip_g1_unmarshal_text(self.h, "".join(texts).encode("ascii", "replace"), len(texts), _p(out)))
+        return out
+
+    def trusted_setup_from_json(self, text):
+        """JSONTrustedSetup (eth/globals.go:33-49): JSON text -> (setup_G1, setup_G1_lagrange) as Kilic images; G2 is skipped"""
+        raw = text.encode("utf-8") if isinstance(text, str) else bytes(text)
+        n1, n2 = C.c_uint64(0), C.c_uint64(0)
+        _chk(lib().kzg_hip_trusted_setup_from_json(self.h, raw, len(raw), None, None, 0, C.byref(n1), C.byref(n2)))
+        cap = max(n1.value, n2.value, 1)
+        mono, lag = g1_empty(cap), g1_empty(cap)
+        _chk(lib().kzg_hip_trusted_setup_from_json(self.h, raw, len(raw), _p(mono), _p(lag), cap, C.byref(n1), C.byref(n2)))
+        return mono[:n1.value], lag[:n2.value]
 
     def mul_g1_vec(self, points, scalars):
         points, scalars = _g1(points), _fr(scalars)
@@ -317,6 +336,10 @@ class KZGSettings:
         if getattr(self, "h", None):
             lib().kzg_hip_kzg_settings_free(self.h)
             self.h = None
+
+    def set_table_budget_gb(self, gb):
+        """HBM budget of the fixed-base commitment table (default 64 GB; 210 opts into the 206 GB 16-bit-window table)"""
+        _chk(lib().kzg_hip_kzg_set_table_budget_gb(self.h, float(gb)))
 
     def table_info(self):
         """(window bits, windows, bytes) of the fixed-base table the commitments walk; zeros before the first commitment"""

@@ -4,8 +4,11 @@
 #include "../../include/kzg_hip.h"
 #include "internal.hpp"
 
+#include <algorithm>
 #include <map>
+#include <memory>
 #include <mutex>
+#include <new>
 #include <string>
 #include <vector>
 #include <cstdio>
@@ -27,6 +30,12 @@ static thread_local std::string g_last_error;
         }                                                                                                    \
     } while (0)
 #define CHK(expr) do { int s_ = (expr); if (s_ != KZG_HIP_OK) return s_; } while (0)
+// no C++ exception may cross the extern "C" boundary (cgo / ctypes callers): host allocations sized by the caller are the
+// only throwing operations in this file
+#define KZG_TRY try {
+#define KZG_CATCH                                                                                             \
+    } catch (const std::bad_alloc &) { g_last_error = "host allocation failed"; return KZG_HIP_ERR_HIP; }    \
+    catch (const std::exception &e_) { g_last_error = e_.what(); return KZG_HIP_ERR_HIP; }
 
 static bool is_pow2(uint64_t v) { return (v & (v - 1)) == 0; }   // bls.IsPowerOfTwo (bls/globals.go:72-74): true for 0
 static uint64_t next_pow2(uint64_t v) { if (v == 0) return 1; uint64_t p = 1; while (p < v) p <<= 1; return p; }   // fft.go:11-16
@@ -79,7 +88,7 @@ struct kzg_hip_kzg {
     g1a *d_secret_a = nullptr;   // affine table for the MSM
     g1a *d_fixed = nullptr;      // fixed-base window table (lazily built)
     msm_plan fixed_plan{};
-    void *d_ws = nullptr; size_t ws_bytes = 0;
+    double budget_gb = -1.0;             // fixed-base table budget; < 0: default policy (ensure_fixed_table)
     hipStream_t copy_stream = nullptr;   // uploads of the host-buffer batch entry point, overlapped with the walk of the previous chunk
     hipEvent_t copy_done[2] = {nullptr, nullptr};
 };
@@ -141,13 +150,32 @@ static fr scale2_root_of_unity(unsigned k) {   // 7^((r-1)/2^k), bls/globals.go:
     return acc;
 }
 
+// G1-FFT twiddles leave Montgomery form (Kilic FromRed) and are split k = k2 lambda + k1 once, on the host
+static int upload_g1_twiddles(kzg_hip_fft *fs) {
+    size_t bytes = (fs->W + 1) * sizeof(fr);
+    std::vector<fr> ge(fs->W + 1), gr(fs->W + 1);
+    for (uint64_t i = 0; i <= fs->W; i++) ge[i] = glv_decompose(from_mont<FrP>(fs->h_expanded[i]));
+    for (uint64_t i = 0; i <= fs->W; i++) gr[i] = ge[fs->W - i];
+    HIPCHK(hipMalloc((void **)&fs->d_glv_expanded, bytes));
+    HIPCHK(hipMalloc((void **)&fs->d_glv_reversed, bytes));
+    HIPCHK(hipMemcpy(fs->d_glv_expanded, ge.data(), bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(fs->d_glv_reversed, gr.data(), bytes, hipMemcpyHostToDevice));
+    return KZG_HIP_OK;
+}
+static bool device_is_gfx950(int device) {
+    hipDeviceProp_t pr;
+    return hipGetDeviceProperties(&pr, device) == hipSuccess && strncmp(pr.gcnArchName, "gfx950", 6) == 0;
+}
 int kzg_hip_fft_settings_new(int device, unsigned max_scale, kzg_hip_fft **out) {
     if (!out || max_scale > 31) return KZG_HIP_ERR_BAD_ARG;
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0 || device < 0 || device >= ndev) return KZG_HIP_ERR_NO_DEVICE;
+    if (!device_is_gfx950(device)) return KZG_HIP_ERR_NO_DEVICE;   // kernels are built for gfx950 only; there is no fallback
     HIPCHK(hipSetDevice(device));
-    kzg_hip_fft *fs = new kzg_hip_fft;
+    KZG_TRY
+    std::unique_ptr<kzg_hip_fft, void (*)(kzg_hip_fft *)> own(new kzg_hip_fft, kzg_hip_fft_settings_free);   // frees on every error path
+    kzg_hip_fft *fs = own.get();
     fs->device = device; fs->max_scale = max_scale; fs->W = 1ull << max_scale;
     HIPCHK(hipStreamCreateWithFlags(&fs->stream, hipStreamNonBlocking));
     // expandRootOfUnity (fft.go:21-32): W + 1 powers, first and last are 1; reversed copy (fft.go:49-54)
@@ -161,29 +189,23 @@ int kzg_hip_fft_settings_new(int device, unsigned max_scale, kzg_hip_fft **out) 
     HIPCHK(hipMalloc((void **)&fs->d_reversed, bytes));
     HIPCHK(hipMemcpy(fs->d_expanded, fs->h_expanded.data(), bytes, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(fs->d_reversed, fs->h_reversed.data(), bytes, hipMemcpyHostToDevice));
-    {   // G1-FFT twiddles leave Montgomery form (Kilic FromRed) and are split k = k2 lambda + k1 once, on the host
-        std::vector<fr> ge(fs->W + 1), gr(fs->W + 1);
-        for (uint64_t i = 0; i <= fs->W; i++) ge[i] = glv_decompose(from_mont<FrP>(fs->h_expanded[i]));
-        for (uint64_t i = 0; i <= fs->W; i++) gr[i] = ge[fs->W - i];
-        HIPCHK(hipMalloc((void **)&fs->d_glv_expanded, bytes));
-        HIPCHK(hipMalloc((void **)&fs->d_glv_reversed, bytes));
-        HIPCHK(hipMemcpy(fs->d_glv_expanded, ge.data(), bytes, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(fs->d_glv_reversed, gr.data(), bytes, hipMemcpyHostToDevice));
-    }
+    CHK(upload_g1_twiddles(fs));
     fr invs[64]; fr half = inv<FrP>(fr_from_u64(2));
     invs[0] = one<FrP>();
     for (int i = 1; i < 64; i++) invs[i] = mul(invs[i - 1], half);
     HIPCHK(hipMalloc((void **)&fs->d_inv_pow2, sizeof invs));
     HIPCHK(hipMemcpy(fs->d_inv_pow2, invs, sizeof invs, hipMemcpyHostToDevice));
-    *out = fs;
+    *out = own.release();
     return KZG_HIP_OK;
+    KZG_CATCH
 }
 void kzg_hip_fft_settings_free(kzg_hip_fft *fs) {
     if (!fs) return;
     hipSetDevice(fs->device);
-    hipStreamSynchronize(fs->stream);
+    if (fs->stream) hipStreamSynchronize(fs->stream);
     hipFree(fs->d_expanded); hipFree(fs->d_reversed); hipFree(fs->d_inv_pow2); hipFree(fs->d_glv_expanded); hipFree(fs->d_glv_reversed);
-    hipStreamDestroy(fs->stream);
+    if (fs->stream) hipStreamDestroy(fs->stream);
+    (void)hipGetLastError();
     delete fs;
 }
 uint64_t kzg_hip_fft_max_width(const kzg_hip_fft *fs) { return fs ? fs->W : 0; }
@@ -462,33 +484,43 @@ int kzg_hip_generate_testing_setup_g1(kzg_hip_fft *fs, const void *secret_fr, ui
 // ---------------------------------------------------------------------------------------------------------
 // KZGSettings
 // ---------------------------------------------------------------------------------------------------------
+// uploads n Kilic images, converts to the device-internal domain, normalises and keeps Jacobian + affine copies resident.
+// Every error path frees what was built (the handle is owned by a unique_ptr until the last step).
+static int kzg_settings_build(kzg_hip_fft *fs, const void *points_g1, uint64_t n, kzg_hip_kzg **out) {
+    dev_guard g(fs);
+    hipStream_t s = fs->stream;
+    std::unique_ptr<kzg_hip_kzg, void (*)(kzg_hip_kzg *)> own(new kzg_hip_kzg, kzg_hip_kzg_settings_free);
+    kzg_hip_kzg *ks = own.get();
+    ks->fs = fs; ks->n_setup = n;
+    dtmp<g1j> d_raw(s);
+    CHK(d_raw.alloc(n));
+    HIPCHK(hipMalloc((void **)&ks->d_secret, n * sizeof(g1j)));
+    HIPCHK(hipMalloc((void **)&ks->d_secret_a, n * sizeof(g1a)));
+    HIPCHK(hipMemcpyAsync(d_raw.p, points_g1, n * sizeof(g1j), hipMemcpyHostToDevice, s));
+    launch_g1_from_kilic(s, d_raw.p, n);
+    launch_g1_normalize(s, d_raw.p, ks->d_secret, n);
+    launch_g1_to_affine(s, ks->d_secret, ks->d_secret_a, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    *out = own.release();
+    return KZG_HIP_OK;
+}
 int kzg_hip_kzg_settings_new(kzg_hip_fft *fs, const void *secret_g1, uint64_t n_setup, kzg_hip_kzg **out) {
     if (!fs || !out || !secret_g1) return KZG_HIP_ERR_BAD_ARG;
     *out = nullptr;
     if (n_setup < fs->W) return KZG_HIP_ERR_LEN_MISMATCH;   // kzg.go:25-27
-    dev_guard g(fs);
-    hipStream_t s = fs->stream;
-    kzg_hip_kzg *ks = new kzg_hip_kzg;
-    ks->fs = fs; ks->n_setup = n_setup;
-    dtmp<g1j> d_raw(s);
-    CHK(d_raw.alloc(n_setup));
-    HIPCHK(hipMalloc((void **)&ks->d_secret, n_setup * sizeof(g1j)));
-    HIPCHK(hipMalloc((void **)&ks->d_secret_a, n_setup * sizeof(g1a)));
-    HIPCHK(hipMemcpyAsync(d_raw.p, secret_g1, n_setup * sizeof(g1j), hipMemcpyHostToDevice, s));
-    launch_g1_from_kilic(s, d_raw.p, n_setup);
-    launch_g1_normalize(s, d_raw.p, ks->d_secret, n_setup);
-    launch_g1_to_affine(s, ks->d_secret, ks->d_secret_a, n_setup);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(s));
-    *out = ks;
-    return KZG_HIP_OK;
+    KZG_TRY
+    return kzg_settings_build(fs, secret_g1, n_setup, out);
+    KZG_CATCH
 }
 void kzg_hip_kzg_settings_free(kzg_hip_kzg *ks) {
     if (!ks) return;
     hipSetDevice(ks->fs->device);
-    hipFree(ks->d_secret); hipFree(ks->d_secret_a); hipFree(ks->d_fixed); hipFree(ks->d_ws);
+    hipDeviceSynchronize();   // _dev callers may still have work in flight that reads the tables: drain the device first
+    hipFree(ks->d_secret); hipFree(ks->d_secret_a); hipFree(ks->d_fixed);
     if (ks->copy_stream) hipStreamDestroy(ks->copy_stream);
     for (int i = 0; i < 2; i++) if (ks->copy_done[i]) hipEventDestroy(ks->copy_done[i]);
+    (void)hipGetLastError();
     delete ks;
 }
 
@@ -509,46 +541,57 @@ static uint32_t fb_windows(uint32_t c) {
 }
 
 // Lazily builds the fixed-base table T[(w n + i) D + d - 1] = d 2^(c w) SecretG1[i] (k_msm.hip).  The window size is the
-// largest whose table fits the HBM budget: KZG_HIP_FB_BUDGET_GB if set, else what is free on the device minus 40 GB of
-// headroom for the FK20 tables and workspaces, capped at 210 GB.  On an otherwise empty 288 GB MI355X, n = 4096 gets
-// c = 16: 16 windows, 206 GB (measured: c = 13 20 windows 55k, c = 14 19 windows 60.2k, c = 15 18 windows 57.9k,
-// c = 16 16 windows 68.7k commitments/s); a second settings object built while the first is alive gets a smaller table.
+// largest whose table fits the HBM budget.  Budget, in this order: kzg_hip_kzg_set_table_budget_gb (per handle, the opt-in for
+// the 206 GB c = 16 table), the KZG_HIP_FB_BUDGET_GB environment variable, else the DEFAULT of 64 GB (n = 4096: c = 14,
+// 19 windows, 61 GB) clipped to free HBM - 24 GB so that several settings objects (monomial + eth Lagrange + FK20) co-reside.
+// Measured, n = 4096, 512 blobs per launch: c = 11 (10 GB) ~39k, c = 13 (32 GB) ~55k, c = 14 (61 GB) ~77k, c = 16 (206 GB,
+// 16 windows) ~88k commitments/s (bench.py table_sweep).  If the allocation fails (another process on the GPU, fragmentation)
+// the next smaller window is tried, and finally the bucket path, which needs no table: a commitment never fails for lack of HBM.
 static int ensure_fixed_table(kzg_hip_kzg *ks, hipStream_t s) {
     if (ks->d_fixed || ks->fixed_plan.c == 0xffffffffu) return KZG_HIP_OK;
-    double budget_gb = table_budget_gb("KZG_HIP_FB_BUDGET_GB", 210.0, 40.0);
-    uint32_t best = 0;
+    double budget_gb = ks->budget_gb >= 0.0 ? ks->budget_gb : table_budget_gb("KZG_HIP_FB_BUDGET_GB", 64.0, 24.0);
+    if (ks->n_setup < 64) { ks->fixed_plan.c = 0xffffffffu; return KZG_HIP_OK; }   // classic path only
     for (uint32_t c = 16; c >= 5; c--) {
         if (c == 15) continue;                               // measured slower than c = 14 (18 windows, 116 GB)
         double bytes = (double)fb_windows(c) * (double)ks->n_setup * (double)(1u << (c - 1)) * sizeof(g1a);
-        if (bytes <= budget_gb * 1e9) { best = c; break; }
+        if (bytes > budget_gb * 1e9) continue;
+        msm_plan p{};
+        p.c = c; p.nwin = fb_windows(c); p.nb = 1u << (c - 1); p.ngroups = 1; p.fixed = 1; p.table_n = ks->n_setup;
+        size_t entries = (size_t)p.nwin * ks->n_setup * p.nb;
+        g1a *tab = nullptr;
+        if (hipMalloc((void **)&tab, entries * sizeof(g1a)) != hipSuccess) { (void)hipGetLastError(); continue; }   // retry smaller
+        hipError_t e = launch_fb_build(s, ks->d_secret_a, ks->n_setup, p.c, p.nwin, tab);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { (void)hipGetLastError(); hipFree(tab); continue; }   // temporaries of the build did not fit
+        ks->d_fixed = tab; ks->fixed_plan = p;
+        return KZG_HIP_OK;
     }
-    if (!best || ks->n_setup < 64) { ks->fixed_plan.c = 0xffffffffu; return KZG_HIP_OK; }   // classic path only
-    msm_plan p{};
-    p.c = best; p.nwin = fb_windows(best); p.nb = 1u << (best - 1); p.ngroups = 1; p.fixed = 1; p.table_n = ks->n_setup;
-    size_t entries = (size_t)p.nwin * ks->n_setup * p.nb;
-    HIPCHK(hipMalloc((void **)&ks->d_fixed, entries * sizeof(g1a)));
-    HIPCHK(launch_fb_build(s, ks->d_secret_a, ks->n_setup, p.c, p.nwin, ks->d_fixed));
-    HIPCHK(hipStreamSynchronize(s));
-    ks->fixed_plan = p;
+    ks->fixed_plan.c = 0xffffffffu;                          // no table fits: bucket path
     return KZG_HIP_OK;
 }
 
-// MSM of `batch` resident scalar rows against SecretG1[:n]; out = batch normalised points (device)
+// MSM of `batch` resident scalar rows against SecretG1[:n]; out = batch normalised points (device).  The partial-sum / bucket
+// workspace is allocated per call, stream-ordered on the launch stream (hipMallocAsync pool: no device synchronisation after the
+// first use), so concurrent callers on different streams never share scratch memory.
 static int commit_rows(kzg_hip_kzg *ks, hipStream_t s, const fr *d_sc, uint64_t n, uint64_t batch, g1j *d_out) {
     CHK(ensure_fixed_table(ks, s));
     bool fixed = ks->d_fixed != nullptr;
     msm_plan p = fixed ? ks->fixed_plan : classic_plan(n);
     size_t ws_main = fixed ? fb_partials_bytes(n, batch) : msm_workspace_bytes(p, n, batch);
-    size_t need = ws_main + batch * sizeof(g1j);
-    if (need > ks->ws_bytes) {
-        if (ks->d_ws) { HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipFree(ks->d_ws)); ks->d_ws = nullptr; }
-        HIPCHK(hipMalloc(&ks->d_ws, need));
-        ks->ws_bytes = need;
-    }
-    g1j *d_raw = (g1j *)((uint8_t *)ks->d_ws + ws_main);
-    if (fixed) launch_fb_msm(s, ks->d_fixed, p.table_n, p.c, p.nwin, d_sc, n, batch, ks->d_ws, d_out, true);   // sums, normalises, converts
-    else { launch_msm(s, p, ks->d_secret_a, d_sc, n, batch, ks->d_ws, d_raw); launch_g1_normalize(s, d_raw, d_out, batch, true); }
+    dtmp<uint8_t> d_ws(s);
+    CHK(d_ws.alloc(ws_main + batch * sizeof(g1j)));
+    g1j *d_raw = (g1j *)(d_ws.p + ws_main);
+    if (fixed) launch_fb_msm(s, ks->d_fixed, p.table_n, p.c, p.nwin, d_sc, n, batch, d_ws.p, d_out, true);   // sums, normalises, converts
+    else { launch_msm(s, p, ks->d_secret_a, d_sc, n, batch, d_ws.p, d_raw); launch_g1_normalize(s, d_raw, d_out, batch, true); }
     HIPCHK(hipGetLastError());
+    return KZG_HIP_OK;
+}
+int kzg_hip_kzg_set_table_budget_gb(kzg_hip_kzg *ks, double gb) {
+    if (!ks || !(gb >= 0.0)) return KZG_HIP_ERR_BAD_ARG;
+    dev_guard g(ks->fs);
+    if (ks->d_fixed) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(ks->d_fixed)); ks->d_fixed = nullptr; }
+    ks->fixed_plan = msm_plan{};
+    ks->budget_gb = gb;
     return KZG_HIP_OK;
 }
 
@@ -666,10 +709,15 @@ int kzg_hip_toeplitz_part2(kzg_hip_kzg *ks, const void *coeffs_fr, const void *x
 }
 int kzg_hip_toeplitz_part3(kzg_hip_kzg *ks, const void *h_ext_fft_g1, uint64_t n, void *out_g1) {
     if (!ks) return KZG_HIP_ERR_BAD_ARG;
-    std::vector<g1j> full(n ? n : 1);
+    if (n > ks->fs->W) return KZG_HIP_ERR_TOO_WIDE;            // FFTG1 error -> panic, fk20_single.go:80-84
+    if (!is_pow2(n)) return KZG_HIP_ERR_NOT_POW2;
+    if (n == 0 || !h_ext_fft_g1 || !out_g1) return KZG_HIP_ERR_BAD_ARG;
+    KZG_TRY
+    std::vector<g1j> full(n);
     CHK(kzg_hip_fft_g1(ks->fs, h_ext_fft_g1, n, 1, full.data()));   // fk20_single.go:80-87
     memcpy(out_g1, full.data(), (n / 2) * sizeof(g1j));
     return KZG_HIP_OK;
+    KZG_CATCH
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -697,21 +745,22 @@ static int fk20_core_new(kzg_hip_kzg *ks, uint64_t n2, uint64_t l, fk20_core *c)
     launch_g1_normalize(s, d_f.p, c->d_files, l * k2);
     HIPCHK(hipGetLastError());
     {   // fixed-base table over the file points, sized by KZG_HIP_FK20_FB_BUDGET_GB (default: min(48 GB, free HBM - 12 GB)):
-        // scale 12, l = 1: c = 13, 20 windows, 32 GB;  scale 16, l = 16 (65 536 file points): c = 9, 29 windows, 47 GB
+        // scale 12, l = 1: c = 13, 20 windows, 32 GB;  scale 16, l = 16 (65 536 file points): c = 9, 29 windows, 47 GB.
+        // An allocation failure falls back to the next smaller window and finally to the table-free double-and-add path.
         double budget_gb = table_budget_gb("KZG_HIP_FK20_FB_BUDGET_GB", 48.0, 12.0);
-        uint64_t npts = l * k2; uint32_t best = 0;
-        for (uint32_t cc = 14; cc >= 4; cc--) {
+        uint64_t npts = l * k2;
+        dtmp<g1a> d_fa(s);
+        if (npts >= 64) { CHK(d_fa.alloc(npts)); launch_g1_to_affine(s, c->d_files, d_fa.p, npts); }
+        for (uint32_t cc = 14; cc >= 4 && npts >= 64; cc--) {
             double bytes = (double)fb_windows(cc) * (double)npts * (double)(1u << (cc - 1)) * sizeof(g1a);
-            if (bytes <= budget_gb * 1e9) { best = cc; break; }
-        }
-        if (best && npts >= 64) {
-            dtmp<g1a> d_fa(s);
-            CHK(d_fa.alloc(npts));
-            launch_g1_to_affine(s, c->d_files, d_fa.p, npts);
-            c->fb_c = best; c->fb_nwin = fb_windows(best);
-            HIPCHK(hipMalloc((void **)&c->d_files_fb, (size_t)c->fb_nwin * npts * (1u << (best - 1)) * sizeof(g1a)));
-            HIPCHK(launch_fb_build(s, d_fa.p, npts, c->fb_c, c->fb_nwin, c->d_files_fb));
-            HIPCHK(hipStreamSynchronize(s));
+            if (bytes > budget_gb * 1e9) continue;
+            g1a *tab = nullptr;
+            if (hipMalloc((void **)&tab, (size_t)fb_windows(cc) * npts * (1u << (cc - 1)) * sizeof(g1a)) != hipSuccess) { (void)hipGetLastError(); continue; }
+            hipError_t e = launch_fb_build(s, d_fa.p, npts, cc, fb_windows(cc), tab);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) { (void)hipGetLastError(); hipFree(tab); continue; }
+            c->d_files_fb = tab; c->fb_c = cc; c->fb_nwin = fb_windows(cc);
+            break;
         }
     }
     HIPCHK(hipStreamSynchronize(s));
@@ -792,14 +841,15 @@ int kzg_hip_fk20_single_settings_new(kzg_hip_kzg *ks, uint64_t n2, kzg_hip_fk20s
     if (n2 < 2) return KZG_HIP_ERR_BAD_ARG;              // kzg.go:50-52
     kzg_hip_fk20s *fk = new kzg_hip_fk20s;
     int st = fk20_core_new(ks, n2, 1, &fk->c);
-    if (st) { delete fk; return st; }
+    if (st) { kzg_hip_fk20_single_settings_free(fk); return st; }
     *out = fk;
     return KZG_HIP_OK;
 }
 void kzg_hip_fk20_single_settings_free(kzg_hip_fk20s *fk) {
     if (!fk) return;
-    hipSetDevice(fk->c.ks->fs->device);
+    if (fk->c.ks) { hipSetDevice(fk->c.ks->fs->device); hipDeviceSynchronize(); }
     hipFree(fk->c.d_files); hipFree(fk->c.d_files_fb);
+    (void)hipGetLastError();
     delete fk;
 }
 int kzg_hip_fk20_single_x_ext_fft(const kzg_hip_fk20s *fk, void *out_g1) {
@@ -859,14 +909,15 @@ int kzg_hip_fk20_multi_settings_new(kzg_hip_kzg *ks, uint64_t n2, uint64_t chunk
     if (chunk_len < 1) return KZG_HIP_ERR_BAD_ARG;            // kzg.go:89-91
     kzg_hip_fk20m *fk = new kzg_hip_fk20m;
     int st = fk20_core_new(ks, n2, chunk_len, &fk->c);
-    if (st) { delete fk; return st; }
+    if (st) { kzg_hip_fk20_multi_settings_free(fk); return st; }
     *out = fk;
     return KZG_HIP_OK;
 }
 void kzg_hip_fk20_multi_settings_free(kzg_hip_fk20m *fk) {
     if (!fk) return;
-    hipSetDevice(fk->c.ks->fs->device);
+    if (fk->c.ks) { hipSetDevice(fk->c.ks->fs->device); hipDeviceSynchronize(); }
     hipFree(fk->c.d_files); hipFree(fk->c.d_files_fb);
+    (void)hipGetLastError();
     delete fk;
 }
 int kzg_hip_fk20_multi(kzg_hip_fk20m *fk, const void *poly_fr, uint64_t n, void *out_g1) {
@@ -946,6 +997,7 @@ int kzg_hip_recover_poly_from_samples(kzg_hip_fft *fs, const void *samples_fr, c
     if (!fs || !samples_fr || !present || !out_fr || n == 0) return KZG_HIP_ERR_BAD_ARG;
     if (n > fs->W) return KZG_HIP_ERR_TOO_WIDE;
     if (!is_pow2(n)) return KZG_HIP_ERR_NOT_POW2;
+    KZG_TRY
     std::vector<uint64_t> missing;
     for (uint64_t i = 0; i < n; i++) if (!present[i]) missing.push_back(i);   // recover_from_samples.go:44-49
     if (missing.size() >= n) return KZG_HIP_ERR_BAD_ARG;
@@ -980,6 +1032,7 @@ int kzg_hip_recover_poly_from_samples(kzg_hip_fft *fs, const void *samples_fr, c
     HIPCHK(hipMemcpyAsync(out_fr, d_b.p, n * sizeof(fr), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return flag ? KZG_HIP_ERR_RECOVERY : KZG_HIP_OK;
+    KZG_CATCH
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -997,56 +1050,44 @@ int kzg_hip_eth_settings_new(kzg_hip_fft *fs, const void *lagrange_g1, uint64_t 
     *out = nullptr;
     if (n == 0 || !is_pow2(n)) return KZG_HIP_ERR_NOT_POW2;
     if (n > fs->W) return KZG_HIP_ERR_TOO_WIDE;
+    KZG_TRY
     std::vector<g1j> br(n);
+    std::vector<fr> dom(n);
     const g1j *src = (const g1j *)lagrange_g1;
     uint32_t logn = ilog2(n);
     for (uint64_t i = 0; i < n; i++) {   // bitReversalPermutation (eth/helpers.go, used at eth/globals.go:48)
         uint64_t r = 0;
         for (uint32_t b = 0; b < logn; b++) if (i & (1ull << b)) r |= 1ull << (logn - 1 - b);
         br[i] = src[r];
+        // natural-order scale-log2(n) domain = every (W / n)-th expanded root; DomainFr[i] = domain[bitrev(i)] (eth/globals.go:61-66)
+        dom[i] = fs->h_expanded[r * (fs->W / n)];
     }
-    kzg_hip_eth *eth = new kzg_hip_eth;
+    std::unique_ptr<kzg_hip_eth, void (*)(kzg_hip_eth *)> own(new kzg_hip_eth, kzg_hip_eth_settings_free);
+    kzg_hip_eth *eth = own.get();
     eth->fs = fs; eth->n = n;
     // KZGSettings requires len(setup) >= MaxWidth (kzg.go:25-27); the eth setup is exactly its own width, so build it directly
+    CHK(kzg_settings_build(fs, br.data(), n, &eth->ks));
     {
         dev_guard g(fs);
-        hipStream_t s = fs->stream;
-        kzg_hip_kzg *ks = new kzg_hip_kzg;
-        ks->fs = fs; ks->n_setup = n;
-        dtmp<g1j> d_raw(s);
-        CHK(d_raw.alloc(n));
-        HIPCHK(hipMalloc((void **)&ks->d_secret, n * sizeof(g1j)));
-        HIPCHK(hipMalloc((void **)&ks->d_secret_a, n * sizeof(g1a)));
-        HIPCHK(hipMemcpyAsync(d_raw.p, br.data(), n * sizeof(g1j), hipMemcpyHostToDevice, s));
-        launch_g1_from_kilic(s, d_raw.p, n);
-        launch_g1_normalize(s, d_raw.p, ks->d_secret, n);
-        launch_g1_to_affine(s, ks->d_secret, ks->d_secret_a, n);
         HIPCHK(hipMalloc((void **)&eth->d_domain, n * sizeof(fr)));
-        // natural-order scale-log2(n) domain = every (W / n)-th expanded root; DomainFr[i] = domain[bitrev(i)]
-        std::vector<fr> dom(n);
-        for (uint64_t i = 0; i < n; i++) {
-            uint64_t r = 0;
-            for (uint32_t b = 0; b < logn; b++) if (i & (1ull << b)) r |= 1ull << (logn - 1 - b);
-            dom[i] = fs->h_expanded[r * (fs->W / n)];
-        }
-        HIPCHK(hipMemcpyAsync(eth->d_domain, dom.data(), n * sizeof(fr), hipMemcpyHostToDevice, s));
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(s));
-        eth->ks = ks;
+        HIPCHK(hipMemcpy(eth->d_domain, dom.data(), n * sizeof(fr), hipMemcpyHostToDevice));
     }
-    *out = eth;
+    *out = own.release();
     return KZG_HIP_OK;
+    KZG_CATCH
 }
 void kzg_hip_eth_settings_free(kzg_hip_eth *eth) {
     if (!eth) return;
     hipSetDevice(eth->fs->device);
+    kzg_hip_kzg_settings_free(eth->ks);   // drains the device first
     hipFree(eth->d_domain);
-    kzg_hip_kzg_settings_free(eth->ks);
+    (void)hipGetLastError();
     delete eth;
 }
 int kzg_hip_eth_blob_to_kzg_commitment_batch(kzg_hip_eth *eth, const void *blobs_le32, uint64_t batch, void *out48, uint8_t *ok) {
     if (!eth || !blobs_le32 || !out48 || !ok) return KZG_HIP_ERR_BAD_ARG;
     if (!batch) return KZG_HIP_OK;
+    KZG_TRY
     dev_guard g(eth->fs);
     hipStream_t s = eth->fs->stream;
     uint64_t n = eth->n;
@@ -1068,6 +1109,7 @@ int kzg_hip_eth_blob_to_kzg_commitment_batch(kzg_hip_eth *eth, const void *blobs
         if (bad[b]) memset((uint8_t *)out48 + 48 * b, 0, 48);
     }
     return KZG_HIP_OK;
+    KZG_CATCH
 }
 int kzg_hip_eth_compute_kzg_proof(kzg_hip_eth *eth, const void *poly_fr, uint64_t n, const void *z_fr, void *out48, void *y_fr) {
     if (!eth || !poly_fr || !z_fr || !out48) return KZG_HIP_ERR_BAD_ARG;
@@ -1092,6 +1134,90 @@ int kzg_hip_eth_compute_kzg_proof(kzg_hip_eth *eth, const void *poly_fr, uint64_
     if (y_fr) HIPCHK(hipMemcpyAsync(y_fr, d_z.p + 1, sizeof(fr), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return KZG_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// setup (un)marshalling (row f4): G1Point.MarshalText / UnmarshalText (bls/bls_all.go:20-39) and the JSON trusted setup of
+// eth/globals.go:33-49.  Hex coding and JSON scanning are host work; decompression + subgroup check run on the device.
+// ---------------------------------------------------------------------------------------------------------
+static int hex_nibble(char c) { return c >= '0' && c <= '9' ? c - '0' : c >= 'a' && c <= 'f' ? c - 'a' + 10 : c >= 'A' && c <= 'F' ? c - 'A' + 10 : -1; }
+int kzg_hip_g1_marshal_text(kzg_hip_fft *fs, const void *points_g1, uint64_t n, char *out_hex96) {
+    if (!fs || (n && (!points_g1 || !out_hex96))) return KZG_HIP_ERR_BAD_ARG;
+    KZG_TRY
+    std::vector<uint8_t> raw(48 * n);
+    CHK(kzg_hip_g1_to_compressed(fs, points_g1, n, raw.data()));
+    static const char dig[] = "0123456789abcdef";                       // hex.EncodeToString: lower case, no 0x prefix
+    for (uint64_t i = 0; i < 48 * n; i++) { out_hex96[2 * i] = dig[raw[i] >> 4]; out_hex96[2 * i + 1] = dig[raw[i] & 15]; }
+    return KZG_HIP_OK;
+    KZG_CATCH
+}
+int kzg_hip_g1_unmarshal_text(kzg_hip_fft *fs, const char *hex96, uint64_t n, void *out_g1) {
+    if (!fs || (n && (!hex96 || !out_g1))) return KZG_HIP_ERR_BAD_ARG;
+    KZG_TRY
+    std::vector<uint8_t> raw(48 * n);
+    for (uint64_t i = 0; i < 48 * n; i++) {
+        int hi = hex_nibble(hex96[2 * i]), lo = hex_nibble(hex96[2 * i + 1]);
+        if (hi < 0 || lo < 0) return KZG_HIP_ERR_BAD_POINT;             // hex.DecodeString error (bls/bls_all.go:29-32)
+        raw[i] = (uint8_t)(hi << 4 | lo);
+    }
+    return kzg_hip_g1_from_compressed(fs, raw.data(), n, out_g1);
+    KZG_CATCH
+}
+// finds "key" : [ "..." , ... ] in `js` and appends the decoded 48-byte strings; *found = 0 when the key is absent
+static int json_hex48_array(const char *js, uint64_t len, const char *key, std::vector<uint8_t> &out, uint64_t *count, int *found) {
+    *count = 0; *found = 0;
+    std::string pat = std::string("\"") + key + "\"";
+    const char *end = js + len, *p = js;
+    for (;;) {                                                           // the key must be followed by ':' (skips "setup_G1" inside "setup_G1_lagrange")
+        p = std::search(p, end, pat.begin(), pat.end());
+        if (p == end) return KZG_HIP_OK;
+        p += pat.size();
+        const char *q = p;
+        while (q < end && (*q == ' ' || *q == '\t' || *q == '\n' || *q == '\r')) q++;
+        if (q < end && *q == ':') { p = q + 1; break; }
+    }
+    while (p < end && *p != '[') { if (*p != ' ' && *p != '\t' && *p != '\n' && *p != '\r') return KZG_HIP_ERR_BAD_ARG; p++; }
+    if (p == end) return KZG_HIP_ERR_BAD_ARG;
+    p++;
+    *found = 1;
+    for (;;) {
+        while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r' || *p == ',')) p++;
+        if (p == end) return KZG_HIP_ERR_BAD_ARG;
+        if (*p == ']') return KZG_HIP_OK;
+        if (*p != '"') return KZG_HIP_ERR_BAD_ARG;
+        p++;
+        const char *q = p;
+        while (q < end && *q != '"') q++;
+        if (q == end) return KZG_HIP_ERR_BAD_ARG;
+        if (q - p != 96) return KZG_HIP_ERR_BAD_POINT;                   // FromCompressedG1 wants exactly 48 bytes
+        for (int i = 0; i < 48; i++) {
+            int hi = hex_nibble(p[2 * i]), lo = hex_nibble(p[2 * i + 1]);
+            if (hi < 0 || lo < 0) return KZG_HIP_ERR_BAD_POINT;
+            out.push_back((uint8_t)(hi << 4 | lo));
+        }
+        (*count)++;
+        p = q + 1;
+    }
+}
+int kzg_hip_trusted_setup_from_json(kzg_hip_fft *fs, const char *json, uint64_t json_len, void *out_setup_g1, void *out_lagrange_g1, uint64_t capacity,
+                                    uint64_t *n_setup_g1, uint64_t *n_lagrange_g1) {
+    if (!fs || !json || !n_setup_g1 || !n_lagrange_g1) return KZG_HIP_ERR_BAD_ARG;
+    KZG_TRY
+    std::vector<uint8_t> mono, lagr;
+    int f1 = 0, f2 = 0;
+    CHK(json_hex48_array(json, json_len, "setup_G1", mono, n_setup_g1, &f1));
+    CHK(json_hex48_array(json, json_len, "setup_G1_lagrange", lagr, n_lagrange_g1, &f2));
+    if (!f1 && !f2) return KZG_HIP_ERR_BAD_ARG;                          // not a trusted-setup document
+    if (out_setup_g1 && *n_setup_g1) {
+        if (*n_setup_g1 > capacity) return KZG_HIP_ERR_LEN_MISMATCH;
+        CHK(kzg_hip_g1_from_compressed(fs, mono.data(), *n_setup_g1, out_setup_g1));
+    }
+    if (out_lagrange_g1 && *n_lagrange_g1) {
+        if (*n_lagrange_g1 > capacity) return KZG_HIP_ERR_LEN_MISMATCH;
+        CHK(kzg_hip_g1_from_compressed(fs, lagr.data(), *n_lagrange_g1, out_lagrange_g1));
+    }
+    return KZG_HIP_OK;
+    KZG_CATCH
 }
 
 // ---------------------------------------------------------------------------------------------------------

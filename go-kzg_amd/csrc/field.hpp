@@ -12,7 +12,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define KZG_HD __host__ __device__ __forceinline__
 #define KZG_HD_NOINLINE __host__ __device__ __noinline__
 #else

@@ -308,6 +308,14 @@ __global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_decompress(const uint8_t *in
     if (!equal<FpP>(sqr(acc), y2)) { atomicOr(bad, 1u); out[t] = g1_to_kilic(g1_inf()); return; }
     if (y_is_larger(from_mont<FpP>(acc)) != ((f & 0x20) != 0)) acc = neg<FpP>(acc);
     g1j o; o.x = xm; o.y = acc; o.z = one<FpP>();
+    {   // subgroup check (Kilic G1.FromCompressed: "point is not on correct subgroup"): [r]P == inf.  Everything downstream (the GLV
+        // split phi(P) = lambda P, the "cannot happen for points of G1" fast paths) assumes membership, so it is enforced here, where
+        // points enter.  r in standard form as an 8-limb scalar; the windowed multiplication uses the complete addition.
+        fr rk;
+        for (int i = 0; i < 8; i++) rk.l[i] = FrP::mod(i);
+        g1j tbl[15];
+        if (!is_inf(g1_mul_windowed(o, rk, tbl))) { atomicOr(bad, 1u); out[t] = g1_to_kilic(g1_inf()); return; }
+    }
     out[t] = g1_to_kilic(o);   // API output: Kilic image
 }
 void launch_g1_decompress(hipStream_t s, const uint8_t *in48, g1j *out, uint64_t n, uint32_t *bad_flag) {

@@ -89,9 +89,24 @@ int kzg_hip_g1_mul_vec(kzg_hip_fft *fs, const void *points_g1, const void *scala
 /* GenerateTestingSetup, G1 half (setup.go:9-26): out[i] = [secret^i] G1 */
 int kzg_hip_generate_testing_setup_g1(kzg_hip_fft *fs, const void *secret_fr, uint64_t n, void *out_g1);
 
+/* G1Point.MarshalText / UnmarshalText over a slice (bls/bls_all.go:20-39): n points <-> n x 96 lower-case hex characters (no 0x
+ * prefix, no terminator).  Unmarshal returns KZG_HIP_ERR_BAD_POINT for a non-hex character or an invalid point. */
+int kzg_hip_g1_marshal_text(kzg_hip_fft *fs, const void *points_g1, uint64_t n, char *out_hex96);
+int kzg_hip_g1_unmarshal_text(kzg_hip_fft *fs, const char *hex96, uint64_t n, void *out_g1);
+/* JSONTrustedSetup (eth/globals.go:33-49): decodes the "setup_G1" and "setup_G1_lagrange" arrays of a trusted-setup JSON
+ * document (the format of eth/trusted_setup.json) into Kilic images, decompressing and subgroup-checking on the device.  Other
+ * keys ("setup_G2", "roots_of_unity") are skipped: G2 stays with the CPU backend.  Counts are always written; the arrays only when
+ * the out pointer is non-NULL (call once with NULL to size the buffers).  `capacity` = points each out array can hold. */
+int kzg_hip_trusted_setup_from_json(kzg_hip_fft *fs, const char *json, uint64_t json_len, void *out_setup_g1, void *out_lagrange_g1,
+                                    uint64_t capacity, uint64_t *n_setup_g1, uint64_t *n_lagrange_g1);
+
 /* ---- KZGSettings: NewKZGSettings, prover side (kzg.go:21-36); the setup is uploaded once and stays in HBM ---- */
 int kzg_hip_kzg_settings_new(kzg_hip_fft *fs, const void *secret_g1, uint64_t n_setup, kzg_hip_kzg **out);
 void kzg_hip_kzg_settings_free(kzg_hip_kzg *ks);
+/* HBM budget (GB, decimal) of the fixed-base commitment table of this settings object; call before the first commitment (a
+ * later call frees the table, which is rebuilt lazily).  Default without this call: KZG_HIP_FB_BUDGET_GB, else 64 GB
+ * (n = 4096: signed 14-bit windows, 61 GB); 210 selects the 16-bit-window table (206 GB, 16 additions per coefficient). */
+int kzg_hip_kzg_set_table_budget_gb(kzg_hip_kzg *ks, double gb);
 /* KZGSettings.CommitToPoly (kzg_single_proofs.go:17-19) */
 int kzg_hip_commit_to_poly(kzg_hip_kzg *ks, const void *coeffs_fr, uint64_t n, void *out_g1);
 /* `batch` polynomials of n coefficients each -> `batch` commitments */

@@ -284,7 +284,13 @@ API int ko_g1_from_compressed(g1_t *o, const uint8_t *in) {
     int gt = 0;
     for (int i = 5; i >= 0; i--) { if (ys.l[i] > FP_HALF_PM1.l[i]) { gt = 1; break; } if (ys.l[i] < FP_HALF_PM1.l[i]) break; }
     if (gt != !!(in[0] & 0x20)) fp_neg(&y, &y);
-    o->x = xm; o->y = y; o->z = FP_ONE; return KO_OK;
+    o->x = xm; o->y = y; o->z = FP_ONE;
+    /* Kilic G1.FromCompressed rejects curve points outside the order-r subgroup ("point is not on correct subgroup")
+     * [restated from memory of kilic/bls12-381 g1.go]: [r]P must be the point at infinity */
+    g1_t t; g1_set_inf(&t);
+    for (int i = 254; i >= 0; i--) { g1_dbl(&t, &t); if ((FR_R.l[i / 64] >> (i % 64)) & 1) g1_add(&t, &t, o); }
+    if (!g1_is_inf(&t)) return KO_ERR_BAD_POINT;
+    return KO_OK;
 }
 API int ko_g1_from_compressed_batch(g1_t *o, const uint8_t *in, u64 n) {
     for (u64 i = 0; i < n; i++) { int s = ko_g1_from_compressed(&o[i], in + 48 * i); if (s) return s; }

@@ -49,6 +49,13 @@ def assert_points_equal(got, want):
 
 
 # ------------------------------------------------------------------ F_r FFT (fft_fr_test.go)
+FK20_PINS = json.load(open(os.path.join(GOLDEN, "fk20_pins.json")))    # oracle byte pins of the full-size FK20 configs (make_fk20_pins.py)
+
+
+def proofs_sha256(fs, proofs):
+    return hashlib.sha256(fs.to_compressed_g1(proofs).tobytes()).hexdigest()
+
+
 def test_fft_settings_roots(kz):
     for scale in (4, 12):
         fs, ofs = kz.FFTSettings(scale), ko.FFTSettings(scale)
@@ -192,6 +199,20 @@ def test_compress_decompress_edge_cases(kz, fs16):
     if not ok:
         with pytest.raises(kz.KzgPanic):
             fs16.from_compressed_g1(notoncurve)
+    # on the curve but outside the order-r subgroup (x = 4; cofactor-order component): Kilic's FromCompressed rejects it
+    # ("point is not on correct subgroup"), so do the oracle and the device -- for both roots
+    for flag in (0x80, 0xA0):
+        outside = np.zeros((1, 48), dtype=np.uint8)
+        outside[0, 0] = flag
+        outside[0, 47] = 0x04
+        with pytest.raises(ValueError):
+            ko.g1_decompress(outside)
+        with pytest.raises(kz.KzgPanic) as e:
+            fs16.from_compressed_g1(outside)
+        assert e.value.status == kz.ERR_BAD_POINT
+        mixed = np.concatenate([comp[:3], outside, comp[3:]])            # one bad point poisons the slice, as UnmarshalText's error does
+        with pytest.raises(kz.KzgPanic):
+            fs16.from_compressed_g1(mixed)
 
 
 def test_fr_from_32_to_32(kz, fs16):
@@ -305,6 +326,21 @@ def test_kzg_settings_errors(kz):
 def setup_1337():
     raw = np.frombuffer(open(os.path.join(GOLDEN, "trusted_setup_g1.bin"), "rb").read(), dtype=np.uint8)
     return ko.g1_decompress(raw)
+
+
+def test_commit_c16_table_opt_in(kz, setup_1337):
+    """the 206 GB table (signed 16-bit windows, 16 additions per coefficient) is an explicit opt-in: set_table_budget_gb(210).
+    Runs before the module's shared 4096-point settings exist, so the device is empty enough for it."""
+    fs = kz.FFTSettings(12)
+    ks = kz.KZGSettings(fs, setup_1337)
+    ks.set_table_budget_gb(210.0)
+    blobs = np.stack([ko.synthetic_blob(1 + b) for b in range(3)])
+    got = ks.commit_to_poly_batch(blobs)
+    c, w, nbytes = ks.table_info()
+    assert (c, w) == (16, 16) and 200e9 < nbytes < 210e9
+    assert comp_hex(got[:1])[0] == DERIVED["F_blob_seed1"]["commit_monomial_s1337"]
+    assert_points_equal(got[2], ko.lincomb_g1(setup_1337, blobs[2]))
+    ks.close(); fs.close()
 
 
 @pytest.fixture(scope="module")
@@ -493,6 +529,8 @@ def test_fk20_single_4096_config4a(kz, ks4096):
     for i in range(4096):
         want[i] = ko.g1_mul(gen, ks_fr[i])
     assert_points_equal(proofs, want)
+    # byte pin: SHA-256 of all 4096 compressed proofs as the CPU oracle produced them (tests/golden/fk20_pins.json)
+    assert proofs_sha256(ks4096.fs, proofs) == FK20_PINS["config4a_da_using_fk20_seed4"]["sha256"]
     fk.close()
 
 
@@ -514,6 +552,11 @@ def test_fk20_multi_scale16_config5(kz):
     s = ko.fr_from_ints([(x + y) % ko.R_MOD for x, y in zip(ai, bi)])
     pa, pb, ps = fk.da_using_fk20_multi(a), fk.da_using_fk20_multi(b), fk.da_using_fk20_multi(s)
     assert pa.shape == (4096, 3, 6)
+    # byte pin: all 4096 coset proofs of seed 5 against the oracle's full-size run (tests/golden/make_fk20_pins.py, 7 minutes
+    # of CPU there): a permutation or offset confined to positions the sampled identity below does not visit cannot hide
+    pin = FK20_PINS["config5_da_using_fk20_multi_seed5"]
+    assert proofs_sha256(fs, pa) == pin["sha256"]
+    assert comp_hex(pa[:1])[0] == pin["first"] and comp_hex(pa[-1:])[0] == pin["last"]
     L = ko.lib()
     tmp = ko.g1_empty(1)
     for j in range(4096):                                                      # linearity, every position
@@ -603,6 +646,72 @@ def test_concurrent_callers_share_a_handle(kz, ks4096, setup_1337):
         assert np.array_equal(got[i], want[i])
 
 
+def test_dev_entry_points_on_two_streams_do_not_share_scratch(kz, ks4096):
+    """_dev calls enqueue and return; two callers on DIFFERENT streams used to share one per-handle partial-sum workspace
+    (round-1 advisor finding).  Interleave launches of different batch shapes on two streams and compare with serial results."""
+    import torch
+    L = kz.lib()
+    blobs = np.stack([ko.synthetic_blob(300 + i) for i in range(40)])
+    d_in = torch.from_numpy(blobs.view(np.int64)).cuda()
+    want = ks4096.commit_to_poly_batch(blobs)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for rep in range(4):
+        o1 = torch.zeros((33, 18), dtype=torch.int64, device="cuda")
+        o2 = torch.zeros((7, 18), dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        for _ in range(3):                                   # several launches in flight on each stream
+            assert L.kzg_hip_commit_to_poly_batch_dev(ks4096.h, d_in.data_ptr(), 4096, 33, o1.data_ptr(), s1.cuda_stream) == 0
+            assert L.kzg_hip_commit_to_poly_batch_dev(ks4096.h, d_in[33:].data_ptr(), 4096, 7, o2.data_ptr(), s2.cuda_stream) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(o1.cpu().numpy().view(np.uint64).reshape(-1, 3, 6), want[:33])
+        assert np.array_equal(o2.cpu().numpy().view(np.uint64).reshape(-1, 3, 6), want[33:])
+
+
+def test_trusted_setup_from_json(kz, setup_1337):
+    """JSONTrustedSetup (eth/globals.go:33-49) through the C ABI: the document is rebuilt here in the format of
+    eth/trusted_setup.json from the committed 48-byte fixtures (the 2 MB file itself is not committed)"""
+    fs = kz.FFTSettings(12)
+    mono = open(os.path.join(GOLDEN, "trusted_setup_g1.bin"), "rb").read()
+    lag = open(os.path.join(GOLDEN, "trusted_setup_g1_lagrange.bin"), "rb").read()
+    hexes = lambda raw: [raw[48 * i:48 * i + 48].hex() for i in range(len(raw) // 48)]      # noqa: E731
+    doc = json.dumps({"setup_G1": hexes(mono), "setup_G2": ["00" * 96] * 3, "setup_G1_lagrange": hexes(lag), "roots_of_unity": [1, 2, 3]}, indent=2)
+    got_mono, got_lag = fs.trusted_setup_from_json(doc)
+    assert got_mono.shape == (4096, 3, 6) and got_lag.shape == (4096, 3, 6)
+    assert np.array_equal(got_mono, ko.g1_affine(setup_1337))
+    assert hashlib.sha256(fs.to_compressed_g1(got_lag).tobytes()).hexdigest() == PINS["setup_G1_lagrange"]
+    # text round trip and the error behaviour of UnmarshalText (bls/bls_all.go:24-39)
+    assert fs.g1_marshal_text(got_mono[:5]) == hexes(mono)[:5]
+    assert np.array_equal(fs.g1_unmarshal_text(hexes(mono)[:5]), got_mono[:5])
+    with pytest.raises(kz.KzgPanic) as e:
+        fs.g1_unmarshal_text(["zz" + hexes(mono)[1][2:]])
+    assert e.value.status == kz.ERR_BAD_POINT
+    with pytest.raises(kz.KzgPanic):
+        fs.trusted_setup_from_json(json.dumps({"setup_G1": [hexes(mono)[0][:-2]]}))           # 47 bytes
+    with pytest.raises(kz.KzgPanic):
+        fs.trusted_setup_from_json(json.dumps({"something": "else"}))
+    only_lag, = [fs.trusted_setup_from_json(json.dumps({"setup_G1_lagrange": hexes(lag)[:8]}))]
+    assert only_lag[0].shape[0] == 0 and only_lag[1].shape[0] == 8
+    fs.close()
+
+
+def test_table_budget_setter_and_default(kz, setup_1337, monkeypatch):
+    """default budget 64 GB -> c = 14 for n = 4096; the setter rebuilds at another size; results identical"""
+    monkeypatch.delenv("KZG_HIP_FB_BUDGET_GB", raising=False)
+    fs = kz.FFTSettings(12)
+    ks = kz.KZGSettings(fs, setup_1337)
+    blob = ko.synthetic_blob(1)
+    c0 = ks.commit_to_poly(blob)
+    assert ks.table_info()[0] == 14 and ks.table_info()[2] <= 64e9
+    ks.set_table_budget_gb(1.0)
+    assert ks.table_info() == (0, 0, 0)
+    c1 = ks.commit_to_poly(blob)
+    assert ks.table_info()[0] == 7
+    assert np.array_equal(c0, c1)
+    assert comp_hex(c0[None])[0] == DERIVED["F_blob_seed1"]["commit_monomial_s1337"]
+    ks.close(); fs.close()
+
+
 def test_c_abi_misuse_returns_status_codes(kz):
     import ctypes as C
     L = kz.lib()
@@ -643,6 +752,7 @@ def test_fk20_single_scale13_config4b(kz):
     poly_i = ko.fr_to_ints(blob)
     proofs = fk.fk20_single(blob)
     assert proofs.shape == (n, 3, 6)
+    assert proofs_sha256(fs, proofs) == FK20_PINS["config4b_fk20_single_seed1"]["sha256"]      # all 4096 proofs, oracle byte pin
     w = pyref.root_of_unity(12)
     gen = ko.g1_generator()
     for i in (0, 1, 2, 1234, 4095):
@@ -653,6 +763,7 @@ def test_fk20_single_scale13_config4b(kz):
     # DA form on the same settings: 4096 coefficients -> 8192 proofs, sample + linearity
     pa = fk.da_using_fk20(blob)
     assert pa.shape == (2 * n, 3, 6)
+    assert proofs_sha256(fs, pa) == FK20_PINS["config4b_da_using_fk20_seed1"]["sha256"]        # all 8192 proofs of the DA form
     w2 = pyref.root_of_unity(13)
     for pos in (0, 3, 8191):
         d = pyref.single_proof_dlog(poly_i, S_TEST, pow(w2, pyref.rev_bits(pos, 13), ko.R_MOD))

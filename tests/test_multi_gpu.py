@@ -157,3 +157,52 @@ def test_sharded_fk20_multi_hip_backend_two_ranks_one_gpu():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert res == [(0, True), (1, True)]
+
+
+def _gpu_worker_scale16(rank, world, port, q):
+    import hashlib
+    import json
+    import torch
+    import torch.distributed as dist
+    import gokzg_amd as kz
+    from gokzg_amd import multi_gpu
+    from oracle import koracle as ko
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["KZG_HIP_FB_BUDGET_GB"] = "1"
+    os.environ["KZG_HIP_FK20_FB_BUDGET_GB"] = "8"
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n2, l = 65536, 16
+    fs = kz.FFTSettings(16)
+    ks = kz.KZGSettings(fs, fs.generate_testing_setup_g1(ko.fr_from_ints([S_TEST]), n2))
+    fk = kz.FK20MultiSettings(ks, n2, l)
+    poly = ko.synthetic_blob(5, n2 // 2)
+    be = multi_gpu.HipFK20MultiBackend(fk)
+    d_poly = torch.from_numpy(poly.view(np.int64).copy()).cuda()
+    got = multi_gpu.da_using_fk20_multi_sharded(be, d_poly, n2 // 2, be.k2)
+    torch.cuda.synchronize()
+    proofs = got.cpu().numpy().view(np.uint64).reshape(-1, 3, 6)
+    pin = json.load(open(os.path.join(ROOT, "tests", "golden", "fk20_pins.json")))["config5_da_using_fk20_multi_seed5"]
+    ok = proofs.shape[0] == pin["count"] and hashlib.sha256(fs.to_compressed_g1(proofs).tobytes()).hexdigest() == pin["sha256"]
+    q.put((rank, bool(ok)))
+    fk.close(); ks.close(); fs.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_fk20_multi_scale16_two_ranks_one_gpu_byte_pin():
+    """BASELINE config 5 through the SHARDED driver at full size (n2 = 65536, chunk 16, seed 5): two ranks, real device calls, the
+    slices cross a real all-gather; all 4096 compressed proofs hash to the oracle's pin (tests/golden/fk20_pins.json) on both ranks"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gpu_worker_scale16, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=900) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]

@@ -105,6 +105,21 @@ def test_point_compression_kat():
     assert pyref.g1_compress(pyref.g1_mul(pyref.G, int(k["scalar"]))) == bytes(k["expected_bytes"])
 
 
+def test_decompress_rejects_points_outside_the_subgroup():
+    # (4, sqrt(68)) is on y^2 = x^3 + 4 but has a cofactor-order component: [r]P != inf (checked with the big-int restatement);
+    # Kilic's G1.FromCompressed returns "point is not on correct subgroup" for it
+    x = 4
+    y = pow((x ** 3 + 4) % pyref.P, (pyref.P + 1) // 4, pyref.P)
+    assert y * y % pyref.P == (x ** 3 + 4) % pyref.P
+    assert pyref.g1_add(pyref.g1_mul((x, y), pyref.R - 1), (x, y)) is not None      # not the identity -> outside G1
+    for flag in (0x80, 0xA0):
+        b = np.zeros((1, 48), dtype=np.uint8)
+        b[0, 0], b[0, 47] = flag, 4
+        with pytest.raises(ValueError):
+            ko.g1_decompress(b)
+    ko.g1_decompress(ko.g1_compress(ko.g1_generator()[None]))                        # members still pass
+
+
 def test_empty_lincomb_is_zero():
     out = ko.lincomb_g1(ko.g1_empty(0), ko.fr_empty(0))  # bls/bls_test.go:69-78
     assert ko.g1_equal(out, ko.g1_zero()[0])
