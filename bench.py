@@ -154,6 +154,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharded-fk20-multi", action="store_true", help="also time ONE FK20Multi through the sharded driver at world size 1")
     ap.add_argument("--no-fk20", action="store_true")
+    ap.add_argument("--table-gb", type=float, default=210.0, help="HBM budget of the commitment table for the headline (library default: 64)")
     args = ap.parse_args()
 
     import torch
@@ -181,6 +182,7 @@ def main():
     raw = np.frombuffer(open(os.path.join(ROOT, "tests", "golden", "trusted_setup_g1.bin"), "rb").read(), dtype=np.uint8)
     setup = fs.from_compressed_g1(raw)                      # 4096 x [1337^i]G1, decompressed on the device
     ks = kz.KZGSettings(fs, setup)
+    ks.set_table_budget_gb(args.table_gb)                   # explicit opt-in to the 16-bit-window table (206 GB); table_sweep has the others
 
     def mont_blobs(seed, batch, n=N_COEFF):
         """synthetic scalars as Montgomery images: vectorised splitmix + mod r on the host, FrFrom32 on the device"""

@@ -83,6 +83,8 @@ def lib():
         "kzg_hip_commit_to_poly": (i32, [vp, vp, u64, vp]), "kzg_hip_commit_to_poly_batch": (i32, [vp, vp, u64, u64, vp]),
         "kzg_hip_commit_to_poly_batch_dev": (i32, [vp, vp, u64, u64, vp, vp]),
         "kzg_hip_compute_proof_single": (i32, [vp, vp, u64, u64, vp]),
+        "kzg_hip_compute_proof_single_batch": (i32, [vp, vp, u64, u64, vp, vp]),
+        "kzg_hip_compute_proof_single_batch_dev": (i32, [vp, vp, u64, u64, vp, vp, vp]),
         "kzg_hip_compute_proof_multi": (i32, [vp, vp, u64, u64, u64, vp]),
         "kzg_hip_check_proof_multi_interpolation": (i32, [vp, vp, u64, vp, vp, vp]),
         "kzg_hip_toeplitz_part2": (i32, [vp, vp, vp, u64, vp]), "kzg_hip_toeplitz_part3": (i32, [vp, vp, u64, vp]),
@@ -101,6 +103,7 @@ def lib():
         "kzg_hip_eth_compute_kzg_proof": (i32, [vp, vp, u64, vp, vp, vp]),
         "kzg_hip_zero_poly_via_multiplication": (i32, [vp, vp, u64, u64, vp, vp]),
         "kzg_hip_recover_poly_from_samples": (i32, [vp, vp, vp, u64, vp]),
+        "kzg_hip_bench_drop_in": (i32, [vp, i32, vp, u64, u64, u32, u32, vp, C.POINTER(C.c_double)]),
         "kzg_hip_kzg_table_info": (i32, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(u64)]),
         "kzg_hip_prof_reset": (None, [vp, i32]), "kzg_hip_prof_read": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64)]),
     }
@@ -341,6 +344,13 @@ class KZGSettings:
         """HBM budget of the fixed-base commitment table (default 64 GB; 210 opts into the 206 GB 16-bit-window table)"""
         _chk(lib().kzg_hip_kzg_set_table_budget_gb(self.h, float(gb)))
 
+    def bench_drop_in(self, blobs, threads, calls, op=0):
+        """`threads` native host threads x `calls` blocking one-polynomial calls (kzg_hip_bench_drop_in): (calls per second, last results)"""
+        blobs = np.ascontiguousarray(blobs, dtype=np.uint64)
+        out, secs = g1_empty(threads), C.c_double(0)
+        _chk(lib().kzg_hip_bench_drop_in(self.h, op, _p(blobs), blobs.shape[1], blobs.shape[0], threads, calls, _p(out), C.byref(secs)))
+        return threads * calls / secs.value, out
+
     def table_info(self):
         """(window bits, windows, bytes) of the fixed-base table the commitments walk; zeros before the first commitment"""
         c, w, b = C.c_uint32(0), C.c_uint32(0), C.c_uint64(0)
@@ -365,6 +375,15 @@ class KZGSettings:
         out = g1_empty(1)
         _chk(lib().kzg_hip_compute_proof_single(self.h, _p(poly), poly.shape[0], x, _p(out)))
         return out[0]
+
+    def compute_proof_single_batch(self, polys, xs):
+        """ComputeProofSingle on a batch: polys (batch, n, 4), xs (batch,) uint64 -> (batch, 3, 6)"""
+        polys = np.ascontiguousarray(polys, dtype=np.uint64)
+        xs = np.ascontiguousarray(xs, dtype=np.uint64)
+        b, n = polys.shape[0], polys.shape[1]
+        out = g1_empty(b)
+        _chk(lib().kzg_hip_compute_proof_single_batch(self.h, _p(polys), n, b, _p(xs), _p(out)))
+        return out
 
     def compute_proof_multi(self, poly, x, n):
         """KZGSettings.ComputeProofMulti (kzg_multi_proofs.go:13-43), reference quirk (divisor X^n) included"""

@@ -3,6 +3,7 @@
 // There is deliberately NO CPU fallback: without a gfx950 device every constructor returns KZG_HIP_ERR_NO_DEVICE.
 #include "../../include/kzg_hip.h"
 #include "internal.hpp"
+#include "coalesce.hpp"
 
 #include <algorithm>
 #include <map>
@@ -10,6 +11,9 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
+#include <chrono>
+#include <condition_variable>
 #include <vector>
 #include <cstdio>
 #include <cstring>
@@ -91,6 +95,7 @@ struct kzg_hip_kzg {
     double budget_gb = -1.0;             // fixed-base table budget; < 0: default policy (ensure_fixed_table)
     hipStream_t copy_stream = nullptr;   // uploads of the host-buffer batch entry point, overlapped with the walk of the previous chunk
     hipEvent_t copy_done[2] = {nullptr, nullptr};
+    std::unique_ptr<coalescer> co_commit, co_proof;   // merge concurrent one-polynomial calls into batched launches (coalesce.hpp)
 };
 struct fk20_core {
     kzg_hip_kzg *ks = nullptr;
@@ -98,6 +103,7 @@ struct fk20_core {
     g1j *d_files = nullptr;          // l x 2k points: xExtFFT (single) / xExtFFTFiles (multi)
     g1a *d_files_fb = nullptr;       // fixed-base table over the l x 2k file points (k_fb_mul_vec); null -> double-and-add path
     uint32_t fb_c = 0, fb_nwin = 0;
+    std::unique_ptr<coalescer> co_da;   // concurrent DAUsingFK20 / DAUsingFK20Multi calls
 };
 struct kzg_hip_fk20s { fk20_core c; };
 struct kzg_hip_fk20m { fk20_core c; };
@@ -573,15 +579,17 @@ static int ensure_fixed_table(kzg_hip_kzg *ks, hipStream_t s) {
 // MSM of `batch` resident scalar rows against SecretG1[:n]; out = batch normalised points (device).  The partial-sum / bucket
 // workspace is allocated per call, stream-ordered on the launch stream (hipMallocAsync pool: no device synchronisation after the
 // first use), so concurrent callers on different streams never share scratch memory.
-static int commit_rows(kzg_hip_kzg *ks, hipStream_t s, const fr *d_sc, uint64_t n, uint64_t batch, g1j *d_out) {
+static int commit_rows(kzg_hip_kzg *ks, hipStream_t s, const fr *d_sc, uint64_t n, uint64_t batch, g1j *d_out, uint64_t sc_stride = 0) {
     CHK(ensure_fixed_table(ks, s));
     bool fixed = ks->d_fixed != nullptr;
+    if (!sc_stride) sc_stride = n;
+    if (!fixed && sc_stride != n) return KZG_HIP_ERR_BAD_ARG;   // (internal) the bucket path wants dense rows
     msm_plan p = fixed ? ks->fixed_plan : classic_plan(n);
     size_t ws_main = fixed ? fb_partials_bytes(n, batch) : msm_workspace_bytes(p, n, batch);
     dtmp<uint8_t> d_ws(s);
     CHK(d_ws.alloc(ws_main + batch * sizeof(g1j)));
     g1j *d_raw = (g1j *)(d_ws.p + ws_main);
-    if (fixed) launch_fb_msm(s, ks->d_fixed, p.table_n, p.c, p.nwin, d_sc, n, batch, d_ws.p, d_out, true);   // sums, normalises, converts
+    if (fixed) launch_fb_msm(s, ks->d_fixed, p.table_n, p.c, p.nwin, d_sc, sc_stride, n, batch, d_ws.p, d_out, true);   // sums, normalises, converts
     else { launch_msm(s, p, ks->d_secret_a, d_sc, n, batch, d_ws.p, d_raw); launch_g1_normalize(s, d_raw, d_out, batch, true); }
     HIPCHK(hipGetLastError());
     return KZG_HIP_OK;
@@ -639,25 +647,130 @@ int kzg_hip_commit_to_poly_batch(kzg_hip_kzg *ks, const void *coeffs_fr, uint64_
     HIPCHK(hipStreamSynchronize(s));
     return KZG_HIP_OK;
 }
+// ---- one-polynomial calls: concurrent callers on a handle are merged into batched launches (coalesce.hpp) ----
+static bool coalescing_enabled() {
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("KZG_HIP_COALESCE"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on != 0;
+}
+// rows per staging buffer: as many as fit 32 MiB of pinned memory per direction, within [4, 256]
+static uint64_t coalesce_rows(size_t in_row, size_t out_row) {
+    size_t row = in_row > out_row ? in_row : out_row;
+    uint64_t r = (32u << 20) / (row ? row : 1);
+    return r < 4 ? 4 : (r > 256 ? 256 : r);
+}
+static coalescer *get_coalescer(kzg_hip_fft *fs, std::unique_ptr<coalescer> &slot, size_t in_row, size_t out_row) {
+    std::lock_guard<std::mutex> lk(fs->mu);
+    if (!slot) slot.reset(new coalescer(fs->device, in_row, out_row, coalesce_rows(in_row, out_row)));
+    return slot.get();
+}
+// uploads the batch's rows (pinned, row stride in_row_bytes) as dense n_max-wide rows and zero-fills the tails
+static int coalesce_upload_rows(coalesce_buf &b, uint64_t batch, size_t in_row_bytes, uint64_t n_max, fr *d_rows, uint64_t *d_meta) {
+    hipStream_t s = b.stream;
+    HIPCHK(hipMemcpyAsync(d_meta, b.h_meta, batch * sizeof(coalesce_row), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpy2DAsync(d_rows, n_max * sizeof(fr), b.h_in, in_row_bytes, n_max * sizeof(fr), batch, hipMemcpyHostToDevice, s));
+    launch_fr_zero_tails(s, d_rows, n_max, batch, d_meta, 2);
+    return KZG_HIP_OK;
+}
 int kzg_hip_commit_to_poly(kzg_hip_kzg *ks, const void *coeffs_fr, uint64_t n, void *out_g1) {
-    return kzg_hip_commit_to_poly_batch(ks, coeffs_fr, n, 1, out_g1);
+    if (!coalescing_enabled() || !ks || !out_g1 || !coeffs_fr || n == 0 || n > ks->n_setup)
+        return kzg_hip_commit_to_poly_batch(ks, coeffs_fr, n, 1, out_g1);         // argument errors and n == 0 take the plain path
+    KZG_TRY
+    coalescer *co = get_coalescer(ks->fs, ks->co_commit, ks->n_setup * sizeof(fr), sizeof(g1j));
+    auto exec = [ks, co](coalesce_buf &b, uint64_t batch) -> int {
+        hipSetDevice(ks->fs->device);
+        hipStream_t s = b.stream;
+        { dev_guard g(ks->fs); CHK(ensure_fixed_table(ks, s)); }                    // the lazy table build is the only shared mutation
+        uint64_t n_max = 0;
+        for (uint64_t i = 0; i < batch; i++) n_max = b.h_meta[i].n > n_max ? b.h_meta[i].n : n_max;
+        dtmp<fr> d_rows(s); dtmp<uint64_t> d_meta(s); dtmp<g1j> d_out(s);
+        CHK(d_rows.alloc(batch * n_max)); CHK(d_meta.alloc(2 * batch)); CHK(d_out.alloc(batch));
+        static const bool trace = getenv("KZG_HIP_COALESCE_TRACE") != nullptr;      // phase times on stderr (adds two synchronisations)
+        const auto t0 = std::chrono::steady_clock::now();
+        // Uniform rows (the normal case: every caller commits a full blob) are read IN PLACE from the pinned staging buffer: each
+        // scalar is loaded exactly once by the table walk, so the 128 KiB per blob stream over PCIe under the walk's own latency
+        // hiding instead of costing a separate 0.5 ms copy.  Ragged batches are compacted and zero-filled on the device.
+        bool uniform = ks->d_fixed != nullptr;
+        for (uint64_t i = 0; i < batch && uniform; i++) uniform = b.h_meta[i].n == n_max;
+        const fr *d_src = d_rows.p; uint64_t stride = n_max;
+        if (uniform) {
+            void *dp = nullptr;
+            HIPCHK(hipHostGetDevicePointer(&dp, b.h_in, 0));
+            d_src = (const fr *)dp; stride = co->in_row_bytes() / sizeof(fr);
+        } else CHK(coalesce_upload_rows(b, batch, co->in_row_bytes(), n_max, d_rows.p, d_meta.p));
+        if (trace) hipStreamSynchronize(s);
+        const auto t1 = std::chrono::steady_clock::now();
+        CHK(commit_rows(ks, s, d_src, n_max, batch, d_out.p, stride));
+        if (trace) hipStreamSynchronize(s);
+        const auto t2 = std::chrono::steady_clock::now();
+        HIPCHK(hipMemcpyAsync(b.h_out, d_out.p, batch * sizeof(g1j), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (trace) {
+            auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::micro>(c - a).count(); };
+            fprintf(stderr, "[commit batch %llu] upload %.0f us, kernels %.0f us, download %.0f us\n", (unsigned long long)batch, us(t0, t1), us(t1, t2),
+                    us(t2, std::chrono::steady_clock::now()));
+        }
+        return KZG_HIP_OK;
+    };
+    return co->submit(coeffs_fr, n * sizeof(fr), n, 0, out_g1, sizeof(g1j), exec, KZG_HIP_ERR_HIP);
+    KZG_CATCH
 }
 
-int kzg_hip_compute_proof_single(kzg_hip_kzg *ks, const void *poly_fr, uint64_t n, uint64_t x, void *out_g1) {
-    if (!ks || !poly_fr || !out_g1 || n < 2) return KZG_HIP_ERR_BAD_ARG;
+// ComputeProofSingle over `batch` resident polynomials: x[b] -> bls.AsFr (kzg_single_proofs.go:39-40), quotient by (X - x[b])
+// (polyLongDiv, poly.go:14-40), commitment of the n - 1 quotient coefficients (:53)
+static int proof_single_rows(kzg_hip_kzg *ks, hipStream_t s, const fr *d_poly, uint64_t n, uint64_t batch, const uint64_t *d_x_u64, uint64_t x_stride, g1j *d_out) {
+    dtmp<fr> d_q(s), d_x(s);
+    CHK(d_q.alloc(batch * (n - 1))); CHK(d_x.alloc(batch));
+    launch_fr_from_u64(s, d_x_u64, x_stride, d_x.p, batch);
+    launch_quotient_linear(s, d_poly, n, n, batch, d_x.p, d_q.p, n - 1);
+    return commit_rows(ks, s, d_q.p, n - 1, batch, d_out);
+}
+int kzg_hip_compute_proof_single_batch_dev(kzg_hip_kzg *ks, const void *d_poly_fr, uint64_t n, uint64_t batch, const void *d_x_u64, void *d_out_g1, void *stream) {
+    if (!ks || !d_out_g1 || n < 2) return KZG_HIP_ERR_BAD_ARG;
     if (n - 1 > ks->n_setup) return KZG_HIP_ERR_LEN_MISMATCH;   // SecretG1[:len(quotient)], kzg_single_proofs.go:53
+    if (!batch) return KZG_HIP_OK;
+    if (!d_poly_fr || !d_x_u64) return KZG_HIP_ERR_BAD_ARG;
+    dev_guard g(ks->fs);
+    return proof_single_rows(ks, (hipStream_t)stream, (const fr *)d_poly_fr, n, batch, (const uint64_t *)d_x_u64, 1, (g1j *)d_out_g1);
+}
+int kzg_hip_compute_proof_single_batch(kzg_hip_kzg *ks, const void *poly_fr, uint64_t n, uint64_t batch, const uint64_t *xs, void *out_g1) {
+    if (!ks || !out_g1 || n < 2) return KZG_HIP_ERR_BAD_ARG;
+    if (n - 1 > ks->n_setup) return KZG_HIP_ERR_LEN_MISMATCH;
+    if (!batch) return KZG_HIP_OK;
+    if (!poly_fr || !xs) return KZG_HIP_ERR_BAD_ARG;
     dev_guard g(ks->fs);
     hipStream_t s = ks->fs->stream;
-    dtmp<fr> d_poly(s), d_q(s), d_x(s); dtmp<g1j> d_out(s);
-    CHK(d_poly.alloc(n)); CHK(d_q.alloc(n)); CHK(d_x.alloc(1)); CHK(d_out.alloc(1));
-    fr xf = fr_from_u64(x);   // bls.AsFr(&tmp, x), kzg_single_proofs.go:39-40
-    HIPCHK(hipMemcpyAsync(d_poly.p, poly_fr, n * sizeof(fr), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(d_x.p, &xf, sizeof xf, hipMemcpyHostToDevice, s));
-    launch_quotient_linear(s, d_poly.p, n, d_x.p, d_q.p);
-    CHK(commit_rows(ks, s, d_q.p, n - 1, 1, d_out.p));
-    HIPCHK(hipMemcpyAsync(out_g1, d_out.p, sizeof(g1j), hipMemcpyDeviceToHost, s));
+    dtmp<fr> d_poly(s); dtmp<uint64_t> d_x(s); dtmp<g1j> d_out(s);
+    CHK(d_poly.alloc(n * batch)); CHK(d_x.alloc(batch)); CHK(d_out.alloc(batch));
+    HIPCHK(hipMemcpyAsync(d_poly.p, poly_fr, n * batch * sizeof(fr), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_x.p, xs, batch * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    CHK(proof_single_rows(ks, s, d_poly.p, n, batch, d_x.p, 1, d_out.p));
+    HIPCHK(hipMemcpyAsync(out_g1, d_out.p, batch * sizeof(g1j), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return KZG_HIP_OK;
+}
+int kzg_hip_compute_proof_single(kzg_hip_kzg *ks, const void *poly_fr, uint64_t n, uint64_t x, void *out_g1) {
+    if (!ks || !poly_fr || !out_g1 || n < 2) return KZG_HIP_ERR_BAD_ARG;
+    if (!coalescing_enabled() || n - 1 > ks->n_setup) return kzg_hip_compute_proof_single_batch(ks, poly_fr, n, 1, &x, out_g1);
+    KZG_TRY
+    coalescer *co = get_coalescer(ks->fs, ks->co_proof, (ks->n_setup + 1) * sizeof(fr), sizeof(g1j));
+    auto exec = [ks, co](coalesce_buf &b, uint64_t batch) -> int {
+        hipSetDevice(ks->fs->device);
+        hipStream_t s = b.stream;
+        { dev_guard g(ks->fs); CHK(ensure_fixed_table(ks, s)); }
+        uint64_t n_max = 0;
+        for (uint64_t i = 0; i < batch; i++) n_max = b.h_meta[i].n > n_max ? b.h_meta[i].n : n_max;
+        dtmp<fr> d_rows(s); dtmp<uint64_t> d_meta(s); dtmp<g1j> d_out(s);
+        CHK(d_rows.alloc(batch * n_max)); CHK(d_meta.alloc(2 * batch)); CHK(d_out.alloc(batch));
+        CHK(coalesce_upload_rows(b, batch, co->in_row_bytes(), n_max, d_rows.p, d_meta.p));
+        // a shorter polynomial padded with zero high coefficients has the same quotient (followed by zeros)
+        CHK(proof_single_rows(ks, s, d_rows.p, n_max, batch, d_meta.p + 1, 2, d_out.p));
+        HIPCHK(hipMemcpyAsync(b.h_out, d_out.p, batch * sizeof(g1j), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return KZG_HIP_OK;
+    };
+    return co->submit(poly_fr, n * sizeof(fr), n, x, out_g1, sizeof(g1j), exec, KZG_HIP_ERR_HIP);
+    KZG_CATCH
 }
 
 int kzg_hip_compute_proof_multi(kzg_hip_kzg *ks, const void *poly_fr, uint64_t len, uint64_t x, uint64_t n, void *out_g1) {
@@ -885,8 +998,32 @@ int kzg_hip_da_using_fk20_batch(kzg_hip_fk20s *fk, const void *poly_fr, uint64_t
     if (!batch) return KZG_HIP_OK;
     return fk20_run_host(&fk->c, poly_fr, n, n, batch, 0, 1, 1, out_g1);
 }
+// one DAUsingFK20 / DAUsingFK20Multi call through the handle's coalescer: concurrent callers share one batched run
+static int fk20_da_coalesced(fk20_core *c, const void *poly_fr, uint64_t n, void *out_g1) {
+    KZG_TRY
+    const uint64_t on = 2 * c->k;
+    coalescer *co = get_coalescer(c->ks->fs, c->co_da, n * sizeof(fr), on * sizeof(g1j));
+    auto exec = [c, co, n, on](coalesce_buf &b, uint64_t batch) -> int {
+        hipSetDevice(c->ks->fs->device);
+        hipStream_t s = b.stream;
+        dtmp<fr> d_poly(s); dtmp<g1j> d_out(s);
+        CHK(d_poly.alloc(batch * n)); CHK(d_out.alloc(batch * on));
+        HIPCHK(hipMemcpyAsync(d_poly.p, b.h_in, batch * co->in_row_bytes(), hipMemcpyHostToDevice, s));
+        CHK(fk20_run_dev(c, s, d_poly.p, n, n, batch, 1, 1, d_out.p));
+        HIPCHK(hipMemcpyAsync(b.h_out, d_out.p, batch * on * sizeof(g1j), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return KZG_HIP_OK;
+    };
+    return co->submit(poly_fr, n * sizeof(fr), n, 0, out_g1, on * sizeof(g1j), exec, KZG_HIP_ERR_HIP);
+    KZG_CATCH
+}
 int kzg_hip_da_using_fk20(kzg_hip_fk20s *fk, const void *poly_fr, uint64_t n, void *out_g1) {
-    return kzg_hip_da_using_fk20_batch(fk, poly_fr, n, 1, out_g1);
+    if (!fk || !poly_fr || !out_g1) return KZG_HIP_ERR_BAD_ARG;
+    if (n > fk->c.ks->fs->W / 2) return KZG_HIP_ERR_TOO_WIDE;   // fk20_single.go:178-180
+    if (!is_pow2(n)) return KZG_HIP_ERR_NOT_POW2;               // fk20_single.go:181-183
+    if (2 * n != fk->c.n2) return KZG_HIP_ERR_LEN_MISMATCH;
+    if (!coalescing_enabled()) return fk20_run_host(&fk->c, poly_fr, n, n, 1, 0, 1, 1, out_g1);
+    return fk20_da_coalesced(&fk->c, poly_fr, n, out_g1);
 }
 int kzg_hip_da_using_fk20_batch_dev(kzg_hip_fk20s *fk, const void *d_poly_fr, uint64_t n, uint64_t batch, void *d_out_g1, void *stream) {
     if (!fk || !d_poly_fr || !d_out_g1) return KZG_HIP_ERR_BAD_ARG;
@@ -937,7 +1074,8 @@ int kzg_hip_da_using_fk20_multi(kzg_hip_fk20m *fk, const void *poly_fr, uint64_t
     if (n > fk->c.ks->fs->W / 2) return KZG_HIP_ERR_TOO_WIDE;     // fk20_multi.go:115-117
     if (!is_pow2(n)) return KZG_HIP_ERR_NOT_POW2;                 // fk20_multi.go:118-120
     if (2 * n != fk->c.n2) return KZG_HIP_ERR_LEN_MISMATCH;
-    return fk20_run_host(&fk->c, poly_fr, n, n, 1, 0, 1, 1, out_g1);
+    if (!coalescing_enabled()) return fk20_run_host(&fk->c, poly_fr, n, n, 1, 0, 1, 1, out_g1);
+    return fk20_da_coalesced(&fk->c, poly_fr, n, out_g1);
 }
 int kzg_hip_da_using_fk20_multi_batch_dev(kzg_hip_fk20m *fk, const void *d_poly_fr, uint64_t n, uint64_t batch, void *d_out_g1, void *stream) {
     if (!fk || !d_poly_fr || !d_out_g1) return KZG_HIP_ERR_BAD_ARG;
@@ -1229,6 +1367,34 @@ int kzg_hip_kzg_table_info(kzg_hip_kzg *ks, uint32_t *window_bits, uint32_t *win
     *window_bits = have ? ks->fixed_plan.c : 0; *windows = have ? ks->fixed_plan.nwin : 0;
     *table_bytes = have ? (uint64_t)ks->fixed_plan.nwin * ks->fixed_plan.table_n * ks->fixed_plan.nb * sizeof(g1a) : 0;
     return KZG_HIP_OK;
+}
+// bench.py's drop_in leg: `threads` host threads (std::thread, no interpreter lock in the way) each make `calls` blocking
+// ONE-polynomial calls to the reference-shaped entry point on host buffers, exactly what a goroutine per blob would do through
+// cgo.  op 0: kzg_hip_commit_to_poly, 1: kzg_hip_compute_proof_single (x = 17 + thread).  blobs: nblobs x n Fr; out: threads x G1.
+int kzg_hip_bench_drop_in(kzg_hip_kzg *ks, int op, const void *blobs_fr, uint64_t n, uint64_t nblobs, unsigned threads, unsigned calls, void *out_g1,
+                          double *seconds) {
+    if (!ks || !blobs_fr || !out_g1 || !seconds || !threads || !calls || !nblobs) return KZG_HIP_ERR_BAD_ARG;
+    KZG_TRY
+    std::vector<std::thread> ts;
+    std::vector<int> status(threads, 0);
+    std::mutex mu; std::condition_variable cv; unsigned arrived = 0; bool go = false;
+    for (unsigned t = 0; t < threads; t++)
+        ts.emplace_back([&, t] {
+            { std::unique_lock<std::mutex> lk(mu); arrived++; cv.notify_all(); cv.wait(lk, [&] { return go; }); }
+            for (unsigned c = 0; c < calls; c++) {
+                const uint8_t *in = (const uint8_t *)blobs_fr + ((uint64_t)(t + c) % nblobs) * n * sizeof(fr);
+                int st = op == 0 ? kzg_hip_commit_to_poly(ks, in, n, (uint8_t *)out_g1 + (size_t)t * sizeof(g1j))
+                                 : kzg_hip_compute_proof_single(ks, in, n, 17 + t, (uint8_t *)out_g1 + (size_t)t * sizeof(g1j));
+                if (st) { status[t] = st; break; }
+            }
+        });
+    std::chrono::steady_clock::time_point t0;
+    { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return arrived == threads; }); go = true; t0 = std::chrono::steady_clock::now(); cv.notify_all(); }
+    for (auto &th : ts) th.join();
+    *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (int st : status) if (st) return st;
+    return KZG_HIP_OK;
+    KZG_CATCH
 }
 void kzg_hip_prof_reset(kzg_hip_fft *fs, int enable) {
     (void)fs;

@@ -1,0 +1,187 @@
+// coalesce.hpp -- request coalescing behind the reference's one-object-per-call API.
+//
+// The reference's methods take ONE polynomial per call (KZGSettings.CommitToPoly kzg_single_proofs.go:17-19,
+// ComputeProofSingle :36-54, FK20SingleSettings.DAUsingFK20 fk20_single.go:176-196) and are called from many goroutines; one
+// polynomial fills 1-3 % of an MI355X.  Concurrent calls on a handle are therefore merged into batched launches:
+//
+//   caller thread:  reserve a row in the OPEN staging buffer (pinned host memory)  ->  copy its input into that row (in
+//                   parallel with the other callers)  ->  if fewer than MAX_EXEC batches are on the device, close the buffer and
+//                   become its leader, else sleep  ->  when the batch is done, copy its own result out of the pinned output rows.
+//   leader:         waits until every reserved row is filled, then runs the batch on the buffer's own stream (inputs read from
+//                   pinned memory, batched kernels, one D2H) and wakes the batch's callers.
+//
+// Up to MAX_EXEC batches execute concurrently on separate streams: the end of a batch (reduction trees, one inversion per
+// polynomial) is latency-bound and uses a fraction of the CUs, so the next batch's table walk overlaps it.  The elected leader
+// holds its buffer open for at most `window` microseconds until it has its share (concurrency / MAX_EXEC) of the callers that
+// are inside submit() right now; a steady lone caller never waits, and without concurrency nothing is added to its latency.
+// The executing function is supplied by the handle (commit / proof / FK20); everything here is host-side C++.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <vector>
+
+namespace kzg {
+
+struct coalesce_row {        // what the executor sees for row b of a batch
+    uint64_t n;              // valid input elements of this row (the rest of the row is unspecified: the executor zero-fills on device)
+    uint64_t arg;            // per-request scalar argument (ComputeProofSingle's x)
+};
+
+struct coalesce_buf {
+    enum state_t { FREE_OPEN, CLOSED, DRAINING } state = FREE_OPEN;
+    uint8_t *h_in = nullptr, *h_out = nullptr;   // pinned: max_batch x in_row_bytes, max_batch x out_row_bytes
+    coalesce_row *h_meta = nullptr;              // pinned copy of `rows` for the executor's H2D (filled by the leader)
+    std::vector<coalesce_row> rows;              // reserved rows, in order
+    uint64_t ready = 0;                          // rows whose input copy has finished
+    std::atomic<uint64_t> outstanding{0};        // callers that still have to copy their result out
+    int status = 0;
+    hipStream_t stream = nullptr;
+    std::condition_variable cv;                  // this batch's callers (and its leader-to-be) sleep here
+};
+
+class coalescer {
+  public:
+    static constexpr int NBUF = 4, MAX_EXEC = 3;
+    // exec(buf, batch): inputs are in buf.h_in (row stride in_row_bytes), results go to buf.h_out (row stride out_row_bytes);
+    // must block until the results are in host memory; returns a status that every request of the batch receives
+    using exec_fn = std::function<int(coalesce_buf &, uint64_t batch)>;
+
+    coalescer(int device, size_t in_row_bytes, size_t out_row_bytes, uint64_t max_batch)
+        : device_(device), in_row_(in_row_bytes), out_row_(out_row_bytes), max_batch_(max_batch) {
+        if (const char *e = getenv("KZG_HIP_COALESCE_US")) window_us_ = atol(e);
+        if (const char *e = getenv("KZG_HIP_COALESCE_EXEC")) { max_exec_ = atoi(e); if (max_exec_ < 1) max_exec_ = 1; if (max_exec_ > NBUF - 1) max_exec_ = NBUF - 1; }
+    }
+    ~coalescer() {
+        if (getenv("KZG_HIP_COALESCE_STATS") && batches_)
+            fprintf(stderr, "[coalescer] %llu requests in %llu batches (avg %.1f), %.3f ms per batch on the device side\n", (unsigned long long)requests_,
+                    (unsigned long long)batches_, (double)requests_ / batches_, exec_s_ / batches_ * 1e3);
+        for (auto &b : bufs_) {
+            if (b.h_in) hipHostFree(b.h_in);
+            if (b.h_out) hipHostFree(b.h_out);
+            if (b.h_meta) hipHostFree(b.h_meta);
+            if (b.stream) hipStreamDestroy(b.stream);
+        }
+        (void)hipGetLastError();
+    }
+    size_t in_row_bytes() const { return in_row_; }
+    size_t out_row_bytes() const { return out_row_; }
+
+    // one request: `in` holds in_bytes (<= in_row_bytes), the result (out_bytes <= out_row_bytes) is written to `out`.
+    // Wake-ups are targeted (one condition variable per role and per buffer): with 64-256 callers one notify_all per event costs
+    // more than the batch itself.
+    int submit(const void *in, size_t in_bytes, uint64_t n, uint64_t arg, void *out, size_t out_bytes, const exec_fn &exec, int alloc_error_status) {
+        hipSetDevice(device_);                   // caller threads (goroutine-backed OS threads) start on device 0
+        std::unique_lock<std::mutex> lk(mu_);
+        inside_++;
+        // reserve a row in the open buffer
+        int bi;
+        for (;;) {
+            bi = open_;
+            if (bi >= 0 && bufs_[bi].rows.size() < max_batch_) break;
+            cv_reserve_.wait(lk);
+        }
+        coalesce_buf &b = bufs_[bi];
+        if (!b.h_in) {   // first use of this buffer: pinned staging + its stream (under the lock: NBUF times per handle)
+            if (hipHostMalloc((void **)&b.h_in, in_row_ * max_batch_, hipHostMallocDefault) != hipSuccess ||
+                hipHostMalloc((void **)&b.h_out, out_row_ * max_batch_, hipHostMallocDefault) != hipSuccess ||
+                hipHostMalloc((void **)&b.h_meta, sizeof(coalesce_row) * max_batch_, hipHostMallocDefault) != hipSuccess ||
+                hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking) != hipSuccess) {
+                (void)hipGetLastError();
+                if (b.h_in) { hipHostFree(b.h_in); b.h_in = nullptr; }
+                if (b.h_out) { hipHostFree(b.h_out); b.h_out = nullptr; }
+                if (b.h_meta) { hipHostFree(b.h_meta); b.h_meta = nullptr; }
+                inside_--;
+                return alloc_error_status;
+            }
+        }
+        const uint64_t row = b.rows.size();
+        b.rows.push_back(coalesce_row{n, arg});
+        b.outstanding++;
+        if (gathering_ == bi) cv_leader_.notify_all();                     // a leader is holding this buffer open for stragglers
+        lk.unlock();
+        memcpy(b.h_in + row * in_row_, in, in_bytes);                      // parallel across callers
+        lk.lock();
+        b.ready++;
+        if (b.state == coalesce_buf::CLOSED && b.ready == b.rows.size()) cv_leader_.notify_all();   // its leader waits for the last row
+        // wait for the batch; lead it if a device slot is free
+        for (;;) {
+            if (b.state == coalesce_buf::DRAINING) break;
+            if (b.state == coalesce_buf::FREE_OPEN && executing_ < max_exec_ && gathering_ < 0) {
+                executing_++;
+                // Gather: this batch's share of the callers that are inside submit() now (or were, moments ago: `peak_` halves
+                // per batch) get up to `window_us_` to join, so that N concurrent callers run as MAX_EXEC overlapping batches of
+                // N / MAX_EXEC instead of a convoy of tiny ones.
+                peak_ = inside_ > peak_ / 2 ? inside_ : peak_ / 2;
+                uint64_t target = (peak_ + max_exec_ - 1) / max_exec_;
+                if (target > max_batch_) target = max_batch_;
+                if (window_us_ > 0 && b.rows.size() < target) {
+                    gathering_ = bi;
+                    const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window_us_);
+                    while (b.rows.size() < target)
+                        if (cv_leader_.wait_until(lk, deadline) == std::cv_status::timeout) break;
+                    gathering_ = -1;
+                }
+                // close this buffer, open a free one
+                b.state = coalesce_buf::CLOSED;
+                open_ = -1;
+                for (int k = 1; k < NBUF; k++) {
+                    const int o = (bi + k) % NBUF;
+                    if (bufs_[o].state == coalesce_buf::FREE_OPEN && bufs_[o].outstanding.load() == 0) { open_ = o; break; }
+                }
+                if (open_ >= 0) cv_reserve_.notify_all();                  // callers that found this buffer full
+                while (b.ready < b.rows.size()) cv_leader_.wait(lk);       // every reserved row filled
+                const uint64_t batch = b.rows.size();
+                for (uint64_t i = 0; i < batch; i++) b.h_meta[i] = b.rows[i];
+                lk.unlock();
+                const auto t0 = std::chrono::steady_clock::now();
+                int st = exec(b, batch);
+                const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                lk.lock();
+                batches_++; requests_ += batch; exec_s_ += dt;
+                b.status = st;
+                b.state = coalesce_buf::DRAINING;
+                executing_--;
+                b.cv.notify_all();                                         // this batch's callers
+                if (open_ >= 0 && open_ != bi) bufs_[open_].cv.notify_one();   // one caller of the accumulating batch becomes its leader
+                break;
+            }
+            b.cv.wait(lk);
+        }
+        const int st = b.status;
+        inside_--;
+        lk.unlock();
+        if (st == 0) memcpy(out, b.h_out + row * out_row_, out_bytes);
+        if (b.outstanding.fetch_sub(1) == 1) {                              // last one out recycles the buffer (only it re-takes the lock)
+            lk.lock();
+            b.rows.clear(); b.ready = 0; b.state = coalesce_buf::FREE_OPEN;
+            if (open_ < 0) { open_ = bi; cv_reserve_.notify_all(); }
+        }
+        return st;
+    }
+
+  private:
+    std::mutex mu_;
+    std::condition_variable cv_reserve_, cv_leader_;
+    coalesce_buf bufs_[NBUF];
+    int open_ = 0;               // buffer accepting reservations, -1 while all are busy
+    int executing_ = 0;          // batches on the device
+    int max_exec_ = MAX_EXEC;
+    uint64_t inside_ = 0;        // callers currently inside submit()
+    uint64_t peak_ = 0;          // decaying maximum of inside_: the concurrency the gather targets are derived from
+    int gathering_ = -1;         // buffer whose elected leader is still waiting for stragglers
+    long window_us_ = 150;       // upper bound of that wait (KZG_HIP_COALESCE_US; 0 disables)
+    uint64_t batches_ = 0, requests_ = 0;   // statistics (KZG_HIP_COALESCE_STATS=1 prints them when the handle is freed)
+    double exec_s_ = 0;
+    int device_;
+    size_t in_row_, out_row_;
+    uint64_t max_batch_;
+};
+
+}  // namespace kzg

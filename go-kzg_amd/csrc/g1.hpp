@@ -171,6 +171,39 @@ struct g1x_acc {
     KZG_HD g1j to_jac() const { return inf ? g1_inf() : g1x_to_jac(g1xq_pack(v)); }
 };
 
+// XYZZ + XYZZ on the same lazy limbs (add-2008-s, 12M + 2S, the Y3 pair under one reduction: 11.5M + 2S): the reduction trees that
+// sum the per-lane accumulators of a table walk.  Both operands obey the accumulator invariant (X, Y, ZZ, ZZZ) <= (11, 5, 2, 2):
+//   U1 = X1 ZZ2, U2 = X2 ZZ1, S1 = Y1 ZZZ2, S2 = Y2 ZZZ1 : 2 (products <= 22);  P = U2 - U1 (M = 3) : 5;  R = S2 - S1 (M = 3) : 5
+//   PP = P^2, PPP = P PP, Q = U1 PP : 2;  X3 = R^2 - PPP - 2 Q : 2 + 3 + 3 + 3 = 11;  Q - X3 (M = 12) : 14
+//   Y3 = R (Q - X3) + (3 p - S1) PPP in one reduction (5 * 14 + 3 * 2 = 76 <= 600) : 2;  ZZ3 = (ZZ1 ZZ2) PP, ZZZ3 = (ZZZ1 ZZZ2) PPP : 2
+// so the sum obeys the invariant again.  Returns false (a untouched) when P == 0, i.e. the operands are equal or opposite.
+KZG_HD bool g1xq_add_fast(g1xq &a, const g1xq &b) {
+    fq u1 = mulq(a.x, b.zz), u2 = mulq(b.x, a.zz);
+    fq s1 = mulq(a.y, b.zzz), s2 = mulq(b.y, a.zzz);
+    fq pp_ = subq<3>(u2, u1), r = subq<3>(s2, s1);
+    fq pp = sqrq(pp_);
+    if (is_zero_mod_p_q(pp)) return false;
+    fq ppp = mulq(pp_, pp), q_ = mulq(u1, pp);
+    fq x3 = subq<3>(subq<3>(subq<3>(sqrq(r), ppp), q_), q_);
+    fq zero_q;
+#pragma unroll
+    for (int i = 0; i < 13; i++) zero_q.l[i] = 0;
+    fq y3 = dot2q_inl(r, subq<12>(q_, x3), subq<3>(zero_q, s1), ppp);
+    a.zz = mulq(mulq(a.zz, b.zz), pp);
+    a.zzz = mulq(mulq(a.zzz, b.zzz), ppp);
+    a.x = x3; a.y = y3;
+    return true;
+}
+// accumulator + accumulator with infinity flags; equal / opposite operands take the generic complete formulas
+KZG_HD g1j g1_add(const g1j &p, const g1j &q);
+KZG_HD void g1x_acc_merge(g1x_acc &a, const g1xq &bv, bool binf) {
+    if (binf) return;
+    if (a.inf) { a.v = bv; a.inf = false; return; }
+    if (g1xq_add_fast(a.v, bv)) return;
+    g1j s = g1_add(g1x_to_jac(g1xq_pack(a.v)), g1x_to_jac(g1xq_pack(bv)));
+    if (is_inf(s)) a.inf = true; else a.v = g1xq_unpack(g1x_from_jac(s));
+}
+
 KZG_HD g1j g1_sub(const g1j &p, const g1j &q) { return g1_add(p, g1_neg(q)); }
 
 // Projective equality (bls.EqualG1)

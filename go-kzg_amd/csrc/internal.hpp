@@ -20,8 +20,11 @@ void launch_das_ext(hipStream_t s, fr *vals, uint64_t n, uint64_t batch, const f
 // toeplitzCoeffsStepStrided (fk20_single.go:89-103): out[b][file][0..2k) from poly[b][0..n), optionally scaled.
 void launch_toeplitz_coeffs(hipStream_t s, const fr *poly, uint64_t poly_stride, uint64_t n, uint64_t l, uint64_t batch, fr *out,
                             const fr *scale);
-// quotient of poly by (X - x) (polyLongDiv with divisor [-x, 1], poly.go:14-40): q has n - 1 entries
-void launch_quotient_linear(hipStream_t s, const fr *poly, uint64_t n, const fr *x, fr *q);
+// quotients of `batch` polynomials (rows of poly_stride, n coefficients used) by (X - x[b]) (polyLongDiv with divisor [-x, 1],
+// poly.go:14-40): row b of q (stride q_stride) gets n - 1 entries
+void launch_quotient_linear(hipStream_t s, const fr *poly, uint64_t poly_stride, uint64_t n, uint64_t batch, const fr *x, fr *q, uint64_t q_stride);
+void launch_fr_from_u64(hipStream_t s, const uint64_t *in, uint64_t in_stride, fr *out, uint64_t n);   // bls.AsFr over a slice
+void launch_fr_zero_tails(hipStream_t s, fr *rows, uint64_t n_max, uint64_t batch, const uint64_t *lens, uint64_t lens_stride);
 // returns (via *flag != 0) whether any of vals[0..n) is non-zero
 void launch_fr_any_nonzero(hipStream_t s, const fr *vals, uint64_t n, uint32_t *flag);
 void launch_fr_powers(hipStream_t s, const fr *base, uint64_t n, fr *out);   // out[i] = base^i
@@ -77,8 +80,8 @@ void launch_msm_window_table(hipStream_t s, const g1a *pts, uint64_t n, uint32_t
 // fixed-base table MSM over the device-resident setup (see k_msm.hip)
 size_t fb_partials_bytes(uint64_t n, uint64_t batch);
 hipError_t launch_fb_build(hipStream_t s, const g1a *pts, uint64_t n, uint32_t c, uint32_t nwin, g1a *table);
-void launch_fb_msm(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, uint64_t n, uint64_t batch,
-                   void *partials, g1j *out, bool to_kilic);
+void launch_fb_msm(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, uint64_t sc_stride, uint64_t n,
+                   uint64_t batch, void *partials, g1j *out, bool to_kilic);
 
 // out[(b, f, jj)] = scalars[b][f * row + j0 + jj] * P[f * row + j0 + jj] over a fixed-base table of table_n = nfiles * row points
 void launch_fb_mul_vec(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, uint64_t row, uint64_t j0,

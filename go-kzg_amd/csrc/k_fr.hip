@@ -225,12 +225,14 @@ void launch_toeplitz_coeffs(hipStream_t s, const fr *poly, uint64_t poly_stride,
 // 256 lanes each run a contiguous segment with carry-in 0, a suffix scan composes the 256 segment maps, then every
 // lane adds x^(distance) * carry.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_quotient_linear(const fr *poly, uint64_t n, const fr *xp, fr *q) {
+__global__ __launch_bounds__(256) void k_quotient_linear(const fr *poly_all, uint64_t poly_stride, uint64_t n, const fr *xp, fr *q_all, uint64_t q_stride) {
     __shared__ fr head[256], xpow[256], cin[256];
     const uint32_t t = threadIdx.x;
+    const fr *poly = poly_all + (uint64_t)blockIdx.x * poly_stride;      // one workgroup per polynomial of the batch
+    fr *q = q_all + (uint64_t)blockIdx.x * q_stride;
     const uint64_t nq = n - 1, m = (nq + 255) / 256;
     const uint64_t lo = (uint64_t)t * m, hi = (lo + m < nq) ? lo + m : nq;
-    const fr x = *xp;
+    const fr x = xp[blockIdx.x];
     fr acc = zero<FrP>(), pw = one<FrP>();
     if (lo < nq) {
         for (uint64_t i = hi; i-- > lo;) { acc = add(poly[i + 1], mul(x, acc)); q[i] = acc; pw = mul(pw, x); }
@@ -260,8 +262,31 @@ __global__ __launch_bounds__(256) void k_quotient_linear(const fr *poly, uint64_
         }
     }
 }
-void launch_quotient_linear(hipStream_t s, const fr *poly, uint64_t n, const fr *x, fr *q) {
-    hipLaunchKernelGGL(k_quotient_linear, dim3(1), dim3(256), 0, s, poly, n, x, q);
+void launch_quotient_linear(hipStream_t s, const fr *poly, uint64_t poly_stride, uint64_t n, uint64_t batch, const fr *x, fr *q, uint64_t q_stride) {
+    if (!batch) return;
+    hipLaunchKernelGGL(k_quotient_linear, dim3((uint32_t)batch), dim3(256), 0, s, poly, poly_stride, n, x, q, q_stride);
+}
+// bls.AsFr over a slice (bls/bignum_kilic.go:61-65): out[i] = Montgomery image of the uint64 in[i * in_stride]
+__global__ void k_fr_from_u64(const uint64_t *in, uint64_t in_stride, fr *out, uint64_t n) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t < n) out[t] = fr_from_u64(in[t * in_stride]);
+}
+void launch_fr_from_u64(hipStream_t s, const uint64_t *in, uint64_t in_stride, fr *out, uint64_t n) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_fr_from_u64, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, in, in_stride, out, n);
+}
+// coalesced one-polynomial calls of different lengths share a batch: row b holds lens[b * lens_stride] coefficients, the rest of
+// the n_max-wide row is zero-filled here (zero coefficients add nothing to a commitment or a quotient)
+__global__ void k_fr_zero_tails(fr *rows, uint64_t n_max, const uint64_t *lens, uint64_t lens_stride, uint64_t total) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    uint64_t b = t / n_max, i = t % n_max;
+    if (i >= lens[b * lens_stride]) rows[t] = zero<FrP>();
+}
+void launch_fr_zero_tails(hipStream_t s, fr *rows, uint64_t n_max, uint64_t batch, const uint64_t *lens, uint64_t lens_stride) {
+    uint64_t total = n_max * batch;
+    if (!total) return;
+    hipLaunchKernelGGL(k_fr_zero_tails, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, rows, n_max, lens, lens_stride, total);
 }
 
 __global__ void k_fr_any_nonzero(const fr *vals, uint64_t n, uint32_t *flag) {

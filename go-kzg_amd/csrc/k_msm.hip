@@ -198,6 +198,9 @@ void launch_msm(hipStream_t s, const msm_plan &p, const g1a *table, const fr *sc
 // n = 4096, c = 11: 24 x 4096 x 1024 x 96 B = 9.7 GB, 98 304 mixed adds per commitment.
 // ---------------------------------------------------------------------------------------------------------
 #define FB_BLOCK 128
+#ifndef FB_ACC_WAVES
+#define FB_ACC_WAVES 2
+#endif
 
 // pass 1: lane (w, i, seg) walks d = seg S + 1 .. (seg + 1) S with mixed additions from (seg S + 1) b (a short double-and-add);
 // X, Y go to the table slot, Z to ztmp.  S = D / segs keeps >= 4 waves per SIMD busy even for the 65 536-row n = 4096 tables.
@@ -251,14 +254,42 @@ __global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_build_pass2(uint64_t lanes, 
     }
 }
 
+// a lane's XYZZ accumulator as it travels through LDS and the partial-sum workspace: the 4 x 13 lazy limbs as they are (no
+// pack / unpack / reduction between the walk and the trees) + the infinity flag.  53 words: an odd stride, so the LDS tree has no
+// bank conflicts.
+struct fb_partial { uint32_t w[52]; uint32_t inf; };
+__device__ __forceinline__ void fb_partial_store(fb_partial &o, const g1x_acc &a) {
+#pragma unroll
+    for (int i = 0; i < 13; i++) { o.w[i] = a.v.x.l[i]; o.w[13 + i] = a.v.y.l[i]; o.w[26 + i] = a.v.zz.l[i]; o.w[39 + i] = a.v.zzz.l[i]; }
+    o.inf = a.inf ? 1u : 0u;
+}
+__device__ __forceinline__ void fb_partial_load(const fb_partial &p, g1xq &v) {
+#pragma unroll
+    for (int i = 0; i < 13; i++) { v.x.l[i] = p.w[i]; v.y.l[i] = p.w[13 + i]; v.zz.l[i] = p.w[26 + i]; v.zzz.l[i] = p.w[39 + i]; }
+}
+// block-wide sum of the lanes' accumulators into lane 0's: log2(FB_BLOCK) levels of the lazy XYZZ + XYZZ addition through LDS
+__device__ __forceinline__ void fb_block_reduce(g1x_acc &acc, fb_partial *buf, uint32_t tid) {
+    fb_partial_store(buf[tid], acc);
+    __syncthreads();
+#pragma nounroll
+    for (uint32_t off = FB_BLOCK / 2; off >= 1; off >>= 1) {
+        if (tid < off) {
+            g1xq v; fb_partial_load(buf[tid + off], v);
+            g1x_acc_merge(acc, v, buf[tid + off].inf != 0);
+            fb_partial_store(buf[tid], acc);
+        }
+        __syncthreads();
+    }
+}
+
 // main kernel: lane handles points i = lane, lane + L, ... of one blob; block tree-reduces through LDS
-__global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_accumulate(const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, uint32_t D, const fr *scalars,
-                                                            uint64_t n, uint32_t blocks_per_blob, g1j *partials) {
-    __shared__ g1j buf[FB_BLOCK];
+__global__ __launch_bounds__(FB_BLOCK, FB_ACC_WAVES) void k_fb_accumulate(const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, uint32_t D, const fr *scalars,
+                                                            uint64_t sc_stride, uint64_t n, uint32_t blocks_per_blob, fb_partial *partials) {
+    __shared__ fb_partial buf[FB_BLOCK];
     const uint32_t tid = threadIdx.x;
     const uint64_t blob = blockIdx.x / blocks_per_blob; const uint32_t blk = blockIdx.x % blocks_per_blob;
     const uint64_t L = (uint64_t)blocks_per_blob * FB_BLOCK;
-    const fr *sc = scalars + blob * n;
+    const fr *sc = scalars + blob * sc_stride;   // rows may be wider than n (pinned staging rows read in place over PCIe)
     g1x_acc acc; acc.init();   // XYZZ, unpacked lazy limbs: 10 products per mixed addition, no pack / reduce per product
     for (uint64_t i = (uint64_t)blk * FB_BLOCK + tid; i < n; i += L) {
         fr k = from_mont<FrP>(sc[i]);
@@ -281,36 +312,44 @@ __global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_accumulate(const g1a *table,
             }
         }
     }
-    buf[tid] = acc.to_jac();
-    __syncthreads();
-#pragma nounroll
-    for (uint32_t off = FB_BLOCK / 2; off >= 1; off >>= 1) {
-        if (tid < off) buf[tid] = g1_add(buf[tid], buf[tid + off]);
-        __syncthreads();
-    }
-    if (tid == 0) partials[blockIdx.x] = buf[0];
+    fb_block_reduce(acc, buf, tid);
+    if (tid == 0) fb_partial_store(partials[blockIdx.x], acc);
 }
-// one wavefront per blob: the blob's partial sums are added by a tree through LDS (a lone commitment has 32 of them: 5 levels
-// instead of 31 serial additions), then lane 0 normalises and converts
-__global__ __launch_bounds__(64) void k_fb_finish(const g1j *partials, uint32_t blocks_per_blob, uint64_t batch, g1j *out, int to_kilic) {
-    __shared__ g1j buf[64];
+// one wavefront per blob: the blob's partial sums are added by the same lazy tree (a lone commitment has 32 of them: 5 levels
+// instead of 31 serial additions), then lane 0 normalises (one inversion: 1 / (ZZ ZZZ)) and converts
+__global__ __launch_bounds__(64) void k_fb_finish(const fb_partial *partials, uint32_t blocks_per_blob, uint64_t batch, g1j *out, int to_kilic) {
+    __shared__ fb_partial buf[64];
     const uint64_t b = blockIdx.x;
     const uint32_t tid = threadIdx.x;
-    g1j acc = g1_inf();
+    g1x_acc acc; acc.init();
 #pragma nounroll
-    for (uint32_t j = tid; j < blocks_per_blob; j += 64) acc = g1_add(acc, partials[b * blocks_per_blob + j]);
-    buf[tid] = acc;
-    __syncthreads();
+    for (uint32_t j = tid; j < blocks_per_blob; j += 64) {
+        const fb_partial &pj = partials[b * blocks_per_blob + j];
+        g1xq v; fb_partial_load(pj, v);
+        g1x_acc_merge(acc, v, pj.inf != 0);
+    }
     const uint32_t live = blocks_per_blob < 64 ? blocks_per_blob : 64;
     uint32_t off = 1;
-    while (off * 2 < live) off *= 2;                      // largest power of two below `live`
+    while (off < live) off *= 2;                          // smallest power of two >= live
+    fb_partial_store(buf[tid], acc);
+    __syncthreads();
 #pragma nounroll
-    for (; off >= 1; off >>= 1) {
-        if (tid < off && tid + off < live) buf[tid] = g1_add(buf[tid], buf[tid + off]);
+    for (off >>= 1; off >= 1; off >>= 1) {
+        if (tid < off && tid + off < live) {
+            g1xq v; fb_partial_load(buf[tid + off], v);
+            g1x_acc_merge(acc, v, buf[tid + off].inf != 0);
+            fb_partial_store(buf[tid], acc);
+        }
         __syncthreads();
     }
     if (tid == 0) {
-        g1j r = g1_normalize(buf[0]);
+        g1j r;
+        if (acc.inf) r = g1_inf();
+        else {   // x = X / ZZ, y = Y / ZZZ with ONE inversion: i = 1 / (ZZ ZZZ), 1 / ZZ = i ZZZ, 1 / ZZZ = i ZZ
+            g1x px = g1xq_pack(acc.v);
+            fp i = inv<FpP>(mul(px.zz, px.zzz));
+            r.x = mul(px.x, mul(i, px.zzz)); r.y = mul(px.y, mul(i, px.zz)); r.z = one<FpP>();
+        }
         out[b] = to_kilic ? g1_to_kilic(r) : r;
     }
 }
@@ -378,19 +417,19 @@ static uint32_t fb_blocks_per_blob(uint64_t n, uint64_t batch) {
     if (bpb < 1) bpb = 1;
     return (uint32_t)bpb;
 }
-size_t fb_partials_bytes(uint64_t n, uint64_t batch) { return (size_t)fb_blocks_per_blob(n, batch) * batch * sizeof(g1j); }
+size_t fb_partials_bytes(uint64_t n, uint64_t batch) { return (((size_t)fb_blocks_per_blob(n, batch) * batch * sizeof(fb_partial)) + 15) / 16 * 16; }
 
 // out[b] = the NORMALISED sum (Z = one), as Kilic images when to_kilic: the per-blob partial sums are added and inverted in one
 // latency-bound kernel instead of two
-void launch_fb_msm(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, uint64_t n, uint64_t batch,
-                   void *partials, g1j *out, bool to_kilic) {
+void launch_fb_msm(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, uint64_t sc_stride, uint64_t n,
+                   uint64_t batch, void *partials, g1j *out, bool to_kilic) {
     if (!batch) return;
     uint32_t bpb = fb_blocks_per_blob(n, batch);
     prof_begin(s, "fb_accumulate");
-    hipLaunchKernelGGL(k_fb_accumulate, dim3((uint32_t)(batch * bpb)), dim3(FB_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars, n, bpb,
-                       (g1j *)partials);
+    hipLaunchKernelGGL(k_fb_accumulate, dim3((uint32_t)(batch * bpb)), dim3(FB_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars, sc_stride, n, bpb,
+                       (fb_partial *)partials);
     prof_end(s, "fb_accumulate");
-    hipLaunchKernelGGL(k_fb_finish, dim3((uint32_t)batch), dim3(64), 0, s, (const g1j *)partials, bpb, batch, out, to_kilic ? 1 : 0);
+    hipLaunchKernelGGL(k_fb_finish, dim3((uint32_t)batch), dim3(64), 0, s, (const fb_partial *)partials, bpb, batch, out, to_kilic ? 1 : 0);
 }
 // builds the table for `n` affine points: rows (2^(c w) P_i) first, then all multiples window-slab by window-slab
 hipError_t launch_fb_build(hipStream_t s, const g1a *pts, uint64_t n, uint32_t c, uint32_t nwin, g1a *table) {

@@ -114,6 +114,11 @@ int kzg_hip_commit_to_poly_batch(kzg_hip_kzg *ks, const void *coeffs_fr, uint64_
 int kzg_hip_commit_to_poly_batch_dev(kzg_hip_kzg *ks, const void *d_coeffs_fr, uint64_t n, uint64_t batch, void *d_out_g1, void *stream);
 /* KZGSettings.ComputeProofSingle (kzg_single_proofs.go:36-54; poly.go:14-40): x is a uint64 as in the reference */
 int kzg_hip_compute_proof_single(kzg_hip_kzg *ks, const void *poly_fr, uint64_t n, uint64_t x, void *out_g1);
+/* `batch` polynomials of n coefficients each, evaluation point xs[b] for polynomial b -> `batch` proofs; the _dev form takes
+ * device pointers (polynomials, uint64 xs, outputs) and a stream */
+int kzg_hip_compute_proof_single_batch(kzg_hip_kzg *ks, const void *poly_fr, uint64_t n, uint64_t batch, const uint64_t *xs, void *out_g1);
+int kzg_hip_compute_proof_single_batch_dev(kzg_hip_kzg *ks, const void *d_poly_fr, uint64_t n, uint64_t batch, const void *d_x_u64, void *d_out_g1,
+                                           void *stream);
 /* KZGSettings.ToeplitzPart2 / ToeplitzPart3 (fk20_single.go:59-87); part3 writes n/2 points */
 int kzg_hip_toeplitz_part2(kzg_hip_kzg *ks, const void *coeffs_fr, const void *x_ext_fft_g1, uint64_t n, void *out_g1);
 int kzg_hip_toeplitz_part3(kzg_hip_kzg *ks, const void *h_ext_fft_g1, uint64_t n, void *out_g1);
@@ -177,6 +182,11 @@ int kzg_hip_recover_poly_from_samples(kzg_hip_fft *fs, const void *samples_fr, c
 /* ---- instrumentation for bench.py: HIP-event time of the dominant kernel since the last reset (ms) and launch count ---- */
 void kzg_hip_prof_reset(kzg_hip_fft *fs, int enable);
 int kzg_hip_prof_read(kzg_hip_fft *fs, const char *kernel, double *total_ms, uint64_t *launches);
+/* drop-in measurement: `threads` host threads each make `calls` blocking one-polynomial calls (op 0: kzg_hip_commit_to_poly,
+ * op 1: kzg_hip_compute_proof_single) on host buffers taken round-robin from blobs_fr (nblobs x n Fr); out_g1 holds `threads`
+ * points (each thread's last result); *seconds = wall time from the common start to the last return */
+int kzg_hip_bench_drop_in(kzg_hip_kzg *ks, int op, const void *blobs_fr, uint64_t n, uint64_t nblobs, unsigned threads, unsigned calls, void *out_g1,
+                          double *seconds);
 /* shape of the fixed-base table CommitToPoly walks (built lazily by the first commitment): signed window bits c, window count and
  * bytes of HBM; all zero before the first commitment or when the setup is too small for a table (classic bucket path) */
 int kzg_hip_kzg_table_info(kzg_hip_kzg *ks, uint32_t *window_bits, uint32_t *windows, uint64_t *table_bytes);

@@ -646,6 +646,69 @@ def test_concurrent_callers_share_a_handle(kz, ks4096, setup_1337):
         assert np.array_equal(got[i], want[i])
 
 
+def test_64_threads_single_blob_calls_are_coalesced_and_bit_exact(kz, ks4096, setup_1337):
+    """the reference API is one polynomial per call (kzg_single_proofs.go:17-19,36-54); 64 host threads calling it concurrently
+    are merged into batched launches (coalesce.hpp).  Every result is compared with the batched call, a sample with the oracle;
+    ragged lengths and per-call x values share batches."""
+    import threading
+    rng = np.random.default_rng(64)
+    T, ROUNDS = 64, 3
+    blobs = np.stack([ko.synthetic_blob(500 + i) for i in range(T)])
+    lens = [4096 if i % 4 else int(rng.integers(2, 4096)) for i in range(T)]
+    xs = [int(rng.integers(1, 2**63)) for _ in range(T)]
+    want_c = ks4096.commit_to_poly_batch(blobs)
+    want_p = ks4096.compute_proof_single_batch(blobs, np.array(xs, dtype=np.uint64))
+    got_c = [[None] * ROUNDS for _ in range(T)]
+    got_r = [None] * T
+    got_p = [None] * T
+    errs = []
+    start = threading.Barrier(T)
+
+    def work(i):
+        try:
+            start.wait()
+            for r in range(ROUNDS):
+                got_c[i][r] = ks4096.commit_to_poly(blobs[i])
+            got_r[i] = ks4096.commit_to_poly(blobs[i][:lens[i]])
+            got_p[i] = ks4096.compute_proof_single(blobs[i], xs[i])
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(T)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs[:2]
+    for i in range(T):
+        for r in range(ROUNDS):
+            assert np.array_equal(got_c[i][r], want_c[i]), (i, r)
+        assert np.array_equal(got_p[i], want_p[i]), i
+    for i in (0, 4, 17, 40, 63):
+        assert_points_equal(got_c[i][0], ko.lincomb_g1(setup_1337, blobs[i]))
+        assert_points_equal(got_r[i], ko.lincomb_g1(setup_1337[:lens[i]], blobs[i][:lens[i]]))
+    oks = ko.KZGSettings(ko.FFTSettings(12), setup_1337)
+    for i in (3, 33):
+        assert_points_equal(got_p[i], oks.compute_proof_single(blobs[i], xs[i]))
+    # FK20 all-proofs through the same mechanism: 6 threads, one polynomial each
+    fk = kz.FK20SingleSettings(ks4096, 4096)
+    polys = np.stack([ko.synthetic_blob(700 + i)[:2048] for i in range(6)])
+    want_f = fk.da_using_fk20_batch(polys)
+    got_f = [None] * 6
+
+    def fwork(i):
+        try:
+            got_f[i] = fk.da_using_fk20(polys[i])
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=fwork, args=(i,)) for i in range(6)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs[:2]
+    for i in range(6):
+        assert np.array_equal(got_f[i], want_f[i]), i
+    fk.close()
+
+
 def test_dev_entry_points_on_two_streams_do_not_share_scratch(kz, ks4096):
     """_dev calls enqueue and return; two callers on DIFFERENT streams used to share one per-handle partial-sum workspace
     (round-1 advisor finding).  Interleave launches of different batch shapes on two streams and compare with serial results."""
