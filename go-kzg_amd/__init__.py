@@ -73,7 +73,10 @@ def lib():
         "kzg_hip_fft_fr_batch_dev": (i32, [vp, vp, u64, u64, i32, vp, vp]), "kzg_hip_fft_g1_batch_dev": (i32, [vp, vp, u64, u64, i32, vp, vp]),
         "kzg_hip_das_fft_extension_batch_dev": (i32, [vp, vp, u64, u64, vp]),
         "kzg_hip_fr_from_le32": (i32, [vp, vp, u64, vp, C.POINTER(i32)]), "kzg_hip_fr_to_le32": (i32, [vp, vp, u64, vp]),
-        "kzg_hip_lincomb_g1": (i32, [vp, vp, vp, u64, vp]), "kzg_hip_g1_to_compressed": (i32, [vp, vp, u64, vp]),
+        "kzg_hip_lincomb_g1": (i32, [vp, vp, vp, u64, vp]),
+        "kzg_hip_points_new": (i32, [vp, vp, u64, pp]), "kzg_hip_points_free": (None, [vp]), "kzg_hip_points_count": (u64, [vp]),
+        "kzg_hip_lincomb_points": (i32, [vp, vp, u64, vp]), "kzg_hip_lincomb_points_batch": (i32, [vp, vp, u64, u64, vp]),
+        "kzg_hip_lincomb_points_batch_dev": (i32, [vp, vp, u64, u64, vp, vp]), "kzg_hip_g1_to_compressed": (i32, [vp, vp, u64, vp]),
         "kzg_hip_g1_from_compressed": (i32, [vp, vp, u64, vp]), "kzg_hip_g1_mul_vec": (i32, [vp, vp, vp, u64, vp]),
         "kzg_hip_generate_testing_setup_g1": (i32, [vp, vp, u64, vp]),
         "kzg_hip_g1_marshal_text": (i32, [vp, vp, u64, vp]), "kzg_hip_g1_unmarshal_text": (i32, [vp, C.c_char_p, u64, vp]),
@@ -318,6 +321,35 @@ class FFTSettings:
         secret_fr = _fr(secret_fr)
         out = g1_empty(n)
         _chk(lib().kzg_hip_generate_testing_setup_g1(self.h, _p(secret_fr), n, _p(out)))
+        return out
+
+
+class G1Points:
+    """a point set kept in HBM for repeated bls.LinCombG1 calls (kzg_hip_points_*): CommitToEvalPoly's secretG1IFFT, eth's Lagrange setup"""
+
+    def __init__(self, fs, points):
+        points = _g1(points)
+        h = C.c_void_p()
+        _chk(lib().kzg_hip_points_new(fs.h, _p(points), points.shape[0], C.byref(h)))
+        self.h, self.fs, self.n = h, fs, points.shape[0]
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().kzg_hip_points_free(self.h)
+            self.h = None
+
+    def lin_comb(self, factors):
+        """bls.LinCombG1(points[:len(factors)], factors)"""
+        factors = _fr(factors)
+        out = g1_empty(1)
+        _chk(lib().kzg_hip_lincomb_points(self.h, _p(factors), factors.shape[0], _p(out)))
+        return out[0]
+
+    def lin_comb_batch(self, factors):
+        factors = np.ascontiguousarray(factors, dtype=np.uint64)
+        b, n = factors.shape[0], factors.shape[1]
+        out = g1_empty(b)
+        _chk(lib().kzg_hip_lincomb_points_batch(self.h, _p(factors), n, b, _p(out)))
         return out
 
 

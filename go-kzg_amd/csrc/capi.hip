@@ -262,12 +262,29 @@ int kzg_hip_fft_fr_batch(kzg_hip_fft *fs, const void *vals_fr, uint64_t n, uint6
     return fft_fr_impl(fs, vals_fr, n, n, batch, inv, out_fr);
 }
 
-// G1 FFT on resident rows: in (row stride in_stride, first n_valid entries used, the rest = inf) -> data (batch x n),
-// NOT scaled by 1/n (callers fold the scale where it is cheapest).
-static void g1_fft_rows(kzg_hip_fft *fs, hipStream_t s, const g1j *d_in, uint64_t in_stride, uint64_t n_valid, g1j *d_data, uint64_t n, uint64_t batch, int inv) {
+// G1 FFT on resident rows: in (row stride in_stride, first n_valid entries used, the rest = inf) -> data (batch x n).
+// scale: nullptr, or a device Fr every output is multiplied by (the n^-1 of the inverse transform, fft_g1.go:72-85); FK20 callers
+// fold their scale into the Toeplitz coefficients instead.  Few butterflies (a lone transform) take the direct radix-16 passes,
+// whose latency is log16(n) scalar multiplications; batches take the radix-2 network, which does 7.5 times less work.
+static bool g1_fft_direct_mode(uint64_t n, uint64_t batch) {
+    static int forced = -1;
+    if (forced < 0) { const char *e = getenv("KZG_HIP_G1_FFT"); forced = !e ? 0 : (e[0] == 'd' ? 1 : 2); }   // "direct" / "radix2" force a path (A/B runs)
+    if (forced) return forced == 1;
+    return n >= 2 && n * batch <= 8192;
+}
+static int g1_fft_rows(kzg_hip_fft *fs, hipStream_t s, const g1j *d_in, uint64_t in_stride, uint64_t n_valid, g1j *d_data, uint64_t n, uint64_t batch, int inv,
+                       const fr *scale = nullptr) {
+    if (g1_fft_direct_mode(n, batch)) {
+        dtmp<g1j> d_tmp(s);
+        CHK(d_tmp.alloc(n * batch));
+        launch_g1_fft_direct(s, d_in, in_stride, n_valid, d_data, d_tmp.p, n, batch, inv ? fs->d_reversed : fs->d_expanded, fs->W, scale);
+        return KZG_HIP_OK;
+    }
     launch_g1_bitrev_copy(s, d_in, in_stride, n_valid, d_data, n, batch);
     const fr *roots = inv ? fs->d_glv_reversed : fs->d_glv_expanded;
     for (uint64_t m = 1; m < n; m <<= 1) launch_g1_fft_stage(s, d_data, n, batch, m, roots, fs->W);
+    if (scale) launch_g1_mul_vec(s, d_data, n * batch, scale, 0, n * batch, d_data);
+    return KZG_HIP_OK;
 }
 
 int kzg_hip_fft_g1(kzg_hip_fft *fs, const void *vals_g1, uint64_t n, int inv, void *out_g1) {
@@ -281,14 +298,9 @@ int kzg_hip_fft_g1(kzg_hip_fft *fs, const void *vals_g1, uint64_t n, int inv, vo
     CHK(d_in.alloc(n)); CHK(d_data.alloc(n));
     HIPCHK(hipMemcpyAsync(d_in.p, vals_g1, n * sizeof(g1j), hipMemcpyHostToDevice, s));
     launch_g1_from_kilic(s, d_in.p, n);
-    g1_fft_rows(fs, s, d_in.p, n, n, d_data.p, n, 1, inv);
-    if (inv) {   // fft_g1.go:72-85: every output times n^-1
-        launch_g1_mul_vec(s, d_data.p, n, fs->d_inv_pow2 + ilog2(n), 0, n, d_in.p);
-        launch_g1_normalize(s, d_in.p, d_data.p, n, true);
-    } else {
-        launch_g1_normalize(s, d_data.p, d_in.p, n, true);
-        std::swap(d_in.p, d_data.p);
-    }
+    CHK(g1_fft_rows(fs, s, d_in.p, n, n, d_data.p, n, 1, inv, inv ? fs->d_inv_pow2 + ilog2(n) : nullptr));   // fft_g1.go:72-85: inverse: every output times n^-1
+    launch_g1_normalize(s, d_data.p, d_in.p, n, true);
+    std::swap(d_in.p, d_data.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out_g1, d_data.p, n * sizeof(g1j), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -334,11 +346,8 @@ int kzg_hip_fft_g1_batch_dev(kzg_hip_fft *fs, const void *d_vals_g1, uint64_t n,
     CHK(d_in.alloc(n * batch)); CHK(d_data.alloc(n * batch));
     HIPCHK(hipMemcpyAsync(d_in.p, d_vals_g1, n * batch * sizeof(g1j), hipMemcpyDeviceToDevice, s));
     launch_g1_from_kilic(s, d_in.p, n * batch);
-    g1_fft_rows(fs, s, d_in.p, n, n, d_data.p, n, batch, inv);
-    if (inv) {
-        launch_g1_mul_vec(s, d_data.p, n * batch, fs->d_inv_pow2 + ilog2(n), 0, n * batch, d_in.p);
-        launch_g1_normalize(s, d_in.p, (g1j *)d_out_g1, n * batch, true);
-    } else launch_g1_normalize(s, d_data.p, (g1j *)d_out_g1, n * batch, true);
+    CHK(g1_fft_rows(fs, s, d_in.p, n, n, d_data.p, n, batch, inv, inv ? fs->d_inv_pow2 + ilog2(n) : nullptr));
+    launch_g1_normalize(s, d_data.p, (g1j *)d_out_g1, n * batch, true);
     HIPCHK(hipGetLastError());
     return KZG_HIP_OK;
 }
@@ -357,15 +366,102 @@ int kzg_hip_das_fft_extension(kzg_hip_fft *fs, void *vals_fr, uint64_t n) { retu
 // ---------------------------------------------------------------------------------------------------------
 // MSM
 // ---------------------------------------------------------------------------------------------------------
-static msm_plan classic_plan(uint64_t n) {
-    // Only window sizes that divide 256 keep the TOP window balanced (255 mod c == c - 1): with c = 9 the top window
-    // has 3 bits, 8 of its 256 buckets receive n / 8 points each and one wavefront per blob becomes a 20 ms tail.
+// bucket-MSM plan: signed 8-bit windows over the GLV halves (k_msm.hip); `folded`: the table also holds the 2^64 multiples
+static msm_plan classic_plan(uint64_t n, bool folded = false) {
     msm_plan p{};
-    p.c = n < 256 ? 4 : 8;
-    p.nwin = 255 / p.c + 1; p.nb = 1u << (p.c - 1); p.ngroups = p.nwin; p.fixed = 0; p.table_n = n;
+    p.c = 8; p.nwin = 16; p.nb = 128; p.ngroups = folded ? 8 : 16; p.fixed = 0; p.table_n = n;
     return p;
 }
 static void set_inf_image(void *out_g1) { g1j z = g1_to_kilic(g1_inf()); memcpy(out_g1, &z, sizeof z); }   // Kilic Zero(): (0, R, 0)
+
+// ---- cached point sets for bls.LinCombG1 (bls/bls_kilic.go:132-150): callers such as CommitToEvalPoly (kzg_single_proofs.go:12-14,
+// the IFFT of the setup) and eth/helpers.go:99,159,199 (the Lagrange setup) multiply the SAME points by fresh scalars every call.
+// The handle keeps them in HBM as affine device-internal images together with 2^64 P_i, which folds the 16 windows of each GLV
+// half onto 8 bucket groups: 56 instead of 120 doublings on the critical path of a lone MSM.
+struct kzg_hip_points {
+    kzg_hip_fft *fs = nullptr;
+    uint64_t n = 0;
+    g1a *d_tab = nullptr;          // [P_0 .. P_{n-1} | 2^64 P_0 .. 2^64 P_{n-1}], affine, (0, 0) = inf
+};
+__global__ __launch_bounds__(128, 2) void k_points_shift64(const g1a *pts, uint64_t n, g1j *out) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    g1a p = pts[t];
+    if (is_inf(p)) { out[t] = g1_inf(); return; }
+    g1jq q = g1jq_unpack(to_jac(p));
+#pragma nounroll
+    for (int i = 0; i < 64; i++) q = g1jq_dbl(q);
+    out[t] = g1jq_pack(q);
+}
+void kzg_hip_points_free(kzg_hip_points *pts) {
+    if (!pts) return;
+    hipSetDevice(pts->fs->device);
+    hipDeviceSynchronize();
+    hipFree(pts->d_tab);
+    (void)hipGetLastError();
+    delete pts;
+}
+int kzg_hip_points_new(kzg_hip_fft *fs, const void *points_g1, uint64_t n, kzg_hip_points **out) {
+    if (!fs || !out || (n && !points_g1)) return KZG_HIP_ERR_BAD_ARG;
+    *out = nullptr;
+    KZG_TRY
+    dev_guard g(fs);
+    hipStream_t s = fs->stream;
+    std::unique_ptr<kzg_hip_points, void (*)(kzg_hip_points *)> own(new kzg_hip_points, kzg_hip_points_free);
+    own->fs = fs; own->n = n;
+    if (n) {
+        dtmp<g1j> d_raw(s), d_hi(s);
+        CHK(d_raw.alloc(n)); CHK(d_hi.alloc(n));
+        HIPCHK(hipMalloc((void **)&own->d_tab, 2 * n * sizeof(g1a)));
+        HIPCHK(hipMemcpyAsync(d_raw.p, points_g1, n * sizeof(g1j), hipMemcpyHostToDevice, s));
+        launch_g1_from_kilic(s, d_raw.p, n);
+        launch_g1_to_affine(s, d_raw.p, own->d_tab, n);
+        hipLaunchKernelGGL(k_points_shift64, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, s, own->d_tab, n, d_hi.p);
+        launch_g1_to_affine(s, d_hi.p, own->d_tab + n, n);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    *out = own.release();
+    return KZG_HIP_OK;
+    KZG_CATCH
+}
+uint64_t kzg_hip_points_count(const kzg_hip_points *pts) { return pts ? pts->n : 0; }
+// batch MSMs against points[:n]: scalars in rows of n; out = batch normalised Kilic images (device)
+static int lincomb_points_rows(kzg_hip_points *pts, hipStream_t s, const fr *d_sc, uint64_t n, uint64_t batch, g1j *d_out) {
+    msm_plan p = classic_plan(pts->n, true);
+    dtmp<uint8_t> d_ws(s);
+    CHK(d_ws.alloc(msm_workspace_bytes(p, n, batch)));
+    launch_msm(s, p, pts->d_tab, d_sc, n, n, batch, d_ws.p, d_out, true);
+    HIPCHK(hipGetLastError());
+    return KZG_HIP_OK;
+}
+int kzg_hip_lincomb_points_batch_dev(kzg_hip_points *pts, const void *d_scalars_fr, uint64_t n, uint64_t batch, void *d_out_g1, void *stream) {
+    if (!pts || !d_out_g1) return KZG_HIP_ERR_BAD_ARG;
+    if (n > pts->n) return KZG_HIP_ERR_LEN_MISMATCH;          // bls.LinCombG1 length mismatch panic, bls_kilic.go:133-135
+    if (!batch) return KZG_HIP_OK;
+    if (n == 0 || !d_scalars_fr) return KZG_HIP_ERR_BAD_ARG;
+    hipSetDevice(pts->fs->device);
+    return lincomb_points_rows(pts, (hipStream_t)stream, (const fr *)d_scalars_fr, n, batch, (g1j *)d_out_g1);
+}
+int kzg_hip_lincomb_points_batch(kzg_hip_points *pts, const void *scalars_fr, uint64_t n, uint64_t batch, void *out_g1) {
+    if (!pts || !out_g1) return KZG_HIP_ERR_BAD_ARG;
+    if (n > pts->n) return KZG_HIP_ERR_LEN_MISMATCH;
+    if (!batch) return KZG_HIP_OK;
+    if (n == 0) { for (uint64_t b = 0; b < batch; b++) set_inf_image((uint8_t *)out_g1 + b * sizeof(g1j)); return KZG_HIP_OK; }   // bls/bls_test.go:69-78
+    if (!scalars_fr) return KZG_HIP_ERR_BAD_ARG;
+    dev_guard g(pts->fs);
+    hipStream_t s = pts->fs->stream;
+    dtmp<fr> d_sc(s); dtmp<g1j> d_out(s);
+    CHK(d_sc.alloc(n * batch)); CHK(d_out.alloc(batch));
+    HIPCHK(hipMemcpyAsync(d_sc.p, scalars_fr, n * batch * sizeof(fr), hipMemcpyHostToDevice, s));
+    CHK(lincomb_points_rows(pts, s, d_sc.p, n, batch, d_out.p));
+    HIPCHK(hipMemcpyAsync(out_g1, d_out.p, batch * sizeof(g1j), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return KZG_HIP_OK;
+}
+int kzg_hip_lincomb_points(kzg_hip_points *pts, const void *scalars_fr, uint64_t n, void *out_g1) {
+    return kzg_hip_lincomb_points_batch(pts, scalars_fr, n, 1, out_g1);
+}
 
 int kzg_hip_lincomb_g1(kzg_hip_fft *fs, const void *points_g1, const void *scalars_fr, uint64_t n, void *out_g1) {
     if (!fs || !out_g1) return KZG_HIP_ERR_BAD_ARG;
@@ -373,17 +469,16 @@ int kzg_hip_lincomb_g1(kzg_hip_fft *fs, const void *points_g1, const void *scala
     if (!points_g1 || !scalars_fr) return KZG_HIP_ERR_BAD_ARG;
     dev_guard g(fs);
     hipStream_t s = fs->stream;
-    msm_plan p = classic_plan(n);
+    msm_plan p = classic_plan(n);                               // one-shot points: no 2^64 rows (computing them costs the 64 doublings they save)
     dtmp<g1j> d_pts(s), d_out(s); dtmp<g1a> d_tab(s); dtmp<fr> d_sc(s); dtmp<uint8_t> d_ws(s);
-    CHK(d_pts.alloc(n)); CHK(d_out.alloc(2)); CHK(d_tab.alloc(n)); CHK(d_sc.alloc(n)); CHK(d_ws.alloc(msm_workspace_bytes(p, n, 1)));
+    CHK(d_pts.alloc(n)); CHK(d_out.alloc(1)); CHK(d_tab.alloc(n)); CHK(d_sc.alloc(n)); CHK(d_ws.alloc(msm_workspace_bytes(p, n, 1)));
     HIPCHK(hipMemcpyAsync(d_pts.p, points_g1, n * sizeof(g1j), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_sc.p, scalars_fr, n * sizeof(fr), hipMemcpyHostToDevice, s));
     launch_g1_from_kilic(s, d_pts.p, n);
     launch_g1_to_affine(s, d_pts.p, d_tab.p, n);
-    launch_msm(s, p, d_tab.p, d_sc.p, n, 1, d_ws.p, d_out.p);
-    launch_g1_normalize(s, d_out.p, d_out.p + 1, 1, true);
+    launch_msm(s, p, d_tab.p, d_sc.p, n, n, 1, d_ws.p, d_out.p, true);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out_g1, d_out.p + 1, sizeof(g1j), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out_g1, d_out.p, sizeof(g1j), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return KZG_HIP_OK;
 }
@@ -583,14 +678,12 @@ static int commit_rows(kzg_hip_kzg *ks, hipStream_t s, const fr *d_sc, uint64_t 
     CHK(ensure_fixed_table(ks, s));
     bool fixed = ks->d_fixed != nullptr;
     if (!sc_stride) sc_stride = n;
-    if (!fixed && sc_stride != n) return KZG_HIP_ERR_BAD_ARG;   // (internal) the bucket path wants dense rows
-    msm_plan p = fixed ? ks->fixed_plan : classic_plan(n);
+    msm_plan p = fixed ? ks->fixed_plan : classic_plan(ks->n_setup);
     size_t ws_main = fixed ? fb_partials_bytes(n, batch) : msm_workspace_bytes(p, n, batch);
     dtmp<uint8_t> d_ws(s);
-    CHK(d_ws.alloc(ws_main + batch * sizeof(g1j)));
-    g1j *d_raw = (g1j *)(d_ws.p + ws_main);
+    CHK(d_ws.alloc(ws_main));
     if (fixed) launch_fb_msm(s, ks->d_fixed, p.table_n, p.c, p.nwin, d_sc, sc_stride, n, batch, d_ws.p, d_out, true);   // sums, normalises, converts
-    else { launch_msm(s, p, ks->d_secret_a, d_sc, n, batch, d_ws.p, d_raw); launch_g1_normalize(s, d_raw, d_out, batch, true); }
+    else launch_msm(s, p, ks->d_secret_a, d_sc, sc_stride, n, batch, d_ws.p, d_out, true);
     HIPCHK(hipGetLastError());
     return KZG_HIP_OK;
 }
@@ -854,7 +947,7 @@ static int fk20_core_new(kzg_hip_kzg *ks, uint64_t n2, uint64_t l, fk20_core *c)
     CHK(d_x.alloc(l * k)); CHK(d_f.alloc(l * k2));
     HIPCHK(hipMalloc((void **)&c->d_files, l * k2 * sizeof(g1j)));
     hipLaunchKernelGGL(k_fk20_x, dim3((uint32_t)((l * k + 255) / 256)), dim3(256), 0, s, ks->d_secret, n, l, k, d_x.p);
-    g1_fft_rows(fs, s, d_x.p, k, k, d_f.p, k2, l, 0);   // toeplitzPart1: FFTG1(x || inf^k), fk20_single.go:40-56
+    CHK(g1_fft_rows(fs, s, d_x.p, k, k, d_f.p, k2, l, 0));   // toeplitzPart1: FFTG1(x || inf^k), fk20_single.go:40-56
     launch_g1_normalize(s, d_f.p, c->d_files, l * k2);
     HIPCHK(hipGetLastError());
     {   // fixed-base table over the file points, sized by KZG_HIP_FK20_FB_BUDGET_GB (default: min(48 GB, free HBM - 12 GB)):
@@ -909,8 +1002,8 @@ static int fk20_finish(fk20_core *c, hipStream_t s, const g1j *d_hext, uint64_t 
     uint64_t k = c->k, k2 = 2 * k, on = da ? k2 : k;
     dtmp<g1j> d_a(s), d_b(s);
     CHK(d_a.alloc(batch * k2)); CHK(d_b.alloc(batch * k2));
-    g1_fft_rows(fs, s, d_hext, k2, k2, d_a.p, k2, batch, 1);          // ToeplitzPart3, fk20_single.go:80-87
-    g1_fft_rows(fs, s, d_a.p, k2, k, d_b.p, on, batch, 0);            // fk20_single.go:163-167 / :129
+    CHK(g1_fft_rows(fs, s, d_hext, k2, k2, d_a.p, k2, batch, 1));          // ToeplitzPart3, fk20_single.go:80-87
+    CHK(g1_fft_rows(fs, s, d_a.p, k2, k, d_b.p, on, batch, 0));            // fk20_single.go:163-167 / :129
     if (bit_reverse) { launch_g1_bitrev_copy(s, d_b.p, on, on, d_a.p, on, batch); launch_g1_normalize(s, d_a.p, d_out, batch * on, true); }
     else launch_g1_normalize(s, d_b.p, d_out, batch * on, true);
     HIPCHK(hipGetLastError());

@@ -300,6 +300,91 @@ inline fr glv_decompose(const fr &k) {
     return o;
 }
 
+// Balanced GLV split for VARIABLE scalars, on the device (the bucket MSM): k P = s1 |k1| P + s2 |k2| phi(P) with both magnitudes
+// below 2^126.5, so 16 signed 8-bit windows cover each half with no carry out of the top window.
+//   a = min(k, r - k) (sign sg), q = round(a / lambda) = floor((a + hl) / lambda), hl = floor(lambda / 2),
+//   k1 = a - q lambda in [-hl, hl], k2 = q <= (r / 2 + hl) / lambda < 2^126.5;   neg1 = sg ^ (k1 < 0), neg2 = sg.
+// The quotient is a Barrett estimate with mu = floor(2^256 / lambda) (129 bits): floor(floor(a' / 2^127) mu / 2^129) is q - 2 .. q,
+// fixed by at most two conditional subtractions.  Checked against Python big integers in tests/test_host_arith.py.
+struct glv_halves { uint32_t k1[4], k2[4]; uint32_t neg1, neg2; };
+KZG_HD glv_halves glv_split_signed(const fr &k) {
+    const uint32_t LAM[4] = {0xffffffffu, 0x00000000u, 0x0001a402u, 0xac45a401u};
+    const uint32_t HL[4] = {0x7fffffffu, 0x00000000u, 0x8000d201u, 0x5622d200u};
+    const uint32_t MU[5] = {0xf6cfee30u, 0x63f6e522u, 0xe01faaddu, 0x7c6becf1u, 0x00000001u};
+    const uint32_t HALF_R[8] = {0x80000000u, 0x7fffffffu, 0x7fff2dffu, 0xa9ded201u, 0x04d0ec02u, 0x199cec04u, 0x94cebea4u, 0x39f6d3a9u};
+    // sg = k > (r - 1) / 2;  a = sg ? r - k : k
+    uint32_t gt = 0, decided = 0;
+#pragma unroll
+    for (int i = 7; i >= 0; i--) {
+        uint32_t g = k.l[i] > HALF_R[i], l = k.l[i] < HALF_R[i];
+        gt |= g & ~decided; decided |= g | l;
+    }
+    const uint32_t sg = gt & 1u;
+    uint32_t a[9], br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { uint32_t d = subb(FrP::mod(i), k.l[i], br); a[i] = sg ? d : k.l[i]; }
+    // a += hl  (a < 2^254 + 2^127)
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) a[i] = addc(a[i], i < 4 ? HL[i] : 0u, c);
+    a[8] = 0;
+    // t = a >> 127 (4 limbs);  prod = t * mu (9 limbs);  q = prod >> 129
+    uint32_t t[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) t[i] = (a[3 + i] >> 31) | (a[4 + i] << 1);
+    uint32_t prod[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) prod[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint64_t cy = 0;
+#pragma unroll
+        for (int j = 0; j < 5; j++) { uint64_t x = (uint64_t)t[i] * MU[j] + prod[i + j] + cy; prod[i + j] = (uint32_t)x; cy = x >> 32; }
+        prod[i + 5] = (uint32_t)cy;
+    }
+    uint32_t q[5];
+#pragma unroll
+    for (int i = 0; i < 4; i++) q[i] = (prod[4 + i] >> 1) | (prod[5 + i] << 31);
+    q[4] = 0;
+    // rem = a - q lambda (5 limbs are enough: rem < 3 lambda)
+    uint32_t ql[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) ql[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint64_t cy = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (i + j < 5) { uint64_t x = (uint64_t)q[i] * LAM[j] + ql[i + j] + cy; ql[i + j] = (uint32_t)x; cy = x >> 32; }
+        }
+        if (i + 4 < 5) ql[i + 4] += (uint32_t)cy;
+    }
+    uint32_t rem[5]; br = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) rem[i] = subb(a[i], ql[i], br);
+#pragma unroll
+    for (int rep = 0; rep < 2; rep++) {   // rem >= lambda: rem -= lambda, q += 1
+        uint32_t d[5]; uint32_t b2 = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) d[i] = subb(rem[i], i < 4 ? LAM[i] : 0u, b2);
+        const uint32_t ge = b2 ^ 1u;
+        uint32_t cc = ge;
+#pragma unroll
+        for (int i = 0; i < 5; i++) rem[i] = ge ? d[i] : rem[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { uint32_t x = q[i] + cc; cc = x < cc ? 1u : 0u; q[i] = x; }
+    }
+    // k1 = rem - hl (signed)
+    glv_halves o;
+    uint32_t d1[4], d2[4], b1 = 0, b2 = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { d1[i] = subb(rem[i], HL[i], b1); d2[i] = subb(HL[i], rem[i], b2); }
+#pragma unroll
+    for (int i = 0; i < 4; i++) { o.k1[i] = b1 ? d2[i] : d1[i]; o.k2[i] = q[i]; }
+    o.neg1 = sg ^ b1; o.neg2 = sg;
+    return o;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Jacobian arithmetic on unpacked, lazily reduced coordinates (fq) for the GLV scalar multiplication of the G1 FFT.
 // Bound invariant (value < B p): every point that lives in the loop has (X, Y, Z) <= (19, 20, 4).
@@ -406,6 +491,39 @@ KZG_HD g1j g1_mul_glv_fast(const g1j &p, const fr &kk, g1jq *tbl) {
         if (b) { g1jq q = tbl[(b < 0 ? -b : b) - 1]; if (b < 0) q.y = subq<20>(zero_q, q.y); q.x = mulq(q.x, beta); acc.add(q); }
     }
     return acc.inf ? g1_inf() : g1jq_pack(acc.v);
+}
+
+// the same regular schedule for a VARIABLE scalar split on the device (glv_split_signed): signs are applied to the digits, so
+// s1 |k1| P + s2 |k2| phi(P) costs exactly what g1_mul_glv_fast costs.  Result unpacked (bounds (19, 20, 4)); returns false for inf.
+KZG_HD bool g1_mul_glv_signed_q(const g1j &p, const glv_halves &h, g1jq *tbl, g1jq &out) {
+    tbl[0] = g1jq_unpack(p);
+    for (int i = 1; i < 16; i++) {
+        if (i & 1) tbl[i] = g1jq_dbl(tbl[i >> 1]);
+        else {
+            g1jq o;
+            if (!g1jq_add(o, tbl[i - 1], tbl[0])) o = g1jq_unpack(g1_add(g1jq_pack(tbl[i - 1]), p));   // cannot happen for points of G1
+            tbl[i] = o;
+        }
+    }
+    fr kk;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { kk.l[i] = h.k1[i]; kk.l[4 + i] = h.k2[i]; }
+    int8_t d1[27], d2[27];
+    uint32_t c1 = 0, c2 = 0;
+    for (int j = 0; j < 27; j++) { d1[j] = (int8_t)glv_digit5(kk, 0, j, c1); d2[j] = (int8_t)glv_digit5(kk, 4, j, c2); }
+    const fq beta = unpackq(glv_beta());
+    fq zero_q;
+#pragma unroll
+    for (int i = 0; i < 13; i++) zero_q.l[i] = 0;
+    g1jq_acc acc; acc.inf = true;
+    for (int j = 26; j >= 0; j--) {
+        for (int t = 0; t < 5; t++) acc.dbl();
+        int a = h.neg1 ? -d1[j] : d1[j], b = h.neg2 ? -d2[j] : d2[j];
+        if (a) { g1jq q = tbl[(a < 0 ? -a : a) - 1]; if (a < 0) q.y = subq<20>(zero_q, q.y); acc.add(q); }
+        if (b) { g1jq q = tbl[(b < 0 ? -b : b) - 1]; if (b < 0) q.y = subq<20>(zero_q, q.y); q.x = mulq(q.x, beta); acc.add(q); }
+    }
+    out = acc.v;
+    return !acc.inf;
 }
 
 // ---- width-5 NAF variant: what the G1 FFT stages run ------------------------------------------------------------------------

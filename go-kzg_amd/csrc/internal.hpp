@@ -53,6 +53,9 @@ void launch_g1_bitrev_copy(hipStream_t s, const g1j *in, uint64_t in_stride, uin
 // one radix-2 DIT stage on bit-reversed data (replaces the loop of _fftG1, fft_g1.go:44-55); `roots` holds the twiddles as
 // GLV pairs (k mod lambda, k div lambda) in standard form, see g1_mul_glv
 void launch_g1_fft_stage(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, uint64_t m, const fr *roots, uint64_t W);
+// latency mode: Stockham passes of radix 16 evaluated directly (k_g1.hip); result in data, tmp = batch x n scratch, scale optional
+void launch_g1_fft_direct(hipStream_t s, const g1j *in, uint64_t in_stride, uint64_t n_valid, g1j *data, g1j *tmp, uint64_t n, uint64_t batch, const fr *roots,
+                          uint64_t W, const fr *scale);
 // to_kilic: also leave the device-internal Montgomery domain (R' = 2^390) for Kilic's (2^384): every API output path ends here
 void launch_g1_normalize(hipStream_t s, const g1j *in, g1j *out, uint64_t n, bool to_kilic = false);
 void launch_g1_from_kilic(hipStream_t s, g1j *data, uint64_t n);   // in place: caller-supplied points enter the internal domain
@@ -63,17 +66,18 @@ void launch_g1_fixed_base_powers(hipStream_t s, const fr *powers, uint64_t n, g1
 
 // ---------------- k_msm.hip ----------------
 struct msm_plan {
-    uint32_t c;        // window bits (signed digits in [-2^(c-1), 2^(c-1)])
-    uint32_t nwin;     // windows
-    uint32_t nb;       // buckets per group = 2^(c-1)
-    uint32_t ngroups;  // nwin (per-window bucket sets) or 1 (fixed base: windows folded into the table)
-    uint32_t fixed;    // table holds 2^(c w) P_i at [w * table_n + i]
-    uint64_t table_n;  // points per window row of the table
+    uint32_t c;        // window bits (fixed-base walk: signed digits in [-2^(c-1), 2^(c-1)]; bucket MSM: always 8)
+    uint32_t nwin;     // windows of the fixed-base walk
+    uint32_t nb;       // 2^(c-1)
+    uint32_t ngroups;  // bucket MSM: 16 window groups (points only) or 8 (table also holds 2^64 P_i at [table_n + i])
+    uint32_t fixed;    // 1: plan of a fixed-base table (k_fb_*), 0: bucket MSM
+    uint64_t table_n;  // points per row of the table
 };
 size_t msm_workspace_bytes(const msm_plan &p, uint64_t n, uint64_t batch);
-// batch MSMs over the same affine table: out[b] = sum_i scalars[b][i] * P_i  (Jacobian, not normalised)
-void launch_msm(hipStream_t s, const msm_plan &p, const g1a *table, const fr *scalars, uint64_t n, uint64_t batch, void *workspace,
-                g1j *out);
+// batch MSMs over the same affine points, scalars in rows of sc_stride: out[b] = sum_i scalars[b][i] * P_i, NORMALISED (Z = one),
+// as Kilic images when to_kilic
+void launch_msm(hipStream_t s, const msm_plan &p, const g1a *table, const fr *scalars, uint64_t sc_stride, uint64_t n, uint64_t batch, void *workspace, g1j *out,
+                bool to_kilic);
 // fixed-base window table: out[w * n + i] = 2^(c w) * pts[i], affine
 void launch_msm_window_table(hipStream_t s, const g1a *pts, uint64_t n, uint32_t c, uint32_t nwin, g1j *tmp, g1a *out);
 

@@ -164,6 +164,87 @@ void launch_g1_fft_stage(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, u
     prof_end(s, "g1_fft_stage");
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Latency mode of the G1 transform (a lone FFTG1 / DAUsingFK20 call, fft_g1.go:58-94).  A radix-2 stage of one 4096-point transform
+// has 2048 butterflies = 32 wavefronts on 1024 SIMDs, and each stage costs the latency of one scalar multiplication (~2 ms): 12
+// stages are 22 ms on a GPU that is 97 % idle.  Here the transform runs as Stockham passes of radix R = 16 evaluated DIRECTLY:
+//   out[(j / Ns) Ns R + k + u Ns] = sum_{t < R} w^(t (n / (Ns R)) (Ns u + k)) * in[j + t n / R],   k = j mod Ns,
+// one lane per (output, term): 16 n lanes per pass, all independent, then a 4-level sum inside each group of 16 lanes.  7.5 times
+// the scalar multiplications of the radix-2 network, but only log16(n) sequential ones: 3 passes for n = 4096.  The scalars are
+// split on the device (glv_split_signed), so the 1 / n of the inverse transform is folded into the last pass.  Natural order in
+// and out (no bit reversal); `in` rows may be zero-padded (index >= n_valid -> inf).
+// ---------------------------------------------------------------------------------------------------------
+struct g1jq_slot { uint32_t w[39]; uint32_t inf; uint32_t pad; };            // 41 words: odd stride, no LDS bank conflicts
+#define G1_DIRECT_BLOCK 64              // one wavefront per workgroup: the dispatcher spreads 1024 of them over the 1024 SIMDs
+__global__ __launch_bounds__(G1_DIRECT_BLOCK, 2) void k_g1_fft_direct(const g1j *in, uint64_t in_stride, uint64_t n_valid, g1j *out, uint32_t logn, uint32_t logR,
+                                                            uint64_t Ns, const fr *roots, uint64_t W, const fr *scale, uint64_t total) {
+    __shared__ g1jq_slot buf[G1_DIRECT_BLOCK];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + tid;
+    const uint64_t n = 1ull << logn, R = 1ull << logR, cols = n >> logR;
+    const uint32_t tt = (uint32_t)(t & (R - 1));
+    const uint64_t u = (t >> logR) & (R - 1), jb = t >> (2 * logR), j = jb % cols, b = jb / cols;
+    const bool live = t < total;
+    g1jq_acc acc; acc.inf = true;
+    uint64_t oidx = 0;
+    if (live) {
+        const uint64_t k = j & (Ns - 1), idx = j + (uint64_t)tt * cols;
+        oidx = b * n + (j - k) * R + k + u * Ns;
+        g1j x = idx < n_valid ? in[b * in_stride + idx] : g1_inf();
+        if (!is_inf(x)) {
+            const uint64_t e = ((uint64_t)tt * (cols / Ns) * (Ns * u + k)) & (n - 1);
+            if (e == 0 && !scale) { acc.v = g1jq_unpack(x); acc.inf = false; }
+            else {
+                fr sc = roots[e * (W >> logn)];
+                if (scale) sc = mul(sc, *scale);
+                g1jq tbl[16];
+                acc.inf = !g1_mul_glv_signed_q(x, glv_split_signed(from_mont<FrP>(sc)), tbl, acc.v);
+            }
+        }
+    }
+    // sum of the R terms of an output: lanes tt = 0 .. R - 1 are adjacent
+    auto store = [&](uint32_t i) {
+#pragma unroll
+        for (int q = 0; q < 13; q++) { buf[i].w[q] = acc.v.x.l[q]; buf[i].w[13 + q] = acc.v.y.l[q]; buf[i].w[26 + q] = acc.v.z.l[q]; }
+        buf[i].inf = acc.inf ? 1u : 0u;
+    };
+    store(tid);
+    __syncthreads();
+#pragma nounroll
+    for (uint32_t off = (uint32_t)R / 2; off >= 1; off >>= 1) {
+        if (tt < off && !buf[tid + off].inf) {
+            g1jq q;
+#pragma unroll
+            for (int i = 0; i < 13; i++) { q.x.l[i] = buf[tid + off].w[i]; q.y.l[i] = buf[tid + off].w[13 + i]; q.z.l[i] = buf[tid + off].w[26 + i]; }
+            acc.add(q);
+            store(tid);
+        }
+        __syncthreads();
+    }
+    if (live && tt == 0) out[oidx] = acc.inf ? g1_inf() : g1jq_pack(acc.v);
+}
+// runs the passes; the result lands in `data` (batch x n).  tmp: batch x n scratch points.  scale: nullptr or a device Fr that
+// multiplies every output (folded into the last pass).
+void launch_g1_fft_direct(hipStream_t s, const g1j *in, uint64_t in_stride, uint64_t n_valid, g1j *data, g1j *tmp, uint64_t n, uint64_t batch, const fr *roots,
+                          uint64_t W, const fr *scale) {
+    const uint32_t logn = ilog2g(n);
+    uint32_t npass = (logn + 3) / 4;
+    if (!npass) { launch_g1_bitrev_copy(s, in, in_stride, n_valid, data, n, batch); return; }   // n == 1: copy (a 0-bit reversal)
+    // pass p writes data when the number of passes after it is even
+    const g1j *src = in; uint64_t src_stride = in_stride, src_valid = n_valid, Ns = 1;
+    uint32_t bits_left = logn;
+    prof_begin(s, "g1_fft_direct");
+    for (uint32_t p = 0; p < npass; p++) {
+        const uint32_t logR = bits_left >= 4 ? 4u : bits_left;
+        g1j *dst = ((npass - 1 - p) & 1u) ? tmp : data;
+        const uint64_t total = batch * n << logR;
+        hipLaunchKernelGGL(k_g1_fft_direct, dim3((uint32_t)((total + G1_DIRECT_BLOCK - 1) / G1_DIRECT_BLOCK)), dim3(G1_DIRECT_BLOCK), 0, s, src, src_stride, src_valid, dst, logn, logR, Ns,
+                           roots, W, (p + 1 == npass) ? scale : nullptr, total);
+        src = dst; src_stride = n; src_valid = n; Ns <<= logR; bits_left -= logR;
+    }
+    prof_end(s, "g1_fft_direct");
+}
+
 __global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_normalize(const g1j *in, g1j *out, uint64_t n, int to_kilic) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= n) return;

@@ -19,61 +19,83 @@ namespace kzg {
 
 #define MSM_SORT_T 1024
 #define MSM_ACC_BLOCK 128
+#define MSM_NB 128                      // buckets per window group: signed 8-bit digits, |d| in 1..128
 
+// a lane's XYZZ accumulator as it travels through LDS and the workspaces: the 4 x 13 lazy limbs as they are (no pack / unpack /
+// reduction between the walks and the trees) + the infinity flag.  53 words: an odd stride, so LDS trees have no bank conflicts.
+struct fb_partial { uint32_t w[52]; uint32_t inf; };
+__device__ __forceinline__ void fb_partial_store(fb_partial &o, const g1x_acc &a) {
+#pragma unroll
+    for (int i = 0; i < 13; i++) { o.w[i] = a.v.x.l[i]; o.w[13 + i] = a.v.y.l[i]; o.w[26 + i] = a.v.zz.l[i]; o.w[39 + i] = a.v.zzz.l[i]; }
+    o.inf = a.inf ? 1u : 0u;
+}
+__device__ __forceinline__ void fb_partial_load(const fb_partial &p, g1xq &v) {
+#pragma unroll
+    for (int i = 0; i < 13; i++) { v.x.l[i] = p.w[i]; v.y.l[i] = p.w[13 + i]; v.zz.l[i] = p.w[26 + i]; v.zzz.l[i] = p.w[39 + i]; }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Variable-base MSM (bls.LinCombG1 on caller-supplied points, bls/bls_kilic.go:132-150): Pippenger buckets over the GLV halves.
+//   k_i P_i = s1 |k1| P_i + s2 |k2| phi(P_i), |k1|, |k2| < 2^126.5 (glv_split_signed): 16 signed 8-bit windows per half, no carry
+//   out of the top one.  ngroups = 16: one bucket group per window (120 doublings in the final Horner);  ngroups = 8: the table
+//   also holds 2^64 P_i (a cached point set, kzg_hip_points_new), window w >= 8 of a half uses it and the Horner has 56 doublings.
+// Pipeline per blob:  sort (workgroup per blob, LDS histogram + scatter)  ->  accumulate (S lanes per bucket walk a share of its
+// list with mixed additions, LDS merge)  ->  reduce (128 lanes per window group: suffix scan + tree, sum_d d B_d = sum_m
+// sum_{d >= m} B_d)  ->  combine (Horner over the groups, then normalise).  Everything between the kernels is lazy XYZZ limbs.
+// Sums are taken in a data-dependent order; the group law is commutative and the result is normalised, so the output bytes do
+// not depend on it.
+// ---------------------------------------------------------------------------------------------------------
 struct msm_ws_layout {
     size_t entries_off, offsets_off, buckets_off, gsum_off, per_blob;
     uint64_t K, nent;
 };
 static msm_ws_layout ws_layout(const msm_plan &p, uint64_t n) {
     msm_ws_layout L;
-    L.K = (uint64_t)p.ngroups * p.nb;
-    L.nent = n * p.nwin;
+    L.K = (uint64_t)p.ngroups * MSM_NB;
+    L.nent = n * 32;                                      // 2 halves x 16 windows
     size_t o = 0;
     L.entries_off = o; o += ((L.nent * 4 + 15) / 16) * 16;
     L.offsets_off = o; o += (((L.K + 1) * 4 + 15) / 16) * 16;
-    L.buckets_off = o; o += L.K * sizeof(g1j);
-    L.gsum_off = o; o += (size_t)p.ngroups * sizeof(g1j);
+    L.buckets_off = o; o += ((L.K * sizeof(fb_partial) + 15) / 16) * 16;
+    L.gsum_off = o; o += (((size_t)p.ngroups * sizeof(fb_partial) + 15) / 16) * 16;
     L.per_blob = o;
     return L;
 }
 size_t msm_workspace_bytes(const msm_plan &p, uint64_t n, uint64_t batch) { return ws_layout(p, n).per_blob * batch; }
 
-__device__ __forceinline__ uint32_t scalar_bits(const fr &k, uint32_t off, uint32_t c) {
-    uint32_t idx = off >> 5, sh = off & 31;
-    if (idx >= 8) return 0;
-    uint64_t v = k.l[idx];
-    if (idx + 1 < 8) v |= (uint64_t)k.l[idx + 1] << 32;
-    return (uint32_t)(v >> sh) & ((1u << c) - 1u);
-}
-
-// visits every non-zero signed digit of scalar k: f(window, |digit|, negative)
-template <class Fn> __device__ __forceinline__ void for_each_digit(const fr &k, uint32_t c, uint32_t nwin, uint32_t nb, Fn f) {
-    uint32_t carry = 0;
-    for (uint32_t w = 0; w < nwin; w++) {
-        uint32_t raw = scalar_bits(k, w * c, c) + carry;
-        if (raw > nb) { carry = 1; uint32_t mag = (1u << c) - raw; if (mag) f(w, mag, 1u); }   // raw == 2^c: digit 0, carry 1
-        else { carry = 0; if (raw) f(w, raw, 0u); }
+// visits every non-zero signed digit of the GLV halves of scalar k (Montgomery form): f(window 0..15, |digit| 1..128, half, negative)
+template <class Fn> __device__ __forceinline__ void for_each_glv_digit(const fr &k_mont, Fn f) {
+    const glv_halves h = glv_split_signed(from_mont<FrP>(k_mont));   // Kilic FromRed (bls_kilic.go:141-147), then the split
+#pragma unroll
+    for (uint32_t half = 0; half < 2; half++) {
+        const uint32_t *mag = half ? h.k2 : h.k1;
+        const uint32_t sgn = half ? h.neg2 : h.neg1;
+        uint32_t carry = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 16; w++) {
+            uint32_t raw = ((mag[w >> 2] >> ((w & 3) * 8)) & 255u) + carry;
+            if (raw > MSM_NB) { carry = 1; f(w, 256u - raw, half, sgn ^ 1u); }       // raw <= 256: 256 - raw in 0..127; 0 -> digit 0, carry 1
+            else { carry = 0; f(w, raw, half, sgn); }
+        }
     }
 }
 
-__global__ __launch_bounds__(MSM_SORT_T) void k_msm_sort(msm_plan p, const fr *scalars, uint64_t n, uint8_t *ws, size_t per_blob, size_t entries_off,
-                                                         size_t offsets_off, uint32_t K) {
+__global__ __launch_bounds__(MSM_SORT_T) void k_msm_sort(uint32_t ngroups, uint64_t table_n, const fr *scalars, uint64_t sc_stride, uint64_t n, uint8_t *ws,
+                                                         size_t per_blob, size_t entries_off, size_t offsets_off, uint32_t K) {
     extern __shared__ uint32_t smem[];
     uint32_t *hist = smem, *part = smem + K;
     const uint32_t tid = threadIdx.x;
     const uint64_t b = blockIdx.x;
-    const fr *sc = scalars + b * n;
+    const fr *sc = scalars + b * sc_stride;
     uint32_t *entries = (uint32_t *)(ws + b * per_blob + entries_off);
     uint32_t *offsets = (uint32_t *)(ws + b * per_blob + offsets_off);
+    const uint32_t wmask = ngroups - 1;                     // 15: a group per window; 7: windows 8..15 fold onto 0..7 (2^64 P_i rows)
     for (uint32_t i = tid; i < K; i += MSM_SORT_T) hist[i] = 0;
     __syncthreads();
-    for (uint64_t i = tid; i < n; i += MSM_SORT_T) {
-        fr k = from_mont<FrP>(sc[i]);
-        for_each_digit(k, p.c, p.nwin, p.nb, [&](uint32_t w, uint32_t mag, uint32_t) {
-            uint32_t key = (p.fixed ? 0u : w * p.nb) + mag - 1;
-            atomicAdd(&hist[key], 1u);
+    for (uint64_t i = tid; i < n; i += MSM_SORT_T)
+        for_each_glv_digit(sc[i], [&](uint32_t w, uint32_t mag, uint32_t, uint32_t) {
+            if (mag) atomicAdd(&hist[(w & wmask) * MSM_NB + mag - 1], 1u);
         });
-    }
     __syncthreads();
     // exclusive prefix sum over K bins: per-thread chunk sums, block scan of the 1024 partials, write back
     const uint32_t per = (K + MSM_SORT_T - 1) / MSM_SORT_T;
@@ -91,103 +113,220 @@ __global__ __launch_bounds__(MSM_SORT_T) void k_msm_sort(msm_plan p, const fr *s
     for (uint32_t i = lo; i < hi; i++) { uint32_t cnt = hist[i]; offsets[i] = run; hist[i] = run; run += cnt; }
     if (tid == MSM_SORT_T - 1) offsets[K] = part[tid];
     __syncthreads();
-    for (uint64_t i = tid; i < n; i += MSM_SORT_T) {
-        fr k = from_mont<FrP>(sc[i]);
-        for_each_digit(k, p.c, p.nwin, p.nb, [&](uint32_t w, uint32_t mag, uint32_t neg) {
-            uint32_t key = (p.fixed ? 0u : w * p.nb) + mag - 1;
-            uint32_t slot = atomicAdd(&hist[key], 1u);
-            uint32_t tidx = p.fixed ? (uint32_t)(w * p.table_n + i) : (uint32_t)i;
-            entries[slot] = (tidx << 1) | neg;
+    for (uint64_t i = tid; i < n; i += MSM_SORT_T)
+        for_each_glv_digit(sc[i], [&](uint32_t w, uint32_t mag, uint32_t half, uint32_t neg) {
+            if (!mag) return;
+            uint32_t slot = atomicAdd(&hist[(w & wmask) * MSM_NB + mag - 1], 1u);
+            uint32_t pidx = (uint32_t)i + ((w & ~wmask) ? (uint32_t)table_n : 0u);      // window >= 8 of a folded plan: the 2^64 P_i row
+            entries[slot] = (pidx << 2) | (half << 1) | neg;
         });
-    }
 }
 
+// S lanes per (blob, bucket): each walks its share of the bucket's sorted list, then the S partial sums are merged through LDS
 __global__ __launch_bounds__(MSM_ACC_BLOCK, 2) void k_msm_accumulate(const g1a *table, uint8_t *ws, size_t per_blob, size_t entries_off, size_t offsets_off,
-                                                                  size_t buckets_off, uint32_t K, uint64_t total) {
-    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    uint64_t b = t / K; uint32_t key = (uint32_t)(t % K);
-    const uint32_t *entries = (const uint32_t *)(ws + b * per_blob + entries_off);
-    const uint32_t *offsets = (const uint32_t *)(ws + b * per_blob + offsets_off);
-    g1j *buckets = (g1j *)(ws + b * per_blob + buckets_off);
-    uint32_t s = offsets[key], e = offsets[key + 1];
+                                                                  size_t buckets_off, uint32_t K, uint32_t S, uint64_t total) {
+    __shared__ fb_partial buf[MSM_ACC_BLOCK];
+    const uint32_t tid = threadIdx.x;
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + tid;
+    const bool live = t < total;
+    const uint32_t sidx = (uint32_t)(t % S);
+    const uint64_t bk = t / S;
+    const uint64_t b = bk / K; const uint32_t key = (uint32_t)(bk % K);
     g1x_acc acc; acc.init();
+    if (live) {
+        const uint32_t *entries = (const uint32_t *)(ws + b * per_blob + entries_off);
+        const uint32_t *offsets = (const uint32_t *)(ws + b * per_blob + offsets_off);
+        const uint32_t s0 = offsets[key], len = offsets[key + 1] - s0;
+        const uint32_t s = s0 + (uint32_t)((uint64_t)len * sidx / S), e = s0 + (uint32_t)((uint64_t)len * (sidx + 1) / S);
 #pragma nounroll
-    for (uint32_t i = s; i < e; i++) {
-        uint32_t en = entries[i];
-        g1a q = table[en >> 1];
-        if (en & 1u) q.y = neg<FpP>(q.y);
-        acc.add(q);
+        for (uint32_t i = s; i < e; i++) {
+            const uint32_t en = entries[i];
+            g1a q = table[en >> 2];
+            if (en & 2u) q.x = mul(q.x, glv_beta());       // phi(x, y) = (beta x, y)
+            if (en & 1u) q.y = neg<FpP>(q.y);
+            acc.add(q);
+        }
     }
-    buckets[key] = acc.to_jac();
+    if (S > 1) {                                           // block-uniform: S divides the block size
+        fb_partial_store(buf[tid], acc);
+        __syncthreads();
+#pragma nounroll
+        for (uint32_t off = S / 2; off >= 1; off >>= 1) {
+            if (sidx < off) {
+                g1xq v; fb_partial_load(buf[tid + off], v);
+                g1x_acc_merge(acc, v, buf[tid + off].inf != 0);
+                fb_partial_store(buf[tid], acc);
+            }
+            __syncthreads();
+        }
+    }
+    if (live && sidx == 0) fb_partial_store(((fb_partial *)(ws + b * per_blob + buckets_off))[key], acc);
 }
 
-// sum_{k=1..nb} k * B_k for one (blob, group): 64 lanes x segments of m = nb / 64 buckets
-__global__ __launch_bounds__(64) void k_msm_reduce(uint8_t *ws, size_t per_blob, size_t buckets_off, size_t gsum_off, uint32_t nb, uint32_t ngroups) {
-    __shared__ g1j buf[64];
-    const uint32_t lane = threadIdx.x;
+// sum_{d=1..128} d * B_d for one (blob, window group) = sum_m T_m with the suffix sums T_m = sum_{d >= m} B_d: a Hillis-Steele
+// suffix scan over the 128 lanes (7 steps) and a tree sum (7 steps), every step one lazy XYZZ + XYZZ addition
+__global__ __launch_bounds__(MSM_NB) void k_msm_reduce(uint8_t *ws, size_t per_blob, size_t buckets_off, size_t gsum_off, uint32_t ngroups) {
+    __shared__ fb_partial buf[MSM_NB];
+    const uint32_t d = threadIdx.x;
     const uint64_t b = blockIdx.x / ngroups; const uint32_t g = blockIdx.x % ngroups;
-    const g1j *buckets = (const g1j *)(ws + b * per_blob + buckets_off) + (uint64_t)g * nb;
-    g1j *gsum = (g1j *)(ws + b * per_blob + gsum_off);
-    const uint32_t m = nb >= 64 ? nb / 64 : 1;
-    const uint32_t lo = lane * m, hi = lo + m;
-    g1j s = g1_inf(), w = g1_inf();
-    if (lo < nb) {
-#pragma nounroll
-        for (uint32_t k = hi; k-- > lo;) { s = g1_add(s, buckets[k]); w = g1_add(w, s); }
-    }
-    // T1 = sum_L w_L
-    buf[lane] = w;
+    const fb_partial *buckets = (const fb_partial *)(ws + b * per_blob + buckets_off) + (uint64_t)g * MSM_NB;
+    g1x_acc acc; acc.inf = buckets[d].inf != 0;
+    if (!acc.inf) fb_partial_load(buckets[d], acc.v);
+    fb_partial_store(buf[d], acc);
     __syncthreads();
 #pragma nounroll
-    for (uint32_t off = 32; off >= 1; off >>= 1) {
-        if (lane < off) buf[lane] = g1_add(buf[lane], buf[lane + off]);
+    for (uint32_t off = 1; off < MSM_NB; off <<= 1) {
+        g1xq v; bool vinf = true;
+        if (d + off < MSM_NB) { vinf = buf[d + off].inf != 0; if (!vinf) fb_partial_load(buf[d + off], v); }
+        __syncthreads();
+        if (!vinf) { g1x_acc_merge(acc, v, false); fb_partial_store(buf[d], acc); }
         __syncthreads();
     }
-    g1j t1 = buf[0];
-    __syncthreads();
-    // T2 = sum_L L * s_L
-    buf[lane] = g1_mul_small(s, lane);
-    __syncthreads();
 #pragma nounroll
-    for (uint32_t off = 32; off >= 1; off >>= 1) {
-        if (lane < off) buf[lane] = g1_add(buf[lane], buf[lane + off]);
+    for (uint32_t off = MSM_NB / 2; off >= 1; off >>= 1) {
+        if (d < off) {
+            g1xq v; fb_partial_load(buf[d + off], v);
+            g1x_acc_merge(acc, v, buf[d + off].inf != 0);
+            fb_partial_store(buf[d], acc);
+        }
         __syncthreads();
     }
-    if (lane == 0) gsum[g] = g1_add(t1, g1_mul_small(buf[0], m));
+    if (d == 0) fb_partial_store(((fb_partial *)(ws + b * per_blob + gsum_off))[g], acc);
 }
 
-__global__ __launch_bounds__(64) void k_msm_combine(uint8_t *ws, size_t per_blob, size_t gsum_off, uint32_t c, uint32_t ngroups, uint64_t batch, g1j *out) {
-    uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    if (b >= batch) return;
-    const g1j *gsum = (const g1j *)(ws + b * per_blob + gsum_off);
-    // ~250 doublings on the critical path of ONE lane: lazy unpacked coordinates (8.5 us per doubling instead of 15)
-    g1jq_acc acc; acc.inf = true;
+// ---------------------------------------------------------------------------------------------------------
+// Wave-cooperative XYZZ arithmetic for the serial tails.  A chain of dependent group operations on ONE point (the Horner over the
+// window groups: 120 doublings) is bound by the latency of one F_p product after the other on one SIMD.  The products INSIDE a
+// doubling / addition are mostly independent, so the four wavefronts of a 256-thread workgroup (one per SIMD of the CU) each take
+// one product of a dependency level and exchange the results through LDS: a doubling is 3 levels deep instead of 9 products, an
+// addition 4 instead of 13.  Lane column c of every wave works on the same point c (64 points per workgroup); all four waves keep
+// a full replica of the running point, so control flow stays identical across them.
+// LDS: two alternating sets of four 13-limb slots per column, limb-major (conflict-free), one barrier per level.
+// ---------------------------------------------------------------------------------------------------------
+struct coop_lds { uint32_t x[2][4][13][64]; };
+struct coop_ctx {
+    coop_lds *L; uint32_t wave, col, set;
+    __device__ __forceinline__ void put(const fq &v) {
+#pragma unroll
+        for (int i = 0; i < 13; i++) L->x[set][wave][i][col] = v.l[i];
+    }
+    __device__ __forceinline__ fq get(uint32_t slot) const {
+        fq v;
+#pragma unroll
+        for (int i = 0; i < 13; i++) v.l[i] = L->x[set][slot][i][col];
+        return v;
+    }
+    __device__ __forceinline__ void exchange() { __syncthreads(); }          // after put(), before get(): one barrier per level
+    __device__ __forceinline__ void next() { set ^= 1u; }                    // the following level writes the other set
+};
+// p <- 2 p (dbl-2008-s-1, a = 0) on lazy limbs, bounds (X, Y, ZZ, ZZZ) <= (11, 5, 2, 2) in and out:
+//   U = 2 Y : 10;  V = U^2, XX = X^2 : 2 (100, 121 <= 600);  M = 3 XX : 6;  W = U V, S = X V, ZZ' = V ZZ, MM = M^2 : 2
+//   X' = MM - 2 S (M = 5) : 7;  T1 = M (S - X') (S - X' with M = 8 : 10, 60), T2 = W Y : 2;  Y' = T1 - T2 (M = 3) : 5;  ZZZ' = W ZZZ : 2
+__device__ __forceinline__ void coop_xyzz_dbl(g1xq &p, coop_ctx &c) {
+    const fq u = addq(p.y, p.y);
+    fq mine;
+    if (c.wave == 0) mine = sqrq(u); else if (c.wave == 1) mine = sqrq(p.x); else mine = u;
+    c.put(mine); c.exchange();
+    const fq v = c.get(0), xx = c.get(1);
+    c.next();
+    const fq m = addq(addq(xx, xx), xx);
+    if (c.wave == 0) mine = mulq(u, v); else if (c.wave == 1) mine = mulq(p.x, v); else if (c.wave == 2) mine = mulq(v, p.zz); else mine = sqrq(m);
+    c.put(mine); c.exchange();
+    const fq w = c.get(0), s_ = c.get(1), zz3 = c.get(2), mm = c.get(3);
+    c.next();
+    const fq x3 = subq<5>(mm, addq(s_, s_));
+    if (c.wave == 0) mine = mulq(m, subq<8>(s_, x3)); else if (c.wave == 1) mine = mulq(w, p.y); else mine = mulq(w, p.zzz);
+    c.put(mine); c.exchange();
+    const fq t1 = c.get(0), t2 = c.get(1), zzz3 = c.get(2);
+    c.next();
+    p.x = x3; p.y = subq<3>(t1, t2); p.zz = zz3; p.zzz = zzz3;
+}
+// a <- a + b (add-2008-s), bounds as in g1xq_add_fast.  Returns false when P == 0 (equal / opposite operands): `a` is then
+// untouched and the caller takes the generic path.  All four waves compute the same verdict.
+__device__ __forceinline__ bool coop_xyzz_add(g1xq &a, const g1xq &b, coop_ctx &c) {
+    fq mine;
+    if (c.wave == 0) mine = mulq(a.x, b.zz); else if (c.wave == 1) mine = mulq(b.x, a.zz); else if (c.wave == 2) mine = mulq(a.y, b.zzz); else mine = mulq(b.y, a.zzz);
+    c.put(mine); c.exchange();
+    const fq u1 = c.get(0), u2 = c.get(1), s1 = c.get(2), s2 = c.get(3);
+    c.next();
+    const fq pp_ = subq<3>(u2, u1), r = subq<3>(s2, s1);
+    if (c.wave == 0) mine = sqrq(pp_); else if (c.wave == 1) mine = sqrq(r); else if (c.wave == 2) mine = mulq(a.zz, b.zz); else mine = mulq(a.zzz, b.zzz);
+    c.put(mine); c.exchange();
+    const fq pp = c.get(0), rr = c.get(1), zz12 = c.get(2), zzz12 = c.get(3);
+    c.next();
+    const bool ok = !is_zero_mod_p_q(pp);
+    if (c.wave == 0) mine = mulq(pp_, pp); else if (c.wave == 1) mine = mulq(u1, pp); else mine = mulq(zz12, pp);
+    c.put(mine); c.exchange();
+    const fq ppp = c.get(0), q_ = c.get(1), zz3 = c.get(2);
+    c.next();
+    const fq x3 = subq<3>(subq<3>(subq<3>(rr, ppp), q_), q_);
+    if (c.wave == 0) mine = mulq(r, subq<12>(q_, x3)); else if (c.wave == 1) mine = mulq(s1, ppp); else mine = mulq(zzz12, ppp);
+    c.put(mine); c.exchange();
+    const fq t1 = c.get(0), t2 = c.get(1), zzz3 = c.get(2);
+    c.next();
+    if (ok) { a.x = x3; a.y = subq<3>(t1, t2); a.zz = zz3; a.zzz = zzz3; }
+    return ok;
+}
+
+// Horner over the window groups (8 doublings per group), then normalise and convert.  The doublings are the critical path of a
+// lone MSM (120 for 16 groups, 56 for 8): workgroup = 4 cooperating waves, lane column = blob (64 blobs per workgroup).
+__global__ __launch_bounds__(256) void k_msm_combine(uint8_t *ws, size_t per_blob, size_t gsum_off, uint32_t ngroups, uint64_t batch, g1j *out, int to_kilic) {
+    __shared__ coop_lds lds;
+    coop_ctx c; c.L = &lds; c.wave = threadIdx.x >> 6; c.col = threadIdx.x & 63u; c.set = 0;
+    const uint64_t b = blockIdx.x * 64ull + c.col;
+    const bool live = b < batch;
+    const fb_partial *gsum = (const fb_partial *)(ws + (live ? b : 0) * per_blob + gsum_off);
+    g1x_acc acc; acc.init();
+    acc.v = g1xq_from_affine(g1a_inf());                   // defined limbs while the accumulator is still empty (results are discarded)
 #pragma nounroll
     for (uint32_t g = ngroups; g-- > 0;) {
 #pragma nounroll
-        for (uint32_t j = 0; j < c; j++) acc.dbl();
-        g1j w = gsum[g];
-        if (!is_inf(w)) acc.add(g1jq_unpack(w));
+        for (uint32_t j = 0; j < 8; j++) {                 // barriers inside: every thread runs the doubling, empty accumulators ignore it
+            g1xq d = acc.v;
+            coop_xyzz_dbl(d, c);
+            if (!acc.inf) acc.v = d;
+        }
+        const bool winf = !live || gsum[g].inf != 0;
+        g1xq w;
+        if (winf) w = acc.v; else fb_partial_load(gsum[g], w);
+        g1xq sum = acc.v;
+        const bool ok = coop_xyzz_add(sum, w, c);
+        if (winf) continue;                                // nothing to add (the barriers above were still executed by everyone)
+        if (acc.inf) { acc.v = w; acc.inf = false; }
+        else if (ok) acc.v = sum;
+        else g1x_acc_merge(acc, w, false);                 // equal or opposite operands: generic complete formulas, same on all four waves
     }
-    out[b] = acc.inf ? g1_inf() : g1jq_pack(acc.v);
+    if (live && c.wave == 0) {
+        g1j r;
+        if (acc.inf) r = g1_inf();
+        else {   // x = X / ZZ, y = Y / ZZZ with one inversion
+            g1x px = g1xq_pack(acc.v);
+            fp i = inv<FpP>(mul(px.zz, px.zzz));
+            r.x = mul(px.x, mul(i, px.zzz)); r.y = mul(px.y, mul(i, px.zz)); r.z = one<FpP>();
+        }
+        out[b] = to_kilic ? g1_to_kilic(r) : r;
+    }
 }
 
-void launch_msm(hipStream_t s, const msm_plan &p, const g1a *table, const fr *scalars, uint64_t n, uint64_t batch, void *workspace, g1j *out) {
+void launch_msm(hipStream_t s, const msm_plan &p, const g1a *table, const fr *scalars, uint64_t sc_stride, uint64_t n, uint64_t batch, void *workspace, g1j *out,
+                bool to_kilic) {
     if (!batch) return;
     msm_ws_layout L = ws_layout(p, n);
     uint8_t *ws = (uint8_t *)workspace;
     uint32_t K = (uint32_t)L.K;
     size_t sh = (size_t)(K + MSM_SORT_T) * 4;
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_msm_sort), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(k_msm_sort, dim3((uint32_t)batch), dim3(MSM_SORT_T), sh, s, p, scalars, n, ws, L.per_blob, L.entries_off, L.offsets_off, K);
-    uint64_t total = batch * L.K;
+    hipLaunchKernelGGL(k_msm_sort, dim3((uint32_t)batch), dim3(MSM_SORT_T), sh, s, p.ngroups, p.table_n, scalars, sc_stride, n, ws, L.per_blob, L.entries_off,
+                       L.offsets_off, K);
+    // lanes per bucket: fill one round of resident wavefronts (131 072 lanes) when the batch alone does not, at most 16
+    uint32_t S = 1;
+    while (S < 16 && batch * L.K * S * 2 <= 131072) S *= 2;
+    uint64_t total = batch * L.K * S;
     prof_begin(s, "msm_accumulate");
     hipLaunchKernelGGL(k_msm_accumulate, dim3((uint32_t)((total + MSM_ACC_BLOCK - 1) / MSM_ACC_BLOCK)), dim3(MSM_ACC_BLOCK), 0, s, table, ws, L.per_blob,
-                       L.entries_off, L.offsets_off, L.buckets_off, K, total);
+                       L.entries_off, L.offsets_off, L.buckets_off, K, S, total);
     prof_end(s, "msm_accumulate");
-    hipLaunchKernelGGL(k_msm_reduce, dim3((uint32_t)(batch * p.ngroups)), dim3(64), 0, s, ws, L.per_blob, L.buckets_off, L.gsum_off, p.nb, p.ngroups);
-    hipLaunchKernelGGL(k_msm_combine, dim3((uint32_t)((batch + 63) / 64)), dim3(64), 0, s, ws, L.per_blob, L.gsum_off, p.c, p.ngroups, batch, out);
+    hipLaunchKernelGGL(k_msm_reduce, dim3((uint32_t)(batch * p.ngroups)), dim3(MSM_NB), 0, s, ws, L.per_blob, L.buckets_off, L.gsum_off, p.ngroups);
+    hipLaunchKernelGGL(k_msm_combine, dim3((uint32_t)((batch + 63) / 64)), dim3(256), 0, s, ws, L.per_blob, L.gsum_off, p.ngroups, batch, out, to_kilic ? 1 : 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -254,19 +393,6 @@ __global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_build_pass2(uint64_t lanes, 
     }
 }
 
-// a lane's XYZZ accumulator as it travels through LDS and the partial-sum workspace: the 4 x 13 lazy limbs as they are (no
-// pack / unpack / reduction between the walk and the trees) + the infinity flag.  53 words: an odd stride, so the LDS tree has no
-// bank conflicts.
-struct fb_partial { uint32_t w[52]; uint32_t inf; };
-__device__ __forceinline__ void fb_partial_store(fb_partial &o, const g1x_acc &a) {
-#pragma unroll
-    for (int i = 0; i < 13; i++) { o.w[i] = a.v.x.l[i]; o.w[13 + i] = a.v.y.l[i]; o.w[26 + i] = a.v.zz.l[i]; o.w[39 + i] = a.v.zzz.l[i]; }
-    o.inf = a.inf ? 1u : 0u;
-}
-__device__ __forceinline__ void fb_partial_load(const fb_partial &p, g1xq &v) {
-#pragma unroll
-    for (int i = 0; i < 13; i++) { v.x.l[i] = p.w[i]; v.y.l[i] = p.w[13 + i]; v.zz.l[i] = p.w[26 + i]; v.zzz.l[i] = p.w[39 + i]; }
-}
 // block-wide sum of the lanes' accumulators into lane 0's: log2(FB_BLOCK) levels of the lazy XYZZ + XYZZ addition through LDS
 __device__ __forceinline__ void fb_block_reduce(g1x_acc &acc, fb_partial *buf, uint32_t tid) {
     fb_partial_store(buf[tid], acc);
@@ -280,6 +406,14 @@ __device__ __forceinline__ void fb_block_reduce(g1x_acc &acc, fb_partial *buf, u
         }
         __syncthreads();
     }
+}
+
+__device__ __forceinline__ uint32_t scalar_bits(const fr &k, uint32_t off, uint32_t c) {
+    uint32_t idx = off >> 5, sh = off & 31;
+    if (idx >= 8) return 0;
+    uint64_t v = k.l[idx];
+    if (idx + 1 < 8) v |= (uint64_t)k.l[idx + 1] << 32;
+    return (uint32_t)(v >> sh) & ((1u << c) - 1u);
 }
 
 // main kernel: lane handles points i = lane, lane + L, ... of one blob; block tree-reduces through LDS

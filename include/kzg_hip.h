@@ -80,6 +80,17 @@ int kzg_hip_fr_to_le32(kzg_hip_fft *fs, const void *in_fr, uint64_t n, void *out
 
 /* ---- bls.LinCombG1 (bls/bls_kilic.go:132-150): Pippenger MSM; n == 0 -> infinity ---- */
 int kzg_hip_lincomb_g1(kzg_hip_fft *fs, const void *points_g1, const void *scalars_fr, uint64_t n, void *out_g1);
+/* Cached point set for repeated LinCombG1 on the SAME points (CommitToEvalPoly's IFFT of the setup, kzg_single_proofs.go:12-14;
+ * the Lagrange setup of eth/helpers.go:99,159,199): uploaded and converted once, resident in HBM with its 2^64 multiples.
+ * kzg_hip_lincomb_points[_batch]: out[b] = LinCombG1(points[:n], scalars[b]); n <= the set's size (KZG_HIP_ERR_LEN_MISMATCH
+ * otherwise, the reference's length-mismatch panic); n == 0 -> infinity.  The _dev form takes device pointers and a stream. */
+typedef struct kzg_hip_points kzg_hip_points;
+int kzg_hip_points_new(kzg_hip_fft *fs, const void *points_g1, uint64_t n, kzg_hip_points **out);
+void kzg_hip_points_free(kzg_hip_points *pts);
+uint64_t kzg_hip_points_count(const kzg_hip_points *pts);
+int kzg_hip_lincomb_points(kzg_hip_points *pts, const void *scalars_fr, uint64_t n, void *out_g1);
+int kzg_hip_lincomb_points_batch(kzg_hip_points *pts, const void *scalars_fr, uint64_t n, uint64_t batch, void *out_g1);
+int kzg_hip_lincomb_points_batch_dev(kzg_hip_points *pts, const void *d_scalars_fr, uint64_t n, uint64_t batch, void *d_out_g1, void *stream);
 /* bls.ToCompressedG1 over a slice (bls/bls_kilic.go:114-116): n points -> n x 48 B ZCash form */
 int kzg_hip_g1_to_compressed(kzg_hip_fft *fs, const void *points_g1, uint64_t n, void *out48);
 /* bls.FromCompressedG1 over a slice (bls/bls_kilic.go:118-121) */

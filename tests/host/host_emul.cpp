@@ -106,3 +106,12 @@ int he_g1jq_add_entry(g1j *o, const g1j *a, const g1j *b, int negate) {
 }
 int he_g1_equal(const g1j *a, const g1j *b) { return g1_equal(IN(a), IN(b)); }
 }
+
+// balanced GLV split of a standard-form scalar: out = k1[4] | k2[4] | neg1 | neg2 (10 x u32)
+extern "C" void he_glv_split_signed(uint32_t *out, const uint32_t *k_std) {
+    kzg::fr k;
+    for (int i = 0; i < 8; i++) k.l[i] = k_std[i];
+    kzg::glv_halves h = kzg::glv_split_signed(k);
+    for (int i = 0; i < 4; i++) { out[i] = h.k1[i]; out[4 + i] = h.k2[i]; }
+    out[8] = h.neg1; out[9] = h.neg2;
+}

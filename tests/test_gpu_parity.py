@@ -272,6 +272,51 @@ def test_lincomb_matches_oracle(kz, fs16, n):
         fs16.lin_comb_g1(pts, ko.fr_empty(n + 1))
 
 
+LAMBDA = 0xac45a4010001a40200000000ffffffff
+
+
+def test_lincomb_edge_scalars_and_cached_points(kz, fs16, setup_1337):
+    """bls.LinCombG1 through the GLV bucket pipeline: scalars around the split boundaries (0, +-1, lambda, r/2, digits 0x80 / 0x7f
+    that carry through every window) and a cached point set (kzg_hip_points_*: the same points, 2^64 multiples resident) --
+    every result against the oracle's Kilic-style MultiExp, ragged lengths, a batch, infinity and duplicate points included"""
+    r = ko.R_MOD
+    edge = [0, 1, 2, r - 1, r - 2, LAMBDA, LAMBDA - 1, LAMBDA + 1, LAMBDA // 2, LAMBDA // 2 + 1, (r - 1) // 2, (r + 1) // 2, r - LAMBDA,
+            int("80" * 31, 16), int("7f" * 31, 16), int("ff" * 31, 16), int("0180" * 15, 16), (1 << 254) % r, (1 << 128) - 1, 1 << 64, (1 << 64) - 1]
+    n = 300
+    rng = np.random.default_rng(300)
+    pts = setup_1337[:n].copy()
+    pts[5] = ko.g1_zero()[0]
+    pts[7] = pts[6]
+    pts[9] = ko.g1_sub(ko.g1_zero()[0], pts[8])
+    scal = rand_fr(rng, n)
+    scal[:len(edge)] = ko.fr_from_ints(edge)
+    scal[8] = scal[9]                                       # k P + k (-P): a bucket that sums to infinity
+    want = ko.lincomb_g1(pts, scal)
+    assert_points_equal(fs16.lin_comb_g1(pts, scal), want)
+    cached = kz.G1Points(fs16, pts)
+    assert_points_equal(cached.lin_comb(scal), want)
+    for m in (1, 2, 21, 299):                               # LinCombG1(points[:m], scalars[:m])
+        assert_points_equal(cached.lin_comb(scal[:m]), ko.lincomb_g1(pts[:m], scal[:m]))
+    batch = np.stack([scal, np.roll(scal, 3, axis=0), rand_fr(rng, n)])
+    got = cached.lin_comb_batch(batch)
+    for b in range(3):
+        assert_points_equal(got[b], ko.lincomb_g1(pts, batch[b]))
+    assert np.array_equal(cached.lin_comb(ko.fr_empty(0)), ko.g1_zero()[0])
+    with pytest.raises(kz.KzgPanic):
+        cached.lin_comb(rand_fr(rng, n + 1))
+    cached.close()
+    # full size: CommitToEvalPoly's use (kzg_single_proofs.go:12-14) with the Lagrange setup as the cached set == vector F (eth form)
+    lag = ko.reverse_bit_order(ko.g1_decompress(np.frombuffer(open(os.path.join(GOLDEN, "trusted_setup_g1_lagrange.bin"), "rb").read(), dtype=np.uint8)))
+    fs12 = kz.FFTSettings(12)
+    lag_set = kz.G1Points(fs12, lag)
+    blobs = np.stack([ko.synthetic_blob(1 + b) for b in range(4)])
+    got = lag_set.lin_comb_batch(blobs)
+    assert comp_hex(got[:1])[0] == DERIVED["F_blob_seed1"]["commit_eth_bitrev_lagrange"]
+    assert_points_equal(got[3], ko.lincomb_g1(lag, blobs[3]))
+    assert np.array_equal(lag_set.lin_comb(blobs[2]), got[2])
+    lag_set.close(); fs12.close()
+
+
 def test_generate_testing_setup(kz, fs16):
     s = ko.fr_from_ints([S_TEST])
     got = fs16.generate_testing_setup_g1(s, 33)

@@ -204,3 +204,27 @@ def test_table_walk_accumulator_fast_path(he):
         for q in pts:
             want = ko.g1_add(want, q)
         assert np.array_equal(ko.g1_compress(got), ko.g1_compress(want)), name
+
+
+def test_glv_split_signed_for_variable_scalars(he):
+    """the device-side balanced GLV split of the bucket MSM: k == s1 |k1| + s2 |k2| lambda (mod r), both magnitudes < 2^126.5
+    (16 signed 8-bit windows, no carry out of the top one) -- against Python big integers, structured and random scalars"""
+    lam = 0xac45a4010001a40200000000ffffffff
+    r = ko.R_MOD
+    assert (lam * lam + lam + 1) % r == 0
+    rng = np.random.default_rng(7)
+    vals = [0, 1, 2, lam - 1, lam, lam + 1, lam // 2, lam // 2 + 1, (r - 1) // 2, (r - 1) // 2 + 1, r - 1, r - 2, r - lam, 2 * lam, 2 * lam - 1,
+            (lam + 1) * (lam // 2), (1 << 254) % r, (1 << 255) % r, r - lam // 2, r - lam // 2 - 1]
+    vals += [(q * lam + d) % r for q in (0, 1, lam // 2 - 1, lam // 2, lam // 2 + 1, lam - 1) for d in (-2, -1, 0, 1, 2, lam // 2, lam // 2 + 1)]
+    vals += [int.from_bytes(rng.bytes(32), "little") % r for _ in range(20000)]
+    out = np.zeros(10, dtype=np.uint32)
+    for v in vals:
+        k = np.frombuffer(int(v).to_bytes(32, "little"), dtype=np.uint32).copy()
+        he.he_glv_split_signed(p(out), p(k))
+        k1 = sum(int(out[i]) << (32 * i) for i in range(4))
+        k2 = sum(int(out[4 + i]) << (32 * i) for i in range(4))
+        assert out[8] in (0, 1) and out[9] in (0, 1)
+        s1, s2 = (-1 if out[8] else 1), (-1 if out[9] else 1)
+        assert (s1 * k1 + s2 * k2 * lam - v) % r == 0, hex(v)
+        assert k1 <= lam // 2 + 1 and k2 < (1 << 127) and k1 < (1 << 127), hex(v)
+        assert (k1 >> 120) < 127 and (k2 >> 120) < 127, hex(v)       # top signed window: raw + carry <= 128, no carry out

@@ -31,5 +31,11 @@ print("FFT_Fr(4096)                  %.3f ms" % timeit(lambda: fs.fft(blob, Fals
 print("DASFFTExtension(2048)         %.3f ms" % timeit(lambda: fs.das_fft_extension(blob[:2048].copy()), 100))
 print("FFTG1(4096)                   %.3f ms" % timeit(lambda: fs.fft_g1(setup, False), 5))
 print("LinCombG1(4096 caller points) %.3f ms" % timeit(lambda: fs.lin_comb_g1(setup, blob), 20))
+cached = kz.G1Points(fs, setup)
+print("LinCombG1(4096 cached points) %.3f ms" % timeit(lambda: cached.lin_comb(blob), 20))
+blobs64, _ = fs.fr_from_32(bench.splitmix_blobs_le32(1, 64, 4096).reshape(-1, 32))
+blobs64 = blobs64.reshape(64, 4096, 4)
+t = timeit(lambda: cached.lin_comb_batch(blobs64), 5)
+print("LinCombG1 batch 64 (cached)   %.3f ms = %.0f MSM/s (host buffers)" % (t, 64 / t * 1e3))
 fk = kz.FK20SingleSettings(ks, 4096)
 print("DAUsingFK20(2048 -> 4096)     %.3f ms" % timeit(lambda: fk.da_using_fk20(blob[:2048].copy()), 5))
