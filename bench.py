@@ -12,17 +12,27 @@ library's own FromCompressedG1).  One step = one pass of the hot path over one b
 collective ("scaling": "weak"); value = commitments of all ranks / max-over-ranks time.
 
 Extra objects on the JSON line:
-  roofline      -- dominant kernel (k_fb_accumulate, the fixed-base table walk): algorithmic bytes per launch / HIP-event launch
-                   time vs 8 TB/s, plus the PMC traffic of the committed rocprofv3 passes (profiles/r01_pmc_traffic.json).
-  cpu_baseline  -- the oracle's restatement of bls.LinCombG1 (Kilic-style Pippenger) timed on one host core (rank 0, N = 1).
-  fk20          -- secondary metric: DAUsingFK20 (2048 coefficients -> 4096 proofs) all-proofs/s, own timed loop.
+  roofline      -- dominant kernel of the commitment step (k_fb_accumulate, the fixed-base table walk): algorithmic bytes per launch /
+                   HIP-event launch time vs 8 TB/s, the PMC traffic of the committed rocprofv3 passes (profiles/), and `mac`: the
+                   kernel's v_mad_u64_u32 rate against the rate MEASURED on this GPU in this run (kzg_hip_calibrate).
+  roofline_fk20 -- the same for the FK20 half of the metric (dominant kernel k_g1_fft_stage).
+  cpu_baseline  -- the oracle's restatement of bls.LinCombG1 (Kilic-style Pippenger) on the host: one core and all cores (one blob
+                   per core), CPU model and core count stated; the Go toolchain probe (rank 0, N = 1).
+  table_sweep   -- commitments/s against the HBM budget of the fixed-base table (10 / 32 / 64 / 210 GB).
+  drop_in       -- the reference's ONE-blob-per-call API from 1 .. 256 native host threads (host buffers, coalesced in the library).
+  lincomb       -- variable-base bls.LinCombG1 on a cached point set (GLV bucket MSM), batch 1 / 64 / 512.
+  latency       -- single-call latencies of the reference-shaped entry points.
+  fk20          -- DAUsingFK20 (2048 coefficients -> 4096 proofs) all-proofs/s, own timed loop, self-checked against the byte pin.
   fk20_multi    -- BASELINE config 5: DAUsingFK20Multi at scale 16, chunk 16 (32768 coefficients -> 4096 coset proofs).
   reference_benchmarks -- FFT_Fr / DAS extension / FFT_G1 at scale 12 beside the reference's published BENCH.md numbers.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import shutil
+import subprocess
 import sys
 import time
 
@@ -127,8 +137,8 @@ def shard_units(total_units, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def cpu_baseline(seconds_budget=12.0):
-    """oracle (kind 'port'): Kilic-style bls.LinCombG1 on 4096 points, single thread, bounded sample"""
+def _cpu_worker(seconds_budget):
+    """one host core: as many oracle LinCombG1(4096) as fit the budget; returns (count, seconds)"""
     from oracle import koracle as ko
     raw = np.frombuffer(open(os.path.join(ROOT, "tests", "golden", "trusted_setup_g1.bin"), "rb").read(), dtype=np.uint8)
     setup = ko.g1_decompress(raw)
@@ -138,9 +148,50 @@ def cpu_baseline(seconds_budget=12.0):
     while time.perf_counter() - t0 < seconds_budget:
         ko.lincomb_g1(setup, blobs[n % 4])
         n += 1
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "commitments/s", "cores": 1, "kind": "port",
-            "sample": "%d x LinCombG1(n=4096) in %.1f s, oracle/kzg_oracle.c (Kilic-style Pippenger c=9), 1 thread" % (n, dt)}
+    return n, time.perf_counter() - t0
+
+
+def cpu_baseline(seconds_budget=6.0):
+    """oracle (kind 'port'): Kilic-style bls.LinCombG1 on 4096 points.  `value` = ONE thread (the reference is single-threaded);
+    `all_cores` = one blob per core on every host core (the metric is a per-second throughput).  Must run before the
+    process initialises HIP (the all-cores leg forks)."""
+    import multiprocessing as mp
+    nproc = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else nproc
+    try:   # a container's CPU quota (cgroup v2) bounds what "all cores" can mean here
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(float(quota) / float(period) + 0.999)))
+    except (OSError, ValueError):
+        pass
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    go = shutil.which("go")
+    go_version = None
+    if go:
+        try:
+            go_version = subprocess.run([go, "version"], capture_output=True, text=True, timeout=20).stdout.strip()
+        except (OSError, subprocess.SubprocessError):
+            go_version = "present, `go version` failed"
+    n1, dt1 = _cpu_worker(seconds_budget)
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [seconds_budget] * cores)
+    wall = time.perf_counter() - t0
+    total = sum(r[0] for r in res)
+    return {"value": n1 / dt1, "unit": "commitments/s", "cores": 1, "kind": "port",
+            "sample": "%d x LinCombG1(n=4096) in %.1f s, oracle/kzg_oracle.c (Kilic-style Pippenger c=9), 1 thread" % (n1, dt1),
+            "cpu_model": model, "nproc": nproc, "usable_cores": cores,
+            "all_cores": {"value": sum(r[0] / r[1] for r in res), "unit": "commitments/s", "cores": cores,
+                          "sample": "%d x LinCombG1(n=4096), one blob per core on %d processes, %.1f s wall" % (total, cores, wall)},
+            "go_toolchain": go_version or "absent (`go`: command not found): the Go/Kilic reference cannot be timed on this host (BASELINE.md 3)",
+            "reference_published": "BENCH.md Kilic column, Ryzen 9 5950X, 1 thread: see reference_benchmarks"}
 
 
 def main():
@@ -155,12 +206,17 @@ def main():
     ap.add_argument("--sharded-fk20-multi", action="store_true", help="also time ONE FK20Multi through the sharded driver at world size 1")
     ap.add_argument("--no-fk20", action="store_true")
     ap.add_argument("--table-gb", type=float, default=210.0, help="HBM budget of the commitment table for the headline (library default: 64)")
+    ap.add_argument("--no-extras", action="store_true", help="skip table_sweep / drop_in / lincomb / latency (profiling runs)")
     args = ap.parse_args()
+
+    rank, world, local = dist_env()
+    base = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        base = cpu_baseline()                               # first: the all-cores leg forks, which must precede HIP initialisation
 
     import torch
     import gokzg_amd as kz
 
-    rank, world, local = dist_env()
     if args.gpus != world and world == 1 and args.gpus > 1:
         raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available() or kz.device_count() < 1:
@@ -183,6 +239,17 @@ def main():
     setup = fs.from_compressed_g1(raw)                      # 4096 x [1337^i]G1, decompressed on the device
     ks = kz.KZGSettings(fs, setup)
     ks.set_table_budget_gb(args.table_gb)                   # explicit opt-in to the 16-bit-window table (206 GB); table_sweep has the others
+    cal_mad, cal_add, cal_fpmul = fs.calibrate()            # measured on THIS GPU: v_mad_u64_u32 / v_add_u32 lane-ops/s, lazy F_p products/s
+    golden = os.path.join(ROOT, "tests", "golden")
+    pins = json.load(open(os.path.join(golden, "fk20_pins.json")))
+    pmc = {}
+    for name in ("r02_pmc.json", "r01_pmc_traffic.json"):   # counters of the committed rocprofv3 passes (tools/profile_round.sh)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+            pmc["_file"] = "profiles/" + name
+            break
+        except (OSError, ValueError):
+            continue
 
     def mont_blobs(seed, batch, n=N_COEFF):
         """synthetic scalars as Montgomery images: vectorised splitmix + mod r on the host, FrFrom32 on the device"""
@@ -261,35 +328,98 @@ def main():
         alg_bytes = B * BYTES_PER_COMMIT + BYTES_SETUP
         ach = alg_bytes / avg_s * 1e-9
         tab_c, tab_w, tab_bytes = ks.table_info()
-        traffic, pm, pm_ok = None, {}, False
+        traffic, pm, pm_ok = None, pmc.get("k_fb_accumulate", pmc), False
         try:   # HBM bytes per launch from the committed PMC passes (profiles/), only when the workload matches that measurement
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             if pm["kernel"] == "k_" + dominant.decode() and pm["batch"] == B and pm["n"] == N_COEFF and pm["table_c"] == tab_c:
                 traffic = pm["fetch_bytes_per_launch"] + pm["write_bytes_per_launch"]
                 pm_ok = True
-        except (OSError, KeyError, ValueError):
+        except (KeyError, TypeError):
             pass
         roofline = {"bound": "hbm", "kernel": "k_" + dominant.decode(), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_s * 1e3,
                     "algorithmic_bytes_per_launch": alg_bytes,
                     "table": {"window_bits": tab_c, "windows": tab_w, "GB": tab_bytes / 1e9},
-                    "note": "integer-VALU-bound kernel; traffic (PMC, profiles/r01_pmc_traffic.json) exceeds the algorithmic bytes by design: fixed-base table gathers trade HBM bandwidth for integer work (DESIGN.md 4)"}
+                    "traffic_source": pmc.get("_file") if pm_ok else None,
+                    "note": "integer-issue-bound kernel (see mac / issue); traffic (PMC passes committed under profiles/) exceeds the algorithmic bytes by design: fixed-base table gathers trade HBM bandwidth for integer work (DESIGN.md 4)"}
 
         if tab_w:
-            # What actually bounds the walk is VALU issue: one wave64 instruction per 4 cycles per SIMD, v_mad_u64_u32 included (the
-            # PMC passes show the G1 kernels at 4.1-4.9 cycles per VALU instruction).  Instructions per launch come
-            # from the committed SQ_INSTS_VALU pass of this workload; the multiply count is derived: one XYZZ mixed addition =
-            # 8 products (338 mads) + 2 squarings (260 mads), B * n * windows of them per launch (zero digits: < 2^-15).
-            mads = B * N_COEFF * tab_w * (8 * 338 + 2 * 260)
-            peak = 256 * 4 * 2.4e9 / 4
-            valu = {"bound": "VALU issue (1 wave64 instruction / 4 cycles / SIMD, 1024 SIMDs, 2.4 GHz nominal)", "peak_Ginst_s": peak * 1e-9,
-                    "mads_per_launch": mads}
+            # What bounds the walk is integer issue, not HBM.  One XYZZ mixed addition = 6 products (338 v_mad_u64_u32 each) + 2 squarings
+            # (260) + one two-product reduction (507) = 3055 multiply-adds; B * n * windows of them per launch (zero digits: < 2^-15).
+            # `mac` sets that against the v_mad_u64_u32 rate MEASURED in this run (8 waves per SIMD, independent chains); `issue` adds
+            # the non-multiply instructions (SQ_INSTS_VALU of the committed counter pass) at the measured v_add_u32 rate: the share of
+            # the launch time that pure instruction issue of this mix explains.
+            mads = B * N_COEFF * tab_w * (6 * 338 + 2 * 260 + 507)
+            roofline["mac"] = {"mads_per_launch": mads, "achieved_Tmad_s": mads / avg_s * 1e-12, "measured_peak_Tmad_s": cal_mad * 1e-12,
+                               "frac": mads / avg_s / cal_mad, "measured_v_add_u32_Tops_s": cal_add * 1e-12, "measured_fp_products_G_s": cal_fpmul * 1e-9,
+                               "fp_product_equivalents_G_s": mads / 338.0 / avg_s * 1e-9,
+                               "note": "peak = kzg_hip_calibrate on this GPU in this run (tools/microbench.hip loops); the guide's SIMD-32 figure "
+                                       "(one wave64 VALU instruction per 2 cycles) holds for v_add_u32 / v_mov, the 64-bit multiply-add issues at ~5.3 cycles"}
             if pm_ok and "valu_insts_per_launch" in pm:
-                valu.update({"insts_per_launch": pm["valu_insts_per_launch"], "achieved_Ginst_s": pm["valu_insts_per_launch"] / avg_s * 1e-9,
-                             "frac": pm["valu_insts_per_launch"] / avg_s / peak, "mad_share": mads / 64 / pm["valu_insts_per_launch"]})
-            roofline["valu"] = valu
+                other = pm["valu_insts_per_launch"] * 64.0 - mads
+                model_s = mads / cal_mad + max(other, 0.0) / cal_add
+                roofline["issue"] = {"valu_wave_insts_per_launch": pm["valu_insts_per_launch"], "mad_share_of_insts": mads / 64.0 / pm["valu_insts_per_launch"],
+                                     "issue_model_ms": model_s * 1e3, "frac_of_launch_explained": model_s / avg_s,
+                                     "note": "mads / measured mad rate + other VALU / measured add rate; the rest is dependency / memory stalls at 2 waves per SIMD"}
+
+    table_sweep = drop_in = lincomb = latency = None
+    if not args.no_extras and not args.no_fk20:
+        # --- commitments/s against the HBM budget of the fixed-base table (library default: 64 GB -> c = 14; the headline opts into 210)
+        table_sweep = {}
+        for gb in (10.0, 33.0, 64.0):
+            ks.set_table_budget_gb(gb)
+            step()
+            torch.cuda.synchronize()
+            tsecs = timed_steps(step, 5, 1, torch.cuda.synchronize, barrier, max_over_ranks)
+            c_, w_, b_ = ks.table_info()
+            table_sweep["%g" % gb] = {"commitments_per_s": B * world * 5 / tsecs, "window_bits": c_, "windows": w_, "table_GB": b_ / 1e9}
+        ks.set_table_budget_gb(args.table_gb)
+        step()
+        torch.cuda.synchronize()
+        c_, w_, b_ = ks.table_info()
+        table_sweep["%g" % args.table_gb] = {"commitments_per_s": value, "window_bits": c_, "windows": w_, "table_GB": b_ / 1e9, "headline": True}
+
+        # --- the reference's API is ONE blob per call: T native host threads, each calling kzg_hip_commit_to_poly on host buffers
+        host_blobs = blobs_h[:64].copy()
+        drop_in = {"entry": "kzg_hip_commit_to_poly (host buffers, blocking, one 4096-coefficient blob per call)", "threads": {}}
+        ks.bench_drop_in(host_blobs, 8, 4)
+        for T in (1, 8, 64, 256):
+            rate_, outs = ks.bench_drop_in(host_blobs, T, 200 if T == 1 else 60)
+            drop_in["threads"][str(T)] = {"commitments_per_s": rate_, "frac_of_device_resident_batch": rate_ / (value / world)}
+        want0 = d_out[(T - 1 + 59) % 64].cpu().numpy().view(np.uint64).reshape(3, 6)      # thread T-1's last call used blob (T-1 + 59) % 64
+        drop_in["bit_exact_vs_batched_path"] = bool(np.array_equal(outs[T - 1], want0))
+        prate_, _ = ks.bench_drop_in(host_blobs, 64, 40, op=1)
+        drop_in["compute_proof_single_64_threads_per_s"] = prate_
+
+        # --- variable-base bls.LinCombG1 on a cached point set (the seam eth/helpers.go:99,159,199 and CommitToEvalPoly go through)
+        pts = kz.G1Points(fs, setup)
+        d_lc_out = torch.zeros((512, 18), dtype=torch.int64, device="cuda")
+        lincomb = {"kernel_chain": "k_msm_sort / accumulate / reduce / combine (GLV halves, signed 8-bit windows, 2^64 rows cached)", "n": N_COEFF, "batch": {}}
+        for bs in (1, 64, 512):
+            def lc_step(bs=bs):
+                st = lib.kzg_hip_lincomb_points_batch_dev(pts.h, d_blobs.data_ptr(), N_COEFF, bs, d_lc_out.data_ptr(), stream)
+                if st:
+                    raise RuntimeError("lincomb_points_batch_dev status %d" % st)
+            reps = 10 if bs < 512 else 3
+            lsecs = timed_steps(lc_step, reps, 1, torch.cuda.synchronize, barrier, max_over_ranks)
+            lincomb["batch"][str(bs)] = {"msm_per_s": bs * world * reps / lsecs, "ms_per_step": lsecs / reps * 1e3}
+        lincomb["matches_fixed_base_commitments"] = bool(torch.equal(d_lc_out[:B], d_out[:B])) if B <= 512 else None
+
+        # --- single-call latencies through the host-buffer entry points (ms)
+        def lat(fn, reps):
+            for _ in range(3):
+                fn()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            return (time.perf_counter() - t0) / reps * 1e3
+        one = blobs_h[0]
+        latency = {"CommitToPoly_4096_ms": lat(lambda: ks.commit_to_poly(one), 30), "ComputeProofSingle_4096_ms": lat(lambda: ks.compute_proof_single(one, 17), 30),
+                   "LinCombG1_4096_one_shot_ms": lat(lambda: fs.lin_comb_g1(setup, one), 10), "LinCombG1_4096_cached_points_ms": lat(lambda: pts.lin_comb(one), 10),
+                   "FFTG1_4096_ms": lat(lambda: fs.fft_g1(setup, False), 3)}
+        pts.close()
 
     fk20 = None
+    roofline_fk20 = None
     if not args.no_fk20:
         fk = kz.FK20SingleSettings(ks, 4096)
         FB = args.fk20_batch
@@ -302,10 +432,56 @@ def main():
             if st:
                 raise RuntimeError("da_using_fk20_batch_dev status %d" % st)
 
-        fsecs = timed_steps(fk_step, max(1, args.steps // 2), 1, torch.cuda.synchronize, barrier, max_over_ranks)
+        fk_step()
+        torch.cuda.synchronize()
+        fk_ok = None
+        if rank == 0:   # self-check of the timed path: polynomial 0 is blob(seed 4)[:2048], byte-pinned by the oracle (tests/golden/fk20_pins.json)
+            p0 = d_proofs[0].cpu().numpy().view(np.uint64).reshape(4096, 3, 6)
+            fk_ok = hashlib.sha256(fs.to_compressed_g1(p0).tobytes()).hexdigest() == pins["config4a_da_using_fk20_seed4"]["sha256"]
+            if not fk_ok:
+                raise SystemExit("bench self-check failed: FK20 proofs of blob(seed 4) do not match the byte pin")
+        fsteps = max(1, args.steps // 2)
+        fsecs = timed_steps(fk_step, fsteps, 1, torch.cuda.synchronize, barrier, max_over_ranks)
         fk20 = {"metric": "FK20 all-proofs/s (DAUsingFK20, 2048 coeffs -> 4096 proofs, scale 12)",
-                "value": FB * world * max(1, args.steps // 2) / fsecs, "batch_per_gpu": FB,
-                "ms_per_all_proofs": fsecs / max(1, args.steps // 2) / FB * 1e3}
+                "value": FB * world * fsteps / fsecs, "batch_per_gpu": FB,
+                "ms_per_all_proofs": fsecs / fsteps / FB * 1e3, "self_check_byte_pin": fk_ok}
+        if not args.no_extras:
+            for _ in range(3):
+                fk.da_using_fk20(polys_h[0])
+            t0 = time.perf_counter()
+            for _ in range(2):
+                fk.da_using_fk20(polys_h[0])
+            fk20["DAUsingFK20_single_call_ms"] = (time.perf_counter() - t0) / 2 * 1e3
+        # roofline of the FK20 half: HIP events around every launch of the dominant kernel (k_g1_fft_stage, 24 launches per step:
+        # 12 radix-2 stages x 2 transforms), separate un-timed pass
+        lib.kzg_hip_prof_reset(fs.h, 1)
+        fk_step()
+        torch.cuda.synchronize()
+        tot2, cnt2 = C.c_double(0), C.c_uint64(0)
+        lib.kzg_hip_prof_read(fs.h, b"g1_fft_stage", C.byref(tot2), C.byref(cnt2))
+        tot3, cnt3 = C.c_double(0), C.c_uint64(0)
+        lib.kzg_hip_prof_read(fs.h, b"fb_mul_vec", C.byref(tot3), C.byref(cnt3))
+        lib.kzg_hip_prof_reset(fs.h, 0)
+        if cnt2.value:
+            kern_s = tot2.value * 1e-3                          # all stage launches of one step (FB polynomials)
+            alg = FB * FK20_BYTES                               # 851 968 B per DAUsingFK20 (poly + xExtFFT + proofs)
+            # multiply-adds of the stage kernel per polynomial: 2 transforms x 20 481 twiddle multiplications (width-5 NAF GLV:
+            # ~126 doublings x 1963 + ~42.7 additions x ~4498 + 38.3k for the 8-entry table) + 24 576 shared (x + wy, x - wy) x 7384
+            mads_unit = 2 * 20481 * (126 * 1963 + 42.7 * 4498 + 38300) + 2 * 24576 * 7384
+            pf = pmc.get("k_g1_fft_stage", {})
+            roofline_fk20 = {"bound": "hbm", "kernel": "k_g1_fft_stage", "achieved": alg / kern_s * 1e-9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": alg / kern_s * 1e-9 / HBM_PEAK_GBS, "launches_per_step": int(cnt2.value), "avg_launch_ms": tot2.value / cnt2.value,
+                             "kernel_ms_per_all_proofs": tot2.value / FB, "algorithmic_bytes_per_step": alg,
+                             "traffic": (pf.get("fetch_bytes_per_step", 0) + pf.get("write_bytes_per_step", 0)) if pf.get("batch") == FB else None,
+                             "traffic_source": pmc.get("_file") if pf.get("batch") == FB else None,
+                             "share_of_step": kern_s / (fsecs / fsteps), "table_walk_ms_per_step": tot3.value if cnt3.value else None,
+                             "mac": {"mads_per_all_proofs": mads_unit, "achieved_Tmad_s": FB * mads_unit / kern_s * 1e-12, "measured_peak_Tmad_s": cal_mad * 1e-12,
+                                     "frac": FB * mads_unit / kern_s / cal_mad},
+                             "counters": {k: pf[k] for k in ("valu_insts_per_step", "sq_wait_inst_any", "sq_active_inst_any", "sq_busy_cycles", "scratch_bytes_per_lane") if k in pf},
+                             "issue": ({"issue_model_ms_per_step": (FB * mads_unit / cal_mad + max(pf["valu_insts_per_step"] * 64.0 - FB * mads_unit, 0.0) / cal_add) * 1e3,
+                                        "frac_of_kernel_time_explained": (FB * mads_unit / cal_mad + max(pf["valu_insts_per_step"] * 64.0 - FB * mads_unit, 0.0) / cal_add) / kern_s}
+                                       if pf.get("batch") == FB and "valu_insts_per_step" in pf else None),
+                             "note": "one step = %d polynomials; the kernel is launched once per radix-2 stage; integer-issue-bound like the table walk" % FB}
         if use_dist:
             # the north star's "RCCL all-gather of proof points over xGMI": every rank ends up with the proofs of 32 blobs of every
             # rank (up to 32 x 4096 x 144 B = 18.9 MB per rank).  Reported beside the throughput; a failure must not cost the bench line.
@@ -341,10 +517,18 @@ def main():
             if st:
                 raise RuntimeError("da_using_fk20_multi_batch_dev status %d" % st)
 
+        fkm_step()
+        torch.cuda.synchronize()
+        fkm_ok = None
+        if rank == 0:   # polynomial 0 is blob(seed 5, 32768): all 4096 coset proofs byte-pinned by the oracle's full-size run
+            p0 = d_mproofs[0].cpu().numpy().view(np.uint64).reshape(4096, 3, 6)
+            fkm_ok = hashlib.sha256(fs16.to_compressed_g1(p0).tobytes()).hexdigest() == pins["config5_da_using_fk20_multi_seed5"]["sha256"]
+            if not fkm_ok:
+                raise SystemExit("bench self-check failed: FK20Multi proofs of blob(seed 5) do not match the byte pin")
         msteps = max(1, args.steps // 2)
         msecs = timed_steps(fkm_step, msteps, 1, torch.cuda.synchronize, barrier, max_over_ranks)
         fk20m = {"metric": "FK20Multi all-coset-proofs/s (DAUsingFK20Multi, scale 16, chunk 16: 32768 coeffs -> 4096 proofs)",
-                 "value": MB * world * msteps / msecs, "batch_per_gpu": MB, "ms_per_all_proofs": msecs / msteps / MB * 1e3}
+                 "value": MB * world * msteps / msecs, "batch_per_gpu": MB, "ms_per_all_proofs": msecs / msteps / MB * 1e3, "self_check_byte_pin": fkm_ok}
         if use_dist or args.sharded_fk20_multi:
             # ONE FK20Multi with its Toeplitz stage sharded over the ranks and an RCCL all-gather of the 144-byte point slices
             # (BASELINE config 5, go-kzg_amd/multi_gpu.py).  A latency figure, reported beside the throughput numbers; a failure
@@ -407,19 +591,16 @@ def main():
             "fft_g1_scale12_per_s": {"value": r_g1, "reference_published": 1e9 / 3745748396, "source": "BENCH.md:55", "batch": GB},
         }
 
-    base = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base = cpu_baseline()
-
     if rank == 0:
         print(json.dumps({
             "metric": "KZG commitments/sec (CommitToPoly, 4096-element blob)", "value": value, "unit": "commitments/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": secs / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "dtype_note": "30/32-bit limbs in u32 lanes, 64-bit accumulators (v_mad_u64_u32): 381-bit F_p and 255-bit F_r Montgomery arithmetic",
             "data": "synthetic",
-            "config": {"workload": "CommitToPoly, 4096-coeff blobs, eth/trusted_setup.json monomial setup (s=1337), %d blobs/step/GPU resident in HBM" % B,
+            "config": {"workload": "CommitToPoly, 4096-coeff blobs, eth/trusted_setup.json monomial setup (s=1337), %d blobs/step/GPU resident in HBM, fixed-base table budget %g GB (opt-in; library default 64 GB, see table_sweep)" % (B, args.table_gb),
                        "global_batch": B * world, "parallelism": "dp%d (independent blobs, no data-path collective)" % world},
-            "roofline": roofline, "cpu_baseline": base, "batch_sweep": batch_sweep, "fk20": fk20, "fk20_multi": fk20m, "reference_benchmarks": ref_benches,
+            "roofline": roofline, "roofline_fk20": roofline_fk20, "cpu_baseline": base, "batch_sweep": batch_sweep, "table_sweep": table_sweep, "drop_in": drop_in,
+            "lincomb": lincomb, "latency": latency, "fk20": fk20, "fk20_multi": fk20m, "reference_benchmarks": ref_benches,
         }))
     if use_dist:
         dist.destroy_process_group()

@@ -106,6 +106,7 @@ def lib():
         "kzg_hip_eth_compute_kzg_proof": (i32, [vp, vp, u64, vp, vp, vp]),
         "kzg_hip_zero_poly_via_multiplication": (i32, [vp, vp, u64, u64, vp, vp]),
         "kzg_hip_recover_poly_from_samples": (i32, [vp, vp, vp, u64, vp]),
+        "kzg_hip_calibrate": (i32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "kzg_hip_bench_drop_in": (i32, [vp, i32, vp, u64, u64, u32, u32, vp, C.POINTER(C.c_double)]),
         "kzg_hip_kzg_table_info": (i32, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(u64)]),
         "kzg_hip_prof_reset": (None, [vp, i32]), "kzg_hip_prof_read": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64)]),
@@ -241,6 +242,12 @@ class FFTSettings:
         out = np.zeros((vals.shape[0], 32), dtype=np.uint8)
         _chk(lib().kzg_hip_fr_to_le32(self.h, _p(vals), vals.shape[0], _p(out)))
         return out
+
+    def calibrate(self):
+        """measured issue rates of this GPU: (v_mad_u64_u32 lane-ops/s, v_add_u32 lane-ops/s, lazy F_p products/s)"""
+        a, b, c = C.c_double(0), C.c_double(0), C.c_double(0)
+        _chk(lib().kzg_hip_calibrate(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def zero_poly_via_multiplication(self, missing_indices, length):
         """FFTSettings.ZeroPolyViaMultiplication (zero_poly.go:116-217): (zero_eval, zero_poly)"""

@@ -179,6 +179,15 @@ int kzg_hip_fft_settings_new(int device, unsigned max_scale, kzg_hip_fft **out) 
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0 || device < 0 || device >= ndev) return KZG_HIP_ERR_NO_DEVICE;
     if (!device_is_gfx950(device)) return KZG_HIP_ERR_NO_DEVICE;   // kernels are built for gfx950 only; there is no fallback
     HIPCHK(hipSetDevice(device));
+    {   // every pipeline allocates its temporaries stream-ordered (hipMallocAsync): keep freed blocks in the device's pool instead of
+        // returning them to the driver at each synchronisation (release threshold 0 is the default and costs ~0.1 ms per call)
+        hipMemPool_t pool = nullptr;
+        if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool) {
+            uint64_t keep = 8ull << 30;                          // up to 8 GiB of idle temporaries stay cached
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        }
+        (void)hipGetLastError();
+    }
     KZG_TRY
     std::unique_ptr<kzg_hip_fft, void (*)(kzg_hip_fft *)> own(new kzg_hip_fft, kzg_hip_fft_settings_free);   // frees on every error path
     kzg_hip_fft *fs = own.get();
@@ -1488,6 +1497,74 @@ int kzg_hip_bench_drop_in(kzg_hip_kzg *ks, int op, const void *blobs_fr, uint64_
     for (int st : status) if (st) return st;
     return KZG_HIP_OK;
     KZG_CATCH
+}
+// ---- live calibration of the instruction rates that bound the integer kernels (bench.py: roofline.mac).  No figure for the
+// v_mad_u64_u32 rate is in the local guides, so it is measured on the GPU the bench runs on: 8 independent chains per lane, every
+// SIMD holding 8 waves, ~4 ms per kernel.  Same loops as tools/microbench.hip.
+#define CAL_ITERS 2048
+__global__ __launch_bounds__(256) void k_cal_mad(uint32_t *out, uint32_t seed) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t x[8]; uint32_t a = seed + t, b = seed * 3 + t;
+    for (int c = 0; c < 8; c++) x[c] = seed + c + t;
+    for (int i = 0; i < CAL_ITERS; i++) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(x[c]) : "v"(a), "v"(b) : "vcc");
+    }
+    uint32_t acc = 0;
+    for (int c = 0; c < 8; c++) acc ^= (uint32_t)x[c] ^ (uint32_t)(x[c] >> 32);
+    out[t] = acc;
+}
+__global__ __launch_bounds__(256) void k_cal_add(uint32_t *out, uint32_t seed) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t x[8]; uint32_t a = seed + t;
+    for (int c = 0; c < 8; c++) x[c] = seed + c + t;
+    for (int i = 0; i < CAL_ITERS; i++) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x[c]) : "v"(a));
+    }
+    uint32_t acc = 0;
+    for (int c = 0; c < 8; c++) acc ^= x[c];
+    out[t] = acc;
+}
+__global__ __launch_bounds__(256) void k_cal_fp_mul(fp *io, int iters) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    fq x = unpackq(io[t]), y = unpackq(io[t ^ 1]);
+    for (int i = 0; i < iters; i++) { x = mulq_inl(x, y); y = mulq_inl(y, x); }
+    io[t] = packq(addq(x, y));
+}
+// lane-operations per second of v_mad_u64_u32 and v_add_u32, and lazy 13-limb F_p products per second (mont_core30), on `fs`'s device
+int kzg_hip_calibrate(kzg_hip_fft *fs, double *mad_per_s, double *add_per_s, double *fp_mul_per_s) {
+    if (!fs || !mad_per_s || !add_per_s || !fp_mul_per_s) return KZG_HIP_ERR_BAD_ARG;
+    dev_guard g(fs);
+    hipStream_t s = fs->stream;
+    int cus = 256;
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, fs->device);
+    const int blocks = cus * 8, threads = 256;
+    dtmp<uint32_t> d(s); dtmp<fp> dfp(s);
+    CHK(d.alloc((size_t)blocks * threads)); CHK(dfp.alloc((size_t)blocks * threads));
+    HIPCHK(hipMemsetAsync(dfp.p, 0x11, (size_t)blocks * threads * sizeof(fp), s));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    auto timed = [&](int which) -> double {
+        float best = 1e30f;
+        for (int rep = 0; rep < 3; rep++) {                  // first repetition warms up, the best of the rest counts
+            hipEventRecord(e0, s);
+            if (which == 0) hipLaunchKernelGGL(k_cal_mad, dim3(blocks), dim3(threads), 0, s, d.p, 12345u);
+            else if (which == 1) hipLaunchKernelGGL(k_cal_add, dim3(blocks), dim3(threads), 0, s, d.p, 12345u);
+            else hipLaunchKernelGGL(k_cal_fp_mul, dim3(blocks), dim3(threads), 0, s, dfp.p, 64);
+            hipEventRecord(e1, s); hipEventSynchronize(e1);
+            float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+            if (rep && ms < best) best = ms;
+        }
+        return (double)best * 1e-3;
+    };
+    const double lanes = (double)blocks * threads;
+    *mad_per_s = lanes * CAL_ITERS * 8 / timed(0);
+    *add_per_s = lanes * CAL_ITERS * 8 / timed(1);
+    *fp_mul_per_s = lanes * 64 * 2 / timed(2);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    HIPCHK(hipGetLastError());
+    return KZG_HIP_OK;
 }
 void kzg_hip_prof_reset(kzg_hip_fft *fs, int enable) {
     (void)fs;

@@ -238,7 +238,9 @@ void launch_g1_fft_direct(hipStream_t s, const g1j *in, uint64_t in_stride, uint
         const uint32_t logR = bits_left >= 4 ? 4u : bits_left;
         g1j *dst = ((npass - 1 - p) & 1u) ? tmp : data;
         const uint64_t total = batch * n << logR;
-        hipLaunchKernelGGL(k_g1_fft_direct, dim3((uint32_t)((total + G1_DIRECT_BLOCK - 1) / G1_DIRECT_BLOCK)), dim3(G1_DIRECT_BLOCK), 0, s, src, src_stride, src_valid, dst, logn, logR, Ns,
+        // 24 KiB of unused dynamic LDS on top of the 10 KiB the kernel needs: at most 4 of these one-wave workgroups fit a CU, so the
+        // 1024 of a 4096-point pass land one per SIMD instead of 8 per CU on half of the chip (measured: 2.7 vs 5.4 ms per pass)
+        hipLaunchKernelGGL(k_g1_fft_direct, dim3((uint32_t)((total + G1_DIRECT_BLOCK - 1) / G1_DIRECT_BLOCK)), dim3(G1_DIRECT_BLOCK), 24 * 1024, s, src, src_stride, src_valid, dst, logn, logR, Ns,
                            roots, W, (p + 1 == npass) ? scale : nullptr, total);
         src = dst; src_stride = n; src_valid = n; Ns <<= logR; bits_left -= logR;
     }

@@ -193,6 +193,9 @@ int kzg_hip_recover_poly_from_samples(kzg_hip_fft *fs, const void *samples_fr, c
 /* ---- instrumentation for bench.py: HIP-event time of the dominant kernel since the last reset (ms) and launch count ---- */
 void kzg_hip_prof_reset(kzg_hip_fft *fs, int enable);
 int kzg_hip_prof_read(kzg_hip_fft *fs, const char *kernel, double *total_ms, uint64_t *launches);
+/* live calibration for the roofline: lane-operations per second of v_mad_u64_u32 and v_add_u32 and lazy 13-limb F_p products per
+ * second (8 resident waves per SIMD, independent chains) on the handle's device */
+int kzg_hip_calibrate(kzg_hip_fft *fs, double *mad_per_s, double *add_per_s, double *fp_mul_per_s);
 /* drop-in measurement: `threads` host threads each make `calls` blocking one-polynomial calls (op 0: kzg_hip_commit_to_poly,
  * op 1: kzg_hip_compute_proof_single) on host buffers taken round-robin from blobs_fr (nblobs x n Fr); out_g1 holds `threads`
  * points (each thread's last result); *seconds = wall time from the common start to the last return */
