@@ -21,21 +21,65 @@ import "C"
 
 import (
 	"fmt"
+	"runtime"
 	"sync"
 	"unsafe"
 
 	"github.com/protolambda/go-kzg/bls"
 )
 
-// one device handle per Go settings object, created on first use (settings are immutable after construction)
+// One device handle per Go settings object, created on first use (settings are immutable after construction).
+// The side tables are keyed by the object's ADDRESS as a uintptr, not by the pointer: they do not keep the settings object
+// alive.  A finalizer on the settings object (and the explicit Close methods below) frees the device handle -- up to 206 GB of
+// HBM for a KZGSettings -- and removes the entry.  KZGSettings points to its FFTSettings and the FK20 settings to their
+// KZGSettings, so the runtime runs the finalizers outermost first (runtime.SetFinalizer: "if A points to B, A's runs first"),
+// which is the order the C side needs (a kzg handle refers to its fft handle).
 var (
 	hipMu       sync.Mutex
-	hipFFT      = map[*FFTSettings]*C.kzg_hip_fft{}
-	hipKZG      = map[*KZGSettings]*C.kzg_hip_kzg{}
-	hipFK20S    = map[*FK20SingleSettings]*C.kzg_hip_fk20s{}
-	hipFK20M    = map[*FK20MultiSettings]*C.kzg_hip_fk20m{}
+	hipFFT      = map[uintptr]*C.kzg_hip_fft{}
+	hipKZG      = map[uintptr]*C.kzg_hip_kzg{}
+	hipFK20S    = map[uintptr]*C.kzg_hip_fk20s{}
+	hipFK20M    = map[uintptr]*C.kzg_hip_fk20m{}
 	HipDeviceID = 0 // one process per GPU: set from LOCAL_RANK before the first call
 )
+
+// CloseHip releases the device side of the settings object now (idempotent; the finalizer does the same at collection).
+func (fs *FFTSettings) CloseHip() {
+	hipMu.Lock()
+	h := hipFFT[uintptr(unsafe.Pointer(fs))]
+	delete(hipFFT, uintptr(unsafe.Pointer(fs)))
+	hipMu.Unlock()
+	if h != nil {
+		C.kzg_hip_fft_settings_free(h)
+	}
+}
+func (ks *KZGSettings) CloseHip() {
+	hipMu.Lock()
+	h := hipKZG[uintptr(unsafe.Pointer(ks))]
+	delete(hipKZG, uintptr(unsafe.Pointer(ks)))
+	hipMu.Unlock()
+	if h != nil {
+		C.kzg_hip_kzg_settings_free(h)
+	}
+}
+func (fk *FK20SingleSettings) CloseHip() {
+	hipMu.Lock()
+	h := hipFK20S[uintptr(unsafe.Pointer(fk))]
+	delete(hipFK20S, uintptr(unsafe.Pointer(fk)))
+	hipMu.Unlock()
+	if h != nil {
+		C.kzg_hip_fk20_single_settings_free(h)
+	}
+}
+func (fk *FK20MultiSettings) CloseHip() {
+	hipMu.Lock()
+	h := hipFK20M[uintptr(unsafe.Pointer(fk))]
+	delete(hipFK20M, uintptr(unsafe.Pointer(fk)))
+	hipMu.Unlock()
+	if h != nil {
+		C.kzg_hip_fk20_multi_settings_free(h)
+	}
+}
 
 func frPtr(v []bls.Fr) unsafe.Pointer {
 	if len(v) == 0 {
@@ -89,7 +133,7 @@ func hipPanicText(st C.int) string {
 func (fs *FFTSettings) hip() *C.kzg_hip_fft {
 	hipMu.Lock()
 	defer hipMu.Unlock()
-	if h, ok := hipFFT[fs]; ok {
+	if h, ok := hipFFT[uintptr(unsafe.Pointer(fs))]; ok {
 		return h
 	}
 	scale := uint8(0)
@@ -97,8 +141,11 @@ func (fs *FFTSettings) hip() *C.kzg_hip_fft {
 		scale++
 	}
 	var h *C.kzg_hip_fft
-	hipMust(C.kzg_hip_fft_settings_new(C.int(HipDeviceID), C.uint(scale), &h))
-	hipFFT[fs] = h
+	if st := C.kzg_hip_fft_settings_new(C.int(HipDeviceID), C.uint(scale), &h); st != C.KZG_HIP_OK {
+		panic(hipPanicText(st)) // the C constructor frees whatever it had built; nothing to release here
+	}
+	hipFFT[uintptr(unsafe.Pointer(fs))] = h
+	runtime.SetFinalizer(fs, (*FFTSettings).CloseHip)
 	return h
 }
 
@@ -106,11 +153,14 @@ func (ks *KZGSettings) hip() *C.kzg_hip_kzg {
 	fh := ks.FFTSettings.hip()
 	hipMu.Lock()
 	defer hipMu.Unlock()
-	if h, ok := hipKZG[ks]; ok {
+	if h, ok := hipKZG[uintptr(unsafe.Pointer(ks))]; ok {
 		return h
 	}
 	var h *C.kzg_hip_kzg
-	hipMust(C.kzg_hip_kzg_settings_new(fh, g1Ptr(ks.SecretG1), C.uint64_t(len(ks.SecretG1)), &h))
-	hipKZG[ks] = h
+	if st := C.kzg_hip_kzg_settings_new(fh, g1Ptr(ks.SecretG1), C.uint64_t(len(ks.SecretG1)), &h); st != C.KZG_HIP_OK {
+		panic(hipPanicText(st))
+	}
+	hipKZG[uintptr(unsafe.Pointer(ks))] = h
+	runtime.SetFinalizer(ks, (*KZGSettings).CloseHip)
 	return h
 }

@@ -9,6 +9,7 @@ package kzg
 import "C"
 
 import (
+	"runtime"
 	"unsafe"
 
 	"github.com/protolambda/go-kzg/bls"
@@ -48,6 +49,77 @@ func (ks *KZGSettings) ComputeProofSingle(poly []bls.Fr, x uint64) *bls.G1Point 
 	return out
 }
 
+// ComputeProofSingleBatch is new API surface (kzg_hip_compute_proof_single_batch): polys[b] evaluated at xs[b].
+func (ks *KZGSettings) ComputeProofSingleBatch(polys [][]bls.Fr, xs []uint64) []bls.G1Point {
+	if len(polys) == 0 {
+		return nil
+	}
+	if len(polys) != len(xs) {
+		panic("ComputeProofSingleBatch: len(polys) != len(xs)")
+	}
+	n := len(polys[0])
+	flat := make([]bls.Fr, 0, n*len(polys))
+	for _, c := range polys {
+		if len(c) != n {
+			panic("ComputeProofSingleBatch: ragged batch")
+		}
+		flat = append(flat, c...)
+	}
+	out := make([]bls.G1Point, len(polys))
+	hipMust(C.kzg_hip_compute_proof_single_batch(ks.hip(), frPtr(flat), C.uint64_t(n), C.uint64_t(len(polys)), (*C.uint64_t)(unsafe.Pointer(&xs[0])), g1Ptr(out)))
+	return out
+}
+
+// SetTableBudgetGB opts this settings object into a bigger (or smaller) fixed-base commitment table than the 64 GB default;
+// 210 selects the 16-bit-window table (206 GB, 16 additions per coefficient).  Call before the first commitment.
+func (ks *KZGSettings) SetTableBudgetGB(gb float64) {
+	hipMust(C.kzg_hip_kzg_set_table_budget_gb(ks.hip(), C.double(gb)))
+}
+
+// G1Points is a point set kept in HBM for repeated bls.LinCombG1 calls on the SAME points (CommitToEvalPoly's secretG1IFFT,
+// kzg_single_proofs.go:12-14; eth's Lagrange setup, eth/helpers.go:99,159,199): uploaded and converted once.
+type G1Points struct{ h *C.kzg_hip_points }
+
+func (fs *FFTSettings) NewG1Points(points []bls.G1Point) *G1Points {
+	p := &G1Points{}
+	hipMust(C.kzg_hip_points_new(fs.hip(), g1Ptr(points), C.uint64_t(len(points)), &p.h))
+	runtime.SetFinalizer(p, (*G1Points).Close)
+	return p
+}
+func (p *G1Points) Close() {
+	if p.h != nil {
+		C.kzg_hip_points_free(p.h)
+		p.h = nil
+	}
+}
+
+// LinComb == bls.LinCombG1(points[:len(factors)], factors)
+func (p *G1Points) LinComb(factors []bls.Fr) *bls.G1Point {
+	out := new(bls.G1Point)
+	hipMust(C.kzg_hip_lincomb_points(p.h, frPtr(factors), C.uint64_t(len(factors)), unsafePointerG1(out)))
+	return out
+}
+
+// LoadTrustedSetupJSON decodes the G1 arrays of a trusted-setup document (JSONTrustedSetup, eth/globals.go:33-49: the init() there
+// would call this instead of json.Unmarshal for SetupG1 / SetupLagrange; SetupG2 stays with encoding/json + Kilic).  Hex decoding
+// happens in the library, decompression and the subgroup check on the device.  Panics like init() does on a malformed document.
+func (fs *FFTSettings) LoadTrustedSetupJSON(text []byte) (setupG1, setupLagrange []bls.G1Point) {
+	if len(text) == 0 {
+		panic("kzg_hip: empty trusted setup")
+	}
+	var n1, n2 C.uint64_t
+	cs := (*C.char)(unsafe.Pointer(&text[0]))
+	hipMust(C.kzg_hip_trusted_setup_from_json(fs.hip(), cs, C.uint64_t(len(text)), nil, nil, 0, &n1, &n2))
+	cap_ := n1
+	if n2 > cap_ {
+		cap_ = n2
+	}
+	setupG1 = make([]bls.G1Point, cap_)
+	setupLagrange = make([]bls.G1Point, cap_)
+	hipMust(C.kzg_hip_trusted_setup_from_json(fs.hip(), cs, C.uint64_t(len(text)), g1Ptr(setupG1), g1Ptr(setupLagrange), cap_, &n1, &n2))
+	return setupG1[:n1], setupLagrange[:n2]
+}
+
 // ToeplitzPart2 replaces fk20_single.go:59-77.
 func (ks *KZGSettings) ToeplitzPart2(toeplitzCoeffs []bls.Fr, xExtFFT []bls.G1Point) (hExtFFT []bls.G1Point) {
 	if uint64(len(toeplitzCoeffs)) != uint64(len(xExtFFT)) {
@@ -69,13 +141,14 @@ func (fk *FK20SingleSettings) hip() *C.kzg_hip_fk20s {
 	kh := fk.KZGSettings.hip()
 	hipMu.Lock()
 	defer hipMu.Unlock()
-	if h, ok := hipFK20S[fk]; ok {
+	if h, ok := hipFK20S[uintptr(unsafe.Pointer(fk))]; ok {
 		return h
 	}
 	var h *C.kzg_hip_fk20s
 	// the Go constructor (kzg.go:43-64) has already validated n2; xExtFFT is rebuilt on the device from SecretG1
 	hipMust(C.kzg_hip_fk20_single_settings_new(kh, C.uint64_t(len(fk.xExtFFT)), &h))
-	hipFK20S[fk] = h
+	hipFK20S[uintptr(unsafe.Pointer(fk))] = h
+	runtime.SetFinalizer(fk, (*FK20SingleSettings).CloseHip)
 	return h
 }
 
@@ -104,13 +177,14 @@ func (fk *FK20MultiSettings) hip() *C.kzg_hip_fk20m {
 	kh := fk.KZGSettings.hip()
 	hipMu.Lock()
 	defer hipMu.Unlock()
-	if h, ok := hipFK20M[fk]; ok {
+	if h, ok := hipFK20M[uintptr(unsafe.Pointer(fk))]; ok {
 		return h
 	}
 	var h *C.kzg_hip_fk20m
 	n2 := uint64(len(fk.xExtFFTFiles[0])) * fk.chunkLen // files hold 2k = n2 / chunkLen points each (kzg.go:99-114)
 	hipMust(C.kzg_hip_fk20_multi_settings_new(kh, C.uint64_t(n2), C.uint64_t(fk.chunkLen), &h))
-	hipFK20M[fk] = h
+	hipFK20M[uintptr(unsafe.Pointer(fk))] = h
+	runtime.SetFinalizer(fk, (*FK20MultiSettings).CloseHip)
 	return h
 }
 
