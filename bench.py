@@ -290,6 +290,8 @@ def main():
         if hx != exp:
             raise SystemExit("bench self-check failed: commitment of blob(seed 1) = %s, expected %s" % (hx, exp))
 
+    tc_, tw_, tb_ = ks.table_info()   # every rank builds its own table; an allocation failure degrades to a smaller window (capi.hip)
+    sys.stderr.write("[rank %d/%d, device %d] commitment table: %d-bit windows x %d, %.1f GB\n" % (rank, world, local, tc_, tw_, tb_ / 1e9))
     lib.kzg_hip_prof_reset(fs.h, 0)
     secs = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, barrier, max_over_ranks)
     value = B * world * args.steps / secs

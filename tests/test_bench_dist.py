@@ -84,3 +84,29 @@ def test_timed_steps_world_size_2_gloo():
     assert abs(res[0][2] - res[1][2]) < 1e-9             # both ranks report the same (max) time
     assert res[0][2] >= 5 * 0.02 * 0.9                    # ... which is the slow rank's
     assert res[0][3] == list(range(10)) == res[1][3]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_under_torch_distributed_run():
+    """bench.py exactly as the driver launches it for N > 1 (python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N),
+    with two ranks on the ONE GPU of the test box: gloo moves the bytes (RCCL refuses two ranks on a device), everything else -- rank
+    sharding of the blobs, barrier + max-over-ranks timing, the all-gather of proofs, the sharded FK20Multi with its byte comparison,
+    the single JSON line from rank 0 -- is the N > 1 code path.  Small tables so that two ranks fit one device."""
+    import json
+    import subprocess
+    env = dict(os.environ, KZG_BENCH_BACKEND="gloo", KZG_HIP_FK20_FB_BUDGET_GB="3", MASTER_ADDR="127.0.0.1")
+    port = 36500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "64", "--fk20-batch", "8", "--fk20-multi-batch", "2",
+           "--table-gb", "4", "--no-extras"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]                      # exactly one JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["global_batch"] == 128
+    assert d["cpu_baseline"] is None                                # rank 0 at N = 1 only
+    assert d["fk20"]["self_check_byte_pin"] is True and d["fk20"]["all_gather_proofs"]["own_slice_intact"] is True
+    assert d["fk20"]["all_gather_proofs"]["ranks"] == 2
+    assert d["fk20_multi"]["self_check_byte_pin"] is True
+    assert d["fk20_multi"]["sharded_one_polynomial"]["matches_unsharded"] is True, d["fk20_multi"]["sharded_one_polynomial"]
