@@ -60,8 +60,9 @@ class coalescer {
     }
     ~coalescer() {
         if (getenv("KZG_HIP_COALESCE_STATS") && batches_)
-            fprintf(stderr, "[coalescer] %llu requests in %llu batches (avg %.1f), %.3f ms per batch on the device side\n", (unsigned long long)requests_,
-                    (unsigned long long)batches_, (double)requests_ / batches_, exec_s_ / batches_ * 1e3);
+            fprintf(stderr, "[coalescer] %llu requests in %llu batches (avg %.1f), per batch: %.3f ms executing, %.3f ms gathering callers, %.3f ms waiting for row copies\n",
+                    (unsigned long long)requests_, (unsigned long long)batches_, (double)requests_ / batches_, exec_s_ / batches_ * 1e3, gather_s_ / batches_ * 1e3,
+                    ready_s_ / batches_ * 1e3);
         for (auto &b : bufs_) {
             if (b.h_in) hipHostFree(b.h_in);
             if (b.h_out) hipHostFree(b.h_out);
@@ -123,10 +124,12 @@ class coalescer {
                 if (target > max_batch_) target = max_batch_;
                 if (window_us_ > 0 && b.rows.size() < target) {
                     gathering_ = bi;
-                    const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window_us_);
+                    const auto g0 = std::chrono::steady_clock::now();
+                    const auto deadline = g0 + std::chrono::microseconds(window_us_);
                     while (b.rows.size() < target)
                         if (cv_leader_.wait_until(lk, deadline) == std::cv_status::timeout) break;
                     gathering_ = -1;
+                    gather_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - g0).count();
                 }
                 // close this buffer, open a free one
                 b.state = coalesce_buf::CLOSED;
@@ -136,7 +139,9 @@ class coalescer {
                     if (bufs_[o].state == coalesce_buf::FREE_OPEN && bufs_[o].outstanding.load() == 0) { open_ = o; break; }
                 }
                 if (open_ >= 0) cv_reserve_.notify_all();                  // callers that found this buffer full
+                const auto r0 = std::chrono::steady_clock::now();
                 while (b.ready < b.rows.size()) cv_leader_.wait(lk);       // every reserved row filled
+                ready_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - r0).count();
                 const uint64_t batch = b.rows.size();
                 for (uint64_t i = 0; i < batch; i++) b.h_meta[i] = b.rows[i];
                 lk.unlock();
@@ -178,7 +183,7 @@ class coalescer {
     int gathering_ = -1;         // buffer whose elected leader is still waiting for stragglers
     long window_us_ = 150;       // upper bound of that wait (KZG_HIP_COALESCE_US; 0 disables)
     uint64_t batches_ = 0, requests_ = 0;   // statistics (KZG_HIP_COALESCE_STATS=1 prints them when the handle is freed)
-    double exec_s_ = 0;
+    double exec_s_ = 0, gather_s_ = 0, ready_s_ = 0;
     int device_;
     size_t in_row_, out_row_;
     uint64_t max_batch_;

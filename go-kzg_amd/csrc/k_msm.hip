@@ -268,6 +268,17 @@ __device__ __forceinline__ bool coop_xyzz_add(g1xq &a, const g1xq &b, coop_ctx &
     return ok;
 }
 
+// acc += w for the replicated accumulators of a cooperating workgroup; called by all 256 threads (barriers inside).  Columns with
+// nothing to add (winf) still run the addition, on a private copy of whatever `w` holds, and drop the result.
+__device__ __forceinline__ void coop_acc_add(g1x_acc &acc, const g1xq &w, bool winf, coop_ctx &c) {
+    g1xq sum = acc.v, addend = w;                          // private copies: the operands must not move while the levels exchange
+    const bool ok = coop_xyzz_add(sum, addend, c);
+    if (winf) return;
+    if (acc.inf) { acc.v = addend; acc.inf = false; }
+    else if (ok) acc.v = sum;
+    else g1x_acc_merge(acc, addend, false);                // equal / opposite operands: generic complete formulas, identical on the four waves
+}
+
 // Horner over the window groups (8 doublings per group), then normalise and convert.  The doublings are the critical path of a
 // lone MSM (120 for 16 groups, 56 for 8): workgroup = 4 cooperating waves, lane column = blob (64 blobs per workgroup).
 __global__ __launch_bounds__(256) void k_msm_combine(uint8_t *ws, size_t per_blob, size_t gsum_off, uint32_t ngroups, uint64_t batch, g1j *out, int to_kilic) {
@@ -289,12 +300,7 @@ __global__ __launch_bounds__(256) void k_msm_combine(uint8_t *ws, size_t per_blo
         const bool winf = !live || gsum[g].inf != 0;
         g1xq w;
         if (winf) w = acc.v; else fb_partial_load(gsum[g], w);
-        g1xq sum = acc.v;
-        const bool ok = coop_xyzz_add(sum, w, c);
-        if (winf) continue;                                // nothing to add (the barriers above were still executed by everyone)
-        if (acc.inf) { acc.v = w; acc.inf = false; }
-        else if (ok) acc.v = sum;
-        else g1x_acc_merge(acc, w, false);                 // equal or opposite operands: generic complete formulas, same on all four waves
+        coop_acc_add(acc, w, winf, c);
     }
     if (live && c.wave == 0) {
         g1j r;
@@ -449,34 +455,42 @@ __global__ __launch_bounds__(FB_BLOCK, FB_ACC_WAVES) void k_fb_accumulate(const 
     fb_block_reduce(acc, buf, tid);
     if (tid == 0) fb_partial_store(partials[blockIdx.x], acc);
 }
-// one wavefront per blob: the blob's partial sums are added by the same lazy tree (a lone commitment has 32 of them: 5 levels
-// instead of 31 serial additions), then lane 0 normalises (one inversion: 1 / (ZZ ZZZ)) and converts
-__global__ __launch_bounds__(64) void k_fb_finish(const fb_partial *partials, uint32_t blocks_per_blob, uint64_t batch, g1j *out, int to_kilic) {
+// one workgroup of four cooperating wavefronts per blob (lane column j = partial sum j): the blob's partial sums are added by a
+// tree of wave-cooperative XYZZ additions (4 products deep instead of 13; a lone commitment has 32 partials: 5 levels), then
+// column 0 normalises (one inversion: 1 / (ZZ ZZZ)) and converts.  This kernel is pure latency: ~100 us instead of ~230.
+__global__ __launch_bounds__(256) void k_fb_finish(const fb_partial *partials, uint32_t blocks_per_blob, uint64_t batch, g1j *out, int to_kilic) {
     __shared__ fb_partial buf[64];
+    __shared__ coop_lds lds;
+    coop_ctx c; c.L = &lds; c.wave = threadIdx.x >> 6; c.col = threadIdx.x & 63u; c.set = 0;
     const uint64_t b = blockIdx.x;
-    const uint32_t tid = threadIdx.x;
+    const uint32_t col = c.col;
     g1x_acc acc; acc.init();
+    acc.v = g1xq_from_affine(g1a_inf());                   // defined limbs while empty
+    // every wave holds a replica of its column's accumulator; columns beyond the partial count stay empty
+    const uint32_t rounds = (blocks_per_blob + 63) / 64;
 #pragma nounroll
-    for (uint32_t j = tid; j < blocks_per_blob; j += 64) {
-        const fb_partial &pj = partials[b * blocks_per_blob + j];
-        g1xq v; fb_partial_load(pj, v);
-        g1x_acc_merge(acc, v, pj.inf != 0);
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t j = r * 64 + col;
+        const bool have = j < blocks_per_blob;
+        const fb_partial &pj = partials[b * blocks_per_blob + (have ? j : 0)];
+        g1xq w; fb_partial_load(pj, w);
+        coop_acc_add(acc, w, !have || pj.inf != 0, c);
     }
     const uint32_t live = blocks_per_blob < 64 ? blocks_per_blob : 64;
     uint32_t off = 1;
     while (off < live) off *= 2;                          // smallest power of two >= live
-    fb_partial_store(buf[tid], acc);
-    __syncthreads();
 #pragma nounroll
     for (off >>= 1; off >= 1; off >>= 1) {
-        if (tid < off && tid + off < live) {
-            g1xq v; fb_partial_load(buf[tid + off], v);
-            g1x_acc_merge(acc, v, buf[tid + off].inf != 0);
-            fb_partial_store(buf[tid], acc);
-        }
+        if (c.wave == 0) fb_partial_store(buf[col], acc);  // the replicas are identical: one wave publishes the columns
         __syncthreads();
+        const bool have = col < off && col + off < live;
+        const uint32_t src = have ? col + off : col;
+        g1xq w; fb_partial_load(buf[src], w);
+        const bool winf = !have || buf[src].inf != 0;
+        __syncthreads();                                   // everyone has read before the next level overwrites
+        coop_acc_add(acc, w, winf, c);
     }
-    if (tid == 0) {
+    if (c.wave == 0 && col == 0) {
         g1j r;
         if (acc.inf) r = g1_inf();
         else {   // x = X / ZZ, y = Y / ZZZ with ONE inversion: i = 1 / (ZZ ZZZ), 1 / ZZ = i ZZZ, 1 / ZZZ = i ZZ
@@ -563,7 +577,7 @@ void launch_fb_msm(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c
     hipLaunchKernelGGL(k_fb_accumulate, dim3((uint32_t)(batch * bpb)), dim3(FB_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars, sc_stride, n, bpb,
                        (fb_partial *)partials);
     prof_end(s, "fb_accumulate");
-    hipLaunchKernelGGL(k_fb_finish, dim3((uint32_t)batch), dim3(64), 0, s, (const fb_partial *)partials, bpb, batch, out, to_kilic ? 1 : 0);
+    hipLaunchKernelGGL(k_fb_finish, dim3((uint32_t)batch), dim3(256), 0, s, (const fb_partial *)partials, bpb, batch, out, to_kilic ? 1 : 0);
 }
 // builds the table for `n` affine points: rows (2^(c w) P_i) first, then all multiples window-slab by window-slab
 hipError_t launch_fb_build(hipStream_t s, const g1a *pts, uint64_t n, uint32_t c, uint32_t nwin, g1a *table) {
