@@ -467,9 +467,10 @@ def main():
         if cnt2.value:
             kern_s = tot2.value * 1e-3                          # all stage launches of one step (FB polynomials)
             alg = FB * FK20_BYTES                               # 851 968 B per DAUsingFK20 (poly + xExtFFT + proofs)
-            # multiply-adds of the stage kernel per polynomial: 2 transforms x 20 481 twiddle multiplications (width-5 NAF GLV:
-            # ~126 doublings x 1963 + ~42.7 additions x ~4498 + 38.3k for the 8-entry table) + 24 576 shared (x + wy, x - wy) x 7384
-            mads_unit = 2 * 20481 * (126 * 1963 + 42.7 * 4498 + 38300) + 2 * 24576 * 7384
+            # multiply-adds of the stage kernel per polynomial: 2 transforms x 20 481 twiddle multiplications (width-5 NAF GLV with
+            # an affine 8-entry table: ~126 doublings x 1963 + ~42.7 mixed additions x ~3484 (3315, + 338 for phi on half of them) + 51.4k for
+            # the table incl. its normalisation; the binary-GCD inversion has no multiplies) + 24 576 shared (x + wy, x - wy) x 7384
+            mads_unit = 2 * 20481 * (126 * 1963 + 42.7 * 3484 + 51400) + 2 * 24576 * 7384
             pf = pmc.get("k_g1_fft_stage", {})
             roofline_fk20 = {"bound": "hbm", "kernel": "k_g1_fft_stage", "achieved": alg / kern_s * 1e-9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": alg / kern_s * 1e-9 / HBM_PEAK_GBS, "launches_per_step": int(cnt2.value), "avg_launch_ms": tot2.value / cnt2.value,

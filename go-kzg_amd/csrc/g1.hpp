@@ -620,6 +620,76 @@ KZG_HD bool g1jq_add_slow_copy(g1jq &acc, const g1jq_t *t, bool ng, bool phi) {
     acc = a2;
     return inf;
 }
+// ---- affine table variant (round 2): the 8 odd multiples are normalised with ONE inversion per scalar multiplication (Montgomery's
+// trick inside the lane), so that the ~43 additions of the loop are MIXED additions (3S + 6M + one two-product reduction = 3315
+// multiply-adds instead of 4329) and a table entry is 104 bytes of scratch instead of 260.
+struct g1aq { fq x, y; };                                   // affine point on lazy limbs, bounds (2, 2)
+// acc += (+-) (phi?) *t : madd-2004-hmv on lazy limbs.  acc bounds (19, 20, 4) in, (11, 2, 2) out:
+//   Z1Z1 = Z1^2 : 2 (16);  U2 = X2 Z1Z1 : 2;  S2 = (Y2 Z1) Z1Z1 : 2 (8, 4);  H = U2 - X1 (M = 20) : 22;  R = +-S2 - Y1 (M = 21) : 23 resp. 24
+//   HH = H^2 : 2 (484 <= 600);  HHH = H HH, V = X1 HH : 2 (44, 38);  X3 = R^2 - HHH - 2 V : 2 + 3 + 3 + 3 = 11  (R^2: 576 <= 600)
+//   Y3 = R (V - X3) + (21 p - Y1) HHH in ONE reduction (24 * 14 + 41 * 2 = 418 <= 600) : 2;  Z3 = Z1 H : 2 (88)
+// Returns false when H == 0 (P == +-Q): the accumulator is untouched and the caller takes the generic path.
+template <bool INL = false> KZG_HD bool g1jq_madd_entry(g1jq &acc, const g1aq *t, bool ng, bool phi) {
+    auto MQ = [](const fq &a_, const fq &b_) { return INL ? mulq_inl(a_, b_) : mulq(a_, b_); };
+    auto SQ = [](const fq &a_) { return INL ? sqrq_inl(a_) : sqrq(a_); };
+    fq zero_q;
+#pragma unroll
+    for (int i = 0; i < 13; i++) zero_q.l[i] = 0;
+    fq z1z1 = SQ(acc.z);
+    fq u2 = phi ? MQ(MQ(t->x, unpackq(glv_beta())), z1z1) : MQ(t->x, z1z1);
+    fq h = subq<20>(u2, acc.x);
+    fq hh = SQ(h);
+    if (is_zero_mod_p_q(hh)) return false;
+    fq s2 = MQ(MQ(t->y, acc.z), z1z1);
+    if (ng) s2 = subq<3>(zero_q, s2);                       // - S2 : 3
+    fq r = subq<21>(s2, acc.y);                             // 23 / 24
+    fq hhh = MQ(h, hh), v = MQ(acc.x, hh);
+    fq x3 = subq<3>(subq<3>(subq<3>(SQ(r), hhh), v), v);
+    fq z3 = MQ(acc.z, h);
+    if (INL) acc.y = dot2q_inl(r, subq<12>(v, x3), subq<21>(zero_q, acc.y), hhh);
+    else acc.y = subq<3>(MQ(r, subq<12>(v, x3)), MQ(acc.y, hhh));   // 2 - (20 * 2 -> 2) : 5
+    acc.x = x3; acc.z = z3;
+    return true;
+}
+KZG_HD g1jq g1aq_entry_point(const g1aq *t, bool ng, bool phi) {
+    g1jq q; q.x = phi ? mulq(t->x, unpackq(glv_beta())) : t->x; q.z = unpackq(one<FpP>());
+    if (ng) { fq zero_q;
+#pragma unroll
+        for (int i = 0; i < 13; i++) zero_q.l[i] = 0;
+        q.y = subq<3>(zero_q, t->y); } else q.y = t->y;
+    return q;
+}
+// the 8 odd multiples P, 3P, .. 15P as affine points: Jacobian multiples (1 doubling + 7 additions) into `jt`, then one inversion of
+// the product of their Z's (binary GCD, ~35 product-equivalents) and 3 products per entry to unwind it, 1S + 3M per entry to scale.
+// p must be a finite point of G1 (no Z is zero and no addition degenerates for points of G1; the degenerate branch is kept for safety).
+KZG_HD void g1_wnaf_table_affine(const g1j &p, g1aq *tbl, g1jq *jt) {
+    {
+        g1jq cur = g1jq_unpack(p);
+        jt[0] = cur;
+        g1jq_t p2;
+        g1jq_t_make(&p2, g1jq_dbl(cur));
+#pragma nounroll
+        for (int i = 1; i < 8; i++) {
+            if (!g1jq_add_entry(cur, &p2, false, false)) g1jq_add_slow_copy(cur, &p2, false, false);
+            jt[i] = cur;
+        }
+    }
+    // prefix products of the Z's go into the (still unused) x slots of the affine table
+    fq run = jt[0].z;
+#pragma nounroll
+    for (int i = 1; i < 8; i++) { tbl[i].x = run; run = mulq(run, jt[i].z); }
+    fq inv_all = unpackq(inv<FpP>(packq(run)));             // 1 / (Z_0 .. Z_7), Montgomery domain in and out
+#pragma nounroll
+    for (int i = 7; i >= 0; i--) {
+        fq zi;
+        if (i) { zi = mulq(inv_all, tbl[i].x); inv_all = mulq(inv_all, jt[i].z); } else zi = inv_all;
+        fq zi2 = sqrq(zi);
+        tbl[i].x = mulq(jt[i].x, zi2);
+        tbl[i].y = mulq(jt[i].y, mulq(zi2, zi));
+    }
+}
+KZG_HD bool g1jq_add_slow_copy_a(g1jq &acc, const g1aq *t, bool ng, bool phi);
+
 // p must not be inf.  `tbl` (8 entries, (2 i + 1) P) lives in the lane's private scratch; the digit arrays d1 / d2 (132 entries
 // each, element i at [i * stride]) are caller storage (private arrays; an LDS byte column per lane was measured: the 33 KB per
 // workgroup cost more in multi-round launches than the scratch reads it saved).
@@ -684,6 +754,56 @@ template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD g1j g1_mul_glv_wnaf
     int st = g1_mul_glv_wnaf_q<INL_DBL, INL_ADD>(p, kk, tbl, d1, d2, stride, q, packed);
     return st == 0 ? g1_inf() : st == 1 ? g1jq_pack(q) : packed;
 }
+KZG_HD bool g1jq_add_slow_copy_a(g1jq &acc, const g1aq *t, bool ng, bool phi) {
+    g1jq a2 = acc, q2 = g1aq_entry_point(t, ng, phi);
+    bool inf = g1jq_add_slow(&a2, &q2);
+    acc = a2;
+    return inf;
+}
+// width-5 NAF GLV multiplication with the AFFINE table (what the G1 FFT stages run since round 2).  Same contract as
+// g1_mul_glv_wnaf_q; `jt` is scratch for the 8 Jacobian multiples (only alive while the table is built).
+template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_mul_glv_wnaf_aq(const g1j &p, const fr &kk, g1aq *tbl, g1jq *jt, int8_t *d1, int8_t *d2, int stride, g1jq &out, g1j &packed) {
+    g1_wnaf_table_affine(p, tbl, jt);
+    const int n1 = glv_wnaf5(kk, 0, d1, stride), n2 = glv_wnaf5(kk, 4, d2, stride);
+    int j = (n1 > n2 ? n1 : n2) - 1;
+    if (j < 0) return 0;                                   // k == 0
+    g1jq acc;
+    bool degenerate = false;
+    {   // top position: at least one of the two digits is non-zero there
+        const int a = d1[j * stride], b = d2[j * stride];
+        if (a) {
+            acc = g1aq_entry_point(&tbl[((a < 0 ? -a : a) - 1) >> 1], a < 0, false);
+            if (b) {
+                const g1aq *t = &tbl[((b < 0 ? -b : b) - 1) >> 1];
+                if (!g1jq_madd_entry(acc, t, b < 0, true)) degenerate = g1jq_add_slow_copy_a(acc, t, b < 0, true);
+            }
+        } else acc = g1aq_entry_point(&tbl[((b < 0 ? -b : b) - 1) >> 1], b < 0, true);
+        j--;
+    }
+    int pend = 0;
+#pragma nounroll
+    for (; j >= 0 && !degenerate; j--) {
+        const int a = d1[j * stride], b = d2[j * stride];
+        pend++;
+        if (!(a | b)) continue;
+#pragma nounroll
+        for (; pend > 0; pend--) acc = INL_DBL ? g1jq_dbl_inl(acc) : g1jq_dbl(acc);
+#pragma nounroll
+        for (int half = 0; half < 2; half++) {
+            const int dg = half ? b : a;
+            if (!dg || degenerate) continue;
+            const g1aq *t = &tbl[((dg < 0 ? -dg : dg) - 1) >> 1];
+            if (g1jq_madd_entry<INL_ADD>(acc, t, dg < 0, half != 0)) continue;
+            degenerate = g1jq_add_slow_copy_a(acc, t, dg < 0, half != 0);
+        }
+    }
+    if (degenerate) { g1j pc = p; fr kc = kk; g1_mul_glv_cold(&packed, &pc, &kc); return 2; }
+#pragma nounroll
+    for (; pend > 0; pend--) acc = g1jq_dbl(acc);
+    out = acc;
+    return 1;
+}
+
 // (P + Q, P - Q) for two finite points, sharing everything but r: add-2007-bl twice is 22M + 10S, this is 13M + 5S (both Y3 as
 // two products under one reduction).  P <= (1, 1, 1) (a canonical point), Q <= (19, 20, 4).  Bounds: H = U2 - U1 : 5, I = (2H)^2,
 // r = 2 (S2 - S1) : 10, r' = -2 (S2 + S1) : 9, X3 : 11, V - X3 : 14, products <= 150.  False when H == 0 (P == +-Q).

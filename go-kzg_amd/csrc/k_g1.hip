@@ -112,8 +112,13 @@ template <int MODE> __global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_fft_stag
         g1jq yq; int st = is_inf(y) ? 0 : 1;
         if (st == 1) {
             if (j) {
+#ifdef KZG_G1_WNAF_JACOBIAN_TABLE
                 g1jq_t tbl[8]; int8_t dg1[132], dg2[132]; g1j packed;
                 st = g1_mul_glv_wnaf_q<true, true>(y, roots[j * (W / (2 * m))], tbl, dg1, dg2, 1, yq, packed);   // roots: (k1, k2) GLV pairs
+#else
+                g1aq tbl[8]; g1jq jt[8]; int8_t dg1[132], dg2[132]; g1j packed;
+                st = g1_mul_glv_wnaf_aq<true, true>(y, roots[j * (W / (2 * m))], tbl, jt, dg1, dg2, 1, yq, packed);   // affine table: mixed additions
+#endif
                 if (st == 2) y = packed; else if (st == 0) y = g1_inf();
             } else yq = g1jq_unpack(y);
         }

@@ -82,12 +82,33 @@ void he_g1_mul_glv_wnaf_inl(g1j *o, const g1j *a, const fr *k_mont) {   // the i
     if (is_inf(pi)) { *o = OUT(g1_inf()); return; }
     g1jq_t tbl[8]; int8_t d1[132], d2[132]; *o = OUT((g1_mul_glv_wnaf<true, true>(pi, glv_decompose(from_mont<FrP>(*k_mont)), tbl, d1, d2, 1)));
 }
+// round 2: the same multiplication with the AFFINE 8-entry table (one inversion per multiplication, mixed additions); inlined and
+// call-based instantiations
+void he_g1_mul_glv_wnaf_affine(g1j *o, const g1j *a, const fr *k_mont, int inl) {
+    g1j pi = IN(a);
+    if (is_inf(pi)) { *o = OUT(g1_inf()); return; }
+    g1aq tbl[8]; g1jq jt[8]; int8_t d1[132], d2[132]; g1jq q; g1j packed;
+    fr kk = glv_decompose(from_mont<FrP>(*k_mont));
+    int st = inl ? g1_mul_glv_wnaf_aq<true, true>(pi, kk, tbl, jt, d1, d2, 1, q, packed) : g1_mul_glv_wnaf_aq<false, false>(pi, kk, tbl, jt, d1, d2, 1, q, packed);
+    *o = OUT(st == 0 ? g1_inf() : st == 1 ? g1jq_pack(q) : packed);
+}
+// acc (= a, any Jacobian image) += sign * phi? * b (normalised to affine here) through g1jq_madd_entry; 1: fast formulas, 0: slow path
+int he_g1jq_madd_entry(g1j *o, const g1j *a, const g1j *b, int negate, int phi, int inl) {
+    g1jq acc = g1jq_unpack(IN(a));
+    g1j bn = g1_normalize(IN(b));
+    g1aq t; t.x = unpackq(bn.x); t.y = unpackq(bn.y);
+    bool ok = inl ? g1jq_madd_entry<true>(acc, &t, negate != 0, phi != 0) : g1jq_madd_entry<false>(acc, &t, negate != 0, phi != 0);
+    if (ok) { *o = OUT(g1jq_pack(acc)); return 1; }
+    bool inf = g1jq_add_slow_copy_a(acc, &t, negate != 0, phi != 0);
+    *o = OUT(inf ? g1_inf() : g1jq_pack(acc));
+    return 0;
+}
 // (a + k b, a - k b) through the butterfly's shared lazy formulas; returns 0 when they decline (a == +-k b or an infinite operand)
 int he_g1_butterfly(g1j *o_sum, g1j *o_dif, const g1j *a, const g1j *b, const fr *k_mont) {
     g1j x = IN(a), y = IN(b);
     if (is_inf(x) || is_inf(y)) return 0;
-    g1jq_t tbl[8]; int8_t d1[132], d2[132]; g1jq yq; g1j packed;
-    int st = g1_mul_glv_wnaf_q<true, true>(y, glv_decompose(from_mont<FrP>(*k_mont)), tbl, d1, d2, 1, yq, packed);
+    g1aq tbl[8]; g1jq jt[8]; int8_t d1[132], d2[132]; g1jq yq; g1j packed;
+    int st = g1_mul_glv_wnaf_aq<true, true>(y, glv_decompose(from_mont<FrP>(*k_mont)), tbl, jt, d1, d2, 1, yq, packed);   // what k_g1_fft_stage<4> runs
     if (st != 1) return 0;
     g1jq sum, dif;
     if (!g1jq_addsub(g1jq_unpack(x), yq, sum, dif)) return 0;

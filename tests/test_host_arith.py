@@ -132,8 +132,11 @@ def test_g1_scalar_mul(he):
             assert np.array_equal(ko.g1_compress(got), ko.g1_compress(want))
             he.he_g1_mul_glv_wnaf(p(got), p(pt), p(k))  # width-5 NAF, 8 odd multiples, every product a call
             assert np.array_equal(ko.g1_compress(got), ko.g1_compress(want))
-            he.he_g1_mul_glv_wnaf_inl(p(got), p(pt), p(k))  # the instantiation the G1 FFT stages run: inlined products, merged reductions
+            he.he_g1_mul_glv_wnaf_inl(p(got), p(pt), p(k))  # round-1 instantiation: Jacobian table, inlined products, merged reductions
             assert np.array_equal(ko.g1_compress(got), ko.g1_compress(want))
+            for inl in (0, 1):                           # round 2: affine table (one inversion), mixed additions; what the G1 FFT stages run
+                he.he_g1_mul_glv_wnaf_affine(p(got), p(pt), p(k), inl)
+                assert np.array_equal(ko.g1_compress(got), ko.g1_compress(want)), inl
     he.he_g1_mul_small.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     for k in (0, 1, 2, 255, 4096, 2**32 - 1):
         got = ko.g1_empty(1)
@@ -155,6 +158,32 @@ def test_wnaf_loop_exceptional_additions(he):
     assert he.he_g1jq_add_entry(p(out), p(a), p(a), 1) == 0 and ko.g1_equal(out[0], ko.g1_zero()[0])
     a2 = ko.g1_add(a, a)                                   # same point, different Jacobian representation (Z != 1)
     assert he.he_g1jq_add_entry(p(out), p(a2), p(ko.g1_add(a, a)), 0) == 0 and ko.g1_equal(out[0], ko.g1_add(a2, a2))
+
+
+def test_wnaf_mixed_addition_and_its_exceptional_cases(he):
+    # acc += +-(phi?) entry with an AFFINE entry (g1jq_madd_entry): accumulators in arbitrary Jacobian images, long chains (the lazy
+    # bounds), doubling / cancellation declined by the fast formulas and handled by the complete ones
+    rng = np.random.default_rng(16)
+    gen = ko.g1_generator()
+    lam = ko.fr_from_ints([0xac45a4010001a40200000000ffffffff])[0]
+    a = ko.g1_add(ko.g1_mul(gen, rand_fr(rng, 1)[0]), ko.g1_mul(gen, rand_fr(rng, 1)[0]))      # Z != 1
+    b = ko.g1_mul(gen, rand_fr(rng, 1)[0])
+    out = ko.g1_empty(1)
+    for inl in (0, 1):
+        for neg in (0, 1):
+            for phi in (0, 1):
+                q = ko.g1_mul(b, lam) if phi else b
+                want = ko.g1_sub(a, q) if neg else ko.g1_add(a, q)
+                assert he.he_g1jq_madd_entry(p(out), p(a), p(b), neg, phi, inl) == 1 and ko.g1_equal(out[0], want), (inl, neg, phi)
+        assert he.he_g1jq_madd_entry(p(out), p(a), p(a), 0, 0, inl) == 0 and ko.g1_equal(out[0], ko.g1_add(a, a))
+        assert he.he_g1jq_madd_entry(p(out), p(a), p(a), 1, 0, inl) == 0 and ko.g1_equal(out[0], ko.g1_zero()[0])
+        acc, want = a.copy(), a.copy()                   # a chain of 300 mixed additions keeps the bound invariant
+        for i in range(300):
+            assert he.he_g1jq_madd_entry(p(out), p(acc), p(b), i & 1, (i >> 1) & 1, inl) == 1
+            q = ko.g1_mul(b, lam) if (i >> 1) & 1 else b
+            want = ko.g1_sub(want, q) if i & 1 else ko.g1_add(want, q)
+            acc = out[0].copy()
+        assert ko.g1_equal(acc, want)
 
 
 def test_fft_butterfly_shared_add_sub(he):
