@@ -470,7 +470,11 @@ def main():
             # multiply-adds of the stage kernel per polynomial: 2 transforms x 20 481 twiddle multiplications (width-5 NAF GLV with
             # an affine 8-entry table: ~126 doublings x 1963 + ~42.7 mixed additions x ~3484 (3315, + 338 for phi on half of them) + 51.4k for
             # the table incl. its normalisation; the binary-GCD inversion has no multiplies) + 24 576 shared (x + wy, x - wy) x 7384
-            mads_unit = 2 * 20481 * (126 * 1963 + 42.7 * 3484 + 51400) + 2 * 24576 * 7384
+            # Fused pipeline (22 stage launches per step): the first two stages of the inverse transform are inside the fixed-base Toeplitz
+            # stage, 2047 + 2046 twiddle multiplications and 4096 butterflies fewer.
+            per_mul = 126 * 1963 + 42.7 * 3484 + 51400
+            fused = int(cnt2.value) == 22
+            mads_unit = ((2 * 20481 - 4093) * per_mul + (2 * 24576 - 4096) * 7384) if fused else (2 * 20481 * per_mul + 2 * 24576 * 7384)
             pf = pmc.get("k_g1_fft_stage", {})
             roofline_fk20 = {"bound": "hbm", "kernel": "k_g1_fft_stage", "achieved": alg / kern_s * 1e-9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": alg / kern_s * 1e-9 / HBM_PEAK_GBS, "launches_per_step": int(cnt2.value), "avg_launch_ms": tot2.value / cnt2.value,
@@ -484,6 +488,7 @@ def main():
                              "issue": ({"issue_model_ms_per_step": (FB * mads_unit / cal_mad + max(pf["valu_insts_per_step"] * 64.0 - FB * mads_unit, 0.0) / cal_add) * 1e3,
                                         "frac_of_kernel_time_explained": (FB * mads_unit / cal_mad + max(pf["valu_insts_per_step"] * 64.0 - FB * mads_unit, 0.0) / cal_add) / kern_s}
                                        if pf.get("batch") == FB and "valu_insts_per_step" in pf else None),
+                             "pipeline": "Toeplitz stage fused with two DIF stages of the inverse transform (k_fb_mul_vec_dif2), 10 DIF + 12 DIT stage launches" if fused else "24 stage launches (unfused)",
                              "note": "one step = %d polynomials; the kernel is launched once per radix-2 stage; integer-issue-bound like the table walk" % FB}
         if use_dist:
             # the north star's "RCCL all-gather of proof points over xGMI": every rank ends up with the proofs of 32 blobs of every

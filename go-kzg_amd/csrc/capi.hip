@@ -1018,7 +1018,34 @@ static int fk20_finish(fk20_core *c, hipStream_t s, const g1j *d_hext, uint64_t 
     HIPCHK(hipGetLastError());
     return KZG_HIP_OK;
 }
+// DA form of a single-file settings object with its table resident: the Toeplitz stage absorbs the first two stages of the inverse
+// transform (k_fb_mul_vec_dif2), the remaining ones run decimation-in-frequency and leave h bit-reversed, which is the layout the
+// forward (decimation-in-time) transform reads: 10 instead of 12 multiplying stages for the inverse transform and no reordering
+// passes.  Same group elements as the plain pipeline; outputs are normalised, so the bytes are identical (tests compare both).
+static bool fk20_fused_ok(const fk20_core *c, uint64_t batch, int da) {
+    static int off = -1;
+    if (off < 0) { const char *e = getenv("KZG_HIP_FK20_FUSE"); off = (e && e[0] == '0') ? 1 : 0; }
+    const uint64_t k2 = 2 * c->k;
+    return !off && da && c->l == 1 && c->d_files_fb && k2 >= 8 && !g1_fft_direct_mode(k2, batch);
+}
+static int fk20_run_fused(fk20_core *c, hipStream_t s, const fr *d_poly, uint64_t poly_stride, uint64_t n, uint64_t batch, int bit_reverse, g1j *d_out) {
+    kzg_hip_fft *fs = c->ks->fs;
+    const uint64_t k2 = 2 * c->k;
+    dtmp<fr> d_tc(s), d_cf(s); dtmp<g1j> d_a(s), d_b(s);
+    CHK(d_tc.alloc(batch * k2)); CHK(d_cf.alloc(batch * k2)); CHK(d_a.alloc(batch * k2)); CHK(d_b.alloc(batch * k2));
+    launch_toeplitz_coeffs(s, d_poly, poly_stride, n, 1, batch, d_tc.p, fs->d_inv_pow2 + ilog2(k2));   // 1 / 2k folded into the scalars
+    fr_fft_rows(fs, s, d_tc.p, k2, k2, d_cf.p, k2, batch, 0);
+    launch_fb_mul_vec_dif2(s, c->d_files_fb, k2, c->fb_c, c->fb_nwin, d_cf.p, fs->d_reversed, fs->W, batch, d_a.p);
+    for (uint64_t m = k2 / 8; m >= 1; m >>= 1) launch_g1_fft_stage_dif(s, d_a.p, k2, batch, m, fs->d_glv_reversed, fs->W);
+    launch_g1_clear_odd(s, d_a.p, batch * k2);                  // h[:k] || inf^k, in bit-reversed order
+    for (uint64_t m = 1; m < k2; m <<= 1) launch_g1_fft_stage(s, d_a.p, k2, batch, m, fs->d_glv_expanded, fs->W);
+    if (bit_reverse) { launch_g1_bitrev_copy(s, d_a.p, k2, k2, d_b.p, k2, batch); launch_g1_normalize(s, d_b.p, d_out, batch * k2, true); }
+    else launch_g1_normalize(s, d_a.p, d_out, batch * k2, true);
+    HIPCHK(hipGetLastError());
+    return KZG_HIP_OK;
+}
 static int fk20_run_dev(fk20_core *c, hipStream_t s, const fr *d_poly, uint64_t poly_stride, uint64_t n, uint64_t batch, int da, int bit_reverse, g1j *d_out) {
+    if (fk20_fused_ok(c, batch, da)) return fk20_run_fused(c, s, d_poly, poly_stride, n, batch, bit_reverse, d_out);
     uint64_t k2 = 2 * c->k;
     dtmp<g1j> d_hext(s);
     CHK(d_hext.alloc(batch * k2));

@@ -662,9 +662,9 @@ KZG_HD g1jq g1aq_entry_point(const g1aq *t, bool ng, bool phi) {
 // the 8 odd multiples P, 3P, .. 15P as affine points: Jacobian multiples (1 doubling + 7 additions) into `jt`, then one inversion of
 // the product of their Z's (binary GCD, ~35 product-equivalents) and 3 products per entry to unwind it, 1S + 3M per entry to scale.
 // p must be a finite point of G1 (no Z is zero and no addition degenerates for points of G1; the degenerate branch is kept for safety).
-KZG_HD void g1_wnaf_table_affine(const g1j &p, g1aq *tbl, g1jq *jt) {
+KZG_HD void g1_wnaf_table_affine_q(const g1jq &p0, g1aq *tbl, g1jq *jt) {   // p0: any lazy Jacobian image with bounds (19, 20, 4)
     {
-        g1jq cur = g1jq_unpack(p);
+        g1jq cur = p0;
         jt[0] = cur;
         g1jq_t p2;
         g1jq_t_make(&p2, g1jq_dbl(cur));
@@ -688,6 +688,7 @@ KZG_HD void g1_wnaf_table_affine(const g1j &p, g1aq *tbl, g1jq *jt) {
         tbl[i].y = mulq(jt[i].y, mulq(zi2, zi));
     }
 }
+KZG_HD void g1_wnaf_table_affine(const g1j &p, g1aq *tbl, g1jq *jt) { g1_wnaf_table_affine_q(g1jq_unpack(p), tbl, jt); }
 KZG_HD bool g1jq_add_slow_copy_a(g1jq &acc, const g1aq *t, bool ng, bool phi);
 
 // p must not be inf.  `tbl` (8 entries, (2 i + 1) P) lives in the lane's private scratch; the digit arrays d1 / d2 (132 entries
@@ -762,8 +763,9 @@ KZG_HD bool g1jq_add_slow_copy_a(g1jq &acc, const g1aq *t, bool ng, bool phi) {
 }
 // width-5 NAF GLV multiplication with the AFFINE table (what the G1 FFT stages run since round 2).  Same contract as
 // g1_mul_glv_wnaf_q; `jt` is scratch for the 8 Jacobian multiples (only alive while the table is built).
-template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_mul_glv_wnaf_aq(const g1j &p, const fr &kk, g1aq *tbl, g1jq *jt, int8_t *d1, int8_t *d2, int stride, g1jq &out, g1j &packed) {
-    g1_wnaf_table_affine(p, tbl, jt);
+// (the multiplicand arrives unpacked: the product of a butterfly's difference in the decimation-in-frequency stages needs no pack / unpack)
+template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_mul_glv_wnaf_aq_q(const g1jq &pq, const fr &kk, g1aq *tbl, g1jq *jt, int8_t *d1, int8_t *d2, int stride, g1jq &out, g1j &packed) {
+    g1_wnaf_table_affine_q(pq, tbl, jt);
     const int n1 = glv_wnaf5(kk, 0, d1, stride), n2 = glv_wnaf5(kk, 4, d2, stride);
     int j = (n1 > n2 ? n1 : n2) - 1;
     if (j < 0) return 0;                                   // k == 0
@@ -797,11 +799,14 @@ template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_mul_glv_wnaf
             degenerate = g1jq_add_slow_copy_a(acc, t, dg < 0, half != 0);
         }
     }
-    if (degenerate) { g1j pc = p; fr kc = kk; g1_mul_glv_cold(&packed, &pc, &kc); return 2; }
+    if (degenerate) { g1j pc = g1jq_pack(pq); fr kc = kk; g1_mul_glv_cold(&packed, &pc, &kc); return 2; }
 #pragma nounroll
     for (; pend > 0; pend--) acc = g1jq_dbl(acc);
     out = acc;
     return 1;
+}
+template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_mul_glv_wnaf_aq(const g1j &p, const fr &kk, g1aq *tbl, g1jq *jt, int8_t *d1, int8_t *d2, int stride, g1jq &out, g1j &packed) {
+    return g1_mul_glv_wnaf_aq_q<INL_DBL, INL_ADD>(g1jq_unpack(p), kk, tbl, jt, d1, d2, stride, out, packed);
 }
 
 // (P + Q, P - Q) for two finite points, sharing everything but r: add-2007-bl twice is 22M + 10S, this is 13M + 5S (both Y3 as

@@ -53,6 +53,10 @@ void launch_g1_bitrev_copy(hipStream_t s, const g1j *in, uint64_t in_stride, uin
 // one radix-2 DIT stage on bit-reversed data (replaces the loop of _fftG1, fft_g1.go:44-55); `roots` holds the twiddles as
 // GLV pairs (k mod lambda, k div lambda) in standard form, see g1_mul_glv
 void launch_g1_fft_stage(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, uint64_t m, const fr *roots, uint64_t W);
+// decimation-in-frequency stage on the same pairs / twiddles: (x, y) -> (x + y, (x - y) w); and the odd-position clear between the
+// FK20 transforms (h[:n] || inf in bit-reversed order)
+void launch_g1_fft_stage_dif(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, uint64_t m, const fr *roots, uint64_t W);
+void launch_g1_clear_odd(hipStream_t s, g1j *data, uint64_t n_total);
 // latency mode: Stockham passes of radix 16 evaluated directly (k_g1.hip); result in data, tmp = batch x n scratch, scale optional
 void launch_g1_fft_direct(hipStream_t s, const g1j *in, uint64_t in_stride, uint64_t n_valid, g1j *data, g1j *tmp, uint64_t n, uint64_t batch, const fr *roots,
                           uint64_t W, const fr *scale);
@@ -90,6 +94,10 @@ void launch_fb_msm(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c
 // out[(b, f, jj)] = scalars[b][f * row + j0 + jj] * P[f * row + j0 + jj] over a fixed-base table of table_n = nfiles * row points
 void launch_fb_mul_vec(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, uint64_t row, uint64_t j0,
                        uint64_t cnt, uint64_t batch, g1j *out);
+// the same stage fused with the first two decimation-in-frequency stages of the inverse G1 transform (single-file tables, N >= 4):
+// out[b][.] = two DIF stages applied to (scalars[b][j] * P_j)_j; roots = ReverseRootsOfUnity (Montgomery) of width W
+void launch_fb_mul_vec_dif2(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, const fr *roots, uint64_t W,
+                            uint64_t batch, g1j *out);
 void launch_g1_sum_files(hipStream_t s, const g1j *tmp, uint64_t nfiles, uint64_t cnt, uint64_t batch, g1j *out);
 
 // profiling hook (HIP events around the dominant kernel), see capi.hip

@@ -145,6 +145,59 @@ template <int MODE> __global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_fft_stag
     row[i0] = g1_add(x, y);
     row[i1] = g1_add(x, g1_neg(y));
 }
+// Decimation-in-frequency form of the same stage: (x, y) -> (x + y, (x - y) w) on the SAME pairs and twiddles (half-size m runs from
+// n / 2 down to 1, natural order in, bit-reversed order out).  Used by the FK20 inverse transform whose first two stages are folded
+// into the fixed-base Toeplitz stage (k_fb_mul_vec_dif2): the remaining stages continue here and leave h in exactly the bit-reversed
+// layout the following forward (decimation-in-time) transform reads, so no reordering pass runs in between.  Same cost per butterfly
+// as the DIT form: the shared (x + y, x - y) formulas, then the width-5 NAF multiplication on the unpacked difference.
+__global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_fft_stage_dif(g1j *data, uint32_t logn, uint64_t m, const fr *roots, uint64_t W, uint64_t total, uint64_t batch) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const uint64_t half = 1ull << (logn - 1), groups = half / m;
+    const uint64_t j = t / (groups * batch), rem = t % (groups * batch), b = rem / groups, g = rem % groups;   // twiddle-major, as in the DIT stage
+    g1j *row = data + (b << logn);
+    uint64_t i0 = g * 2 * m + j, i1 = i0 + m;
+    g1j y = row[i1];
+    g1j x = row[i0];
+    if (!is_inf(x) && !is_inf(y)) {
+        g1jq sum, dif;
+        if (g1jq_addsub(g1jq_unpack(x), g1jq_unpack(y), sum, dif)) {
+            g1j o0; o0.x = packq(sum.x); o0.y = packq(sum.y); o0.z = packq(sum.z);
+            row[i0] = o0;
+            if (j) {
+                g1aq tbl[8]; g1jq jt[8]; int8_t dg1[132], dg2[132]; g1j packed; g1jq dq;
+                int st = g1_mul_glv_wnaf_aq_q<true, true>(dif, roots[j * (W / (2 * m))], tbl, jt, dg1, dg2, 1, dq, packed);
+                row[i1] = st == 1 ? g1jq_pack(dq) : st == 2 ? packed : g1_inf();
+            } else { g1j o1; o1.x = packq(dif.x); o1.y = packq(dif.y); o1.z = o0.z; row[i1] = o1; }
+            return;
+        }
+    }
+    // an infinite operand or x == +-y: generic complete formulas
+    g1j s_ = g1_add(x, y), d_ = g1_add(x, g1_neg(y));
+    if (j && !is_inf(d_)) {
+        g1aq tbl[8]; g1jq jt[8]; int8_t dg1[132], dg2[132]; g1j packed; g1jq dq;
+        int st = g1_mul_glv_wnaf_aq<true, true>(d_, roots[j * (W / (2 * m))], tbl, jt, dg1, dg2, 1, dq, packed);
+        d_ = st == 1 ? g1jq_pack(dq) : st == 2 ? packed : g1_inf();
+    }
+    row[i0] = s_; row[i1] = d_;
+}
+void launch_g1_fft_stage_dif(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, uint64_t m, const fr *roots, uint64_t W) {
+    uint64_t total = n / 2 * batch;
+    if (!total) return;
+    prof_begin(s, "g1_fft_stage");
+    hipLaunchKernelGGL(k_g1_fft_stage_dif, dim3((uint32_t)((total + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, data, ilog2g(n), m, roots, W, total, batch);
+    prof_end(s, "g1_fft_stage");
+}
+// data[b][i] = inf for every odd i: in bit-reversed order these are the coefficients k >= n / 2, i.e. the "h[:n] || inf" padding of
+// fk20_single.go:163-166 between the two transforms
+__global__ void k_g1_clear_odd(g1j *data, uint64_t total_pairs) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t < total_pairs) data[2 * t + 1] = g1_inf();
+}
+void launch_g1_clear_odd(hipStream_t s, g1j *data, uint64_t n_total) {
+    if (n_total < 2) return;
+    hipLaunchKernelGGL(k_g1_clear_odd, dim3((uint32_t)((n_total / 2 + 255) / 256)), dim3(256), 0, s, data, n_total / 2);
+}
 void launch_g1_fft_stage(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, uint64_t m, const fr *roots, uint64_t W) {
     uint64_t total = n / 2 * batch;
     if (!total) return;

@@ -534,6 +534,67 @@ __global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_mul_vec(const g1a *table, ui
     }
     out[t] = acc.to_jac();
 }
+// The FK20 Toeplitz stage fused with the FIRST TWO decimation-in-frequency stages of the inverse G1 transform that follows it
+// (fk20_single.go:72-74 + the first two levels of ToeplitzPart3's FFTG1, :80-87).  With v_j = C[j] X[j], q = N / 4, w = the inverse
+// root of order N and i < q, two DIF stages give
+//     y[i]         =            v_i +           v_{i+q} +          v_{i+2q} +           v_{i+3q}
+//     y[q + i]     = w^{2i}   ( v_i -           v_{i+q} +          v_{i+2q} -           v_{i+3q} )
+//     y[2q + i]    = w^{i}      v_i + w^{i+q}   v_{i+q} - w^{i}    v_{i+2q} - w^{i+q}   v_{i+3q}
+//     y[3q + i]    = w^{3i}     v_i - w^{3i+q}  v_{i+q} - w^{3i}   v_{i+2q} + w^{3i+q}  v_{i+3q}
+// i.e. every output is a FOUR-term fixed-base MSM over the resident X table with scalars C[.] * (a root of unity): 4 x nwin mixed
+// additions (~720 product-equivalents) replace one table walk + two butterfly levels (~1640), the twiddle multiplications of the two
+// widest stages of the transform (a fifth of all of them) disappear.  Lane = (polynomial, output); scalars in Montgomery form;
+// roots = ReverseRootsOfUnity (Montgomery), W = its width.
+__global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_mul_vec_dif2(const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, uint32_t D, const fr *scalars,
+                                                              const fr *roots, uint64_t W, uint64_t total, g1j *out) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const uint64_t N = table_n, q = N >> 2;
+    const uint64_t i = t % q, o = (t / q) & 3u, b = t / N;
+    const uint64_t rs = W / N;                              // stride of the order-N roots inside the width-W table
+    g1x_acc acc; acc.init();
+#pragma nounroll
+    for (uint32_t term = 0; term < 4; term++) {
+        const uint64_t pi = i + term * q;
+        // exponent and sign of the root that multiplies C[pi] in output o (table above)
+        uint64_t e; uint32_t sg;
+        if (o == 0) { e = 0; sg = 0; }
+        else if (o == 1) { e = 2 * i; sg = term & 1u; }
+        else if (o == 2) { e = i + ((term & 1u) ? q : 0); sg = term >> 1; }
+        else { e = 3 * i + ((term & 1u) ? q : 0); sg = (term == 1 || term == 2) ? 1u : 0u; }
+        fr kmont = scalars[b * N + pi];
+        if (e) kmont = mul(kmont, roots[(e & (N - 1)) * rs]);
+        const fr k = from_mont<FrP>(kmont);
+        // the table walk of k_fb_mul_vec for point pi, sign folded into the digits
+        uint32_t raw = scalar_bits(k, 0, c), carry, mag, ng;
+        if (raw > D) { carry = 1; mag = (1u << c) - raw; ng = 1; } else { carry = 0; mag = raw; ng = 0; }
+        g1a qn = table[((uint64_t)0 * table_n + pi) * D + (mag ? mag - 1 : 0)];
+#pragma nounroll
+        for (uint32_t w = 0; w < nwin; w++) {
+            g1a qq = qn;
+            const uint32_t cmag = mag, cng = ng ^ sg;
+            if (w + 1 < nwin) {
+                raw = scalar_bits(k, (w + 1) * c, c) + carry;
+                if (raw > D) { carry = 1; mag = (1u << c) - raw; ng = 1; } else { carry = 0; mag = raw; ng = 0; }
+                qn = table[((uint64_t)(w + 1) * table_n + pi) * D + (mag ? mag - 1 : 0)];
+            }
+            if (cmag) {
+                if (cng) qq.y = neg<FpP>(qq.y);
+                acc.add(qq);
+            }
+        }
+    }
+    out[b * N + o * q + i] = acc.to_jac();
+}
+void launch_fb_mul_vec_dif2(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, const fr *roots, uint64_t W,
+                            uint64_t batch, g1j *out) {
+    uint64_t total = batch * table_n;
+    if (!total) return;
+    prof_begin(s, "fb_mul_vec");
+    hipLaunchKernelGGL(k_fb_mul_vec_dif2, dim3((uint32_t)((total + FB_BLOCK - 1) / FB_BLOCK)), dim3(FB_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars,
+                       roots, W, total, out);
+    prof_end(s, "fb_mul_vec");
+}
 void launch_fb_mul_vec(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, uint64_t row, uint64_t j0,
                        uint64_t cnt, uint64_t batch, g1j *out) {
     uint64_t total = batch * (table_n / row) * cnt;

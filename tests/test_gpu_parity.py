@@ -669,6 +669,21 @@ def test_da_using_fk20_batch_host_buffers(kz, ks4096):
     fk.close()
 
 
+def test_fk20_paths_agree_in_a_fresh_process():
+    """FK20 runs through three pipelines depending on size: direct radix-16 passes (a lone transform), the radix-2 network, and -- for
+    DA forms of single-file settings with a resident table -- the Toeplitz stage fused with two decimation-in-frequency stages.  The
+    choice is made once per process, so the small-scale KATs and the config-4a byte pin are re-run in child processes that force the
+    radix-2 / fused pipeline (KZG_HIP_G1_FFT=radix2) and the unfused one (KZG_HIP_FK20_FUSE=0) at every size."""
+    import subprocess
+    import sys
+    for extra in ({"KZG_HIP_G1_FFT": "radix2"}, {"KZG_HIP_G1_FFT": "radix2", "KZG_HIP_FK20_FUSE": "0"}, {"KZG_HIP_G1_FFT": "direct"}):
+        env = dict(os.environ, **extra)
+        res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k",
+                              "vector_C or vectors_D or config4a or batch_host_buffers or fft_g1_small or full_das_flow"],
+                             env=env, capture_output=True, text=True, timeout=1200)
+        assert res.returncode == 0, (extra, res.stdout[-1500:])
+
+
 def test_concurrent_callers_share_a_handle(kz, ks4096, setup_1337):
     """the reference's settings are read-only after construction (SURVEY.md 8b threading); the library serialises per handle"""
     import threading
