@@ -83,6 +83,7 @@ struct kzg_hip_fft {
     fr *d_expanded = nullptr, *d_reversed = nullptr;
     fr *d_inv_pow2 = nullptr;   // (2^k)^-1, k = 0..63 (Montgomery)
     fr *d_glv_expanded = nullptr, *d_glv_reversed = nullptr;   // twiddles as GLV pairs for the G1 FFT (g1_mul_glv)
+    int8_t *d_wnaf_expanded = nullptr, *d_wnaf_reversed = nullptr;   // ... and their width-5 NAF digit strings (KZG_WNAF_ROW bytes per twiddle)
     std::mutex mu;
 };
 struct kzg_hip_kzg {
@@ -166,6 +167,14 @@ static int upload_g1_twiddles(kzg_hip_fft *fs) {
     HIPCHK(hipMalloc((void **)&fs->d_glv_reversed, bytes));
     HIPCHK(hipMemcpy(fs->d_glv_expanded, ge.data(), bytes, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(fs->d_glv_reversed, gr.data(), bytes, hipMemcpyHostToDevice));
+    // the recoding the stage kernels would otherwise repeat per butterfly (130 steps per half): once per twiddle, here
+    std::vector<int8_t> we((fs->W + 1) * KZG_WNAF_ROW), wr((fs->W + 1) * KZG_WNAF_ROW);
+    for (uint64_t i = 0; i <= fs->W; i++) glv_wnaf5_row(ge[i], &we[i * KZG_WNAF_ROW]);
+    for (uint64_t i = 0; i <= fs->W; i++) memcpy(&wr[i * KZG_WNAF_ROW], &we[(fs->W - i) * KZG_WNAF_ROW], KZG_WNAF_ROW);
+    HIPCHK(hipMalloc((void **)&fs->d_wnaf_expanded, we.size()));
+    HIPCHK(hipMalloc((void **)&fs->d_wnaf_reversed, wr.size()));
+    HIPCHK(hipMemcpy(fs->d_wnaf_expanded, we.data(), we.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(fs->d_wnaf_reversed, wr.data(), wr.size(), hipMemcpyHostToDevice));
     return KZG_HIP_OK;
 }
 static bool device_is_gfx950(int device) {
@@ -218,7 +227,7 @@ void kzg_hip_fft_settings_free(kzg_hip_fft *fs) {
     if (!fs) return;
     hipSetDevice(fs->device);
     if (fs->stream) hipStreamSynchronize(fs->stream);
-    hipFree(fs->d_expanded); hipFree(fs->d_reversed); hipFree(fs->d_inv_pow2); hipFree(fs->d_glv_expanded); hipFree(fs->d_glv_reversed);
+    hipFree(fs->d_expanded); hipFree(fs->d_reversed); hipFree(fs->d_inv_pow2); hipFree(fs->d_glv_expanded); hipFree(fs->d_glv_reversed); hipFree(fs->d_wnaf_expanded); hipFree(fs->d_wnaf_reversed);
     if (fs->stream) hipStreamDestroy(fs->stream);
     (void)hipGetLastError();
     delete fs;
@@ -291,7 +300,8 @@ static int g1_fft_rows(kzg_hip_fft *fs, hipStream_t s, const g1j *d_in, uint64_t
     }
     launch_g1_bitrev_copy(s, d_in, in_stride, n_valid, d_data, n, batch);
     const fr *roots = inv ? fs->d_glv_reversed : fs->d_glv_expanded;
-    for (uint64_t m = 1; m < n; m <<= 1) launch_g1_fft_stage(s, d_data, n, batch, m, roots, fs->W);
+    const int8_t *wnaf = inv ? fs->d_wnaf_reversed : fs->d_wnaf_expanded;
+    for (uint64_t m = 1; m < n; m <<= 1) launch_g1_fft_stage(s, d_data, n, batch, m, roots, wnaf, fs->W);
     if (scale) launch_g1_mul_vec(s, d_data, n * batch, scale, 0, n * batch, d_data);
     return KZG_HIP_OK;
 }
@@ -1036,9 +1046,9 @@ static int fk20_run_fused(fk20_core *c, hipStream_t s, const fr *d_poly, uint64_
     launch_toeplitz_coeffs(s, d_poly, poly_stride, n, 1, batch, d_tc.p, fs->d_inv_pow2 + ilog2(k2));   // 1 / 2k folded into the scalars
     fr_fft_rows(fs, s, d_tc.p, k2, k2, d_cf.p, k2, batch, 0);
     launch_fb_mul_vec_dif2(s, c->d_files_fb, k2, c->fb_c, c->fb_nwin, d_cf.p, fs->d_reversed, fs->W, batch, d_a.p);
-    for (uint64_t m = k2 / 8; m >= 1; m >>= 1) launch_g1_fft_stage_dif(s, d_a.p, k2, batch, m, fs->d_glv_reversed, fs->W);
+    for (uint64_t m = k2 / 8; m >= 1; m >>= 1) launch_g1_fft_stage_dif(s, d_a.p, k2, batch, m, fs->d_glv_reversed, fs->d_wnaf_reversed, fs->W);
     launch_g1_clear_odd(s, d_a.p, batch * k2);                  // h[:k] || inf^k, in bit-reversed order
-    for (uint64_t m = 1; m < k2; m <<= 1) launch_g1_fft_stage(s, d_a.p, k2, batch, m, fs->d_glv_expanded, fs->W);
+    for (uint64_t m = 1; m < k2; m <<= 1) launch_g1_fft_stage(s, d_a.p, k2, batch, m, fs->d_glv_expanded, fs->d_wnaf_expanded, fs->W);
     if (bit_reverse) { launch_g1_bitrev_copy(s, d_a.p, k2, k2, d_b.p, k2, batch); launch_g1_normalize(s, d_b.p, d_out, batch * k2, true); }
     else launch_g1_normalize(s, d_a.p, d_out, batch * k2, true);
     HIPCHK(hipGetLastError());

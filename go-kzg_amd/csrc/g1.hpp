@@ -764,9 +764,7 @@ KZG_HD bool g1jq_add_slow_copy_a(g1jq &acc, const g1aq *t, bool ng, bool phi) {
 // width-5 NAF GLV multiplication with the AFFINE table (what the G1 FFT stages run since round 2).  Same contract as
 // g1_mul_glv_wnaf_q; `jt` is scratch for the 8 Jacobian multiples (only alive while the table is built).
 // (the multiplicand arrives unpacked: the product of a butterfly's difference in the decimation-in-frequency stages needs no pack / unpack)
-template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_mul_glv_wnaf_aq_q(const g1jq &pq, const fr &kk, g1aq *tbl, g1jq *jt, int8_t *d1, int8_t *d2, int stride, g1jq &out, g1j &packed) {
-    g1_wnaf_table_affine_q(pq, tbl, jt);
-    const int n1 = glv_wnaf5(kk, 0, d1, stride), n2 = glv_wnaf5(kk, 4, d2, stride);
+template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_wnaf_loop_aq(const g1jq &pq, const fr &kk, const g1aq *tbl, const int8_t *d1, const int8_t *d2, int stride, int n1, int n2, g1jq &out, g1j &packed) {
     int j = (n1 > n2 ? n1 : n2) - 1;
     if (j < 0) return 0;                                   // k == 0
     g1jq acc;
@@ -804,6 +802,23 @@ template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_mul_glv_wnaf
     for (; pend > 0; pend--) acc = g1jq_dbl(acc);
     out = acc;
     return 1;
+}
+template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_mul_glv_wnaf_aq_q(const g1jq &pq, const fr &kk, g1aq *tbl, g1jq *jt, int8_t *d1, int8_t *d2, int stride, g1jq &out, g1j &packed) {
+    g1_wnaf_table_affine_q(pq, tbl, jt);
+    const int n1 = glv_wnaf5(kk, 0, d1, stride), n2 = glv_wnaf5(kk, 4, d2, stride);
+    return g1_wnaf_loop_aq<INL_DBL, INL_ADD>(pq, kk, tbl, d1, d2, stride, n1, n2, out, packed);
+}
+// the digit strings come PRECOMPUTED (the twiddles of an FFTSettings are fixed: their width-5 NAF recodings are built once on the
+// host with the same glv_wnaf5 and live in HBM): `dg` = 132 bytes for k1 (digit i at [i], the length at [131]) followed by 132 for k2
+#define KZG_WNAF_ROW 264
+template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_mul_glv_wnaf_aq_pre_q(const g1jq &pq, const fr &kk, g1aq *tbl, g1jq *jt, const int8_t *dg, g1jq &out, g1j &packed) {
+    g1_wnaf_table_affine_q(pq, tbl, jt);
+    return g1_wnaf_loop_aq<INL_DBL, INL_ADD>(pq, kk, tbl, dg, dg + 132, 1, (int)(uint8_t)dg[131], (int)(uint8_t)dg[132 + 131], out, packed);
+}
+KZG_HD void glv_wnaf5_row(const fr &kk, int8_t *row) {      // host side of the above
+    int n1 = glv_wnaf5(kk, 0, row, 1), n2 = glv_wnaf5(kk, 4, row + 132, 1);
+    row[130] = 0; row[132 + 130] = 0;
+    row[131] = (int8_t)n1; row[132 + 131] = (int8_t)n2;
 }
 template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_mul_glv_wnaf_aq(const g1j &p, const fr &kk, g1aq *tbl, g1jq *jt, int8_t *d1, int8_t *d2, int stride, g1jq &out, g1j &packed) {
     return g1_mul_glv_wnaf_aq_q<INL_DBL, INL_ADD>(g1jq_unpack(p), kk, tbl, jt, d1, d2, stride, out, packed);

@@ -52,10 +52,10 @@ hipError_t launch_g1_file_msm(hipStream_t s, const g1j *files, const fr *scalars
 void launch_g1_bitrev_copy(hipStream_t s, const g1j *in, uint64_t in_stride, uint64_t n_valid, g1j *out, uint64_t n, uint64_t batch);
 // one radix-2 DIT stage on bit-reversed data (replaces the loop of _fftG1, fft_g1.go:44-55); `roots` holds the twiddles as
 // GLV pairs (k mod lambda, k div lambda) in standard form, see g1_mul_glv
-void launch_g1_fft_stage(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, uint64_t m, const fr *roots, uint64_t W);
+void launch_g1_fft_stage(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, uint64_t m, const fr *roots, const int8_t *wnaf, uint64_t W);   // wnaf: the twiddles' precomputed digit strings (KZG_WNAF_ROW bytes each)
 // decimation-in-frequency stage on the same pairs / twiddles: (x, y) -> (x + y, (x - y) w); and the odd-position clear between the
 // FK20 transforms (h[:n] || inf in bit-reversed order)
-void launch_g1_fft_stage_dif(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, uint64_t m, const fr *roots, uint64_t W);
+void launch_g1_fft_stage_dif(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, uint64_t m, const fr *roots, const int8_t *wnaf, uint64_t W);
 void launch_g1_clear_odd(hipStream_t s, g1j *data, uint64_t n_total);
 // latency mode: Stockham passes of radix 16 evaluated directly (k_g1.hip); result in data, tmp = batch x n scratch, scale optional
 void launch_g1_fft_direct(hipStream_t s, const g1j *in, uint64_t in_stride, uint64_t n_valid, g1j *data, g1j *tmp, uint64_t n, uint64_t batch, const fr *roots,

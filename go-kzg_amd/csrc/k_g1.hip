@@ -90,7 +90,7 @@ void launch_g1_bitrev_copy(hipStream_t s, const g1j *in, uint64_t in_stride, uin
 // One DIT stage with half-size m on bit-reversed data: (x, y) -> (x + w y, x - w y), w = roots[j * W / (2m)].
 // This is the butterfly loop of _fftG1 (fft_g1.go:44-55); the recursion's 4-point leaves (simpleFTG1, :11-31) are
 // the same linear map, so outputs are identical as group elements.
-template <int MODE> __global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_fft_stage(g1j *data, uint32_t logn, uint64_t m, const fr *roots, uint64_t W, uint64_t total, uint64_t batch) {
+template <int MODE, bool PRE = false> __global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_fft_stage(g1j *data, uint32_t logn, uint64_t m, const fr *roots, const int8_t *wnaf, uint64_t W, uint64_t total, uint64_t batch) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= total) return;
     // Twiddle-major lane order: t -> (j, b, g).  All lanes of a wavefront then share ONE twiddle, so (i) the waves with j == 0
@@ -116,8 +116,10 @@ template <int MODE> __global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_fft_stag
                 g1jq_t tbl[8]; int8_t dg1[132], dg2[132]; g1j packed;
                 st = g1_mul_glv_wnaf_q<true, true>(y, roots[j * (W / (2 * m))], tbl, dg1, dg2, 1, yq, packed);   // roots: (k1, k2) GLV pairs
 #else
-                g1aq tbl[8]; g1jq jt[8]; int8_t dg1[132], dg2[132]; g1j packed;
-                st = g1_mul_glv_wnaf_aq<true, true>(y, roots[j * (W / (2 * m))], tbl, jt, dg1, dg2, 1, yq, packed);   // affine table: mixed additions
+                g1aq tbl[8]; g1jq jt[8]; g1j packed;
+                const uint64_t ti = j * (W / (2 * m));                 // twiddle index: GLV pair + its precomputed width-5 NAF digit strings
+                if (PRE) st = g1_mul_glv_wnaf_aq_pre_q<true, true>(g1jq_unpack(y), roots[ti], tbl, jt, wnaf + ti * KZG_WNAF_ROW, yq, packed);   // affine table: mixed additions
+                else { int8_t dg1[132], dg2[132]; st = g1_mul_glv_wnaf_aq<true, true>(y, roots[ti], tbl, jt, dg1, dg2, 1, yq, packed); }
 #endif
                 if (st == 2) y = packed; else if (st == 0) y = g1_inf();
             } else yq = g1jq_unpack(y);
@@ -145,12 +147,19 @@ template <int MODE> __global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_fft_stag
     row[i0] = g1_add(x, y);
     row[i1] = g1_add(x, g1_neg(y));
 }
+// The twiddles' precomputed width-5 NAF digit strings (264 bytes per twiddle in HBM) replace the per-butterfly recoding only where a
+// row is shared by many lanes (>= 512: measured +2.3 % on the 512-polynomial FK20 step); with one wavefront per twiddle every row is a
+// cold read and the recoding in registers is faster (measured -4 % on 64 transforms when the rows were always used).
+#ifndef KZG_WNAF_ROWS_MIN
+#define KZG_WNAF_ROWS_MIN 512          // lanes per twiddle from which the precomputed rows are used (A/B builds: 0 = always, 1 << 60 = never)
+#endif
+static bool g1_wnaf_rows_pay(uint64_t n, uint64_t batch, uint64_t m) { return (n / 2 / m) * batch >= (uint64_t)KZG_WNAF_ROWS_MIN; }
 // Decimation-in-frequency form of the same stage: (x, y) -> (x + y, (x - y) w) on the SAME pairs and twiddles (half-size m runs from
 // n / 2 down to 1, natural order in, bit-reversed order out).  Used by the FK20 inverse transform whose first two stages are folded
 // into the fixed-base Toeplitz stage (k_fb_mul_vec_dif2): the remaining stages continue here and leave h in exactly the bit-reversed
 // layout the following forward (decimation-in-time) transform reads, so no reordering pass runs in between.  Same cost per butterfly
 // as the DIT form: the shared (x + y, x - y) formulas, then the width-5 NAF multiplication on the unpacked difference.
-__global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_fft_stage_dif(g1j *data, uint32_t logn, uint64_t m, const fr *roots, uint64_t W, uint64_t total, uint64_t batch) {
+template <bool PRE> __global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_fft_stage_dif(g1j *data, uint32_t logn, uint64_t m, const fr *roots, const int8_t *wnaf, uint64_t W, uint64_t total, uint64_t batch) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= total) return;
     const uint64_t half = 1ull << (logn - 1), groups = half / m;
@@ -165,8 +174,11 @@ __global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_fft_stage_dif(g1j *data, uin
             g1j o0; o0.x = packq(sum.x); o0.y = packq(sum.y); o0.z = packq(sum.z);
             row[i0] = o0;
             if (j) {
-                g1aq tbl[8]; g1jq jt[8]; int8_t dg1[132], dg2[132]; g1j packed; g1jq dq;
-                int st = g1_mul_glv_wnaf_aq_q<true, true>(dif, roots[j * (W / (2 * m))], tbl, jt, dg1, dg2, 1, dq, packed);
+                g1aq tbl[8]; g1jq jt[8]; g1j packed; g1jq dq;
+                const uint64_t ti = j * (W / (2 * m));
+                int st;
+                if (PRE) st = g1_mul_glv_wnaf_aq_pre_q<true, true>(dif, roots[ti], tbl, jt, wnaf + ti * KZG_WNAF_ROW, dq, packed);
+                else { int8_t dg1[132], dg2[132]; st = g1_mul_glv_wnaf_aq_q<true, true>(dif, roots[ti], tbl, jt, dg1, dg2, 1, dq, packed); }
                 row[i1] = st == 1 ? g1jq_pack(dq) : st == 2 ? packed : g1_inf();
             } else { g1j o1; o1.x = packq(dif.x); o1.y = packq(dif.y); o1.z = o0.z; row[i1] = o1; }
             return;
@@ -175,17 +187,21 @@ __global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_fft_stage_dif(g1j *data, uin
     // an infinite operand or x == +-y: generic complete formulas
     g1j s_ = g1_add(x, y), d_ = g1_add(x, g1_neg(y));
     if (j && !is_inf(d_)) {
-        g1aq tbl[8]; g1jq jt[8]; int8_t dg1[132], dg2[132]; g1j packed; g1jq dq;
-        int st = g1_mul_glv_wnaf_aq<true, true>(d_, roots[j * (W / (2 * m))], tbl, jt, dg1, dg2, 1, dq, packed);
+        g1aq tbl[8]; g1jq jt[8]; g1j packed; g1jq dq;
+        const uint64_t ti = j * (W / (2 * m));
+        int8_t dg1[132], dg2[132];
+        int st = g1_mul_glv_wnaf_aq<true, true>(d_, roots[ti], tbl, jt, dg1, dg2, 1, dq, packed);
         d_ = st == 1 ? g1jq_pack(dq) : st == 2 ? packed : g1_inf();
     }
     row[i0] = s_; row[i1] = d_;
 }
-void launch_g1_fft_stage_dif(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, uint64_t m, const fr *roots, uint64_t W) {
+void launch_g1_fft_stage_dif(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, uint64_t m, const fr *roots, const int8_t *wnaf, uint64_t W) {
     uint64_t total = n / 2 * batch;
     if (!total) return;
     prof_begin(s, "g1_fft_stage");
-    hipLaunchKernelGGL(k_g1_fft_stage_dif, dim3((uint32_t)((total + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, data, ilog2g(n), m, roots, W, total, batch);
+    const dim3 grid((uint32_t)((total + G1_BLOCK - 1) / G1_BLOCK)), block(G1_BLOCK);
+    if (g1_wnaf_rows_pay(n, batch, m)) hipLaunchKernelGGL(k_g1_fft_stage_dif<true>, grid, block, 0, s, data, ilog2g(n), m, roots, wnaf, W, total, batch);
+    else hipLaunchKernelGGL(k_g1_fft_stage_dif<false>, grid, block, 0, s, data, ilog2g(n), m, roots, wnaf, W, total, batch);
     prof_end(s, "g1_fft_stage");
 }
 // data[b][i] = inf for every odd i: in bit-reversed order these are the coefficients k >= n / 2, i.e. the "h[:n] || inf" padding of
@@ -198,7 +214,7 @@ void launch_g1_clear_odd(hipStream_t s, g1j *data, uint64_t n_total) {
     if (n_total < 2) return;
     hipLaunchKernelGGL(k_g1_clear_odd, dim3((uint32_t)((n_total / 2 + 255) / 256)), dim3(256), 0, s, data, n_total / 2);
 }
-void launch_g1_fft_stage(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, uint64_t m, const fr *roots, uint64_t W) {
+void launch_g1_fft_stage(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, uint64_t m, const fr *roots, const int8_t *wnaf, uint64_t W) {
     uint64_t total = n / 2 * batch;
     if (!total) return;
     prof_begin(s, "g1_fft_stage");
@@ -213,11 +229,14 @@ void launch_g1_fft_stage(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, u
     const dim3 grid((uint32_t)((total + G1_BLOCK - 1) / G1_BLOCK)), block(G1_BLOCK);
     const uint32_t logn = ilog2g(n);
     switch (mode) {
-    case 4: hipLaunchKernelGGL(k_g1_fft_stage<4>, grid, block, 0, s, data, logn, m, roots, W, total, batch); break;
-    case 3: hipLaunchKernelGGL(k_g1_fft_stage<3>, grid, block, 0, s, data, logn, m, roots, W, total, batch); break;
-    case 2: hipLaunchKernelGGL(k_g1_fft_stage<2>, grid, block, 0, s, data, logn, m, roots, W, total, batch); break;
-    case 1: hipLaunchKernelGGL(k_g1_fft_stage<1>, grid, block, 0, s, data, logn, m, roots, W, total, batch); break;
-    default: hipLaunchKernelGGL(k_g1_fft_stage<0>, grid, block, 0, s, data, logn, m, roots, W, total, batch); break;
+    case 4:
+        if (g1_wnaf_rows_pay(n, batch, m)) hipLaunchKernelGGL((k_g1_fft_stage<4, true>), grid, block, 0, s, data, logn, m, roots, wnaf, W, total, batch);
+        else hipLaunchKernelGGL((k_g1_fft_stage<4, false>), grid, block, 0, s, data, logn, m, roots, wnaf, W, total, batch);
+        break;
+    case 3: hipLaunchKernelGGL(k_g1_fft_stage<3>, grid, block, 0, s, data, logn, m, roots, wnaf, W, total, batch); break;
+    case 2: hipLaunchKernelGGL(k_g1_fft_stage<2>, grid, block, 0, s, data, logn, m, roots, wnaf, W, total, batch); break;
+    case 1: hipLaunchKernelGGL(k_g1_fft_stage<1>, grid, block, 0, s, data, logn, m, roots, wnaf, W, total, batch); break;
+    default: hipLaunchKernelGGL(k_g1_fft_stage<0>, grid, block, 0, s, data, logn, m, roots, wnaf, W, total, batch); break;
     }
     prof_end(s, "g1_fft_stage");
 }
