@@ -1003,7 +1003,8 @@ static int fk20_hext(fk20_core *c, hipStream_t s, const fr *d_poly, uint64_t pol
     fr_fft_rows(fs, s, d_tc.p, k2, k2, d_cf.p, k2, batch * l, 0);
     if (c->d_files_fb) {
         if (l == 1) launch_fb_mul_vec(s, c->d_files_fb, l * k2, c->fb_c, c->fb_nwin, d_cf.p, k2, j0, cnt, batch, d_hext);
-        else {
+        else if (batch * cnt >= 65536) launch_fb_mul_vec_files(s, c->d_files_fb, l * k2, c->fb_c, c->fb_nwin, d_cf.p, k2, j0, cnt, batch, d_hext);   // enough output positions to fill the GPU: one lane sums all files
+        else {   // few positions (one polynomial, a shard): a lane per (file, position), then the sum over the files
             dtmp<g1j> d_tmp(s);
             CHK(d_tmp.alloc(batch * l * cnt));
             launch_fb_mul_vec(s, c->d_files_fb, l * k2, c->fb_c, c->fb_nwin, d_cf.p, k2, j0, cnt, batch, d_tmp.p);

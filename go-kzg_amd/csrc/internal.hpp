@@ -98,6 +98,9 @@ void launch_fb_mul_vec(hipStream_t s, const g1a *table, uint64_t table_n, uint32
 // out[b][.] = two DIF stages applied to (scalars[b][j] * P_j)_j; roots = ReverseRootsOfUnity (Montgomery) of width W
 void launch_fb_mul_vec_dif2(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, const fr *roots, uint64_t W,
                             uint64_t batch, g1j *out);
+// all files of an output position summed in one lane: out[b][jj] = sum_f scalars[b][f * row + j0 + jj] * P[f * row + j0 + jj]
+void launch_fb_mul_vec_files(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, uint64_t row, uint64_t j0,
+                             uint64_t cnt, uint64_t batch, g1j *out);
 void launch_g1_sum_files(hipStream_t s, const g1j *tmp, uint64_t nfiles, uint64_t cnt, uint64_t batch, g1j *out);
 
 // profiling hook (HIP events around the dominant kernel), see capi.hip

@@ -595,6 +595,48 @@ void launch_fb_mul_vec_dif2(hipStream_t s, const g1a *table, uint64_t table_n, u
                        roots, W, total, out);
     prof_end(s, "fb_mul_vec");
 }
+// FK20Multi's Toeplitz stage (fk20_multi.go:79-91): out[b][jj] = sum over the files f of scalars[b][f * row + j0 + jj] * X_f[j0 + jj],
+// all files of an output position in ONE lane's accumulator (nfiles x nwin mixed additions): no per-file temporaries and no
+// summation pass with generic additions afterwards.
+__global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_mul_vec_files(const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, uint32_t D, const fr *scalars,
+                                                               uint64_t i0, uint64_t cnt, uint64_t row, uint64_t total, g1j *out) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const uint64_t jj = t % cnt, b = t / cnt, nfiles = table_n / row;
+    g1x_acc acc; acc.init();
+#pragma nounroll
+    for (uint64_t f = 0; f < nfiles; f++) {
+        const uint64_t i = f * row + i0 + jj;
+        fr k = from_mont<FrP>(scalars[b * table_n + i]);
+        uint32_t raw = scalar_bits(k, 0, c), carry, mag, ng;
+        if (raw > D) { carry = 1; mag = (1u << c) - raw; ng = 1; } else { carry = 0; mag = raw; ng = 0; }
+        g1a qn = table[((uint64_t)0 * table_n + i) * D + (mag ? mag - 1 : 0)];
+#pragma nounroll
+        for (uint32_t w = 0; w < nwin; w++) {
+            g1a q = qn;
+            const uint32_t cmag = mag, cng = ng;
+            if (w + 1 < nwin) {
+                raw = scalar_bits(k, (w + 1) * c, c) + carry;
+                if (raw > D) { carry = 1; mag = (1u << c) - raw; ng = 1; } else { carry = 0; mag = raw; ng = 0; }
+                qn = table[((uint64_t)(w + 1) * table_n + i) * D + (mag ? mag - 1 : 0)];
+            }
+            if (cmag) {
+                if (cng) q.y = neg<FpP>(q.y);
+                acc.add(q);
+            }
+        }
+    }
+    out[t] = acc.to_jac();
+}
+void launch_fb_mul_vec_files(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, uint64_t row, uint64_t j0,
+                             uint64_t cnt, uint64_t batch, g1j *out) {
+    uint64_t total = batch * cnt;
+    if (!total) return;
+    prof_begin(s, "fb_mul_vec");
+    hipLaunchKernelGGL(k_fb_mul_vec_files, dim3((uint32_t)((total + FB_BLOCK - 1) / FB_BLOCK)), dim3(FB_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars,
+                       j0, cnt, row, total, out);
+    prof_end(s, "fb_mul_vec");
+}
 void launch_fb_mul_vec(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, uint64_t row, uint64_t j0,
                        uint64_t cnt, uint64_t batch, g1j *out) {
     uint64_t total = batch * (table_n / row) * cnt;

@@ -579,6 +579,29 @@ def test_fk20_single_4096_config4a(kz, ks4096):
     fk.close()
 
 
+def test_fk20_multi_batched_file_accumulation(kz):
+    """batches with >= 65536 output positions sum all files of a position in one lane (k_fb_mul_vec_files) instead of a lane per
+    (file, position) + a summation pass: same proofs as the single-polynomial calls (which take the other path), scale 10, chunk 16"""
+    import torch
+    n2, l, B = 1024, 16, 1024
+    fs = kz.FFTSettings(10)
+    ks = kz.KZGSettings(fs, ko.generate_testing_setup_g1(S_TEST, n2))
+    fk = kz.FK20MultiSettings(ks, n2, l)
+    rng = np.random.default_rng(1024)
+    polys = np.stack([rand_fr(rng, n2 // 2) for _ in range(4)])
+    polys = np.concatenate([polys] * (B // 4))                                  # 1024 rows, 4 distinct
+    d_in = torch.from_numpy(polys.view(np.int64)).cuda()
+    d_out = torch.zeros((B, 2 * (n2 // 2) // l, 18), dtype=torch.int64, device="cuda")
+    st = kz.lib().kzg_hip_da_using_fk20_multi_batch_dev(fk.h, d_in.data_ptr(), n2 // 2, B, d_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert st == 0
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy().view(np.uint64).reshape(B, -1, 3, 6)
+    for r in range(4):
+        want = fk.da_using_fk20_multi(polys[r])
+        assert np.array_equal(got[r], want) and np.array_equal(got[B - 4 + r], want), r
+    fk.close(); ks.close(); fs.close()
+
+
 # ------------------------------------------------------------------ BASELINE config 5: FK20Multi at scale 16
 def test_fk20_multi_scale16_config5(kz):
     """FK20MultiDAOptimized / DAUsingFK20Multi, n2 = 65536, chunk length 16 (fk20_multi_test.go:13) -> 4096 coset proofs.
