@@ -688,6 +688,64 @@ KZG_HD void g1_wnaf_table_affine_q(const g1jq &p0, g1aq *tbl, g1jq *jt) {   // p
         tbl[i].y = mulq(jt[i].y, mulq(zi2, zi));
     }
 }
+// The same table by co-Z arithmetic (Meloni; Longa-Miri's precomputation scheme): after the initial doubling, P rescaled to the Z of 2P
+// is free -- (4 X Y^2, 8 Y^4, 2 Y Z) -- and every further odd multiple is ONE co-Z addition (5M + 2S instead of 10M + 3S) that also
+// rescales 2P to the new Z:
+//   T = 2P = (X1, Y1), O = (2i - 1)P = (X2, Y2), same Z:   d = X1 - X2, C = d^2, W1 = X1 C, W2 = X2 C, e = Y1 - Y2, D = e^2,
+//   A1 = Y1 (W1 - W2);   (2i + 1)P = (D - W1 - W2,  e (W1 - X3) - A1,  Z d);   T <- (W1, A1, Z d).
+// The Z's form a chain Z_{i+1} = Z_i d_i, so ONE inversion of the last one unwinds all of them with a product each:
+// 70M + 26S + 1 inversion for the 8 affine multiples instead of 118M + 33S + 1 inversion (30.4k multiply-adds instead of 51.4k).
+// Bounds: the doubling leaves T <= (19, 19, 4) and O_1 = (8, 16, 4); T's X and Y are brought to 2 by a product with one so that the
+// squares fit (d : 2 + 9 = 11, e : 2 + 17 = 19; 361 <= 600); from then on T = (2, 2), O = (8, 5): d : 11, e : 8, W1 - W2 : 5,
+// X3 : 2 + 3 + 3 = 8, W1 - X3 : 11, Y3 : 2 - A1 (M = 3) : 5, Z d : 22 resp. 44.  Returns false if a d vanishes (P of order < 16:
+// never in G1); the caller then builds the table the slow way.
+template <bool INL = false> KZG_HD bool g1_wnaf_table_affine_coz(const g1jq &p0, g1aq *tbl, fq *dz) {
+    auto mulq = [](const fq &a_, const fq &b_) { return INL ? mulq_inl(a_, b_) : kzg::mulq(a_, b_); };   // INL: products inlined (the stage kernels: +x % measured)
+    auto sqrq = [](const fq &a_) { return INL ? sqrq_inl(a_) : kzg::sqrq(a_); };
+    fq one_q = unpackq(one<FpP>());
+    fq tx, ty, z;
+    {   // DBLU: T = 2 P and O_1 = P on T's Z
+        fq a = sqrq(p0.x), b = sqrq(p0.y), c = sqrq(b), s_ = mulq(p0.x, b);
+        fq d = addq(s_, s_); d = addq(d, d);                   // 4 X Y^2 : 8   (= X of the rescaled P)
+        fq e = addq(addq(a, a), a);                            // 6
+        fq f = sqrq(e);
+        fq x3 = subq<17>(f, addq(d, d));                       // 19
+        fq c8 = addq(c, c); c8 = addq(c8, c8); c8 = addq(c8, c8);   // 8 Y^4 : 16 (= Y of the rescaled P)
+        fq y3 = subq<17>(mulq(e, subq<20>(d, x3)), c8);        // 19
+        fq yz = mulq(p0.y, p0.z);
+        z = addq(yz, yz);                                      // 4
+        tx = mulq(x3, one_q); ty = mulq(y3, one_q);            // bounds 2: the squares of the first co-Z addition must fit
+        tbl[0].x = d; tbl[0].y = c8;
+    }
+    bool ok = true;
+#pragma nounroll
+    for (int i = 0; i < 7; i++) {                              // O_{i+1} = T + O_i, T rescaled
+        const fq x2 = tbl[i].x, y2 = tbl[i].y;
+        fq d = subq<9>(tx, x2);                                // 11
+        fq cc = sqrq(d);
+        ok = ok && !is_zero_mod_p_q(cc);
+        fq w1 = mulq(tx, cc), w2 = mulq(x2, cc);
+        fq e = subq<17>(ty, y2);                               // 19 (first step), 8 afterwards
+        fq dd = sqrq(e);
+        fq a1 = mulq(ty, subq<3>(w1, w2));
+        fq x3 = subq<3>(subq<3>(dd, w1), w2);                  // 8
+        fq y3 = subq<3>(mulq(e, subq<9>(w1, x3)), a1);         // 5
+        z = mulq(z, d);
+        dz[i] = d;
+        tx = w1; ty = a1;
+        tbl[i + 1].x = x3; tbl[i + 1].y = y3;
+    }
+    if (!ok) return false;
+    fq zi = unpackq(inv<FpP>(packq(z)));                       // 1 / Z_8
+#pragma nounroll
+    for (int i = 7; i >= 0; i--) {
+        fq zi2 = sqrq(zi);
+        tbl[i].x = mulq(tbl[i].x, zi2);
+        tbl[i].y = mulq(tbl[i].y, mulq(zi2, zi));
+        if (i) zi = mulq(zi, dz[i - 1]);                       // 1 / Z_i = (1 / Z_{i+1}) d_i
+    }
+    return true;
+}
 KZG_HD void g1_wnaf_table_affine(const g1j &p, g1aq *tbl, g1jq *jt) { g1_wnaf_table_affine_q(g1jq_unpack(p), tbl, jt); }
 KZG_HD bool g1jq_add_slow_copy_a(g1jq &acc, const g1aq *t, bool ng, bool phi);
 
@@ -803,8 +861,20 @@ template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_wnaf_loop_aq
     out = acc;
     return 1;
 }
-template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_mul_glv_wnaf_aq_q(const g1jq &pq, const fr &kk, g1aq *tbl, g1jq *jt, int8_t *d1, int8_t *d2, int stride, g1jq &out, g1j &packed) {
+// table for the multiplications below: co-Z chain, Jacobian chain + Montgomery's trick as the (never taken) fallback; `jt` is scratch
+KZG_HD void g1_wnaf_table(const g1jq &pq, g1aq *tbl, g1jq *jt) {
+#ifdef KZG_WNAF_TABLE_JACOBIAN_CHAIN                        // A/B builds
     g1_wnaf_table_affine_q(pq, tbl, jt);
+#else
+#ifdef KZG_WNAF_TABLE_INLINE
+    if (!g1_wnaf_table_affine_coz<true>(pq, tbl, &jt[0].x)) g1_wnaf_table_affine_q(pq, tbl, jt);
+#else
+    if (!g1_wnaf_table_affine_coz<false>(pq, tbl, &jt[0].x)) g1_wnaf_table_affine_q(pq, tbl, jt);   // &jt[0].x: 8 x 39 limbs of scratch, 7 x 13 used
+#endif
+#endif
+}
+template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_mul_glv_wnaf_aq_q(const g1jq &pq, const fr &kk, g1aq *tbl, g1jq *jt, int8_t *d1, int8_t *d2, int stride, g1jq &out, g1j &packed) {
+    g1_wnaf_table(pq, tbl, jt);
     const int n1 = glv_wnaf5(kk, 0, d1, stride), n2 = glv_wnaf5(kk, 4, d2, stride);
     return g1_wnaf_loop_aq<INL_DBL, INL_ADD>(pq, kk, tbl, d1, d2, stride, n1, n2, out, packed);
 }
@@ -812,7 +882,7 @@ template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_mul_glv_wnaf
 // host with the same glv_wnaf5 and live in HBM): `dg` = 132 bytes for k1 (digit i at [i], the length at [131]) followed by 132 for k2
 #define KZG_WNAF_ROW 264
 template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_mul_glv_wnaf_aq_pre_q(const g1jq &pq, const fr &kk, g1aq *tbl, g1jq *jt, const int8_t *dg, g1jq &out, g1j &packed) {
-    g1_wnaf_table_affine_q(pq, tbl, jt);
+    g1_wnaf_table(pq, tbl, jt);
     return g1_wnaf_loop_aq<INL_DBL, INL_ADD>(pq, kk, tbl, dg, dg + 132, 1, (int)(uint8_t)dg[131], (int)(uint8_t)dg[132 + 131], out, packed);
 }
 KZG_HD void glv_wnaf5_row(const fr &kk, int8_t *row) {      // host side of the above

@@ -92,6 +92,15 @@ void he_g1_mul_glv_wnaf_affine(g1j *o, const g1j *a, const fr *k_mont, int inl) 
     int st = inl ? g1_mul_glv_wnaf_aq<true, true>(pi, kk, tbl, jt, d1, d2, 1, q, packed) : g1_mul_glv_wnaf_aq<false, false>(pi, kk, tbl, jt, d1, d2, 1, q, packed);
     *o = OUT(st == 0 ? g1_inf() : st == 1 ? g1jq_pack(q) : packed);
 }
+// the 8 affine odd multiples of a (co-Z chain when coz != 0, Jacobian chain + Montgomery's trick otherwise): out = 8 normalised points
+int he_wnaf_table(g1j *out8, const g1j *a, int coz) {
+    g1jq pq = g1jq_unpack(IN(a));
+    g1aq tbl[8]; g1jq jt[8];
+    int ok = 1;
+    if (coz) ok = (coz == 2 ? g1_wnaf_table_affine_coz<true>(pq, tbl, &jt[0].x) : g1_wnaf_table_affine_coz<false>(pq, tbl, &jt[0].x)) ? 1 : 0; else g1_wnaf_table_affine_q(pq, tbl, jt);
+    for (int i = 0; i < 8; i++) { g1j o; o.x = packq(tbl[i].x); o.y = packq(tbl[i].y); o.z = one<FpP>(); out8[i] = OUT(o); }
+    return ok;
+}
 // acc (= a, any Jacobian image) += sign * phi? * b (normalised to affine here) through g1jq_madd_entry; 1: fast formulas, 0: slow path
 int he_g1jq_madd_entry(g1j *o, const g1j *a, const g1j *b, int negate, int phi, int inl) {
     g1jq acc = g1jq_unpack(IN(a));

@@ -160,6 +160,23 @@ def test_wnaf_loop_exceptional_additions(he):
     assert he.he_g1jq_add_entry(p(out), p(a2), p(ko.g1_add(a, a)), 0) == 0 and ko.g1_equal(out[0], ko.g1_add(a2, a2))
 
 
+def test_wnaf_affine_tables(he):
+    # the 8 odd multiples P, 3P .. 15P as affine points: co-Z chain (what the kernels run) and the Jacobian chain fallback, for
+    # canonical and non-canonical (Z != 1) inputs
+    rng = np.random.default_rng(8)
+    gen = ko.g1_generator()
+    out = ko.g1_empty(8)
+    for trial in range(6):
+        pt = ko.g1_mul(gen, rand_fr(rng, 1)[0])
+        if trial & 1:
+            pt = ko.g1_add(pt, ko.g1_mul(gen, rand_fr(rng, 1)[0]))          # Jacobian image with Z != 1
+        want = [ko.g1_mul(pt, ko.fr_from_ints([2 * i + 1])[0]) for i in range(8)]
+        for coz in (2, 1, 0):                              # 2: products inlined
+            assert he.he_wnaf_table(p(out), p(pt), coz) == 1
+            for i in range(8):
+                assert np.array_equal(out[i], ko.g1_affine(want[i][None])[0]), (trial, coz, i)
+
+
 def test_wnaf_mixed_addition_and_its_exceptional_cases(he):
     # acc += +-(phi?) entry with an AFFINE entry (g1jq_madd_entry): accumulators in arbitrary Jacobian images, long chains (the lazy
     # bounds), doubling / cancellation declined by the fast formulas and handled by the complete ones
