@@ -12,10 +12,18 @@ __device__ __forceinline__ uint32_t bitrev32g(uint32_t v, uint32_t bits) { retur
 
 // k (Montgomery form, as the Go side stores it) * P.  Kilic's MulG1 first leaves Montgomery form (FromRed,
 // bls/bls_kilic.go:42-43); the 15-entry window table lives in the lane's private scratch.
+// Round 2: the scalar is split on the device (glv_split_signed) and the product runs the regular odd-digit schedule on the affine
+// co-Z table (g1_mul_glv_regular_aq): 128 doublings + 66 mixed additions instead of 255 doublings + 64 full additions.
 __device__ __forceinline__ g1j g1_mul_fr(const g1j &p, const fr &k_mont) {
     if (is_inf(p)) return g1_inf();
+#ifdef KZG_G1_MUL_WINDOWED                                   // A/B builds: round 1's 4-bit windows on packed coordinates
     g1j tbl[15];
     return g1_mul_windowed(p, from_mont<FrP>(k_mont), tbl);
+#else
+    g1aq tbl[8]; g1jq jt[8]; g1jq q; g1j packed;
+    const int st = g1_mul_glv_regular_aq<false>(g1jq_unpack(p), glv_split_signed(from_mont<FrP>(k_mont)), tbl, jt, q, packed);
+    return st == 1 ? g1jq_pack(q) : st == 2 ? packed : g1_inf();
+#endif
 }
 
 __global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_mul_vec(const g1j *pts, uint64_t pts_mod, const fr *scalars, uint64_t s_stride, uint64_t n,
@@ -142,7 +150,20 @@ template <int MODE, bool PRE = false> __global__ __launch_bounds__(G1_BLOCK, 2) 
             y = g1_mul_glv_wnaf<MODE >= 2, MODE >= 3>(y, roots[j * (W / (2 * m))], tbl, dg1, dg2, 1);
         }
     } else {
-        if (j && !is_inf(y)) { g1jq tbl[16]; y = g1_mul_glv_fast(y, roots[j * (W / (2 * m))], tbl); }
+        if (j && !is_inf(y)) {
+#ifdef KZG_G1_REGULAR_JACOBIAN_TABLE                         // A/B builds: round 1's 16-entry Jacobian table, 5-bit signed windows
+            g1jq tbl[16]; y = g1_mul_glv_fast(y, roots[j * (W / (2 * m))], tbl);
+#else
+            const fr kk = roots[j * (W / (2 * m))];          // (k1, k2) GLV pair, both halves non-negative
+            glv_halves h;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { h.k1[i] = kk.l[i]; h.k2[i] = kk.l[4 + i]; }
+            h.neg1 = h.neg2 = 0;
+            g1aq tbl[8]; g1jq jt[8]; g1jq q; g1j packed;
+            const int st = g1_mul_glv_regular_aq<true>(g1jq_unpack(y), h, tbl, jt, q, packed);
+            y = st == 1 ? g1jq_pack(q) : st == 2 ? packed : g1_inf();
+#endif
+        }
     }
     row[i0] = g1_add(x, y);
     row[i1] = g1_add(x, g1_neg(y));
@@ -274,8 +295,14 @@ __global__ __launch_bounds__(G1_DIRECT_BLOCK, 2) void k_g1_fft_direct(const g1j 
             else {
                 fr sc = roots[e * (W >> logn)];
                 if (scale) sc = mul(sc, *scale);
+#ifdef KZG_G1_REGULAR_JACOBIAN_TABLE
                 g1jq tbl[16];
                 acc.inf = !g1_mul_glv_signed_q(x, glv_split_signed(from_mont<FrP>(sc)), tbl, acc.v);
+#else
+                g1aq tbl[8]; g1jq jt[8]; g1j packed;
+                const int st = g1_mul_glv_regular_aq<true>(g1jq_unpack(x), glv_split_signed(from_mont<FrP>(sc)), tbl, jt, acc.v, packed);
+                if (st == 2) { acc.inf = is_inf(packed); if (!acc.inf) acc.v = g1jq_unpack(packed); } else acc.inf = st == 0;
+#endif
             }
         }
     }

@@ -92,6 +92,27 @@ void he_g1_mul_glv_wnaf_affine(g1j *o, const g1j *a, const fr *k_mont, int inl) 
     int st = inl ? g1_mul_glv_wnaf_aq<true, true>(pi, kk, tbl, jt, d1, d2, 1, q, packed) : g1_mul_glv_wnaf_aq<false, false>(pi, kk, tbl, jt, d1, d2, 1, q, packed);
     *o = OUT(st == 0 ? g1_inf() : st == 1 ? g1jq_pack(q) : packed);
 }
+// the regular odd-digit schedule on the same table, scalar split on the fly (what the direct G1 FFT passes run)
+void he_g1_mul_glv_regular(g1j *o, const g1j *a, const fr *k_mont, int inl) {
+    g1j pi = IN(a);
+    if (is_inf(pi)) { *o = OUT(g1_inf()); return; }
+    g1aq tbl[8]; g1jq jt[8]; g1jq q; g1j packed;
+    glv_halves h = glv_split_signed(from_mont<FrP>(*k_mont));
+    int st = inl ? g1_mul_glv_regular_aq<true>(g1jq_unpack(pi), h, tbl, jt, q, packed) : g1_mul_glv_regular_aq<false>(g1jq_unpack(pi), h, tbl, jt, q, packed);
+    *o = OUT(st == 0 ? g1_inf() : st == 1 ? g1jq_pack(q) : packed);
+}
+// ... with explicit halves (k1[4] | k2[4] | neg1 | neg2): zero halves, even halves, the generic fallback
+int he_g1_mul_glv_regular_halves(g1j *o, const g1j *a, const uint32_t *hw, int cold) {
+    g1j pi = IN(a);
+    glv_halves h;
+    for (int i = 0; i < 4; i++) { h.k1[i] = hw[i]; h.k2[i] = hw[4 + i]; }
+    h.neg1 = hw[8]; h.neg2 = hw[9];
+    if (cold) { g1j r; g1_mul_glv_signed_cold(&r, &pi, &h); *o = OUT(r); return 2; }
+    g1aq tbl[8]; g1jq jt[8]; g1jq q; g1j packed;
+    int st = g1_mul_glv_regular_aq<true>(g1jq_unpack(pi), h, tbl, jt, q, packed);
+    *o = OUT(st == 0 ? g1_inf() : st == 1 ? g1jq_pack(q) : packed);
+    return st;
+}
 // the 8 affine odd multiples of a (co-Z chain when coz != 0, Jacobian chain + Montgomery's trick otherwise): out = 8 normalised points
 int he_wnaf_table(g1j *out8, const g1j *a, int coz) {
     g1jq pq = g1jq_unpack(IN(a));

@@ -137,11 +137,45 @@ def test_g1_scalar_mul(he):
             for inl in (0, 1):                           # round 2: affine table (one inversion), mixed additions; what the G1 FFT stages run
                 he.he_g1_mul_glv_wnaf_affine(p(got), p(pt), p(k), inl)
                 assert np.array_equal(ko.g1_compress(got), ko.g1_compress(want)), inl
+                he.he_g1_mul_glv_regular(p(got), p(pt), p(k), inl)   # regular odd-digit schedule, scalar split on the fly (direct FFT passes)
+                assert np.array_equal(ko.g1_compress(got), ko.g1_compress(want)), inl
     he.he_g1_mul_small.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     for k in (0, 1, 2, 255, 4096, 2**32 - 1):
         got = ko.g1_empty(1)
         he.he_g1_mul_small(p(got), p(base), k)
         assert ko.g1_equal(got[0], ko.g1_mul(base, ko.fr_from_ints([k])[0]))
+
+
+def test_regular_odd_digit_schedule_halves(he):
+    """g1_mul_glv_regular_aq on explicit halves: s1 k1 P + s2 k2 phi(P) with zero / even / odd / full-width halves and every sign
+    pattern, against the big-integer value k1 s1 + k2 s2 lambda, and the cold generic path on the same inputs."""
+    rng = np.random.default_rng(11)
+    base = ko.g1_mul(ko.g1_generator(), rand_fr(rng, 1)[0])
+    # lambda: the eigenvalue of phi on G1, recovered from the split of a known scalar: k = s1 k1 + s2 k2 lambda (mod r)
+    probe = 0x1234567890abcdef1234567890abcdef1234567890abcdef1234567890abcdef % ko.R_MOD
+    out = np.zeros(10, dtype=np.uint32)
+    ks = np.array([(probe >> (32 * i)) & 0xffffffff for i in range(8)], dtype=np.uint32)
+    he.he_glv_split_signed(p(out), p(ks))
+    k1 = sum(int(out[i]) << (32 * i) for i in range(4)) * (-1 if out[8] else 1)
+    k2 = sum(int(out[4 + i]) << (32 * i) for i in range(4)) * (-1 if out[9] else 1)
+    lam = (probe - k1) * pow(k2, -1, ko.R_MOD) % ko.R_MOD
+    assert (lam * lam + lam + 1) % ko.R_MOD == 0
+    he.he_g1_mul_glv_regular_halves.restype = C.c_int
+    he.he_g1_mul_glv_regular_halves.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    mags = [0, 1, 2, 3, 14, 15, 16, 17, 30, 31, 32, 2**64, 2**64 - 1, 2**127, 2**128 - 1, 2**128 - 2] + [int(rng.integers(0, 2**63)) ** 2 + int(rng.integers(0, 2)) for _ in range(4)]
+    cases = [(a, b) for a in mags[:8] for b in mags[:8]] + [(a, b) for a in mags[8:] for b in (0, 1, 2, mags[-1], 2**128 - 1)] + [(b, a) for a in mags[8:] for b in (0, 2, mags[-2])]
+    for n, (m1, m2) in enumerate(cases):
+        s1, s2 = (n >> 0) & 1, (n >> 1) & 1
+        hw = np.array([(m1 >> (32 * i)) & 0xffffffff for i in range(4)] + [(m2 >> (32 * i)) & 0xffffffff for i in range(4)] + [s1, s2], dtype=np.uint32)
+        k = ((-m1 if s1 else m1) + (-m2 if s2 else m2) * lam) % ko.R_MOD
+        want = ko.g1_mul(base, ko.fr_from_ints([k])[0])
+        got = ko.g1_empty(1)
+        st = he.he_g1_mul_glv_regular_halves(p(got), p(base), p(hw), 0)
+        assert ko.g1_equal(got[0], want), (m1, m2, s1, s2, st)
+        assert st == (0 if (m1 == 0 and m2 == 0) else 1), (m1, m2, st)
+        if n % 7 == 0:
+            he.he_g1_mul_glv_regular_halves(p(got), p(base), p(hw), 1)
+            assert ko.g1_equal(got[0], want), ("cold", m1, m2, s1, s2)
 
 
 def test_wnaf_loop_exceptional_additions(he):
