@@ -613,7 +613,24 @@ KZG_HD_NOINLINE static bool g1jq_add_slow(g1jq *acc, const g1jq *q) {
 }
 // callers hand over COPIES so that their accumulator never has its address taken (it must stay in registers)
 KZG_HD bool g1jq_add_slow_copy(g1jq &acc, const g1jq_t *t, bool ng, bool phi);
-KZG_HD_NOINLINE static void g1_mul_glv_cold(g1j *o, const g1j *p, const fr *kk) { g1j gt[16]; *o = g1_mul_glv(*p, *kk, gt); }
+// s1 k1 P + s2 k2 phi(P) by bitwise double-and-add on the generic complete formulas: the fallback of the fast schedules (an addition
+// that met P == +-Q with an infinite sum: never for points of G1 and the digit schedules used here).  No table: the cold path
+// adds three points to a kernel's scratch frame instead of a 2.3 KB window table.
+KZG_HD_NOINLINE static void g1_mul_glv_bits_cold(g1j *o, const g1j *p, const uint32_t *k1, const uint32_t *k2, uint32_t neg1, uint32_t neg2) {
+    g1j p1 = *p, p2 = *p;
+    p2.x = mul(p2.x, glv_beta());
+    if (neg1) p1.y = neg<FpP>(p1.y);
+    if (neg2) p2.y = neg<FpP>(p2.y);
+    g1j acc = g1_inf();
+#pragma nounroll
+    for (int b = 127; b >= 0; b--) {
+        acc = g1_dbl(acc);
+        if ((k1[b >> 5] >> (b & 31)) & 1u) acc = g1_add(acc, p1);
+        if ((k2[b >> 5] >> (b & 31)) & 1u) acc = g1_add(acc, p2);
+    }
+    *o = acc;
+}
+KZG_HD void g1_mul_glv_cold(g1j *o, const g1j *p, const fr *kk) { g1_mul_glv_bits_cold(o, p, &kk->l[0], &kk->l[4], 0, 0); }
 KZG_HD bool g1jq_add_slow_copy(g1jq &acc, const g1jq_t *t, bool ng, bool phi) {
     g1jq a2 = acc, q2 = g1jq_entry_point(t, ng, phi);
     bool inf = g1jq_add_slow(&a2, &q2);
@@ -659,6 +676,7 @@ KZG_HD g1jq g1aq_entry_point(const g1aq *t, bool ng, bool phi) {
         q.y = subq<3>(zero_q, t->y); } else q.y = t->y;
     return q;
 }
+// (Reference construction, kept for tests/host: the kernels build the table by the co-Z chain below.)
 // the 8 odd multiples P, 3P, .. 15P as affine points: Jacobian multiples (1 doubling + 7 additions) into `jt`, then one inversion of
 // the product of their Z's (binary GCD, ~35 product-equivalents) and 3 products per entry to unwind it, 1S + 3M per entry to scale.
 // p must be a finite point of G1 (no Z is zero and no addition degenerates for points of G1; the degenerate branch is kept for safety).
@@ -820,7 +838,7 @@ KZG_HD bool g1jq_add_slow_copy_a(g1jq &acc, const g1aq *t, bool ng, bool phi) {
     return inf;
 }
 // width-5 NAF GLV multiplication with the AFFINE table (what the G1 FFT stages run since round 2).  Same contract as
-// g1_mul_glv_wnaf_q; `jt` is scratch for the 8 Jacobian multiples (only alive while the table is built).
+// g1_mul_glv_wnaf_q; `dz` is scratch for the 7 Z ratios of the co-Z chain (only alive while the table is built).
 // (the multiplicand arrives unpacked: the product of a butterfly's difference in the decimation-in-frequency stages needs no pack / unpack)
 template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_wnaf_loop_aq(const g1jq &pq, const fr &kk, const g1aq *tbl, const int8_t *d1, const int8_t *d2, int stride, int n1, int n2, g1jq &out, g1j &packed) {
     int j = (n1 > n2 ? n1 : n2) - 1;
@@ -861,28 +879,25 @@ template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_wnaf_loop_aq
     out = acc;
     return 1;
 }
-// table for the multiplications below: co-Z chain, Jacobian chain + Montgomery's trick as the (never taken) fallback; `jt` is scratch
-KZG_HD void g1_wnaf_table(const g1jq &pq, g1aq *tbl, g1jq *jt) {
-#ifdef KZG_WNAF_TABLE_JACOBIAN_CHAIN                        // A/B builds
-    g1_wnaf_table_affine_q(pq, tbl, jt);
+// table for the multiplications below (co-Z chain); `dz`: 7 field elements of scratch.  false: a difference of the chain vanished (P of
+// order < 16, never in G1) -- the callers then take the generic path for the whole product.
+KZG_HD bool g1_wnaf_table(const g1jq &pq, g1aq *tbl, fq *dz) {
+#ifdef KZG_WNAF_TABLE_INLINE                                // A/B builds: the chain's products inlined (+0.3 % measured: not worth the code)
+    return g1_wnaf_table_affine_coz<true>(pq, tbl, dz);
 #else
-#ifdef KZG_WNAF_TABLE_INLINE
-    if (!g1_wnaf_table_affine_coz<true>(pq, tbl, &jt[0].x)) g1_wnaf_table_affine_q(pq, tbl, jt);
-#else
-    if (!g1_wnaf_table_affine_coz<false>(pq, tbl, &jt[0].x)) g1_wnaf_table_affine_q(pq, tbl, jt);   // &jt[0].x: 8 x 39 limbs of scratch, 7 x 13 used
-#endif
+    return g1_wnaf_table_affine_coz<false>(pq, tbl, dz);
 #endif
 }
-template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_mul_glv_wnaf_aq_q(const g1jq &pq, const fr &kk, g1aq *tbl, g1jq *jt, int8_t *d1, int8_t *d2, int stride, g1jq &out, g1j &packed) {
-    g1_wnaf_table(pq, tbl, jt);
+template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_mul_glv_wnaf_aq_q(const g1jq &pq, const fr &kk, g1aq *tbl, fq *dz, int8_t *d1, int8_t *d2, int stride, g1jq &out, g1j &packed) {
+    if (!g1_wnaf_table(pq, tbl, dz)) { g1j pc = g1jq_pack(pq); fr kc = kk; g1_mul_glv_cold(&packed, &pc, &kc); return 2; }
     const int n1 = glv_wnaf5(kk, 0, d1, stride), n2 = glv_wnaf5(kk, 4, d2, stride);
     return g1_wnaf_loop_aq<INL_DBL, INL_ADD>(pq, kk, tbl, d1, d2, stride, n1, n2, out, packed);
 }
 // the digit strings come PRECOMPUTED (the twiddles of an FFTSettings are fixed: their width-5 NAF recodings are built once on the
 // host with the same glv_wnaf5 and live in HBM): `dg` = 132 bytes for k1 (digit i at [i], the length at [131]) followed by 132 for k2
 #define KZG_WNAF_ROW 264
-template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_mul_glv_wnaf_aq_pre_q(const g1jq &pq, const fr &kk, g1aq *tbl, g1jq *jt, const int8_t *dg, g1jq &out, g1j &packed) {
-    g1_wnaf_table(pq, tbl, jt);
+template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_mul_glv_wnaf_aq_pre_q(const g1jq &pq, const fr &kk, g1aq *tbl, fq *dz, const int8_t *dg, g1jq &out, g1j &packed) {
+    if (!g1_wnaf_table(pq, tbl, dz)) { g1j pc = g1jq_pack(pq); fr kc = kk; g1_mul_glv_cold(&packed, &pc, &kc); return 2; }
     return g1_wnaf_loop_aq<INL_DBL, INL_ADD>(pq, kk, tbl, dg, dg + 132, 1, (int)(uint8_t)dg[131], (int)(uint8_t)dg[132 + 131], out, packed);
 }
 // ---- regular variant on the same affine table: what lanes with DIFFERENT scalars run (the direct G1 FFT passes, the late stages of
@@ -893,20 +908,11 @@ template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_mul_glv_wnaf
 // 16-entry Jacobian-table schedule of g1_mul_glv_signed_q (135 doublings, ~52 full additions, table 51k): 518k multiply-adds instead
 // of 599k, products inlined, 0.8 KB of table instead of 2.5 KB.  A half that is zero is skipped altogether (lane-varying, rare: small
 // scalars).  Same contract as g1_wnaf_loop_aq: 1 = `out` holds the product, 0 = infinity, 2 = `packed` holds it (generic path).
-KZG_HD_NOINLINE static void g1_mul_glv_signed_cold(g1j *o, const g1j *p, const glv_halves *h) {
-    fr a, b;
-#pragma unroll
-    for (int i = 0; i < 4; i++) { a.l[i] = h->k1[i]; a.l[4 + i] = 0; b.l[i] = 0; b.l[4 + i] = h->k2[i]; }
-    g1j gt[16];
-    g1j r1 = g1_mul_glv(*p, a, gt), r2 = g1_mul_glv(*p, b, gt);
-    if (h->neg1) r1 = g1_neg(r1);
-    if (h->neg2) r2 = g1_neg(r2);
-    *o = g1_add(r1, r2);
-}
-template <bool INL = true> KZG_HD int g1_mul_glv_regular_aq(const g1jq &pq, const glv_halves &h, g1aq *tbl, g1jq *jt, g1jq &out, g1j &packed) {
+KZG_HD void g1_mul_glv_signed_cold(g1j *o, const g1j *p, const glv_halves *h) { g1_mul_glv_bits_cold(o, p, h->k1, h->k2, h->neg1, h->neg2); }
+template <bool INL = true> KZG_HD int g1_mul_glv_regular_aq(const g1jq &pq, const glv_halves &h, g1aq *tbl, fq *dz, g1jq &out, g1j &packed) {
     const bool on1 = (h.k1[0] | h.k1[1] | h.k1[2] | h.k1[3]) != 0, on2 = (h.k2[0] | h.k2[1] | h.k2[2] | h.k2[3]) != 0;
     if (!on1 && !on2) return 0;
-    g1_wnaf_table(pq, tbl, jt);
+    if (!g1_wnaf_table(pq, tbl, dz)) { g1j pc = g1jq_pack(pq); glv_halves hc = h; g1_mul_glv_signed_cold(&packed, &pc, &hc); return 2; }
     const bool n1 = h.neg1 != 0, n2 = h.neg2 != 0;
     // the digit window of step i is bits 4 i .. 4 i + 4: kept at the top of a 129-bit shift register (bit 128 in the fifth word)
     uint32_t a0 = h.k1[0] | 1u, a1 = h.k1[1], a2 = h.k1[2], a3 = h.k1[3], a4 = 0;
@@ -945,8 +951,8 @@ KZG_HD void glv_wnaf5_row(const fr &kk, int8_t *row) {      // host side of the 
     row[130] = 0; row[132 + 130] = 0;
     row[131] = (int8_t)n1; row[132 + 131] = (int8_t)n2;
 }
-template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_mul_glv_wnaf_aq(const g1j &p, const fr &kk, g1aq *tbl, g1jq *jt, int8_t *d1, int8_t *d2, int stride, g1jq &out, g1j &packed) {
-    return g1_mul_glv_wnaf_aq_q<INL_DBL, INL_ADD>(g1jq_unpack(p), kk, tbl, jt, d1, d2, stride, out, packed);
+template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_mul_glv_wnaf_aq(const g1j &p, const fr &kk, g1aq *tbl, fq *dz, int8_t *d1, int8_t *d2, int stride, g1jq &out, g1j &packed) {
+    return g1_mul_glv_wnaf_aq_q<INL_DBL, INL_ADD>(g1jq_unpack(p), kk, tbl, dz, d1, d2, stride, out, packed);
 }
 
 // (P + Q, P - Q) for two finite points, sharing everything but r: add-2007-bl twice is 22M + 10S, this is 13M + 5S (both Y3 as

@@ -11,19 +11,13 @@ namespace kzg {
 __device__ __forceinline__ uint32_t bitrev32g(uint32_t v, uint32_t bits) { return bits ? (__brev(v) >> (32 - bits)) : 0; }
 
 // k (Montgomery form, as the Go side stores it) * P.  Kilic's MulG1 first leaves Montgomery form (FromRed,
-// bls/bls_kilic.go:42-43); the 15-entry window table lives in the lane's private scratch.
-// Round 2: the scalar is split on the device (glv_split_signed) and the product runs the regular odd-digit schedule on the affine
-// co-Z table (g1_mul_glv_regular_aq): 128 doublings + 66 mixed additions instead of 255 doublings + 64 full additions.
+// bls/bls_kilic.go:42-43).  The scalar is split on the device (glv_split_signed) and the product runs the regular odd-digit schedule
+// on the affine co-Z table (g1_mul_glv_regular_aq): 128 doublings + 66 mixed additions (round 1: 255 doublings + 64 full additions).
 __device__ __forceinline__ g1j g1_mul_fr(const g1j &p, const fr &k_mont) {
     if (is_inf(p)) return g1_inf();
-#ifdef KZG_G1_MUL_WINDOWED                                   // A/B builds: round 1's 4-bit windows on packed coordinates
-    g1j tbl[15];
-    return g1_mul_windowed(p, from_mont<FrP>(k_mont), tbl);
-#else
-    g1aq tbl[8]; g1jq jt[8]; g1jq q; g1j packed;
-    const int st = g1_mul_glv_regular_aq<false>(g1jq_unpack(p), glv_split_signed(from_mont<FrP>(k_mont)), tbl, jt, q, packed);
+    g1aq tbl[8]; fq dz[7]; g1jq q; g1j packed;
+    const int st = g1_mul_glv_regular_aq<false>(g1jq_unpack(p), glv_split_signed(from_mont<FrP>(k_mont)), tbl, dz, q, packed);
     return st == 1 ? g1jq_pack(q) : st == 2 ? packed : g1_inf();
-#endif
 }
 
 __global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_mul_vec(const g1j *pts, uint64_t pts_mod, const fr *scalars, uint64_t s_stride, uint64_t n,
@@ -104,10 +98,11 @@ template <int MODE, bool PRE = false> __global__ __launch_bounds__(G1_BLOCK, 2) 
     // Twiddle-major lane order: t -> (j, b, g).  All lanes of a wavefront then share ONE twiddle, so (i) the waves with j == 0
     // (1/2, 1/4, 1/8 ... of the early stages) skip the scalar multiplication entirely instead of idling beside their
     // neighbours, and (ii) the irregular width-5 NAF digit schedule of g1_mul_glv_wnaf is wave-uniform: no divergence.
-    // MODE 4 (default): width-5 NAF, products of the doubling loop and of the additions inlined, (x + w y, x - w y) by the shared
-    // lazy formulas; 3: generic butterfly additions; 2: only the doublings inlined; 1: every product a call; 0: the regular
-    // signed-window variant (g1_mul_glv_fast).  KZG_HIP_G1_MUL = fast / wnaf / inl / all selects 0 / 1 / 2 / 3 for A/B runs
-    // (tools/ab_g1mul.sh): measured FK20 814 / 865 / 886 / 888 per second for modes 0..3 at batch 128.
+    // MODE 4 (default): width-5 NAF on the affine co-Z table, products of the doubling loop and of the additions inlined,
+    // (x + w y, x - w y) by the shared lazy formulas; MODE 0: the regular odd-digit schedule on the same table, for launches whose
+    // wavefronts straddle many twiddles.  KZG_HIP_G1_MUL = regular / wnaf forces one of them (A/B runs).  Round 1's variants
+    // (Jacobian table; every product a call; only the doublings inlined) measured 814 / 865 / 886 / 888 FK20 per second at batch 128
+    // against 1014 for round 1's final kernel and ~1240 for this one at batch 512.
     const uint64_t half = 1ull << (logn - 1), groups = half / m;
     const uint64_t j = t / (groups * batch), rem = t % (groups * batch), b = rem / groups, g = rem % groups;
     g1j *row = data + (b << logn);
@@ -120,15 +115,10 @@ template <int MODE, bool PRE = false> __global__ __launch_bounds__(G1_BLOCK, 2) 
         g1jq yq; int st = is_inf(y) ? 0 : 1;
         if (st == 1) {
             if (j) {
-#ifdef KZG_G1_WNAF_JACOBIAN_TABLE
-                g1jq_t tbl[8]; int8_t dg1[132], dg2[132]; g1j packed;
-                st = g1_mul_glv_wnaf_q<true, true>(y, roots[j * (W / (2 * m))], tbl, dg1, dg2, 1, yq, packed);   // roots: (k1, k2) GLV pairs
-#else
-                g1aq tbl[8]; g1jq jt[8]; g1j packed;
+                g1aq tbl[8]; fq dz[7]; g1j packed;
                 const uint64_t ti = j * (W / (2 * m));                 // twiddle index: GLV pair + its precomputed width-5 NAF digit strings
-                if (PRE) st = g1_mul_glv_wnaf_aq_pre_q<true, true>(g1jq_unpack(y), roots[ti], tbl, jt, wnaf + ti * KZG_WNAF_ROW, yq, packed);   // affine table: mixed additions
-                else { int8_t dg1[132], dg2[132]; st = g1_mul_glv_wnaf_aq<true, true>(y, roots[ti], tbl, jt, dg1, dg2, 1, yq, packed); }
-#endif
+                if (PRE) st = g1_mul_glv_wnaf_aq_pre_q<true, true>(g1jq_unpack(y), roots[ti], tbl, dz, wnaf + ti * KZG_WNAF_ROW, yq, packed);   // affine table: mixed additions
+                else { int8_t dg1[132], dg2[132]; st = g1_mul_glv_wnaf_aq<true, true>(y, roots[ti], tbl, dz, dg1, dg2, 1, yq, packed); }
                 if (st == 2) y = packed; else if (st == 0) y = g1_inf();
             } else yq = g1jq_unpack(y);
         }
@@ -144,25 +134,16 @@ template <int MODE, bool PRE = false> __global__ __launch_bounds__(G1_BLOCK, 2) 
             }
         }
         if (st == 1) y = g1jq_pack(yq);
-    } else if (MODE >= 1) {
-        if (j && !is_inf(y)) {                                 // roots: (k1, k2) GLV pairs
-            g1jq_t tbl[8]; int8_t dg1[132], dg2[132];
-            y = g1_mul_glv_wnaf<MODE >= 2, MODE >= 3>(y, roots[j * (W / (2 * m))], tbl, dg1, dg2, 1);
-        }
     } else {
         if (j && !is_inf(y)) {
-#ifdef KZG_G1_REGULAR_JACOBIAN_TABLE                         // A/B builds: round 1's 16-entry Jacobian table, 5-bit signed windows
-            g1jq tbl[16]; y = g1_mul_glv_fast(y, roots[j * (W / (2 * m))], tbl);
-#else
             const fr kk = roots[j * (W / (2 * m))];          // (k1, k2) GLV pair, both halves non-negative
             glv_halves h;
 #pragma unroll
             for (int i = 0; i < 4; i++) { h.k1[i] = kk.l[i]; h.k2[i] = kk.l[4 + i]; }
             h.neg1 = h.neg2 = 0;
-            g1aq tbl[8]; g1jq jt[8]; g1jq q; g1j packed;
-            const int st = g1_mul_glv_regular_aq<true>(g1jq_unpack(y), h, tbl, jt, q, packed);
+            g1aq tbl[8]; fq dz[7]; g1jq q; g1j packed;
+            const int st = g1_mul_glv_regular_aq<true>(g1jq_unpack(y), h, tbl, dz, q, packed);
             y = st == 1 ? g1jq_pack(q) : st == 2 ? packed : g1_inf();
-#endif
         }
     }
     row[i0] = g1_add(x, y);
@@ -195,11 +176,11 @@ template <bool PRE> __global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_fft_stag
             g1j o0; o0.x = packq(sum.x); o0.y = packq(sum.y); o0.z = packq(sum.z);
             row[i0] = o0;
             if (j) {
-                g1aq tbl[8]; g1jq jt[8]; g1j packed; g1jq dq;
+                g1aq tbl[8]; fq dz[7]; g1j packed; g1jq dq;
                 const uint64_t ti = j * (W / (2 * m));
                 int st;
-                if (PRE) st = g1_mul_glv_wnaf_aq_pre_q<true, true>(dif, roots[ti], tbl, jt, wnaf + ti * KZG_WNAF_ROW, dq, packed);
-                else { int8_t dg1[132], dg2[132]; st = g1_mul_glv_wnaf_aq_q<true, true>(dif, roots[ti], tbl, jt, dg1, dg2, 1, dq, packed); }
+                if (PRE) st = g1_mul_glv_wnaf_aq_pre_q<true, true>(dif, roots[ti], tbl, dz, wnaf + ti * KZG_WNAF_ROW, dq, packed);
+                else { int8_t dg1[132], dg2[132]; st = g1_mul_glv_wnaf_aq_q<true, true>(dif, roots[ti], tbl, dz, dg1, dg2, 1, dq, packed); }
                 row[i1] = st == 1 ? g1jq_pack(dq) : st == 2 ? packed : g1_inf();
             } else { g1j o1; o1.x = packq(dif.x); o1.y = packq(dif.y); o1.z = o0.z; row[i1] = o1; }
             return;
@@ -208,10 +189,10 @@ template <bool PRE> __global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_fft_stag
     // an infinite operand or x == +-y: generic complete formulas
     g1j s_ = g1_add(x, y), d_ = g1_add(x, g1_neg(y));
     if (j && !is_inf(d_)) {
-        g1aq tbl[8]; g1jq jt[8]; g1j packed; g1jq dq;
+        g1aq tbl[8]; fq dz[7]; g1j packed; g1jq dq;
         const uint64_t ti = j * (W / (2 * m));
         int8_t dg1[132], dg2[132];
-        int st = g1_mul_glv_wnaf_aq<true, true>(d_, roots[ti], tbl, jt, dg1, dg2, 1, dq, packed);
+        int st = g1_mul_glv_wnaf_aq<true, true>(d_, roots[ti], tbl, dz, dg1, dg2, 1, dq, packed);
         d_ = st == 1 ? g1jq_pack(dq) : st == 2 ? packed : g1_inf();
     }
     row[i0] = s_; row[i1] = d_;
@@ -244,7 +225,7 @@ void launch_g1_fft_stage(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, u
     // waves straddle two twiddles.  Otherwise (late stages of small batches: a single 4096-point transform has 64 different
     // twiddles per wave in its last stage, measured 21 ms against 2.3 ms) the regular signed-window schedule runs instead.
     static int forced = -2;
-    if (forced == -2) { const char *e = getenv("KZG_HIP_G1_MUL"); forced = !e ? -1 : e[0] == 'f' ? 0 : e[0] == 'w' ? 1 : e[0] == 'i' ? 2 : e[0] == 'a' ? 3 : 4; }
+    if (forced == -2) { const char *e = getenv("KZG_HIP_G1_MUL"); forced = !e ? -1 : e[0] == 'r' ? 0 : e[0] == 'w' ? 4 : -1; }
     const uint64_t per_twiddle = (n / 2 / m) * batch;
     const int mode = forced >= 0 ? forced : ((per_twiddle % 64 == 0 || per_twiddle >= 256) ? 4 : 0);
     const dim3 grid((uint32_t)((total + G1_BLOCK - 1) / G1_BLOCK)), block(G1_BLOCK);
@@ -254,9 +235,6 @@ void launch_g1_fft_stage(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, u
         if (g1_wnaf_rows_pay(n, batch, m)) hipLaunchKernelGGL((k_g1_fft_stage<4, true>), grid, block, 0, s, data, logn, m, roots, wnaf, W, total, batch);
         else hipLaunchKernelGGL((k_g1_fft_stage<4, false>), grid, block, 0, s, data, logn, m, roots, wnaf, W, total, batch);
         break;
-    case 3: hipLaunchKernelGGL(k_g1_fft_stage<3>, grid, block, 0, s, data, logn, m, roots, wnaf, W, total, batch); break;
-    case 2: hipLaunchKernelGGL(k_g1_fft_stage<2>, grid, block, 0, s, data, logn, m, roots, wnaf, W, total, batch); break;
-    case 1: hipLaunchKernelGGL(k_g1_fft_stage<1>, grid, block, 0, s, data, logn, m, roots, wnaf, W, total, batch); break;
     default: hipLaunchKernelGGL(k_g1_fft_stage<0>, grid, block, 0, s, data, logn, m, roots, wnaf, W, total, batch); break;
     }
     prof_end(s, "g1_fft_stage");
@@ -295,14 +273,9 @@ __global__ __launch_bounds__(G1_DIRECT_BLOCK, 2) void k_g1_fft_direct(const g1j 
             else {
                 fr sc = roots[e * (W >> logn)];
                 if (scale) sc = mul(sc, *scale);
-#ifdef KZG_G1_REGULAR_JACOBIAN_TABLE
-                g1jq tbl[16];
-                acc.inf = !g1_mul_glv_signed_q(x, glv_split_signed(from_mont<FrP>(sc)), tbl, acc.v);
-#else
-                g1aq tbl[8]; g1jq jt[8]; g1j packed;
-                const int st = g1_mul_glv_regular_aq<true>(g1jq_unpack(x), glv_split_signed(from_mont<FrP>(sc)), tbl, jt, acc.v, packed);
+                g1aq tbl[8]; fq dz[7]; g1j packed;
+                const int st = g1_mul_glv_regular_aq<true>(g1jq_unpack(x), glv_split_signed(from_mont<FrP>(sc)), tbl, dz, acc.v, packed);
                 if (st == 2) { acc.inf = is_inf(packed); if (!acc.inf) acc.v = g1jq_unpack(packed); } else acc.inf = st == 0;
-#endif
             }
         }
     }

@@ -87,18 +87,18 @@ void he_g1_mul_glv_wnaf_inl(g1j *o, const g1j *a, const fr *k_mont) {   // the i
 void he_g1_mul_glv_wnaf_affine(g1j *o, const g1j *a, const fr *k_mont, int inl) {
     g1j pi = IN(a);
     if (is_inf(pi)) { *o = OUT(g1_inf()); return; }
-    g1aq tbl[8]; g1jq jt[8]; int8_t d1[132], d2[132]; g1jq q; g1j packed;
+    g1aq tbl[8]; fq dz[7]; int8_t d1[132], d2[132]; g1jq q; g1j packed;
     fr kk = glv_decompose(from_mont<FrP>(*k_mont));
-    int st = inl ? g1_mul_glv_wnaf_aq<true, true>(pi, kk, tbl, jt, d1, d2, 1, q, packed) : g1_mul_glv_wnaf_aq<false, false>(pi, kk, tbl, jt, d1, d2, 1, q, packed);
+    int st = inl ? g1_mul_glv_wnaf_aq<true, true>(pi, kk, tbl, dz, d1, d2, 1, q, packed) : g1_mul_glv_wnaf_aq<false, false>(pi, kk, tbl, dz, d1, d2, 1, q, packed);
     *o = OUT(st == 0 ? g1_inf() : st == 1 ? g1jq_pack(q) : packed);
 }
 // the regular odd-digit schedule on the same table, scalar split on the fly (what the direct G1 FFT passes run)
 void he_g1_mul_glv_regular(g1j *o, const g1j *a, const fr *k_mont, int inl) {
     g1j pi = IN(a);
     if (is_inf(pi)) { *o = OUT(g1_inf()); return; }
-    g1aq tbl[8]; g1jq jt[8]; g1jq q; g1j packed;
+    g1aq tbl[8]; fq dz[7]; g1jq q; g1j packed;
     glv_halves h = glv_split_signed(from_mont<FrP>(*k_mont));
-    int st = inl ? g1_mul_glv_regular_aq<true>(g1jq_unpack(pi), h, tbl, jt, q, packed) : g1_mul_glv_regular_aq<false>(g1jq_unpack(pi), h, tbl, jt, q, packed);
+    int st = inl ? g1_mul_glv_regular_aq<true>(g1jq_unpack(pi), h, tbl, dz, q, packed) : g1_mul_glv_regular_aq<false>(g1jq_unpack(pi), h, tbl, dz, q, packed);
     *o = OUT(st == 0 ? g1_inf() : st == 1 ? g1jq_pack(q) : packed);
 }
 // ... with explicit halves (k1[4] | k2[4] | neg1 | neg2): zero halves, even halves, the generic fallback
@@ -108,17 +108,17 @@ int he_g1_mul_glv_regular_halves(g1j *o, const g1j *a, const uint32_t *hw, int c
     for (int i = 0; i < 4; i++) { h.k1[i] = hw[i]; h.k2[i] = hw[4 + i]; }
     h.neg1 = hw[8]; h.neg2 = hw[9];
     if (cold) { g1j r; g1_mul_glv_signed_cold(&r, &pi, &h); *o = OUT(r); return 2; }
-    g1aq tbl[8]; g1jq jt[8]; g1jq q; g1j packed;
-    int st = g1_mul_glv_regular_aq<true>(g1jq_unpack(pi), h, tbl, jt, q, packed);
+    g1aq tbl[8]; fq dz[7]; g1jq q; g1j packed;
+    int st = g1_mul_glv_regular_aq<true>(g1jq_unpack(pi), h, tbl, dz, q, packed);
     *o = OUT(st == 0 ? g1_inf() : st == 1 ? g1jq_pack(q) : packed);
     return st;
 }
 // the 8 affine odd multiples of a (co-Z chain when coz != 0, Jacobian chain + Montgomery's trick otherwise): out = 8 normalised points
 int he_wnaf_table(g1j *out8, const g1j *a, int coz) {
     g1jq pq = g1jq_unpack(IN(a));
-    g1aq tbl[8]; g1jq jt[8];
+    g1aq tbl[8]; g1jq jt[8]; fq dz[7];
     int ok = 1;
-    if (coz) ok = (coz == 2 ? g1_wnaf_table_affine_coz<true>(pq, tbl, &jt[0].x) : g1_wnaf_table_affine_coz<false>(pq, tbl, &jt[0].x)) ? 1 : 0; else g1_wnaf_table_affine_q(pq, tbl, jt);
+    if (coz) ok = (coz == 2 ? g1_wnaf_table_affine_coz<true>(pq, tbl, dz) : g1_wnaf_table_affine_coz<false>(pq, tbl, dz)) ? 1 : 0; else g1_wnaf_table_affine_q(pq, tbl, jt);
     for (int i = 0; i < 8; i++) { g1j o; o.x = packq(tbl[i].x); o.y = packq(tbl[i].y); o.z = one<FpP>(); out8[i] = OUT(o); }
     return ok;
 }
@@ -137,8 +137,8 @@ int he_g1jq_madd_entry(g1j *o, const g1j *a, const g1j *b, int negate, int phi, 
 int he_g1_butterfly(g1j *o_sum, g1j *o_dif, const g1j *a, const g1j *b, const fr *k_mont) {
     g1j x = IN(a), y = IN(b);
     if (is_inf(x) || is_inf(y)) return 0;
-    g1aq tbl[8]; g1jq jt[8]; int8_t d1[132], d2[132]; g1jq yq; g1j packed;
-    int st = g1_mul_glv_wnaf_aq<true, true>(y, glv_decompose(from_mont<FrP>(*k_mont)), tbl, jt, d1, d2, 1, yq, packed);   // what k_g1_fft_stage<4> runs
+    g1aq tbl[8]; fq dz[7]; int8_t d1[132], d2[132]; g1jq yq; g1j packed;
+    int st = g1_mul_glv_wnaf_aq<true, true>(y, glv_decompose(from_mont<FrP>(*k_mont)), tbl, dz, d1, d2, 1, yq, packed);   // what k_g1_fft_stage<4> runs
     if (st != 1) return 0;
     g1jq sum, dif;
     if (!g1jq_addsub(g1jq_unpack(x), yq, sum, dif)) return 0;
