@@ -10,11 +10,17 @@
 //   leader:         waits until every reserved row is filled, then runs the batch on the buffer's own stream (inputs read from
 //                   pinned memory, batched kernels, one D2H) and wakes the batch's callers.
 //
-// Up to MAX_EXEC batches execute concurrently on separate streams: the end of a batch (reduction trees, one inversion per
-// polynomial) is latency-bound and uses a fraction of the CUs, so the next batch's table walk overlaps it.  The elected leader
-// holds its buffer open for at most `window` microseconds until it has its share (concurrency / MAX_EXEC) of the callers that
-// are inside submit() right now; a steady lone caller never waits, and without concurrency nothing is added to its latency.
+// One batch is in flight up to ~96 concurrent callers, up to MAX_EXEC (on separate streams) beyond: the end of a batch (reduction
+// trees, one inversion per polynomial) is latency-bound and uses a fraction of the CUs, so with hundreds of callers the next batch's
+// table walk overlaps it.  The elected leader holds its buffer open for at most `window` microseconds until it has its share
+// (concurrency / batches in flight) of the recent callers; a steady lone caller never waits: nothing is added to its latency.
 // The executing function is supplied by the handle (commit / proof / FK20); everything here is host-side C++.
+//
+// Wake-ups.  The end of a batch releases all of its callers at once.  Through a condition variable every one of them re-acquires the
+// coalescer's mutex on the way out -- a convoy of futex hand-offs that was measured at ~0.4 ms per batch with 64 callers (the device
+// sat idle 28 % of the time and the next leader's gather window expired with 50 of the 64 callers back).  The callers of a batch
+// therefore sleep on a per-buffer futex word (`epoch`) and leave WITHOUT the mutex when they find the batch done; only leader
+// election and the row reservation take it.  (Linux only, like ROCm.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <atomic>
@@ -23,9 +29,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <climits>
 #include <functional>
 #include <mutex>
 #include <vector>
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 namespace kzg {
 
@@ -34,8 +44,14 @@ struct coalesce_row {        // what the executor sees for row b of a batch
     uint64_t arg;            // per-request scalar argument (ComputeProofSingle's x)
 };
 
+static inline void futex_wait_u32(std::atomic<uint32_t> *a, uint32_t seen) { syscall(SYS_futex, (uint32_t *)a, FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0); }
+static inline void futex_wake_u32(std::atomic<uint32_t> *a, int n) { syscall(SYS_futex, (uint32_t *)a, FUTEX_WAKE_PRIVATE, n, nullptr, nullptr, 0); }
+static_assert(sizeof(std::atomic<uint32_t>) == sizeof(uint32_t), "futex word");
+
 struct coalesce_buf {
-    enum state_t { FREE_OPEN, CLOSED, DRAINING } state = FREE_OPEN;
+    enum state_t : int { FREE_OPEN, CLOSED, DRAINING };
+    std::atomic<int> state{FREE_OPEN};           // written under the coalescer's mutex; DRAINING is also read without it (after `status`)
+    std::atomic<uint32_t> epoch{0};              // futex word: bumped (under the mutex) by every event this buffer's sleepers care about
     uint8_t *h_in = nullptr, *h_out = nullptr;   // pinned: max_batch x in_row_bytes, max_batch x out_row_bytes
     coalesce_row *h_meta = nullptr;              // pinned copy of `rows` for the executor's H2D (filled by the leader)
     std::vector<coalesce_row> rows;              // reserved rows, in order
@@ -43,7 +59,7 @@ struct coalesce_buf {
     std::atomic<uint64_t> outstanding{0};        // callers that still have to copy their result out
     int status = 0;
     hipStream_t stream = nullptr;
-    std::condition_variable cv;                  // this batch's callers (and its leader-to-be) sleep here
+    uint64_t target = 0;                         // rows its gathering leader is waiting for
 };
 
 class coalescer {
@@ -75,12 +91,13 @@ class coalescer {
     size_t out_row_bytes() const { return out_row_; }
 
     // one request: `in` holds in_bytes (<= in_row_bytes), the result (out_bytes <= out_row_bytes) is written to `out`.
-    // Wake-ups are targeted (one condition variable per role and per buffer): with 64-256 callers one notify_all per event costs
-    // more than the batch itself.
+    // Wake-ups are targeted: a futex word per buffer for its callers, one condition variable for the (single) gathering leader and
+    // one for callers that found every buffer busy.
     int submit(const void *in, size_t in_bytes, uint64_t n, uint64_t arg, void *out, size_t out_bytes, const exec_fn &exec, int alloc_error_status) {
         hipSetDevice(device_);                   // caller threads (goroutine-backed OS threads) start on device 0
         std::unique_lock<std::mutex> lk(mu_);
-        inside_++;
+        const uint64_t in_now0 = inside_.fetch_add(1, std::memory_order_relaxed) + 1;
+        if (in_now0 > inside_max_) inside_max_ = in_now0;
         // reserve a row in the open buffer
         int bi;
         for (;;) {
@@ -98,32 +115,43 @@ class coalescer {
                 if (b.h_in) { hipHostFree(b.h_in); b.h_in = nullptr; }
                 if (b.h_out) { hipHostFree(b.h_out); b.h_out = nullptr; }
                 if (b.h_meta) { hipHostFree(b.h_meta); b.h_meta = nullptr; }
-                inside_--;
+                inside_.fetch_sub(1, std::memory_order_relaxed);
                 return alloc_error_status;
             }
         }
         const uint64_t row = b.rows.size();
         b.rows.push_back(coalesce_row{n, arg});
         b.outstanding++;
-        if (gathering_ == bi) cv_leader_.notify_all();                     // a leader is holding this buffer open for stragglers
+        if (gathering_ == bi && b.rows.size() >= b.target) cv_leader_.notify_all();   // the leader holding this buffer open has its share
         lk.unlock();
         memcpy(b.h_in + row * in_row_, in, in_bytes);                      // parallel across callers
         lk.lock();
         b.ready++;
-        if (b.state == coalesce_buf::CLOSED && b.ready == b.rows.size()) cv_leader_.notify_all();   // its leader waits for the last row
+        if (b.state.load(std::memory_order_relaxed) == coalesce_buf::CLOSED && b.ready == b.rows.size()) cv_leader_.notify_all();   // its leader waits for the last row
         // wait for the batch; lead it if a device slot is free
+        bool locked = true;
         for (;;) {
-            if (b.state == coalesce_buf::DRAINING) break;
-            if (b.state == coalesce_buf::FREE_OPEN && executing_ < max_exec_ && gathering_ < 0) {
+            if (b.state.load(std::memory_order_relaxed) == coalesce_buf::DRAINING) break;
+            if (b.state.load(std::memory_order_relaxed) == coalesce_buf::FREE_OPEN && executing_ < exec_limit_ && gathering_ < 0) {
                 executing_++;
-                // Gather: this batch's share of the callers that are inside submit() now (or were, moments ago: `peak_` halves
-                // per batch) get up to `window_us_` to join, so that N concurrent callers run as MAX_EXEC overlapping batches of
-                // N / MAX_EXEC instead of a convoy of tiny ones.
-                peak_ = inside_ > peak_ / 2 ? inside_ : peak_ / 2;
-                uint64_t target = (peak_ + max_exec_ - 1) / max_exec_;
+                // Gather: this batch's share of the concurrent callers gets up to `window_us_` to join, so that N concurrent callers
+                // run as MAX_EXEC overlapping batches of N / MAX_EXEC instead of a convoy of tiny ones.
+                // (`peak_`: the most callers seen inside submit() since the previous batch was formed -- at the moment a leader is
+                // elected most of them are between two calls -- decaying by a quarter per batch once they stop coming)
+                const uint64_t decayed = peak_ - peak_ / 4;
+                peak_ = inside_max_ > decayed ? inside_max_ : decayed;
+                inside_max_ = inside_.load(std::memory_order_relaxed);
+                // Batches in flight: ONE up to ~96 concurrent callers (a table walk over fewer than ~50 polynomials leaves lanes idle
+                // and pays its reduction tree in full, so two half-size walks take 1.3 times one full-size walk: measured 44.6 k/s
+                // against 38.2 k/s with 64 callers), a second and third one beyond, where a batch is large enough to walk
+                // efficiently and the host side of a batch (hundreds of wake-ups and 128 KiB row copies) is worth overlapping
+                // (256 callers: 55.8 k/s with three against 44.0 k/s with one).
+                exec_limit_ = (int)(1 + peak_ / 96);
+                if (exec_limit_ > max_exec_) exec_limit_ = max_exec_;
+                uint64_t target = (peak_ + exec_limit_ - 1) / exec_limit_;
                 if (target > max_batch_) target = max_batch_;
                 if (window_us_ > 0 && b.rows.size() < target) {
-                    gathering_ = bi;
+                    gathering_ = bi; b.target = target;
                     const auto g0 = std::chrono::steady_clock::now();
                     const auto deadline = g0 + std::chrono::microseconds(window_us_);
                     while (b.rows.size() < target)
@@ -132,11 +160,11 @@ class coalescer {
                     gather_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - g0).count();
                 }
                 // close this buffer, open a free one
-                b.state = coalesce_buf::CLOSED;
+                b.state.store(coalesce_buf::CLOSED, std::memory_order_relaxed);
                 open_ = -1;
                 for (int k = 1; k < NBUF; k++) {
                     const int o = (bi + k) % NBUF;
-                    if (bufs_[o].state == coalesce_buf::FREE_OPEN && bufs_[o].outstanding.load() == 0) { open_ = o; break; }
+                    if (bufs_[o].state.load(std::memory_order_relaxed) == coalesce_buf::FREE_OPEN && bufs_[o].outstanding.load() == 0) { open_ = o; break; }
                 }
                 if (open_ >= 0) cv_reserve_.notify_all();                  // callers that found this buffer full
                 const auto r0 = std::chrono::steady_clock::now();
@@ -151,21 +179,29 @@ class coalescer {
                 lk.lock();
                 batches_++; requests_ += batch; exec_s_ += dt;
                 b.status = st;
-                b.state = coalesce_buf::DRAINING;
+                b.state.store(coalesce_buf::DRAINING, std::memory_order_release);
+                b.epoch.fetch_add(1, std::memory_order_release);
                 executing_--;
-                b.cv.notify_all();                                         // this batch's callers
-                if (open_ >= 0 && open_ != bi) bufs_[open_].cv.notify_one();   // one caller of the accumulating batch becomes its leader
+                coalesce_buf *next = (open_ >= 0 && open_ != bi) ? &bufs_[open_] : nullptr;
+                if (next) next->epoch.fetch_add(1, std::memory_order_release);
+                lk.unlock(); locked = false;
+                futex_wake_u32(&b.epoch, INT_MAX);                         // this batch's callers: they leave without the mutex
+                if (next) futex_wake_u32(&next->epoch, 1);                 // one caller of the accumulating batch becomes its leader
                 break;
             }
-            b.cv.wait(lk);
+            const uint32_t seen = b.epoch.load(std::memory_order_relaxed);   // under the mutex: every later event bumps it
+            lk.unlock();
+            futex_wait_u32(&b.epoch, seen);
+            if (b.state.load(std::memory_order_acquire) == coalesce_buf::DRAINING) { locked = false; break; }   // the common wake-up: done
+            lk.lock();
         }
         const int st = b.status;
-        inside_--;
-        lk.unlock();
+        inside_.fetch_sub(1, std::memory_order_relaxed);
+        if (locked) lk.unlock();
         if (st == 0) memcpy(out, b.h_out + row * out_row_, out_bytes);
         if (b.outstanding.fetch_sub(1) == 1) {                              // last one out recycles the buffer (only it re-takes the lock)
             lk.lock();
-            b.rows.clear(); b.ready = 0; b.state = coalesce_buf::FREE_OPEN;
+            b.rows.clear(); b.ready = 0; b.state.store(coalesce_buf::FREE_OPEN, std::memory_order_relaxed);
             if (open_ < 0) { open_ = bi; cv_reserve_.notify_all(); }
         }
         return st;
@@ -177,8 +213,10 @@ class coalescer {
     coalesce_buf bufs_[NBUF];
     int open_ = 0;               // buffer accepting reservations, -1 while all are busy
     int executing_ = 0;          // batches on the device
-    int max_exec_ = MAX_EXEC;
-    uint64_t inside_ = 0;        // callers currently inside submit()
+    int max_exec_ = MAX_EXEC;    // upper bound (KZG_HIP_COALESCE_EXEC)
+    int exec_limit_ = 1;         // batches allowed in flight right now: 1 .. max_exec_ by the number of concurrent callers
+    std::atomic<uint64_t> inside_{0};   // callers currently inside submit()
+    uint64_t inside_max_ = 0;    // its maximum since the last batch was formed (under the mutex)
     uint64_t peak_ = 0;          // decaying maximum of inside_: the concurrency the gather targets are derived from
     int gathering_ = -1;         // buffer whose elected leader is still waiting for stragglers
     long window_us_ = 150;       // upper bound of that wait (KZG_HIP_COALESCE_US; 0 disables)
