@@ -399,21 +399,39 @@ __global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_build_pass2(uint64_t lanes, 
     }
 }
 
-// block-wide sum of the lanes' accumulators into lane 0's: log2(FB_BLOCK) levels of the lazy XYZZ + XYZZ addition through LDS
-__device__ __forceinline__ void fb_block_reduce(g1x_acc &acc, fb_partial *buf, uint32_t tid) {
-    fb_partial_store(buf[tid], acc);
-    __syncthreads();
+// Block-wide sum of the 256 lane accumulators of a table-walk workgroup into lane 0's, WAVE-COOPERATIVELY: while the tree runs, three of
+// the four wavefronts would idle, so each takes one product of a dependency level of the XYZZ addition instead (coop_xyzz_add: 4 levels
+// deep instead of 13 products).  Lane column c of every wave keeps a replica of column c's running sum: the waves publish their 64
+// accumulators one after the other (3 cooperative additions), then a 6-level tree over the columns: 9 additions of depth 4 instead of
+// 7 of depth 13 (and 8 with 256 lanes).  The tree is what a small batch pays in full: a walk over 64 polynomials 0.86 -> 0.8x ms.
+// buf: 64 slots.
+#define FB_ACC_BLOCK 256
+__device__ __forceinline__ void fb_block_reduce_coop(g1x_acc &acc, fb_partial *buf, coop_lds *lds, uint32_t tid) {
+    coop_ctx c; c.L = lds; c.wave = tid >> 6; c.col = tid & 63u; c.set = 0;
+    g1x_acc col; col.init();
 #pragma nounroll
-    for (uint32_t off = FB_BLOCK / 2; off >= 1; off >>= 1) {
-        if (tid < off) {
-            g1xq v; fb_partial_load(buf[tid + off], v);
-            g1x_acc_merge(acc, v, buf[tid + off].inf != 0);
-            fb_partial_store(buf[tid], acc);
-        }
+    for (uint32_t w = 0; w < FB_ACC_BLOCK / 64; w++) {
+        if (c.wave == w) fb_partial_store(buf[c.col], acc);
         __syncthreads();
+        g1xq v; fb_partial_load(buf[c.col], v);
+        const bool vinf = buf[c.col].inf != 0;
+        __syncthreads();                                   // everyone has read before the next wave publishes
+        if (w == 0) { col.v = v; col.inf = vinf; }
+        else coop_acc_add(col, v, vinf, c);
     }
+#pragma nounroll
+    for (uint32_t off = 32; off >= 1; off >>= 1) {
+        if (c.wave == 0) fb_partial_store(buf[c.col], col);   // the replicas are identical: one wave publishes the columns
+        __syncthreads();
+        const bool have = c.col < off;
+        const uint32_t src = have ? c.col + off : c.col;
+        g1xq w; fb_partial_load(buf[src], w);
+        const bool winf = !have || buf[src].inf != 0;
+        __syncthreads();
+        coop_acc_add(col, w, winf, c);
+    }
+    acc = col;                                             // column 0 (of every wave) holds the block's sum
 }
-
 __device__ __forceinline__ uint32_t scalar_bits(const fr &k, uint32_t off, uint32_t c) {
     uint32_t idx = off >> 5, sh = off & 31;
     if (idx >= 8) return 0;
@@ -423,15 +441,16 @@ __device__ __forceinline__ uint32_t scalar_bits(const fr &k, uint32_t off, uint3
 }
 
 // main kernel: lane handles points i = lane, lane + L, ... of one blob; block tree-reduces through LDS
-__global__ __launch_bounds__(FB_BLOCK, FB_ACC_WAVES) void k_fb_accumulate(const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, uint32_t D, const fr *scalars,
+__global__ __launch_bounds__(FB_ACC_BLOCK, FB_ACC_WAVES) void k_fb_accumulate(const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, uint32_t D, const fr *scalars,
                                                             uint64_t sc_stride, uint64_t n, uint32_t blocks_per_blob, fb_partial *partials) {
-    __shared__ fb_partial buf[FB_BLOCK];
+    __shared__ fb_partial buf[64];
+    __shared__ coop_lds lds;
     const uint32_t tid = threadIdx.x;
     const uint64_t blob = blockIdx.x / blocks_per_blob; const uint32_t blk = blockIdx.x % blocks_per_blob;
-    const uint64_t L = (uint64_t)blocks_per_blob * FB_BLOCK;
+    const uint64_t L = (uint64_t)blocks_per_blob * FB_ACC_BLOCK;
     const fr *sc = scalars + blob * sc_stride;   // rows may be wider than n (pinned staging rows read in place over PCIe)
     g1x_acc acc; acc.init();   // XYZZ, unpacked lazy limbs: 10 products per mixed addition, no pack / reduce per product
-    for (uint64_t i = (uint64_t)blk * FB_BLOCK + tid; i < n; i += L) {
+    for (uint64_t i = (uint64_t)blk * FB_ACC_BLOCK + tid; i < n; i += L) {
         fr k = from_mont<FrP>(sc[i]);
         // software pipeline: the gather of window w + 1 is issued before the addition of window w (+1.3 % measured)
         uint32_t raw = scalar_bits(k, 0, c), carry, mag, ng;
@@ -452,7 +471,7 @@ __global__ __launch_bounds__(FB_BLOCK, FB_ACC_WAVES) void k_fb_accumulate(const 
             }
         }
     }
-    fb_block_reduce(acc, buf, tid);
+    fb_block_reduce_coop(acc, buf, &lds, tid);
     if (tid == 0) fb_partial_store(partials[blockIdx.x], acc);
 }
 // one workgroup of four cooperating wavefronts per blob (lane column j = partial sum j): the blob's partial sums are added by a
@@ -659,11 +678,11 @@ static uint32_t fb_blocks_per_blob(uint64_t n, uint64_t batch) {
             if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
             lanes = (uint64_t)(cus > 0 ? cus : 256) * 4 * 2 * 64;
         }
-        if (lanes < FB_BLOCK) lanes = FB_BLOCK;
+        if (lanes < FB_ACC_BLOCK) lanes = FB_ACC_BLOCK;
     }
-    uint64_t target = lanes / FB_BLOCK;
+    uint64_t target = lanes / FB_ACC_BLOCK;
     uint64_t bpb = target / (batch ? batch : 1);
-    uint64_t maxb = (n + FB_BLOCK - 1) / FB_BLOCK;
+    uint64_t maxb = (n + FB_ACC_BLOCK - 1) / FB_ACC_BLOCK;
     if (bpb > maxb) bpb = maxb;
     if (bpb < 1) bpb = 1;
     return (uint32_t)bpb;
@@ -677,7 +696,7 @@ void launch_fb_msm(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c
     if (!batch) return;
     uint32_t bpb = fb_blocks_per_blob(n, batch);
     prof_begin(s, "fb_accumulate");
-    hipLaunchKernelGGL(k_fb_accumulate, dim3((uint32_t)(batch * bpb)), dim3(FB_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars, sc_stride, n, bpb,
+    hipLaunchKernelGGL(k_fb_accumulate, dim3((uint32_t)(batch * bpb)), dim3(FB_ACC_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars, sc_stride, n, bpb,
                        (fb_partial *)partials);
     prof_end(s, "fb_accumulate");
     hipLaunchKernelGGL(k_fb_finish, dim3((uint32_t)batch), dim3(256), 0, s, (const fb_partial *)partials, bpb, batch, out, to_kilic ? 1 : 0);
