@@ -144,7 +144,7 @@ class coalescer {
                 // run as MAX_EXEC overlapping batches of N / MAX_EXEC instead of a convoy of tiny ones.
                 // (`peak_`: the most callers seen inside submit() since the previous batch was formed -- at the moment a leader is
                 // elected most of them are between two calls -- decaying by a quarter per batch once they stop coming)
-                const uint64_t decayed = peak_ - peak_ / 4;
+                const uint64_t decayed = peak_ - (peak_ + 3) / 4;          // rounds up: 3 -> 2 -> 1 -> 0 (a lone caller must end at a target of 1)
                 peak_ = inside_max_ > decayed ? inside_max_ : decayed;
                 inside_max_ = inside_.load(std::memory_order_relaxed);
                 // Batches in flight: ONE up to ~96 concurrent callers (a table walk over fewer than ~50 polynomials leaves lanes idle

@@ -729,6 +729,31 @@ def test_concurrent_callers_share_a_handle(kz, ks4096, setup_1337):
         assert np.array_equal(got[i], want[i])
 
 
+def test_lone_caller_pays_no_gather_window_after_a_burst(kz, ks4096):
+    """coalesce.hpp: the gather target of a batch leader follows the recent concurrency and must decay back to ONE caller -- a lone
+    caller after a burst of 16 threads would otherwise wait the 150 us window on every call (regression: the decay stalled at 3)."""
+    import time
+    blobs = np.stack([ko.synthetic_blob(900 + i) for i in range(16)])
+
+    def median_ms(reps):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            ks4096.commit_to_poly(blobs[0])
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)) * 1e3
+
+    for _ in range(40):
+        ks4096.commit_to_poly(blobs[0])                      # table built, any earlier concurrency forgotten
+    before = median_ms(40)
+    rate, _ = ks4096.bench_drop_in(blobs, 16, 10)
+    assert rate > 0
+    for _ in range(40):
+        ks4096.commit_to_poly(blobs[0])                      # the decay: a quarter per batch
+    after = median_ms(40)
+    assert after < before + 0.08, (before, after)            # the window is 0.15 ms
+
+
 def test_64_threads_single_blob_calls_are_coalesced_and_bit_exact(kz, ks4096, setup_1337):
     """the reference API is one polynomial per call (kzg_single_proofs.go:17-19,36-54); 64 host threads calling it concurrently
     are merged into batched launches (coalesce.hpp).  Every result is compared with the batched call, a sample with the oracle;
