@@ -440,9 +440,13 @@ __device__ __forceinline__ uint32_t scalar_bits(const fr &k, uint32_t off, uint3
     return (uint32_t)(v >> sh) & ((1u << c) - 1u);
 }
 
-// main kernel: lane handles points i = lane, lane + L, ... of one blob; block tree-reduces through LDS
-__global__ __launch_bounds__(FB_ACC_BLOCK, FB_ACC_WAVES) void k_fb_accumulate(const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, uint32_t D, const fr *scalars,
-                                                            uint64_t sc_stride, uint64_t n, uint32_t blocks_per_blob, fb_partial *partials) {
+// main kernel: lane handles points i = lane, lane + L, ... of one blob; the block reduces cooperatively through LDS.
+// SPLIT (small batches: fewer than 32 polynomials would leave most of the 131 072 resident lanes empty): the windows of a point are
+// divided among `wsplit` lanes (virtual point v = q n + i walks windows [q wpg, (q + 1) wpg) of point i; the carry into its first window
+// comes from a scan of the lower digits, bit operations only), so a lone commitment is 4096 x 8 lanes with 2 additions each instead
+// of 4096 lanes with 16: the walk of one polynomial 0.2 -> 0.1 ms.  The unsplit instantiation is the code it was before.
+template <bool SPLIT> __global__ __launch_bounds__(FB_ACC_BLOCK, FB_ACC_WAVES) void k_fb_accumulate(const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, uint32_t D, const fr *scalars,
+                                                            uint64_t sc_stride, uint64_t n, uint32_t blocks_per_blob, uint32_t wsplit, fb_partial *partials) {
     __shared__ fb_partial buf[64];
     __shared__ coop_lds lds;
     const uint32_t tid = threadIdx.x;
@@ -450,17 +454,28 @@ __global__ __launch_bounds__(FB_ACC_BLOCK, FB_ACC_WAVES) void k_fb_accumulate(co
     const uint64_t L = (uint64_t)blocks_per_blob * FB_ACC_BLOCK;
     const fr *sc = scalars + blob * sc_stride;   // rows may be wider than n (pinned staging rows read in place over PCIe)
     g1x_acc acc; acc.init();   // XYZZ, unpacked lazy limbs: 10 products per mixed addition, no pack / reduce per product
-    for (uint64_t i = (uint64_t)blk * FB_ACC_BLOCK + tid; i < n; i += L) {
+    const uint32_t wpg = SPLIT ? (nwin + wsplit - 1) / wsplit : nwin;
+    const uint64_t nv = SPLIT ? n * wsplit : n;
+    for (uint64_t v = (uint64_t)blk * FB_ACC_BLOCK + tid; v < nv; v += L) {
+        const uint64_t i = SPLIT ? v % n : v;
+        const uint32_t w0 = SPLIT ? (uint32_t)(v / n) * wpg : 0u;
+        const uint32_t w1 = SPLIT ? (w0 + wpg < nwin ? w0 + wpg : nwin) : nwin;
+        if (SPLIT && w0 >= w1) continue;
         fr k = from_mont<FrP>(sc[i]);
         // software pipeline: the gather of window w + 1 is issued before the addition of window w (+1.3 % measured)
-        uint32_t raw = scalar_bits(k, 0, c), carry, mag, ng;
-        if (raw > D) { carry = 1; mag = (1u << c) - raw; ng = 1; } else { carry = 0; mag = raw; ng = 0; }
-        g1a qn = table[((uint64_t)0 * table_n + i) * D + (mag ? mag - 1 : 0)];
+        uint32_t raw, carry = 0, mag, ng;
+        if (SPLIT) {
 #pragma nounroll
-        for (uint32_t w = 0; w < nwin; w++) {
+            for (uint32_t w = 0; w < w0; w++) carry = (scalar_bits(k, w * c, c) + carry > D) ? 1u : 0u;
+        }
+        raw = scalar_bits(k, w0 * c, c) + carry;
+        if (raw > D) { carry = 1; mag = (1u << c) - raw; ng = 1; } else { carry = 0; mag = raw; ng = 0; }
+        g1a qn = table[((uint64_t)w0 * table_n + i) * D + (mag ? mag - 1 : 0)];
+#pragma nounroll
+        for (uint32_t w = w0; w < w1; w++) {
             g1a q = qn;
             const uint32_t cmag = mag, cng = ng;
-            if (w + 1 < nwin) {
+            if (w + 1 < w1) {
                 raw = scalar_bits(k, (w + 1) * c, c) + carry;
                 if (raw > D) { carry = 1; mag = (1u << c) - raw; ng = 1; } else { carry = 0; mag = raw; ng = 0; }
                 qn = table[((uint64_t)(w + 1) * table_n + i) * D + (mag ? mag - 1 : 0)];
@@ -666,7 +681,7 @@ void launch_fb_mul_vec(hipStream_t s, const g1a *table, uint64_t table_n, uint32
     prof_end(s, "fb_mul_vec");
 }
 
-static uint32_t fb_blocks_per_blob(uint64_t n, uint64_t batch) {
+static uint32_t fb_blocks_per_blob(uint64_t n, uint64_t batch, uint32_t *wsplit = nullptr) {
     // 131072 lanes = 2048 wavefronts = exactly the resident capacity at 2 waves per SIMD: ONE round.  Measured (512 blobs):
     // 131072 lanes 5.7 ms, 262144 lanes (two rounds) 6.4 ms, 98304 / 65536 lanes 10.4 ms.  KZG_HIP_FB_LANES overrides.
     static uint64_t lanes = 0;
@@ -682,7 +697,11 @@ static uint32_t fb_blocks_per_blob(uint64_t n, uint64_t batch) {
     }
     uint64_t target = lanes / FB_ACC_BLOCK;
     uint64_t bpb = target / (batch ? batch : 1);
-    uint64_t maxb = (n + FB_ACC_BLOCK - 1) / FB_ACC_BLOCK;
+    // small batches: up to 8 lanes per point (each takes a share of the windows) while the launch stays within one round of lanes
+    uint32_t split = 1;
+    while (split < 8 && (batch ? batch : 1) * n * split * 2 <= lanes) split *= 2;
+    if (wsplit) *wsplit = split;
+    uint64_t maxb = (n * split + FB_ACC_BLOCK - 1) / FB_ACC_BLOCK;
     if (bpb > maxb) bpb = maxb;
     if (bpb < 1) bpb = 1;
     return (uint32_t)bpb;
@@ -694,10 +713,14 @@ size_t fb_partials_bytes(uint64_t n, uint64_t batch) { return (((size_t)fb_block
 void launch_fb_msm(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, uint64_t sc_stride, uint64_t n,
                    uint64_t batch, void *partials, g1j *out, bool to_kilic) {
     if (!batch) return;
-    uint32_t bpb = fb_blocks_per_blob(n, batch);
+    uint32_t split = 1;
+    uint32_t bpb = fb_blocks_per_blob(n, batch, &split);
+    if (split > nwin) split = nwin;
     prof_begin(s, "fb_accumulate");
-    hipLaunchKernelGGL(k_fb_accumulate, dim3((uint32_t)(batch * bpb)), dim3(FB_ACC_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars, sc_stride, n, bpb,
-                       (fb_partial *)partials);
+    if (split > 1) hipLaunchKernelGGL(k_fb_accumulate<true>, dim3((uint32_t)(batch * bpb)), dim3(FB_ACC_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars, sc_stride, n,
+                                      bpb, split, (fb_partial *)partials);
+    else hipLaunchKernelGGL(k_fb_accumulate<false>, dim3((uint32_t)(batch * bpb)), dim3(FB_ACC_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars, sc_stride, n, bpb,
+                            1u, (fb_partial *)partials);
     prof_end(s, "fb_accumulate");
     hipLaunchKernelGGL(k_fb_finish, dim3((uint32_t)batch), dim3(256), 0, s, (const fb_partial *)partials, bpb, batch, out, to_kilic ? 1 : 0);
 }
