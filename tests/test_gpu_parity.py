@@ -729,6 +729,42 @@ def test_concurrent_callers_share_a_handle(kz, ks4096, setup_1337):
         assert np.array_equal(got[i], want[i])
 
 
+@pytest.mark.timeout(300)
+def test_coalescer_with_callers_joining_and_leaving(kz, ks4096):
+    """coalesce.hpp sleeps its callers on futex words and elects batch leaders among them: threads that make different numbers of
+    calls (so the concurrency keeps changing, batches of every size form, leaders are elected while others leave) must all return,
+    each with its own result.  A lost wake-up would hang this test (pytest-timeout)."""
+    import threading
+    T = 48
+    blobs = np.stack([ko.synthetic_blob(1200 + i) for i in range(8)])
+    want = ks4096.commit_to_poly_batch(blobs)
+    xs = np.arange(3, 3 + 8, dtype=np.uint64)
+    want_p = ks4096.compute_proof_single_batch(blobs, xs)
+    bad, errs = [], []
+
+    def work(i):
+        try:
+            for r in range((i % 7 + 1) * 3):
+                j = (i + r) % 8
+                if (i + r) % 5 == 0:
+                    if not np.array_equal(ks4096.compute_proof_single(blobs[j], int(xs[j])), want_p[j]):
+                        bad.append((i, r, "proof"))
+                elif not np.array_equal(ks4096.commit_to_poly(blobs[j]), want[j]):
+                    bad.append((i, r, "commit"))
+                if i % 3 == 0 and r % 4 == 3:
+                    import time
+                    time.sleep(0.0007)                       # some callers pause: batches close on the window, not on the count
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    for _ in range(3):
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(T)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+    assert not errs, errs[:2]
+    assert not bad, bad[:5]
+
+
 def test_lone_caller_pays_no_gather_window_after_a_burst(kz, ks4096):
     """coalesce.hpp: the gather target of a batch leader follows the recent concurrency and must decay back to ONE caller -- a lone
     caller after a burst of 16 threads would otherwise wait the 150 us window on every call (regression: the decay stalled at 3)."""
