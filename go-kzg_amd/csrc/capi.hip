@@ -1329,6 +1329,7 @@ struct kzg_hip_eth {
     kzg_hip_kzg *ks = nullptr;     // "SecretG1" = bit-reversed Lagrange setup (kzgSetupLagrange, eth/globals.go:48)
     uint64_t n = 0;
     fr *d_domain = nullptr;        // DomainFr: w^bitrev(i) (eth/globals.go:61-66)
+    std::unique_ptr<coalescer> co_blob;   // concurrent one-blob BlobToKZGCommitment calls (eth/eth.go:145-151) merge into batched launches
 };
 
 int kzg_hip_eth_settings_new(kzg_hip_fft *fs, const void *lagrange_g1, uint64_t n, kzg_hip_eth **out) {
@@ -1365,6 +1366,8 @@ int kzg_hip_eth_settings_new(kzg_hip_fft *fs, const void *lagrange_g1, uint64_t 
 void kzg_hip_eth_settings_free(kzg_hip_eth *eth) {
     if (!eth) return;
     hipSetDevice(eth->fs->device);
+    hipDeviceSynchronize();
+    eth->co_blob.reset();
     kzg_hip_kzg_settings_free(eth->ks);   // drains the device first
     hipFree(eth->d_domain);
     (void)hipGetLastError();
@@ -1374,6 +1377,39 @@ int kzg_hip_eth_blob_to_kzg_commitment_batch(kzg_hip_eth *eth, const void *blobs
     if (!eth || !blobs_le32 || !out48 || !ok) return KZG_HIP_ERR_BAD_ARG;
     if (!batch) return KZG_HIP_OK;
     KZG_TRY
+    if (batch == 1 && coalescing_enabled()) {
+        // eth.BlobToKZGCommitment takes ONE blob per call (eth/eth.go:145-151): concurrent callers share batched launches.  A row is
+        // the blob's 32-byte little-endian elements (read in place from the pinned staging buffer by the conversion kernel); a result
+        // row is the 48 compressed bytes + the "invalid element" flag of BlobToPolynomial.
+        const uint64_t n = eth->n;
+        coalescer *co = get_coalescer(eth->fs, eth->co_blob, n * 32, 64);
+        auto exec = [eth, n](coalesce_buf &b, uint64_t rows) -> int {
+            hipSetDevice(eth->fs->device);
+            hipStream_t s = b.stream;
+            { dev_guard g(eth->fs); CHK(ensure_fixed_table(eth->ks, s)); }
+            dtmp<uint8_t> d_c(s); dtmp<fr> d_poly(s); dtmp<g1j> d_out(s); dtmp<uint32_t> d_bad(s);
+            CHK(d_c.alloc(rows * 48)); CHK(d_poly.alloc(rows * n)); CHK(d_out.alloc(rows)); CHK(d_bad.alloc(rows));
+            HIPCHK(hipMemsetAsync(d_bad.p, 0, rows * 4, s));
+            void *dp_in = nullptr;
+            HIPCHK(hipHostGetDevicePointer(&dp_in, b.h_in, 0));
+            launch_fr_from_le32(s, (const uint8_t *)dp_in, d_poly.p, n, rows, d_bad.p);
+            CHK(commit_rows(eth->ks, s, d_poly.p, n, rows, d_out.p));
+            launch_g1_from_kilic(s, d_out.p, rows);
+            launch_g1_compress(s, d_out.p, d_c.p, rows);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpy2DAsync(b.h_out, 64, d_c.p, 48, 48, rows, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpy2DAsync(b.h_out + 48, 64, d_bad.p, 4, 4, rows, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            return KZG_HIP_OK;
+        };
+        uint8_t row[64];
+        int st = co->submit(blobs_le32, n * 32, n, 0, row, 64, exec, KZG_HIP_ERR_HIP);
+        if (st != KZG_HIP_OK) return st;
+        uint32_t bad; memcpy(&bad, row + 48, 4);
+        ok[0] = bad ? 0 : 1;
+        if (bad) memset(out48, 0, 48); else memcpy(out48, row, 48);
+        return KZG_HIP_OK;
+    }
     dev_guard g(eth->fs);
     hipStream_t s = eth->fs->stream;
     uint64_t n = eth->n;

@@ -176,6 +176,8 @@ void kzg_hip_eth_settings_free(kzg_hip_eth *eth);
 /* BlobToKZGCommitment over `batch` blobs of n x 32 little-endian bytes: out48[b] = commitment, ok[b] = 1, or ok[b] = 0 when a
  * field element is >= r (the reference returns (KZGCommitment{}, false): out48[b] is zeroed). */
 int kzg_hip_eth_blob_to_kzg_commitment_batch(kzg_hip_eth *eth, const void *blobs_le32, uint64_t batch, void *out48, uint8_t *ok);
+/* (batch == 1 is eth.BlobToKZGCommitment itself, eth/eth.go:145-151: concurrent one-blob calls on a handle are coalesced into
+ * batched launches like kzg_hip_commit_to_poly's.) */
 /* ComputeKZGProof (eth/helpers.go:179-203): polynomial in evaluation form (n Fr), z; writes the 48-byte proof and (optionally) y.
  * KZG_HIP_ERR_LEN_MISMATCH: "polynomial has invalid length"; KZG_HIP_ERR_BAD_ARG: "invalid z challenge" (z in the domain). */
 int kzg_hip_eth_compute_kzg_proof(kzg_hip_eth *eth, const void *poly_fr, uint64_t n, const void *z_fr, void *out48, void *y_fr);

@@ -678,6 +678,24 @@ def test_eth_blob_to_kzg_commitment_and_compute_kzg_proof(kz):
         eth.compute_kzg_proof(ko.fr_from_ints(blob_i), ko.fr_from_ints([dom[9]]))
     with pytest.raises(kz.KzgError, match="invalid length"):
         eth.compute_kzg_proof(ko.fr_from_ints(blob_i[:2048]), ko.fr_from_ints([z]))
+    # eth.BlobToKZGCommitment is ONE blob per call: 24 concurrent callers (one of them with an invalid element) share batched launches
+    import threading
+    many = np.stack([blob, bad, edge] * 8)
+    want, want_ok = eth.blob_to_kzg_commitment_batch(many)
+    got, errs = [None] * 24, []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                got[i] = eth.blob_to_kzg_commitment(many[i])
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(24)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs[:2]
+    for i in range(24):
+        assert got[i][1] == bool(want_ok[i]) and got[i][0].tobytes() == want[i].tobytes(), i
     eth.close(); fs.close()
 
 
