@@ -466,6 +466,23 @@ def main():
                 fk.da_using_fk20(polys_h[0])
                 ts.append((time.perf_counter() - t0) * 1e3)
             fk20["DAUsingFK20_single_call_ms"] = float(np.median(ts))      # median of 5 calls, like the `latency` block
+            # the reference's API is one polynomial per call (fk20_single.go:176-196): 64 host threads calling it concurrently are merged
+            # into batched launches by the library (Python threads here: ctypes releases the GIL for the ~50 ms a call blocks)
+            import threading
+            TT, per = 64, 6
+            gate = threading.Barrier(TT + 1)
+            def fk_worker(i):
+                gate.wait()
+                for r in range(per):
+                    fk.da_using_fk20(polys_h[(i + r) % len(polys_h)])
+            for _ in range(4):
+                fk.da_using_fk20(polys_h[0])                               # the staging buffers of the coalescer exist (pinned on first use)
+            ths = [threading.Thread(target=fk_worker, args=(i,)) for i in range(TT)]
+            [t.start() for t in ths]
+            gate.wait()
+            t0 = time.perf_counter()
+            [t.join() for t in ths]
+            fk20["DAUsingFK20_from_64_threads_per_s"] = TT * per / (time.perf_counter() - t0)
         # roofline of the FK20 half: HIP events around every launch of the dominant kernel (k_g1_fft_stage, 24 launches per step:
         # 12 radix-2 stages x 2 transforms), separate un-timed pass
         lib.kzg_hip_prof_reset(fs.h, 1)

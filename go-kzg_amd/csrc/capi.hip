@@ -768,7 +768,7 @@ static bool coalescing_enabled() {
 // rows per staging buffer: as many as fit 32 MiB of pinned memory per direction, within [4, 256]
 static uint64_t coalesce_rows(size_t in_row, size_t out_row) {
     size_t row = in_row > out_row ? in_row : out_row;
-    uint64_t r = (32u << 20) / (row ? row : 1);
+    uint64_t r = (64u << 20) / (row ? row : 1);          // 64 MiB of pinned rows per staging buffer: 113 rows of 4096 proofs (a 56-row cap split 64 callers 56 + 8)
     return r < 4 ? 4 : (r > 256 ? 256 : r);
 }
 static coalescer *get_coalescer(kzg_hip_fft *fs, std::unique_ptr<coalescer> &slot, size_t in_row, size_t out_row) {

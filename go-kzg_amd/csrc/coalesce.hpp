@@ -159,7 +159,11 @@ class coalescer {
                 if (window_us_ > 0 && b.rows.size() < target) {
                     gathering_ = bi; b.target = target;
                     const auto g0 = std::chrono::steady_clock::now();
-                    const auto deadline = g0 + std::chrono::microseconds(window_us_);
+                    // the window grows with the work it precedes: 5 % of the recent execution time of a batch (a 36 ms FK20 batch can
+                    // afford 1.8 ms for callers that need a millisecond to come back -- 32 Python threads re-entered over ~2 ms and ran
+                    // as two alternating half batches, 75 ms per round instead of 40), never less than `window_us_`
+                    const long grown = (long)(exec_ema_s_ * 0.05 * 1e6);
+                    const auto deadline = g0 + std::chrono::microseconds(grown > window_us_ ? grown : window_us_);
                     while (b.rows.size() < target)
                         if (cv_leader_.wait_until(lk, deadline) == std::cv_status::timeout) break;
                     gathering_ = -1;
@@ -184,6 +188,7 @@ class coalescer {
                 const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                 lk.lock();
                 batches_++; requests_ += batch; exec_s_ += dt;
+                exec_ema_s_ = exec_ema_s_ == 0 ? dt : 0.75 * exec_ema_s_ + 0.25 * dt;
                 b.status = st;
                 b.state.store(coalesce_buf::DRAINING, std::memory_order_release);
                 b.bump_all();
@@ -234,6 +239,7 @@ class coalescer {
     long window_us_ = 150;       // upper bound of that wait (KZG_HIP_COALESCE_US; 0 disables)
     uint64_t batches_ = 0, requests_ = 0;   // statistics (KZG_HIP_COALESCE_STATS=1 prints them when the handle is freed)
     double exec_s_ = 0, gather_s_ = 0, ready_s_ = 0;
+    double exec_ema_s_ = 0;      // recent execution time of a batch (the gather window scales with it)
     int device_;
     size_t in_row_, out_row_;
     uint64_t max_batch_;

@@ -6,7 +6,11 @@
 
 namespace kzg {
 
-#define G1_BLOCK 128
+// 256 lanes = one wavefront per SIMD of a CU.  With 128-lane workgroups a half-full launch (32 polynomials: 512 workgroups) ran as if
+// it were full -- the two wavefronts of consecutive workgroups of a CU landed on the same two SIMDs: 60 ms instead of 37.6 ms per FK20 batch.
+#ifndef G1_BLOCK
+#define G1_BLOCK 256
+#endif
 
 __device__ __forceinline__ uint32_t bitrev32g(uint32_t v, uint32_t bits) { return bits ? (__brev(v) >> (32 - bits)) : 0; }
 
@@ -317,7 +321,9 @@ void launch_g1_fft_direct(hipStream_t s, const g1j *in, uint64_t in_stride, uint
         const uint64_t total = batch * n << logR;
         // 24 KiB of unused dynamic LDS on top of the 10 KiB the kernel needs: at most 4 of these one-wave workgroups fit a CU, so the
         // 1024 of a 4096-point pass land one per SIMD instead of 8 per CU on half of the chip (measured: 2.7 vs 5.4 ms per pass)
-        hipLaunchKernelGGL(k_g1_fft_direct, dim3((uint32_t)((total + G1_DIRECT_BLOCK - 1) / G1_DIRECT_BLOCK)), dim3(G1_DIRECT_BLOCK), 24 * 1024, s, src, src_stride, src_valid, dst, logn, logR, Ns,
+        // (only while the pass has at most one wavefront per SIMD: two transforms are 2048 workgroups and want both wave slots)
+        const uint64_t wgs = (total + G1_DIRECT_BLOCK - 1) / G1_DIRECT_BLOCK;
+        hipLaunchKernelGGL(k_g1_fft_direct, dim3((uint32_t)wgs), dim3(G1_DIRECT_BLOCK), wgs <= 1024 ? 24 * 1024 : 0, s, src, src_stride, src_valid, dst, logn, logR, Ns,
                            roots, W, (p + 1 == npass) ? scale : nullptr, total);
         src = dst; src_stride = n; src_valid = n; Ns <<= logR; bits_left -= logR;
     }
