@@ -284,18 +284,26 @@ int kzg_hip_fft_fr_batch(kzg_hip_fft *fs, const void *vals_fr, uint64_t n, uint6
 // scale: nullptr, or a device Fr every output is multiplied by (the n^-1 of the inverse transform, fft_g1.go:72-85); FK20 callers
 // fold their scale into the Toeplitz coefficients instead.  Few butterflies (a lone transform) take the direct radix-16 passes,
 // whose latency is log16(n) scalar multiplications; batches take the radix-2 network, which does 7.5 times less work.
-static bool g1_fft_direct_mode(uint64_t n, uint64_t batch) {
+// Radix of the direct passes for `batch` transforms of n points, as log2: 16 while 16 n batch lanes fit the resident wavefronts twice
+// over (n batch <= 8192: one or two 4096-point transforms, 3 passes), 8 up to n batch = 16384 (3-4 transforms: 4 passes of 131 072 lanes:
+// 12 ms per transform against 19 ms for the 12 launches of the radix-2 network, which are one scalar-multiplication latency each);
+// 0 = the radix-2 network (larger batches fill the chip per stage).  KZG_HIP_G1_FFT = "direct" / "radix2" forces a path (A/B runs).
+static uint32_t g1_fft_direct_logr(uint64_t n, uint64_t batch) {
     static int forced = -1;
-    if (forced < 0) { const char *e = getenv("KZG_HIP_G1_FFT"); forced = !e ? 0 : (e[0] == 'd' ? 1 : 2); }   // "direct" / "radix2" force a path (A/B runs)
-    if (forced) return forced == 1;
-    return n >= 2 && n * batch <= 8192;
+    if (forced < 0) { const char *e = getenv("KZG_HIP_G1_FFT"); forced = !e ? 0 : (e[0] == 'd' ? 1 : 2); }
+    if (forced) return forced == 1 ? 4u : 0u;
+    if (n < 2) return 0;
+    if (n * batch <= 8192) return 4;
+    if (n * batch <= 16384) return 3;
+    return 0;
 }
+static bool g1_fft_direct_mode(uint64_t n, uint64_t batch) { return g1_fft_direct_logr(n, batch) != 0; }
 static int g1_fft_rows(kzg_hip_fft *fs, hipStream_t s, const g1j *d_in, uint64_t in_stride, uint64_t n_valid, g1j *d_data, uint64_t n, uint64_t batch, int inv,
                        const fr *scale = nullptr) {
     if (g1_fft_direct_mode(n, batch)) {
         dtmp<g1j> d_tmp(s);
         CHK(d_tmp.alloc(n * batch));
-        launch_g1_fft_direct(s, d_in, in_stride, n_valid, d_data, d_tmp.p, n, batch, inv ? fs->d_reversed : fs->d_expanded, fs->W, scale);
+        launch_g1_fft_direct(s, d_in, in_stride, n_valid, d_data, d_tmp.p, n, batch, inv ? fs->d_reversed : fs->d_expanded, fs->W, scale, g1_fft_direct_logr(n, batch));
         return KZG_HIP_OK;
     }
     launch_g1_bitrev_copy(s, d_in, in_stride, n_valid, d_data, n, batch);

@@ -307,16 +307,17 @@ __global__ __launch_bounds__(G1_DIRECT_BLOCK, 2) void k_g1_fft_direct(const g1j 
 // runs the passes; the result lands in `data` (batch x n).  tmp: batch x n scratch points.  scale: nullptr or a device Fr that
 // multiplies every output (folded into the last pass).
 void launch_g1_fft_direct(hipStream_t s, const g1j *in, uint64_t in_stride, uint64_t n_valid, g1j *data, g1j *tmp, uint64_t n, uint64_t batch, const fr *roots,
-                          uint64_t W, const fr *scale) {
+                          uint64_t W, const fr *scale, uint32_t max_logr) {
     const uint32_t logn = ilog2g(n);
-    uint32_t npass = (logn + 3) / 4;
+    if (max_logr < 1 || max_logr > 4) max_logr = 4;
+    uint32_t npass = (logn + max_logr - 1) / max_logr;
     if (!npass) { launch_g1_bitrev_copy(s, in, in_stride, n_valid, data, n, batch); return; }   // n == 1: copy (a 0-bit reversal)
     // pass p writes data when the number of passes after it is even
     const g1j *src = in; uint64_t src_stride = in_stride, src_valid = n_valid, Ns = 1;
     uint32_t bits_left = logn;
     prof_begin(s, "g1_fft_direct");
     for (uint32_t p = 0; p < npass; p++) {
-        const uint32_t logR = bits_left >= 4 ? 4u : bits_left;
+        const uint32_t logR = bits_left >= max_logr ? max_logr : bits_left;
         g1j *dst = ((npass - 1 - p) & 1u) ? tmp : data;
         const uint64_t total = batch * n << logR;
         // 24 KiB of unused dynamic LDS on top of the 10 KiB the kernel needs: at most 4 of these one-wave workgroups fit a CU, so the

@@ -702,11 +702,16 @@ def test_eth_blob_to_kzg_commitment_and_compute_kzg_proof(kz):
 # ------------------------------------------------------------------ host-buffer batch APIs, concurrency, C-level misuse
 def test_da_using_fk20_batch_host_buffers(kz, ks4096):
     fk = kz.FK20SingleSettings(ks4096, 4096)
-    polys = np.stack([ko.synthetic_blob(40 + b)[:2048] for b in range(3)])
-    got = fk.da_using_fk20_batch(polys)
+    polys = np.stack([ko.synthetic_blob(40 + b)[:2048] for b in range(6)])
+    got = fk.da_using_fk20_batch(polys[:3])                  # 3 and 4 transforms: direct passes of radix 8; 1-2: radix 16; 5+: radix-2 network
     assert got.shape == (3, 4096, 3, 6)
-    for b in (0, 2):
-        assert np.array_equal(got[b], fk.da_using_fk20(polys[b]))
+    singles = [fk.da_using_fk20(polys[b]) for b in range(6)]
+    for b in range(3):
+        assert np.array_equal(got[b], singles[b])
+    for nb in (2, 4, 6):
+        gotb = fk.da_using_fk20_batch(polys[:nb])
+        for b in range(nb):
+            assert np.array_equal(gotb[b], singles[b]), (nb, b)
     fk.close()
 
 
