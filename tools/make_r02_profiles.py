@@ -49,10 +49,12 @@ def model(mads, insts):
 
 doc = f"""# r02 — kernel statistics and counters at the end of round 2 (1x MI355X)
 
-State: round-1 kernels + lazy XYZZ reduction trees and a wave-cooperative finish in the table walk, GLV bucket MSM with scan reduce and
-wave-cooperative Horner for caller-supplied points, direct radix-16 passes for lone G1 transforms, request coalescing of one-polynomial
-calls; G1 FFT stages with an affine width-5 NAF table (one inversion per multiplication, mixed additions) and precomputed digit rows;
-FK20: Toeplitz stage fused with the first two decimation-in-frequency stages of the inverse transform ({L} stage launches per step).
+State: round-1 kernels + table walk in 256-lane workgroups with a wave-cooperative block tree and finish (windows of a point divided
+among up to 8 lanes below 32 polynomials), GLV bucket MSM with scan reduce and wave-cooperative Horner for caller-supplied points,
+direct radix-16 / radix-8 passes for 1-4 G1 transforms, request coalescing of one-polynomial calls; G1 FFT stages (256-lane workgroups)
+with an affine width-5 NAF table built by co-Z arithmetic (one inversion per multiplication, mixed additions) and precomputed digit
+rows, the regular odd-digit schedule on the same table where wavefronts straddle twiddles; FK20: Toeplitz stage fused with the first
+two decimation-in-frequency stages of the inverse transform ({L} stage launches per step).
 
 Commands (GPU box): `bash tools/profile_round2.sh r02` =
 `cd /tmp && rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras` (summary by
