@@ -343,6 +343,9 @@ void launch_msm(hipStream_t s, const msm_plan &p, const g1a *table, const fr *sc
 // n = 4096, c = 11: 24 x 4096 x 1024 x 96 B = 9.7 GB, 98 304 mixed adds per commitment.
 // ---------------------------------------------------------------------------------------------------------
 #define FB_BLOCK 128
+#ifndef FB_FINISH_LANES_MAX
+#define FB_FINISH_LANES_MAX 4          // partial sums per blob up to which one lane per blob finishes (A/B builds: 0 = always the cooperative kernel)
+#endif
 #ifndef FB_ACC_WAVES
 #define FB_ACC_WAVES 2
 #endif
@@ -529,11 +532,39 @@ __global__ __launch_bounds__(256) void k_fb_finish(const fb_partial *partials, u
         if (acc.inf) r = g1_inf();
         else {   // x = X / ZZ, y = Y / ZZZ with ONE inversion: i = 1 / (ZZ ZZZ), 1 / ZZ = i ZZZ, 1 / ZZZ = i ZZ
             g1x px = g1xq_pack(acc.v);
+#ifdef KZG_FINISH_NOINV                                      // timing experiment only (wrong results): what the inversion costs
+            fp i = mul(px.zz, px.zzz);
+#else
             fp i = inv<FpP>(mul(px.zz, px.zzz));
+#endif
             r.x = mul(px.x, mul(i, px.zzz)); r.y = mul(px.y, mul(i, px.zz)); r.z = one<FpP>();
         }
         out[b] = to_kilic ? g1_to_kilic(r) : r;
     }
+}
+
+// The same for LARGE batches (at most 4 partial sums per blob: 128 blobs and more): one LANE per blob adds its few partials and
+// normalises.  The cooperative kernel above spends a 256-thread workgroup -- and with it a quarter of a CU's registers -- on every blob
+// although there is nothing left to reduce, so 512 blobs ran as two rounds of 110 us inversions; 512 lanes are 8 wavefronts and one
+// round (measured per 512-blob step: 6.02 -> 5.7x ms).
+__global__ __launch_bounds__(64) void k_fb_finish_lanes(const fb_partial *partials, uint32_t blocks_per_blob, uint64_t batch, g1j *out, int to_kilic) {
+    const uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    g1x_acc acc; acc.init();
+#pragma nounroll
+    for (uint32_t j = 0; j < blocks_per_blob; j++) {
+        const fb_partial &pj = partials[b * blocks_per_blob + j];
+        g1xq w; fb_partial_load(pj, w);
+        g1x_acc_merge(acc, w, pj.inf != 0);
+    }
+    g1j r;
+    if (acc.inf) r = g1_inf();
+    else {
+        g1x px = g1xq_pack(acc.v);
+        fp i = inv<FpP>(mul(px.zz, px.zzz));
+        r.x = mul(px.x, mul(i, px.zzz)); r.y = mul(px.y, mul(i, px.zz)); r.z = one<FpP>();
+    }
+    out[b] = to_kilic ? g1_to_kilic(r) : r;
 }
 
 // element-wise fixed-base products over the same table layout: out[b][i] = scalars[b][i] * P_i  (the FK20 Toeplitz stage,
@@ -722,7 +753,8 @@ void launch_fb_msm(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c
     else hipLaunchKernelGGL(k_fb_accumulate<false>, dim3((uint32_t)(batch * bpb)), dim3(FB_ACC_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars, sc_stride, n, bpb,
                             1u, (fb_partial *)partials);
     prof_end(s, "fb_accumulate");
-    hipLaunchKernelGGL(k_fb_finish, dim3((uint32_t)batch), dim3(256), 0, s, (const fb_partial *)partials, bpb, batch, out, to_kilic ? 1 : 0);
+    if (bpb <= FB_FINISH_LANES_MAX) hipLaunchKernelGGL(k_fb_finish_lanes, dim3((uint32_t)((batch + 63) / 64)), dim3(64), 0, s, (const fb_partial *)partials, bpb, batch, out, to_kilic ? 1 : 0);
+    else hipLaunchKernelGGL(k_fb_finish, dim3((uint32_t)batch), dim3(256), 0, s, (const fb_partial *)partials, bpb, batch, out, to_kilic ? 1 : 0);
 }
 // builds the table for `n` affine points: rows (2^(c w) P_i) first, then all multiples window-slab by window-slab
 hipError_t launch_fb_build(hipStream_t s, const g1a *pts, uint64_t n, uint32_t c, uint32_t nwin, g1a *table) {
