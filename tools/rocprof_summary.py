@@ -17,10 +17,12 @@ def main():
     lines = ["| kernel | calls | total ms | avg us | min us | max us | % | wg | grid | scratch B/lane | LDS B |", "|---|---|---|---|---|---|---|---|---|---|---|"]
     for name, n, t, a, mn, mx, wg, grid, scr, lds in rows:
         short = name.split("(")[0].replace("kzg::", "")
-        m = re.match(r"_ZN3kzg\d+([A-Za-z0-9_]*?)(I(?:L[ib]\d+E)+E)?E[A-Zv]", short)   # rocprofv3 7.x stores mangled names
+        m = re.match(r"_ZN3kzg(\d+)", short)              # rocprofv3 7.x stores mangled names: <length><name>[I<template args>E]E<parameters>
         if m:
-            targs = re.findall(r"L[ib](\d+)E", m.group(2) or "")
-            short = m.group(1) + ("<" + ", ".join(targs) + ">" if targs else "")
+            n0 = m.end(); base = short[n0:n0 + int(m.group(1))]; rest = short[n0 + int(m.group(1)):]
+            tm = re.match(r"I((?:L[ib]\d+E)+)E", rest)
+            targs = re.findall(r"L[ib](\d+)E", tm.group(1)) if tm else []
+            short = base + ("<" + ", ".join(targs) + ">" if targs else "")
         lines.append("| %s | %d | %.3f | %.1f | %.1f | %.1f | %.1f | %d | %d | %d | %d |" % (short, n, t / 1e6, a / 1e3, mn / 1e3, mx / 1e3, 100.0 * t / tot, wg, grid, scr, lds))
     out = "\n".join(lines) + "\n"
     if len(sys.argv) > 2:

@@ -13,8 +13,8 @@ c = sqlite3.connect(sys.argv[1]).cursor()
 rows = c.execute("select s.kernel_name, d.start, d.end, d.grid_size_x from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id order by d.start").fetchall()
 import re
 def short(n):
-    m = re.match(r"_ZN3kzg\d+([A-Za-z0-9_]*?)E[A-Z]", n)
-    return m.group(1) if m else n.split("(")[0].replace("kzg::", "")
+    m = re.match(r"_ZN3kzg(\d+)", n)
+    return n[m.end():m.end() + int(m.group(1))] + ("<split>" if "ILb1E" in n else "") if m else n.split("(")[0].replace("kzg::", "")
 rows = [(short(n), s, e, g) for n, s, e, g in rows]
 # the timed region: the last 60 % of the walk launches
 walks = [r for r in rows if r[0].startswith("k_fb_accumulate")]
