@@ -184,7 +184,8 @@ class coalescer {
                 for (uint64_t i = 0; i < batch; i++) b.h_meta[i] = b.rows[i];
                 lk.unlock();
                 const auto t0 = std::chrono::steady_clock::now();
-                int st = exec(b, batch);
+                int st;
+                try { st = exec(b, batch); } catch (...) { st = alloc_error_status; }   // (std::bad_alloc in the executor must not strand the sleepers)
                 const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                 lk.lock();
                 batches_++; requests_ += batch; exec_s_ += dt;
