@@ -364,7 +364,7 @@ def main():
                                      "note": "mads / measured mad rate + other VALU / measured add rate; the rest is dependency / memory stalls at 2 waves per SIMD"}
 
     table_sweep = drop_in = lincomb = latency = None
-    if not args.no_extras and not args.no_fk20:
+    if not args.no_extras and not args.no_fk20 and world == 1:   # single-GPU characterisations: not repeated by every rank of an N > 1 run
         # --- commitments/s against the HBM budget of the fixed-base table (library default: 64 GB -> c = 14; the headline opts into 210)
         table_sweep = {}
         for gb in (10.0, 33.0, 64.0):
@@ -457,7 +457,7 @@ def main():
         fk20 = {"metric": "FK20 all-proofs/s (DAUsingFK20, 2048 coeffs -> 4096 proofs, scale 12)",
                 "value": FB * world * fsteps / fsecs, "batch_per_gpu": FB,
                 "ms_per_all_proofs": fsecs / fsteps / FB * 1e3, "self_check_byte_pin": fk_ok}
-        if not args.no_extras:
+        if not args.no_extras and world == 1:
             for _ in range(3):
                 fk.da_using_fk20(polys_h[0])
             ts = []
