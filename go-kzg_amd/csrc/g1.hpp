@@ -640,7 +640,8 @@ KZG_HD bool g1jq_add_slow_copy(g1jq &acc, const g1jq_t *t, bool ng, bool phi) {
 // ---- affine table variant (round 2): the 8 odd multiples are normalised with ONE inversion per scalar multiplication (Montgomery's
 // trick inside the lane), so that the ~43 additions of the loop are MIXED additions (3S + 6M + one two-product reduction = 3315
 // multiply-adds instead of 4329) and a table entry is 104 bytes of scratch instead of 260.
-struct g1aq { fq x, y; };                                   // affine point on lazy limbs, bounds (2, 2)
+struct g1aq { fq x, y, bx; };                               // affine point on lazy limbs, bounds (2, 2); bx = beta x: the x of phi(P), kept beside
+                                                            // x so that the ~half of the additions that take the phi image skip a product
 // acc += (+-) (phi?) *t : madd-2004-hmv on lazy limbs.  acc bounds (19, 20, 4) in, (11, 2, 2) out:
 //   Z1Z1 = Z1^2 : 2 (16);  U2 = X2 Z1Z1 : 2;  S2 = (Y2 Z1) Z1Z1 : 2 (8, 4);  H = U2 - X1 (M = 20) : 22;  R = +-S2 - Y1 (M = 21) : 23 resp. 24
 //   HH = H^2 : 2 (484 <= 600);  HHH = H HH, V = X1 HH : 2 (44, 38);  X3 = R^2 - HHH - 2 V : 2 + 3 + 3 + 3 = 11  (R^2: 576 <= 600)
@@ -653,7 +654,7 @@ template <bool INL = false> KZG_HD bool g1jq_madd_entry(g1jq &acc, const g1aq *t
 #pragma unroll
     for (int i = 0; i < 13; i++) zero_q.l[i] = 0;
     fq z1z1 = SQ(acc.z);
-    fq u2 = phi ? MQ(MQ(t->x, unpackq(glv_beta())), z1z1) : MQ(t->x, z1z1);
+    fq u2 = MQ(phi ? t->bx : t->x, z1z1);
     fq h = subq<20>(u2, acc.x);
     fq hh = SQ(h);
     if (is_zero_mod_p_q(hh)) return false;
@@ -669,7 +670,7 @@ template <bool INL = false> KZG_HD bool g1jq_madd_entry(g1jq &acc, const g1aq *t
     return true;
 }
 KZG_HD g1jq g1aq_entry_point(const g1aq *t, bool ng, bool phi) {
-    g1jq q; q.x = phi ? mulq(t->x, unpackq(glv_beta())) : t->x; q.z = unpackq(one<FpP>());
+    g1jq q; q.x = phi ? t->bx : t->x; q.z = unpackq(one<FpP>());
     if (ng) { fq zero_q;
 #pragma unroll
         for (int i = 0; i < 13; i++) zero_q.l[i] = 0;
@@ -704,6 +705,7 @@ KZG_HD void g1_wnaf_table_affine_q(const g1jq &p0, g1aq *tbl, g1jq *jt) {   // p
         fq zi2 = sqrq(zi);
         tbl[i].x = mulq(jt[i].x, zi2);
         tbl[i].y = mulq(jt[i].y, mulq(zi2, zi));
+        tbl[i].bx = mulq(tbl[i].x, unpackq(glv_beta()));
     }
 }
 // The same table by co-Z arithmetic (Meloni; Longa-Miri's precomputation scheme): after the initial doubling, P rescaled to the Z of 2P
@@ -755,11 +757,13 @@ template <bool INL = false> KZG_HD bool g1_wnaf_table_affine_coz(const g1jq &p0,
     }
     if (!ok) return false;
     fq zi = unpackq(inv<FpP>(packq(z)));                       // 1 / Z_8
+    const fq beta_q = unpackq(glv_beta());
 #pragma nounroll
     for (int i = 7; i >= 0; i--) {
         fq zi2 = sqrq(zi);
         tbl[i].x = mulq(tbl[i].x, zi2);
         tbl[i].y = mulq(tbl[i].y, mulq(zi2, zi));
+        tbl[i].bx = mulq(tbl[i].x, beta_q);
         if (i) zi = mulq(zi, dz[i - 1]);                       // 1 / Z_i = (1 / Z_{i+1}) d_i
     }
     return true;

@@ -126,7 +126,7 @@ int he_wnaf_table(g1j *out8, const g1j *a, int coz) {
 int he_g1jq_madd_entry(g1j *o, const g1j *a, const g1j *b, int negate, int phi, int inl) {
     g1jq acc = g1jq_unpack(IN(a));
     g1j bn = g1_normalize(IN(b));
-    g1aq t; t.x = unpackq(bn.x); t.y = unpackq(bn.y);
+    g1aq t; t.x = unpackq(bn.x); t.y = unpackq(bn.y); t.bx = mulq(t.x, unpackq(glv_beta()));
     bool ok = inl ? g1jq_madd_entry<true>(acc, &t, negate != 0, phi != 0) : g1jq_madd_entry<false>(acc, &t, negate != 0, phi != 0);
     if (ok) { *o = OUT(g1jq_pack(acc)); return 1; }
     bool inf = g1jq_add_slow_copy_a(acc, &t, negate != 0, phi != 0);
