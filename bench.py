@@ -497,11 +497,11 @@ def main():
             kern_s = tot2.value * 1e-3                          # all stage launches of one step (FB polynomials)
             alg = FB * FK20_BYTES                               # 851 968 B per DAUsingFK20 (poly + xExtFFT + proofs)
             # multiply-adds of the stage kernel per polynomial: 2 transforms x 20 481 twiddle multiplications (width-5 NAF GLV with
-            # an affine 8-entry table: ~126 doublings x 1963 + ~42.7 mixed additions x ~3484 (3315, + 338 for phi on half of them) + 30.4k for
-            # the co-Z table (70M + 26S) incl. its normalisation; the binary-GCD inversion has no multiplies) + 24 576 shared (x + wy, x - wy) x 7384
+            # an affine 8-entry table: ~126 doublings x 1963 + ~42.7 mixed additions x 3315 + 33.1k for the co-Z table (78M + 26S incl. its
+            # normalisation and the beta x of every entry; the binary-GCD inversion has no multiplies) + 24 576 shared (x + wy, x - wy) x 7384
             # Fused pipeline (22 stage launches per step): the first two stages of the inverse transform are inside the fixed-base Toeplitz
             # stage, 2047 + 2046 twiddle multiplications and 4096 butterflies fewer.
-            per_mul = 126 * 1963 + 42.7 * 3484 + 30400
+            per_mul = 126 * 1963 + 42.7 * 3315 + 33100
             fused = int(cnt2.value) == 22
             mads_unit = ((2 * 20481 - 4093) * per_mul + (2 * 24576 - 4096) * 7384) if fused else (2 * 20481 * per_mul + 2 * 24576 * 7384)
             pf = pmc.get("k_g1_fft_stage", {})
