@@ -449,6 +449,30 @@ def test_commit_batch_shapes_fuzz(kz, ks4096, setup_1337):
             assert ko.g1_equal(got[b], want), (batch, n, b)
 
 
+def test_commit_carry_chains_through_every_launch_shape(kz, ks4096, setup_1337):
+    """signed-window recoding carries from window to window; below 32 polynomials the windows of a point are divided among lanes and each
+    lane re-derives the carry into its first window from the lower digits (k_fb_accumulate<true>).  Scalars whose windows sit on the
+    carry boundary for every window width in use (all-ones, 0x8000.., 0x7fff.., 0x8001.., r - 1, powers of two and their neighbours)
+    must give the same commitment through the split walk (1, 2, 8, 16 polynomials), the plain walk (32, 130) and the oracle."""
+    R = ko.R_MOD
+    pats = [R - 1, R - 2, (1 << 255) % R, (1 << 254) - 1, 1, 2, 0]
+    for c in (11, 13, 14, 16):
+        half, full = 1 << (c - 1), (1 << c) - 1
+        for d in (half, half + 1, half - 1, full, full - 1, 1):
+            pats.append(sum(d << (c * w) for w in range(256 // c)) % R)
+        pats.append(sum((half if w % 2 else full) << (c * w) for w in range(256 // c)) % R)
+    pats += [(1 << k) % R for k in range(0, 255, 7)] + [((1 << k) - 1) % R for k in range(1, 255, 11)]
+    rng = np.random.default_rng(7)
+    ints = [pats[i % len(pats)] if i % 3 else int.from_bytes(rng.bytes(32), "little") % R for i in range(4096)]
+    blob = ko.fr_from_ints(ints)
+    want = ko.lincomb_g1(setup_1337, blob)
+    assert_points_equal(ks4096.commit_to_poly(blob), want)
+    for batch in (2, 8, 16, 32, 130):
+        got = ks4096.commit_to_poly_batch(np.stack([blob] * batch))
+        for b in (0, batch // 2, batch - 1):
+            assert_points_equal(got[b], want)
+
+
 def test_commit_linearity_full_size(kz, ks4096):
     # size-independent property at full size: commit(a) + commit(b) == commit(a + b)
     a, b = ko.synthetic_blob(101), ko.synthetic_blob(102)
