@@ -488,6 +488,26 @@ def test_proof_single_4096(kz, ks4096, setup_1337):
     assert ko.g1_equal(proof, ko.g1_mul(ko.g1_generator(), ko.fr_from_ints([d])[0]))
 
 
+def test_g1_mul_vec_edge_scalars(kz):
+    """element-wise k_i P_i (ToeplitzPart2's loop, fk20_single.go:72-74) runs the regular odd-digit GLV schedule with the scalar split on
+    the device: zero and even halves, small and full-width scalars, the point at infinity -- against the oracle's MulG1"""
+    fs = kz.FFTSettings(4)
+    R = ko.R_MOD
+    lam = 0xac45a4010001a40200000000ffffffff
+    ks_ = [0, 1, 2, 3, 15, 16, 17, 31, 32, R - 1, R - 2, lam, lam + 1, lam - 1, 2 * lam, (lam * lam) % R, 1 << 64, (1 << 64) - 1, 1 << 127, (1 << 128) - 1,
+           1 << 128, (1 << 255) % R, 0x5555555555555555555555555555555555555555555555555555555555555555 % R, 7 * lam + 2, (R - 1) // 2, (R + 1) // 2]
+    rng = np.random.default_rng(5)
+    ks_ += [int.from_bytes(rng.bytes(32), "little") % R for _ in range(38)]
+    base = ko.g1_mul(ko.g1_generator(), ko.fr_from_ints([987654321])[0])
+    pts = np.stack([base if i % 5 else ko.g1_mul(base, ko.fr_from_ints([i + 2])[0]) for i in range(len(ks_))])
+    pts[7] = ko.g1_zero()[0]
+    sc = ko.fr_from_ints(ks_)
+    got = fs.mul_g1_vec(pts, sc)
+    for i in range(len(ks_)):
+        assert_points_equal(got[i], ko.g1_mul(pts[i], sc[i]))
+    fs.close()
+
+
 # ------------------------------------------------------------------ G1 FFT (fft_g1.go)
 @pytest.mark.parametrize("n", [1, 2, 4, 8, 32])
 def test_fft_g1_small_matches_oracle(kz, n):
