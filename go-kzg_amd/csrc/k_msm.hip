@@ -342,7 +342,9 @@ void launch_msm(hipStream_t s, const msm_plan &p, const g1a *table, const fr *sc
 // sort, and exactly the same work on every lane (the bucket method's Poisson imbalance and reduce step vanish).
 // n = 4096, c = 11: 24 x 4096 x 1024 x 96 B = 9.7 GB, 98 304 mixed adds per commitment.
 // ---------------------------------------------------------------------------------------------------------
+#ifndef FB_BLOCK
 #define FB_BLOCK 128
+#endif
 #ifndef FB_FINISH_LANES_MAX
 #define FB_FINISH_LANES_MAX 4          // partial sums per blob up to which one lane per blob finishes (A/B builds: 0 = always the cooperative kernel)
 #endif
