@@ -10,6 +10,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+
+def _reap(procs, timeout):
+    """workers have already delivered their results through the queue: give them `timeout` seconds to leave on their own, then kill what is
+    left (a rank that lingers in device teardown must not outlive the test run: an orphan keeps the caller's stdout pipe open); a worker
+    that DID exit has to have exited cleanly"""
+    for p in procs:
+        p.join(timeout=timeout)
+        if p.is_alive():
+            p.kill()
+            p.join(timeout=30)
+        else:
+            assert p.exitcode == 0, p.exitcode
+
 def test_splitmix_blobs_match_oracle_generator():
     import bench
     from oracle import koracle as ko
@@ -77,9 +90,7 @@ def test_timed_steps_world_size_2_gloo():
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in range(2))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    _reap(procs, 60)
     assert [r[1] for r in res] == [7, 7]                  # W + K steps on every rank
     assert abs(res[0][2] - res[1][2]) < 1e-9             # both ranks report the same (max) time
     assert res[0][2] >= 5 * 0.02 * 0.9                    # ... which is the slow rank's
@@ -99,7 +110,16 @@ def test_bench_two_ranks_under_torch_distributed_run():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "64", "--fk20-batch", "8", "--fk20-multi-batch", "2",
            "--table-gb", "4", "--no-extras"]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    # own session: on a timeout the whole process group (launcher + both ranks) is killed, nothing is left holding the device or the pipes
+    import signal
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = proc.communicate(timeout=600)
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, signal.SIGKILL)
+        out, err = proc.communicate()
+        raise AssertionError("bench.py under torch.distributed.run did not finish in 600 s: " + err[-2000:])
+    res = subprocess.CompletedProcess(cmd, proc.returncode, out, err)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]                      # exactly one JSON line, from rank 0
