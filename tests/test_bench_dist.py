@@ -11,6 +11,15 @@ sys.path.insert(0, ROOT)
 
 
 
+
+def _free_port():
+    """a TCP port nobody listens on right now (the kernel picks it): fixed or pid-derived ports can collide with another job on the host and
+    turn the rendezvous into a 30-minute wait"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
 def _reap(procs, timeout):
     """workers have already delivered their results through the queue: give them `timeout` seconds to leave on their own, then kill what is
     left (a rank that lingers in device teardown must not outlive the test run: an orphan keeps the caller's stdout pipe open); a worker
@@ -58,7 +67,7 @@ def _worker(rank, world, port, q):
     import bench
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=180))
     calls = []
 
     def step():
@@ -85,7 +94,7 @@ def test_timed_steps_world_size_2_gloo():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -106,7 +115,7 @@ def test_bench_two_ranks_under_torch_distributed_run():
     import json
     import subprocess
     env = dict(os.environ, KZG_BENCH_BACKEND="gloo", KZG_HIP_FK20_FB_BUDGET_GB="3", MASTER_ADDR="127.0.0.1")
-    port = 36500 + os.getpid() % 2000
+    port = _free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "64", "--fk20-batch", "8", "--fk20-multi-batch", "2",
            "--table-gb", "4", "--no-extras"]

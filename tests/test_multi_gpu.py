@@ -47,6 +47,15 @@ class OracleBackend:
 
 
 
+
+def _free_port():
+    """a TCP port nobody listens on right now (the kernel picks it): fixed or pid-derived ports can collide with another job on the host and
+    turn the rendezvous into a 30-minute wait"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
 def _reap(procs, timeout):
     """workers have already delivered their results through the queue: give them `timeout` seconds to leave on their own, then kill what is
     left (a rank that lingers in device teardown must not outlive the test run: an orphan keeps the caller's stdout pipe open); a worker
@@ -67,7 +76,7 @@ def _worker(rank, world, port, q):
     from oracle import koracle as ko
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=180))
     n2, l = 128, 4
     be = OracleBackend(n2, l)
     poly = ko.synthetic_blob(77, n2 // 2)
@@ -85,7 +94,7 @@ def test_sharded_fk20_multi_world2_gloo():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -132,7 +141,7 @@ def _gpu_worker(rank, world, port, q):
     os.environ["KZG_HIP_FB_BUDGET_GB"] = "1"
     os.environ["KZG_HIP_FK20_FB_BUDGET_GB"] = "1"
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)   # both ranks share the one GPU: RCCL refuses that, gloo moves the bytes
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=180))   # both ranks share the one GPU: RCCL refuses that, gloo moves the bytes
     n2, l = 1024, 16
     fs = kz.FFTSettings(10)
     ks = kz.KZGSettings(fs, ko.generate_testing_setup_g1(S_TEST, n2))
@@ -159,7 +168,7 @@ def test_sharded_fk20_multi_hip_backend_two_ranks_one_gpu():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -181,7 +190,7 @@ def _gpu_worker_scale16(rank, world, port, q):
     os.environ["KZG_HIP_FB_BUDGET_GB"] = "1"
     os.environ["KZG_HIP_FK20_FB_BUDGET_GB"] = "8"
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=180))
     n2, l = 65536, 16
     fs = kz.FFTSettings(16)
     ks = kz.KZGSettings(fs, fs.generate_testing_setup_g1(ko.fr_from_ints([S_TEST]), n2))
@@ -206,7 +215,7 @@ def test_sharded_fk20_multi_scale16_two_ranks_one_gpu_byte_pin():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 35500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_gpu_worker_scale16, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
