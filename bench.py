@@ -363,271 +363,283 @@ def main():
                                      "issue_model_ms": model_s * 1e3, "frac_of_launch_explained": model_s / avg_s,
                                      "note": "mads / measured mad rate + other VALU / measured add rate; the rest is dependency / memory stalls at 2 waves per SIMD"}
 
-    table_sweep = drop_in = lincomb = latency = None
-    if not args.no_extras and not args.no_fk20 and world == 1:   # single-GPU characterisations: not repeated by every rank of an N > 1 run
-        # --- commitments/s against the HBM budget of the fixed-base table (library default: 64 GB -> c = 14; the headline opts into 210)
-        table_sweep = {}
-        for gb in (10.0, 33.0, 64.0):
-            ks.set_table_budget_gb(gb)
+    # Everything below is secondary to the headline measured above.  On one GPU a failure in a secondary leg is recorded in
+    # `secondary_error` and the line is still printed; with several ranks it is raised (a rank that skipped ahead would leave the others
+    # in a barrier).
+    table_sweep = drop_in = lincomb = latency = fk20 = roofline_fk20 = fk20m = ref_benches = None
+    secondary_error = None
+    try:
+        if os.environ.get("KZG_BENCH_FAIL_SECONDARY"):           # test hook (tests/test_bench_dist.py)
+            raise RuntimeError("KZG_BENCH_FAIL_SECONDARY is set")
+        if not args.no_extras and not args.no_fk20 and world == 1:   # single-GPU characterisations: not repeated by every rank of an N > 1 run
+            # --- commitments/s against the HBM budget of the fixed-base table (library default: 64 GB -> c = 14; the headline opts into 210)
+            table_sweep = {}
+            for gb in (10.0, 33.0, 64.0):
+                ks.set_table_budget_gb(gb)
+                step()
+                torch.cuda.synchronize()
+                tsecs = timed_steps(step, 5, 1, torch.cuda.synchronize, barrier, max_over_ranks)
+                c_, w_, b_ = ks.table_info()
+                table_sweep["%g" % gb] = {"commitments_per_s": B * world * 5 / tsecs, "window_bits": c_, "windows": w_, "table_GB": b_ / 1e9}
+            ks.set_table_budget_gb(args.table_gb)
             step()
             torch.cuda.synchronize()
-            tsecs = timed_steps(step, 5, 1, torch.cuda.synchronize, barrier, max_over_ranks)
             c_, w_, b_ = ks.table_info()
-            table_sweep["%g" % gb] = {"commitments_per_s": B * world * 5 / tsecs, "window_bits": c_, "windows": w_, "table_GB": b_ / 1e9}
-        ks.set_table_budget_gb(args.table_gb)
-        step()
-        torch.cuda.synchronize()
-        c_, w_, b_ = ks.table_info()
-        table_sweep["%g" % args.table_gb] = {"commitments_per_s": value, "window_bits": c_, "windows": w_, "table_GB": b_ / 1e9, "headline": True}
+            table_sweep["%g" % args.table_gb] = {"commitments_per_s": value, "window_bits": c_, "windows": w_, "table_GB": b_ / 1e9, "headline": True}
 
-        # --- the reference's API is ONE blob per call: T native host threads, each calling kzg_hip_commit_to_poly on host buffers
-        host_blobs = blobs_h[:64].copy()
-        drop_in = {"entry": "kzg_hip_commit_to_poly (host buffers, blocking, one 4096-coefficient blob per call)", "threads": {}}
-        ks.bench_drop_in(host_blobs, 8, 4)
-        for T in (1, 8, 64, 256):
-            rate_, outs = ks.bench_drop_in(host_blobs, T, 200 if T == 1 else 60)
-            drop_in["threads"][str(T)] = {"commitments_per_s": rate_, "frac_of_device_resident_batch": rate_ / (value / world)}
-        want0 = d_out[(T - 1 + 59) % 64].cpu().numpy().view(np.uint64).reshape(3, 6)      # thread T-1's last call used blob (T-1 + 59) % 64
-        drop_in["bit_exact_vs_batched_path"] = bool(np.array_equal(outs[T - 1], want0))
-        prate_, _ = ks.bench_drop_in(host_blobs, 64, 40, op=1)
-        drop_in["compute_proof_single_64_threads_per_s"] = prate_
+            # --- the reference's API is ONE blob per call: T native host threads, each calling kzg_hip_commit_to_poly on host buffers
+            host_blobs = blobs_h[:64].copy()
+            drop_in = {"entry": "kzg_hip_commit_to_poly (host buffers, blocking, one 4096-coefficient blob per call)", "threads": {}}
+            ks.bench_drop_in(host_blobs, 8, 4)
+            for T in (1, 8, 64, 256):
+                rate_, outs = ks.bench_drop_in(host_blobs, T, 200 if T == 1 else 60)
+                drop_in["threads"][str(T)] = {"commitments_per_s": rate_, "frac_of_device_resident_batch": rate_ / (value / world)}
+            want0 = d_out[(T - 1 + 59) % 64].cpu().numpy().view(np.uint64).reshape(3, 6)      # thread T-1's last call used blob (T-1 + 59) % 64
+            drop_in["bit_exact_vs_batched_path"] = bool(np.array_equal(outs[T - 1], want0))
+            prate_, _ = ks.bench_drop_in(host_blobs, 64, 40, op=1)
+            drop_in["compute_proof_single_64_threads_per_s"] = prate_
 
-        # --- variable-base bls.LinCombG1 on a cached point set (the seam eth/helpers.go:99,159,199 and CommitToEvalPoly go through)
-        pts = kz.G1Points(fs, setup)
-        d_lc_out = torch.zeros((512, 18), dtype=torch.int64, device="cuda")
-        lincomb = {"kernel_chain": "k_msm_sort / accumulate / reduce / combine (GLV halves, signed 8-bit windows, 2^64 rows cached)", "n": N_COEFF, "batch": {}}
-        for bs in (1, 64, 512):
-            def lc_step(bs=bs):
-                st = lib.kzg_hip_lincomb_points_batch_dev(pts.h, d_blobs.data_ptr(), N_COEFF, bs, d_lc_out.data_ptr(), stream)
+            # --- variable-base bls.LinCombG1 on a cached point set (the seam eth/helpers.go:99,159,199 and CommitToEvalPoly go through)
+            pts = kz.G1Points(fs, setup)
+            d_lc_out = torch.zeros((512, 18), dtype=torch.int64, device="cuda")
+            lincomb = {"kernel_chain": "k_msm_sort / accumulate / reduce / combine (GLV halves, signed 8-bit windows, 2^64 rows cached)", "n": N_COEFF, "batch": {}}
+            for bs in (1, 64, 512):
+                def lc_step(bs=bs):
+                    st = lib.kzg_hip_lincomb_points_batch_dev(pts.h, d_blobs.data_ptr(), N_COEFF, bs, d_lc_out.data_ptr(), stream)
+                    if st:
+                        raise RuntimeError("lincomb_points_batch_dev status %d" % st)
+                reps = 10 if bs < 512 else 3
+                lsecs = timed_steps(lc_step, reps, 1, torch.cuda.synchronize, barrier, max_over_ranks)
+                lincomb["batch"][str(bs)] = {"msm_per_s": bs * world * reps / lsecs, "ms_per_step": lsecs / reps * 1e3}
+            lincomb["matches_fixed_base_commitments"] = bool(torch.equal(d_lc_out[:B], d_out[:B])) if B <= 512 else None
+
+            # --- single-call latencies through the host-buffer entry points (ms)
+            # median of the timed calls (a one-off ~50 ms host / driver hiccup somewhere in this block was seen to land in one of the ten
+            # calls of one entry or another and to triple its mean); the slowest call of each entry is reported beside it
+            lat_max = {}
+            def lat(name, fn, reps):
+                for _ in range(3):
+                    fn()
+                ts = []
+                for _ in range(reps):
+                    t0 = time.perf_counter()
+                    fn()
+                    ts.append((time.perf_counter() - t0) * 1e3)
+                lat_max[name] = max(ts)
+                return float(np.median(ts))
+            one = blobs_h[0]
+            latency = {"CommitToPoly_4096_ms": lat("CommitToPoly", lambda: ks.commit_to_poly(one), 30),
+                       "ComputeProofSingle_4096_ms": lat("ComputeProofSingle", lambda: ks.compute_proof_single(one, 17), 30),
+                       "LinCombG1_4096_one_shot_ms": lat("LinCombG1_one_shot", lambda: fs.lin_comb_g1(setup, one), 10),
+                       "LinCombG1_4096_cached_points_ms": lat("LinCombG1_cached", lambda: pts.lin_comb(one), 10),
+                       "FFTG1_4096_ms": lat("FFTG1", lambda: fs.fft_g1(setup, False), 7)}
+            latency["statistic"] = "median of the timed calls after 3 warm-up calls"
+            latency["slowest_call_ms"] = lat_max
+            pts.close()
+
+        fk20 = None
+        roofline_fk20 = None
+        if not args.no_fk20:
+            fk = kz.FK20SingleSettings(ks, 4096)
+            FB = args.fk20_batch
+            polys_h = mont_blobs(4 + rank * FB, FB)[:, :2048, :].copy()
+            d_polys = torch.from_numpy(polys_h.view(np.int64)).cuda()
+            d_proofs = torch.zeros((FB, 4096, 18), dtype=torch.int64, device="cuda")
+
+            def fk_step():
+                st = lib.kzg_hip_da_using_fk20_batch_dev(fk.h, d_polys.data_ptr(), 2048, FB, d_proofs.data_ptr(), stream)
                 if st:
-                    raise RuntimeError("lincomb_points_batch_dev status %d" % st)
-            reps = 10 if bs < 512 else 3
-            lsecs = timed_steps(lc_step, reps, 1, torch.cuda.synchronize, barrier, max_over_ranks)
-            lincomb["batch"][str(bs)] = {"msm_per_s": bs * world * reps / lsecs, "ms_per_step": lsecs / reps * 1e3}
-        lincomb["matches_fixed_base_commitments"] = bool(torch.equal(d_lc_out[:B], d_out[:B])) if B <= 512 else None
+                    raise RuntimeError("da_using_fk20_batch_dev status %d" % st)
 
-        # --- single-call latencies through the host-buffer entry points (ms)
-        # median of the timed calls (a one-off ~50 ms host / driver hiccup somewhere in this block was seen to land in one of the ten
-        # calls of one entry or another and to triple its mean); the slowest call of each entry is reported beside it
-        lat_max = {}
-        def lat(name, fn, reps):
-            for _ in range(3):
-                fn()
-            ts = []
-            for _ in range(reps):
-                t0 = time.perf_counter()
-                fn()
-                ts.append((time.perf_counter() - t0) * 1e3)
-            lat_max[name] = max(ts)
-            return float(np.median(ts))
-        one = blobs_h[0]
-        latency = {"CommitToPoly_4096_ms": lat("CommitToPoly", lambda: ks.commit_to_poly(one), 30),
-                   "ComputeProofSingle_4096_ms": lat("ComputeProofSingle", lambda: ks.compute_proof_single(one, 17), 30),
-                   "LinCombG1_4096_one_shot_ms": lat("LinCombG1_one_shot", lambda: fs.lin_comb_g1(setup, one), 10),
-                   "LinCombG1_4096_cached_points_ms": lat("LinCombG1_cached", lambda: pts.lin_comb(one), 10),
-                   "FFTG1_4096_ms": lat("FFTG1", lambda: fs.fft_g1(setup, False), 7)}
-        latency["statistic"] = "median of the timed calls after 3 warm-up calls"
-        latency["slowest_call_ms"] = lat_max
-        pts.close()
-
-    fk20 = None
-    roofline_fk20 = None
-    if not args.no_fk20:
-        fk = kz.FK20SingleSettings(ks, 4096)
-        FB = args.fk20_batch
-        polys_h = mont_blobs(4 + rank * FB, FB)[:, :2048, :].copy()
-        d_polys = torch.from_numpy(polys_h.view(np.int64)).cuda()
-        d_proofs = torch.zeros((FB, 4096, 18), dtype=torch.int64, device="cuda")
-
-        def fk_step():
-            st = lib.kzg_hip_da_using_fk20_batch_dev(fk.h, d_polys.data_ptr(), 2048, FB, d_proofs.data_ptr(), stream)
-            if st:
-                raise RuntimeError("da_using_fk20_batch_dev status %d" % st)
-
-        fk_step()
-        torch.cuda.synchronize()
-        fk_ok = None
-        if rank == 0:   # self-check of the timed path: polynomial 0 is blob(seed 4)[:2048], byte-pinned by the oracle (tests/golden/fk20_pins.json)
-            p0 = d_proofs[0].cpu().numpy().view(np.uint64).reshape(4096, 3, 6)
-            fk_ok = hashlib.sha256(fs.to_compressed_g1(p0).tobytes()).hexdigest() == pins["config4a_da_using_fk20_seed4"]["sha256"]
-            if not fk_ok:
-                raise SystemExit("bench self-check failed: FK20 proofs of blob(seed 4) do not match the byte pin")
-        fsteps = max(1, args.steps // 2)
-        fsecs = timed_steps(fk_step, fsteps, 1, torch.cuda.synchronize, barrier, max_over_ranks)
-        fk20 = {"metric": "FK20 all-proofs/s (DAUsingFK20, 2048 coeffs -> 4096 proofs, scale 12)",
-                "value": FB * world * fsteps / fsecs, "batch_per_gpu": FB,
-                "ms_per_all_proofs": fsecs / fsteps / FB * 1e3, "self_check_byte_pin": fk_ok}
-        if not args.no_extras and world == 1:
-            for _ in range(3):
-                fk.da_using_fk20(polys_h[0])
-            ts = []
-            for _ in range(5):
-                t0 = time.perf_counter()
-                fk.da_using_fk20(polys_h[0])
-                ts.append((time.perf_counter() - t0) * 1e3)
-            fk20["DAUsingFK20_single_call_ms"] = float(np.median(ts))      # median of 5 calls, like the `latency` block
-            # the reference's API is one polynomial per call (fk20_single.go:176-196): 64 host threads calling it concurrently are merged
-            # into batched launches by the library (Python threads here: ctypes releases the GIL for the ~50 ms a call blocks)
-            import threading
-            TT, per = 64, 6
-            gate = threading.Barrier(TT + 1)
-            def fk_worker(i):
+            fk_step()
+            torch.cuda.synchronize()
+            fk_ok = None
+            if rank == 0:   # self-check of the timed path: polynomial 0 is blob(seed 4)[:2048], byte-pinned by the oracle (tests/golden/fk20_pins.json)
+                p0 = d_proofs[0].cpu().numpy().view(np.uint64).reshape(4096, 3, 6)
+                fk_ok = hashlib.sha256(fs.to_compressed_g1(p0).tobytes()).hexdigest() == pins["config4a_da_using_fk20_seed4"]["sha256"]
+                if not fk_ok:
+                    raise SystemExit("bench self-check failed: FK20 proofs of blob(seed 4) do not match the byte pin")
+            fsteps = max(1, args.steps // 2)
+            fsecs = timed_steps(fk_step, fsteps, 1, torch.cuda.synchronize, barrier, max_over_ranks)
+            fk20 = {"metric": "FK20 all-proofs/s (DAUsingFK20, 2048 coeffs -> 4096 proofs, scale 12)",
+                    "value": FB * world * fsteps / fsecs, "batch_per_gpu": FB,
+                    "ms_per_all_proofs": fsecs / fsteps / FB * 1e3, "self_check_byte_pin": fk_ok}
+            if not args.no_extras and world == 1:
+                for _ in range(3):
+                    fk.da_using_fk20(polys_h[0])
+                ts = []
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    fk.da_using_fk20(polys_h[0])
+                    ts.append((time.perf_counter() - t0) * 1e3)
+                fk20["DAUsingFK20_single_call_ms"] = float(np.median(ts))      # median of 5 calls, like the `latency` block
+                # the reference's API is one polynomial per call (fk20_single.go:176-196): 64 host threads calling it concurrently are merged
+                # into batched launches by the library (Python threads here: ctypes releases the GIL for the ~50 ms a call blocks)
+                import threading
+                TT, per = 64, 6
+                gate = threading.Barrier(TT + 1)
+                def fk_worker(i):
+                    gate.wait()
+                    for r in range(per):
+                        fk.da_using_fk20(polys_h[(i + r) % len(polys_h)])
+                for _ in range(4):
+                    fk.da_using_fk20(polys_h[0])                               # the staging buffers of the coalescer exist (pinned on first use)
+                ths = [threading.Thread(target=fk_worker, args=(i,)) for i in range(TT)]
+                [t.start() for t in ths]
                 gate.wait()
-                for r in range(per):
-                    fk.da_using_fk20(polys_h[(i + r) % len(polys_h)])
-            for _ in range(4):
-                fk.da_using_fk20(polys_h[0])                               # the staging buffers of the coalescer exist (pinned on first use)
-            ths = [threading.Thread(target=fk_worker, args=(i,)) for i in range(TT)]
-            [t.start() for t in ths]
-            gate.wait()
-            t0 = time.perf_counter()
-            [t.join() for t in ths]
-            fk20["DAUsingFK20_from_64_threads_per_s"] = TT * per / (time.perf_counter() - t0)
-        # roofline of the FK20 half: HIP events around every launch of the dominant kernel (k_g1_fft_stage, 24 launches per step:
-        # 12 radix-2 stages x 2 transforms), separate un-timed pass
-        lib.kzg_hip_prof_reset(fs.h, 1)
-        fk_step()
-        torch.cuda.synchronize()
-        tot2, cnt2 = C.c_double(0), C.c_uint64(0)
-        lib.kzg_hip_prof_read(fs.h, b"g1_fft_stage", C.byref(tot2), C.byref(cnt2))
-        tot3, cnt3 = C.c_double(0), C.c_uint64(0)
-        lib.kzg_hip_prof_read(fs.h, b"fb_mul_vec", C.byref(tot3), C.byref(cnt3))
-        lib.kzg_hip_prof_reset(fs.h, 0)
-        if cnt2.value:
-            kern_s = tot2.value * 1e-3                          # all stage launches of one step (FB polynomials)
-            alg = FB * FK20_BYTES                               # 851 968 B per DAUsingFK20 (poly + xExtFFT + proofs)
-            # multiply-adds of the stage kernel per polynomial: 2 transforms x 20 481 twiddle multiplications (width-5 NAF GLV with
-            # an affine 8-entry table: ~126 doublings x 1963 + ~42.7 mixed additions x 3315 + 33.1k for the co-Z table (78M + 26S incl. its
-            # normalisation and the beta x of every entry; the binary-GCD inversion has no multiplies) + 24 576 shared (x + wy, x - wy) x 7384
-            # Fused pipeline (22 stage launches per step): the first two stages of the inverse transform are inside the fixed-base Toeplitz
-            # stage, 2047 + 2046 twiddle multiplications and 4096 butterflies fewer.
-            per_mul = 126 * 1963 + 42.7 * 3315 + 33100
-            fused = int(cnt2.value) == 22
-            mads_unit = ((2 * 20481 - 4093) * per_mul + (2 * 24576 - 4096) * 7384) if fused else (2 * 20481 * per_mul + 2 * 24576 * 7384)
-            pf = pmc.get("k_g1_fft_stage", {})
-            roofline_fk20 = {"bound": "hbm", "kernel": "k_g1_fft_stage", "achieved": alg / kern_s * 1e-9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": alg / kern_s * 1e-9 / HBM_PEAK_GBS, "launches_per_step": int(cnt2.value), "avg_launch_ms": tot2.value / cnt2.value,
-                             "kernel_ms_per_all_proofs": tot2.value / FB, "algorithmic_bytes_per_step": alg,
-                             "traffic": (pf.get("fetch_bytes_per_step", 0) + pf.get("write_bytes_per_step", 0)) if pf.get("batch") == FB else None,
-                             "traffic_source": pmc.get("_file") if pf.get("batch") == FB else None,
-                             "share_of_step": kern_s / (fsecs / fsteps), "table_walk_ms_per_step": tot3.value if cnt3.value else None,
-                             "mac": {"mads_per_all_proofs": mads_unit, "achieved_Tmad_s": FB * mads_unit / kern_s * 1e-12, "measured_peak_Tmad_s": cal_mad * 1e-12,
-                                     "frac": FB * mads_unit / kern_s / cal_mad},
-                             "counters": {k: pf[k] for k in ("valu_insts_per_step", "sq_wait_inst_any", "sq_active_inst_any", "sq_busy_cycles", "scratch_bytes_per_lane") if k in pf},
-                             "issue": ({"issue_model_ms_per_step": (FB * mads_unit / cal_mad + max(pf["valu_insts_per_step"] * 64.0 - FB * mads_unit, 0.0) / cal_add) * 1e3,
-                                        "frac_of_kernel_time_explained": (FB * mads_unit / cal_mad + max(pf["valu_insts_per_step"] * 64.0 - FB * mads_unit, 0.0) / cal_add) / kern_s}
-                                       if pf.get("batch") == FB and "valu_insts_per_step" in pf else None),
-                             "pipeline": "Toeplitz stage fused with two DIF stages of the inverse transform (k_fb_mul_vec_dif2), 10 DIF + 12 DIT stage launches" if fused else "24 stage launches (unfused)",
-                             "note": "one step = %d polynomials; the kernel is launched once per radix-2 stage; integer-issue-bound like the table walk" % FB}
-        if use_dist:
-            # the north star's "RCCL all-gather of proof points over xGMI": every rank ends up with the proofs of 32 blobs of every
-            # rank (up to 32 x 4096 x 144 B = 18.9 MB per rank).  Reported beside the throughput; a failure must not cost the bench line.
-            try:
-                from gokzg_amd import multi_gpu as mg
-                part = d_proofs[:32].contiguous()
-                gsecs = timed_steps(lambda: mg.all_gather_proofs(part), 5, 1, torch.cuda.synchronize, barrier, max_over_ranks)
-                gathered = mg.all_gather_proofs(part)
-                cnt_ = part.shape[0]
-                ok_ = bool(gathered.shape[0] == world * cnt_ and torch.equal(gathered[rank * cnt_:(rank + 1) * cnt_], part))
-                fk20["all_gather_proofs"] = {"ms": gsecs / 5 * 1e3, "bytes_per_rank": int(part.numel() * 8), "ranks": world,
-                                             "GB_s_out_per_rank": part.numel() * 8 * (world - 1) / (gsecs / 5) * 1e-9, "own_slice_intact": ok_}
-            except Exception as e:                           # noqa: BLE001
-                fk20["all_gather_proofs"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        fk.close()
+                t0 = time.perf_counter()
+                [t.join() for t in ths]
+                fk20["DAUsingFK20_from_64_threads_per_s"] = TT * per / (time.perf_counter() - t0)
+            # roofline of the FK20 half: HIP events around every launch of the dominant kernel (k_g1_fft_stage, 24 launches per step:
+            # 12 radix-2 stages x 2 transforms), separate un-timed pass
+            lib.kzg_hip_prof_reset(fs.h, 1)
+            fk_step()
+            torch.cuda.synchronize()
+            tot2, cnt2 = C.c_double(0), C.c_uint64(0)
+            lib.kzg_hip_prof_read(fs.h, b"g1_fft_stage", C.byref(tot2), C.byref(cnt2))
+            tot3, cnt3 = C.c_double(0), C.c_uint64(0)
+            lib.kzg_hip_prof_read(fs.h, b"fb_mul_vec", C.byref(tot3), C.byref(cnt3))
+            lib.kzg_hip_prof_reset(fs.h, 0)
+            if cnt2.value:
+                kern_s = tot2.value * 1e-3                          # all stage launches of one step (FB polynomials)
+                alg = FB * FK20_BYTES                               # 851 968 B per DAUsingFK20 (poly + xExtFFT + proofs)
+                # multiply-adds of the stage kernel per polynomial: 2 transforms x 20 481 twiddle multiplications (width-5 NAF GLV with
+                # an affine 8-entry table: ~126 doublings x 1963 + ~42.7 mixed additions x 3315 + 33.1k for the co-Z table (78M + 26S incl. its
+                # normalisation and the beta x of every entry; the binary-GCD inversion has no multiplies) + 24 576 shared (x + wy, x - wy) x 7384
+                # Fused pipeline (22 stage launches per step): the first two stages of the inverse transform are inside the fixed-base Toeplitz
+                # stage, 2047 + 2046 twiddle multiplications and 4096 butterflies fewer.
+                per_mul = 126 * 1963 + 42.7 * 3315 + 33100
+                fused = int(cnt2.value) == 22
+                mads_unit = ((2 * 20481 - 4093) * per_mul + (2 * 24576 - 4096) * 7384) if fused else (2 * 20481 * per_mul + 2 * 24576 * 7384)
+                pf = pmc.get("k_g1_fft_stage", {})
+                roofline_fk20 = {"bound": "hbm", "kernel": "k_g1_fft_stage", "achieved": alg / kern_s * 1e-9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": alg / kern_s * 1e-9 / HBM_PEAK_GBS, "launches_per_step": int(cnt2.value), "avg_launch_ms": tot2.value / cnt2.value,
+                                 "kernel_ms_per_all_proofs": tot2.value / FB, "algorithmic_bytes_per_step": alg,
+                                 "traffic": (pf.get("fetch_bytes_per_step", 0) + pf.get("write_bytes_per_step", 0)) if pf.get("batch") == FB else None,
+                                 "traffic_source": pmc.get("_file") if pf.get("batch") == FB else None,
+                                 "share_of_step": kern_s / (fsecs / fsteps), "table_walk_ms_per_step": tot3.value if cnt3.value else None,
+                                 "mac": {"mads_per_all_proofs": mads_unit, "achieved_Tmad_s": FB * mads_unit / kern_s * 1e-12, "measured_peak_Tmad_s": cal_mad * 1e-12,
+                                         "frac": FB * mads_unit / kern_s / cal_mad},
+                                 "counters": {k: pf[k] for k in ("valu_insts_per_step", "sq_wait_inst_any", "sq_active_inst_any", "sq_busy_cycles", "scratch_bytes_per_lane") if k in pf},
+                                 "issue": ({"issue_model_ms_per_step": (FB * mads_unit / cal_mad + max(pf["valu_insts_per_step"] * 64.0 - FB * mads_unit, 0.0) / cal_add) * 1e3,
+                                            "frac_of_kernel_time_explained": (FB * mads_unit / cal_mad + max(pf["valu_insts_per_step"] * 64.0 - FB * mads_unit, 0.0) / cal_add) / kern_s}
+                                           if pf.get("batch") == FB and "valu_insts_per_step" in pf else None),
+                                 "pipeline": "Toeplitz stage fused with two DIF stages of the inverse transform (k_fb_mul_vec_dif2), 10 DIF + 12 DIT stage launches" if fused else "24 stage launches (unfused)",
+                                 "note": "one step = %d polynomials; the kernel is launched once per radix-2 stage; integer-issue-bound like the table walk" % FB}
+            if use_dist:
+                # the north star's "RCCL all-gather of proof points over xGMI": every rank ends up with the proofs of 32 blobs of every
+                # rank (up to 32 x 4096 x 144 B = 18.9 MB per rank).  Reported beside the throughput; a failure must not cost the bench line.
+                try:
+                    from gokzg_amd import multi_gpu as mg
+                    part = d_proofs[:32].contiguous()
+                    gsecs = timed_steps(lambda: mg.all_gather_proofs(part), 5, 1, torch.cuda.synchronize, barrier, max_over_ranks)
+                    gathered = mg.all_gather_proofs(part)
+                    cnt_ = part.shape[0]
+                    ok_ = bool(gathered.shape[0] == world * cnt_ and torch.equal(gathered[rank * cnt_:(rank + 1) * cnt_], part))
+                    fk20["all_gather_proofs"] = {"ms": gsecs / 5 * 1e3, "bytes_per_rank": int(part.numel() * 8), "ranks": world,
+                                                 "GB_s_out_per_rank": part.numel() * 8 * (world - 1) / (gsecs / 5) * 1e-9, "own_slice_intact": ok_}
+                except Exception as e:                           # noqa: BLE001
+                    fk20["all_gather_proofs"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            fk.close()
 
-    fk20m = None
-    if not args.no_fk20 and args.fk20_multi_batch > 0:
-        # BASELINE config 5: FK20Multi, scale 16 (n2 = 65536, 32768 coefficients), chunk length 16 -> 4096 coset proofs per polynomial.
-        # Setup [s^i]G1 for the reference's test secret is generated on the device (GenerateTestingSetup).
-        s_test = 1927409816240961209460912649124
-        fs16 = kz.FFTSettings(16, device=local)
-        sec = np.frombuffer((s_test * ((1 << 256) % R_MOD) % R_MOD).to_bytes(32, "little"), dtype=np.uint64).reshape(1, 4)
-        ks16 = kz.KZGSettings(fs16, fs16.generate_testing_setup_g1(sec, 65536))
-        fkm = kz.FK20MultiSettings(ks16, 65536, 16)
-        MB = args.fk20_multi_batch
-        mp_h = mont_blobs(5 + rank * MB, MB, n=32768)
-        d_mp = torch.from_numpy(mp_h.view(np.int64)).cuda()
-        d_mproofs = torch.zeros((MB, 4096, 18), dtype=torch.int64, device="cuda")
+        fk20m = None
+        if not args.no_fk20 and args.fk20_multi_batch > 0:
+            # BASELINE config 5: FK20Multi, scale 16 (n2 = 65536, 32768 coefficients), chunk length 16 -> 4096 coset proofs per polynomial.
+            # Setup [s^i]G1 for the reference's test secret is generated on the device (GenerateTestingSetup).
+            s_test = 1927409816240961209460912649124
+            fs16 = kz.FFTSettings(16, device=local)
+            sec = np.frombuffer((s_test * ((1 << 256) % R_MOD) % R_MOD).to_bytes(32, "little"), dtype=np.uint64).reshape(1, 4)
+            ks16 = kz.KZGSettings(fs16, fs16.generate_testing_setup_g1(sec, 65536))
+            fkm = kz.FK20MultiSettings(ks16, 65536, 16)
+            MB = args.fk20_multi_batch
+            mp_h = mont_blobs(5 + rank * MB, MB, n=32768)
+            d_mp = torch.from_numpy(mp_h.view(np.int64)).cuda()
+            d_mproofs = torch.zeros((MB, 4096, 18), dtype=torch.int64, device="cuda")
 
-        def fkm_step():
-            st = lib.kzg_hip_da_using_fk20_multi_batch_dev(fkm.h, d_mp.data_ptr(), 32768, MB, d_mproofs.data_ptr(), stream)
-            if st:
-                raise RuntimeError("da_using_fk20_multi_batch_dev status %d" % st)
+            def fkm_step():
+                st = lib.kzg_hip_da_using_fk20_multi_batch_dev(fkm.h, d_mp.data_ptr(), 32768, MB, d_mproofs.data_ptr(), stream)
+                if st:
+                    raise RuntimeError("da_using_fk20_multi_batch_dev status %d" % st)
 
-        fkm_step()
-        torch.cuda.synchronize()
-        fkm_ok = None
-        if rank == 0:   # polynomial 0 is blob(seed 5, 32768): all 4096 coset proofs byte-pinned by the oracle's full-size run
-            p0 = d_mproofs[0].cpu().numpy().view(np.uint64).reshape(4096, 3, 6)
-            fkm_ok = hashlib.sha256(fs16.to_compressed_g1(p0).tobytes()).hexdigest() == pins["config5_da_using_fk20_multi_seed5"]["sha256"]
-            if not fkm_ok:
-                raise SystemExit("bench self-check failed: FK20Multi proofs of blob(seed 5) do not match the byte pin")
-        msteps = max(1, args.steps // 2)
-        msecs = timed_steps(fkm_step, msteps, 1, torch.cuda.synchronize, barrier, max_over_ranks)
-        fk20m = {"metric": "FK20Multi all-coset-proofs/s (DAUsingFK20Multi, scale 16, chunk 16: 32768 coeffs -> 4096 proofs)",
-                 "value": MB * world * msteps / msecs, "batch_per_gpu": MB, "ms_per_all_proofs": msecs / msteps / MB * 1e3, "self_check_byte_pin": fkm_ok}
-        if use_dist or args.sharded_fk20_multi:
-            # ONE FK20Multi with its Toeplitz stage sharded over the ranks and an RCCL all-gather of the 144-byte point slices
-            # (BASELINE config 5, go-kzg_amd/multi_gpu.py).  A latency figure, reported beside the throughput numbers; a failure
-            # here must not cost the bench line.
-            try:
-                from gokzg_amd import multi_gpu as mg
-                be = mg.HipFK20MultiBackend(fkm)
-                if use_dist:                                 # every rank works on rank 0's polynomial
-                    dist.broadcast(d_mp[0], src=0)
-                one = d_mp[0].contiguous()
-                ref = torch.empty((4096, 18), dtype=torch.int64, device="cuda")
-                st = lib.kzg_hip_da_using_fk20_multi_batch_dev(fkm.h, one.data_ptr(), 32768, 1, ref.data_ptr(), stream)
-                got = mg.da_using_fk20_multi_sharded(be, one, 32768, 4096)
-                torch.cuda.synchronize()
-                same = bool(st == 0 and torch.equal(got, ref))
-                ssecs = timed_steps(lambda: mg.da_using_fk20_multi_sharded(be, one, 32768, 4096), 3, 1, torch.cuda.synchronize, barrier, max_over_ranks)
-                fk20m["sharded_one_polynomial"] = {"ms": ssecs / 3 * 1e3, "ranks": world, "matches_unsharded": same,
-                                                   "collective": "all_gather of 4096 x 144 B point slices (RCCL)" if use_dist else "none (1 rank)"}
-            except Exception as e:                           # noqa: BLE001
-                fk20m["sharded_one_polynomial"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        fkm.close(); ks16.close(); fs16.close()
+            fkm_step()
+            torch.cuda.synchronize()
+            fkm_ok = None
+            if rank == 0:   # polynomial 0 is blob(seed 5, 32768): all 4096 coset proofs byte-pinned by the oracle's full-size run
+                p0 = d_mproofs[0].cpu().numpy().view(np.uint64).reshape(4096, 3, 6)
+                fkm_ok = hashlib.sha256(fs16.to_compressed_g1(p0).tobytes()).hexdigest() == pins["config5_da_using_fk20_multi_seed5"]["sha256"]
+                if not fkm_ok:
+                    raise SystemExit("bench self-check failed: FK20Multi proofs of blob(seed 5) do not match the byte pin")
+            msteps = max(1, args.steps // 2)
+            msecs = timed_steps(fkm_step, msteps, 1, torch.cuda.synchronize, barrier, max_over_ranks)
+            fk20m = {"metric": "FK20Multi all-coset-proofs/s (DAUsingFK20Multi, scale 16, chunk 16: 32768 coeffs -> 4096 proofs)",
+                     "value": MB * world * msteps / msecs, "batch_per_gpu": MB, "ms_per_all_proofs": msecs / msteps / MB * 1e3, "self_check_byte_pin": fkm_ok}
+            if use_dist or args.sharded_fk20_multi:
+                # ONE FK20Multi with its Toeplitz stage sharded over the ranks and an RCCL all-gather of the 144-byte point slices
+                # (BASELINE config 5, go-kzg_amd/multi_gpu.py).  A latency figure, reported beside the throughput numbers; a failure
+                # here must not cost the bench line.
+                try:
+                    from gokzg_amd import multi_gpu as mg
+                    be = mg.HipFK20MultiBackend(fkm)
+                    if use_dist:                                 # every rank works on rank 0's polynomial
+                        dist.broadcast(d_mp[0], src=0)
+                    one = d_mp[0].contiguous()
+                    ref = torch.empty((4096, 18), dtype=torch.int64, device="cuda")
+                    st = lib.kzg_hip_da_using_fk20_multi_batch_dev(fkm.h, one.data_ptr(), 32768, 1, ref.data_ptr(), stream)
+                    got = mg.da_using_fk20_multi_sharded(be, one, 32768, 4096)
+                    torch.cuda.synchronize()
+                    same = bool(st == 0 and torch.equal(got, ref))
+                    ssecs = timed_steps(lambda: mg.da_using_fk20_multi_sharded(be, one, 32768, 4096), 3, 1, torch.cuda.synchronize, barrier, max_over_ranks)
+                    fk20m["sharded_one_polynomial"] = {"ms": ssecs / 3 * 1e3, "ranks": world, "matches_unsharded": same,
+                                                       "collective": "all_gather of 4096 x 144 B point slices (RCCL)" if use_dist else "none (1 rank)"}
+                except Exception as e:                           # noqa: BLE001
+                    fk20m["sharded_one_polynomial"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            fkm.close(); ks16.close(); fs16.close()
 
-    ref_benches = None
-    if not args.no_fk20:
-        # The three transforms the reference publishes numbers for (BENCH.md, Kilic column, Ryzen 9 5950X, 1 thread), scale 12,
-        # device-resident batches: FFT over F_r (:43), FFT over G1 (:55), DAS FFT extension (:31).
-        def rate(fn, units, reps):
-            secs_ = timed_steps(fn, reps, 1, torch.cuda.synchronize, barrier, max_over_ranks)
-            return units * world * reps / secs_
+        ref_benches = None
+        if not args.no_fk20:
+            # The three transforms the reference publishes numbers for (BENCH.md, Kilic column, Ryzen 9 5950X, 1 thread), scale 12,
+            # device-resident batches: FFT over F_r (:43), FFT over G1 (:55), DAS FFT extension (:31).
+            def rate(fn, units, reps):
+                secs_ = timed_steps(fn, reps, 1, torch.cuda.synchronize, barrier, max_over_ranks)
+                return units * world * reps / secs_
 
-        FB = 1024
-        d_fr = torch.from_numpy(mont_blobs(12 + rank * FB, FB).view(np.int64)).cuda()
-        d_fr_out = torch.empty_like(d_fr)
+            FB = 1024
+            d_fr = torch.from_numpy(mont_blobs(12 + rank * FB, FB).view(np.int64)).cuda()
+            d_fr_out = torch.empty_like(d_fr)
 
-        def fr_step():
-            st = lib.kzg_hip_fft_fr_batch_dev(fs.h, d_fr.data_ptr(), N_COEFF, FB, 0, d_fr_out.data_ptr(), stream)
-            if st:
-                raise RuntimeError("fft_fr_batch_dev status %d" % st)
+            def fr_step():
+                st = lib.kzg_hip_fft_fr_batch_dev(fs.h, d_fr.data_ptr(), N_COEFF, FB, 0, d_fr_out.data_ptr(), stream)
+                if st:
+                    raise RuntimeError("fft_fr_batch_dev status %d" % st)
 
-        d_das = d_fr[:, :2048, :].contiguous()
+            d_das = d_fr[:, :2048, :].contiguous()
 
-        def das_step():
-            st = lib.kzg_hip_das_fft_extension_batch_dev(fs.h, d_das.data_ptr(), 2048, FB, stream)
-            if st:
-                raise RuntimeError("das_fft_extension_batch_dev status %d" % st)
+            def das_step():
+                st = lib.kzg_hip_das_fft_extension_batch_dev(fs.h, d_das.data_ptr(), 2048, FB, stream)
+                if st:
+                    raise RuntimeError("das_fft_extension_batch_dev status %d" % st)
 
-        GB = 64
-        d_g1 = torch.from_numpy(setup.view(np.int64).reshape(1, 4096, 18)).cuda().repeat(GB, 1, 1).contiguous()
-        d_g1_out = torch.empty_like(d_g1)
+            GB = 64
+            d_g1 = torch.from_numpy(setup.view(np.int64).reshape(1, 4096, 18)).cuda().repeat(GB, 1, 1).contiguous()
+            d_g1_out = torch.empty_like(d_g1)
 
-        def g1_step():
-            st = lib.kzg_hip_fft_g1_batch_dev(fs.h, d_g1.data_ptr(), N_COEFF, GB, 0, d_g1_out.data_ptr(), stream)
-            if st:
-                raise RuntimeError("fft_g1_batch_dev status %d" % st)
+            def g1_step():
+                st = lib.kzg_hip_fft_g1_batch_dev(fs.h, d_g1.data_ptr(), N_COEFF, GB, 0, d_g1_out.data_ptr(), stream)
+                if st:
+                    raise RuntimeError("fft_g1_batch_dev status %d" % st)
 
-        r_fr, r_das, r_g1 = rate(fr_step, FB, 5), rate(das_step, FB, 5), rate(g1_step, GB, 2)
-        ref_benches = {
-            "fft_fr_scale12_per_s": {"value": r_fr, "reference_published": 1e9 / 1911871, "source": "BENCH.md:43 (Kilic, 5950X, 1 thread)", "batch": FB},
-            "das_fft_extension_scale12_per_s": {"value": r_das, "reference_published": 1e9 / 1169011, "source": "BENCH.md:31", "batch": FB},
-            "fft_g1_scale12_per_s": {"value": r_g1, "reference_published": 1e9 / 3745748396, "source": "BENCH.md:55", "batch": GB},
-        }
+            r_fr, r_das, r_g1 = rate(fr_step, FB, 5), rate(das_step, FB, 5), rate(g1_step, GB, 2)
+            ref_benches = {
+                "fft_fr_scale12_per_s": {"value": r_fr, "reference_published": 1e9 / 1911871, "source": "BENCH.md:43 (Kilic, 5950X, 1 thread)", "batch": FB},
+                "das_fft_extension_scale12_per_s": {"value": r_das, "reference_published": 1e9 / 1169011, "source": "BENCH.md:31", "batch": FB},
+                "fft_g1_scale12_per_s": {"value": r_g1, "reference_published": 1e9 / 3745748396, "source": "BENCH.md:55", "batch": GB},
+            }
 
+    except Exception as e:                                   # noqa: BLE001
+        if world > 1:
+            raise
+        import traceback
+        secondary_error = "%s: %s | %s" % (type(e).__name__, e, traceback.format_exc().strip().splitlines()[-3:])
     if rank == 0:
         print(json.dumps({
             "metric": "KZG commitments/sec (CommitToPoly, 4096-element blob)", "value": value, "unit": "commitments/s",
@@ -637,7 +649,7 @@ def main():
             "config": {"workload": "CommitToPoly, 4096-coeff blobs, eth/trusted_setup.json monomial setup (s=1337), %d blobs/step/GPU resident in HBM, fixed-base table budget %g GB (opt-in; library default 64 GB, see table_sweep)" % (B, args.table_gb),
                        "global_batch": B * world, "parallelism": "dp%d (independent blobs, no data-path collective)" % world},
             "roofline": roofline, "roofline_fk20": roofline_fk20, "cpu_baseline": base, "batch_sweep": batch_sweep, "table_sweep": table_sweep, "drop_in": drop_in,
-            "lincomb": lincomb, "latency": latency, "fk20": fk20, "fk20_multi": fk20m, "reference_benchmarks": ref_benches,
+            "lincomb": lincomb, "latency": latency, "fk20": fk20, "fk20_multi": fk20m, "reference_benchmarks": ref_benches, "secondary_error": secondary_error,
         }))
     if use_dist:
         dist.destroy_process_group()

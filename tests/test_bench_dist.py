@@ -139,3 +139,20 @@ def test_bench_two_ranks_under_torch_distributed_run():
     assert d["fk20"]["all_gather_proofs"]["ranks"] == 2
     assert d["fk20_multi"]["self_check_byte_pin"] is True
     assert d["fk20_multi"]["sharded_one_polynomial"]["matches_unsharded"] is True, d["fk20_multi"]["sharded_one_polynomial"]
+
+
+@pytest.mark.gpu
+def test_bench_line_survives_a_failing_secondary_leg():
+    """the headline (commitments/s with roofline) is measured first; a failure in any later leg (table sweep, one-blob API, FK20 ...) must
+    not cost the JSON line the driver reads: it is reported in `secondary_error`"""
+    import json
+    import subprocess
+    env = dict(os.environ, KZG_BENCH_FAIL_SECONDARY="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "64", "--table-gb", "4", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["roofline"]["mac"]["frac"] > 0
+    assert "KZG_BENCH_FAIL_SECONDARY" in d["secondary_error"] and d["fk20"] is None
