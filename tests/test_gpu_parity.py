@@ -854,7 +854,7 @@ def test_lone_caller_pays_no_gather_window_after_a_burst(kz, ks4096):
     for _ in range(40):
         ks4096.commit_to_poly(blobs[0])                      # the decay: a quarter per batch
     after = median_ms(40)
-    assert after < before + 0.08, (before, after)            # the window is 0.15 ms
+    assert after < before + 0.10, (before, after)            # the window is 0.15 ms
 
 
 def test_64_threads_single_blob_calls_are_coalesced_and_bit_exact(kz, ks4096, setup_1337):
