@@ -20,6 +20,26 @@ def _free_port():
         sk.bind(("127.0.0.1", 0))
         return sk.getsockname()[1]
 
+
+def _collect(q, procs, n, timeout):
+    """n results from the workers' queue; gives up as soon as every worker has exited without delivering (a crashed rank must fail the
+    test at once, not after the full timeout)"""
+    import queue
+    import time
+    out, t0 = [], time.time()
+    while len(out) < n and time.time() - t0 < timeout:
+        try:
+            out.append(q.get(timeout=2))
+        except queue.Empty:
+            if not any(p.is_alive() for p in procs):
+                try:
+                    while len(out) < n:
+                        out.append(q.get(timeout=1))             # results written just before the exit
+                except queue.Empty:
+                    break
+    assert len(out) == n, "workers delivered %d of %d results (exit codes %s)" % (len(out), n, [p.exitcode for p in procs])
+    return out
+
 def _reap(procs, timeout):
     """workers have already delivered their results through the queue: give them `timeout` seconds to leave on their own, then kill what is
     left (a rank that lingers in device teardown must not outlive the test run: an orphan keeps the caller's stdout pipe open); a worker
@@ -98,7 +118,7 @@ def test_timed_steps_world_size_2_gloo():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in range(2))
+    res = sorted(_collect(q, procs, 2, 120))
     _reap(procs, 60)
     assert [r[1] for r in res] == [7, 7]                  # W + K steps on every rank
     assert abs(res[0][2] - res[1][2]) < 1e-9             # both ranks report the same (max) time
