@@ -11,6 +11,10 @@
 // Everything is plain C++ so the same source is compiled for the host by the unit tests (tests/host).
 #pragma once
 #include <stdint.h>
+// branch weights for paths that exist for completeness only (P == +-Q in a table walk, an infinite operand of a butterfly): the compiler
+// moves them out of the straight line of the hot loops
+#define KZG_LIKELY(x) __builtin_expect(!!(x), 1)
+#define KZG_UNLIKELY(x) __builtin_expect(!!(x), 0)
 
 #if defined(__HIPCC__)
 #define KZG_HD __host__ __device__ __forceinline__

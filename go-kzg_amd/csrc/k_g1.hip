@@ -128,7 +128,7 @@ template <int MODE, bool PRE = false> __global__ __launch_bounds__(G1_BLOCK, 2) 
         }
         if (st == 1 && !is_inf(x)) {
             g1jq sum, dif;
-            if (g1jq_addsub(g1jq_unpack(x), yq, sum, dif)) {
+            if (KZG_LIKELY(g1jq_addsub(g1jq_unpack(x), yq, sum, dif))) {
                 fp z3 = packq(sum.z);
                 g1j o0, o1;
                 o0.x = packq(sum.x); o0.y = packq(sum.y); o0.z = z3;
@@ -176,7 +176,7 @@ template <bool PRE> __global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_fft_stag
     g1j x = row[i0];
     if (!is_inf(x) && !is_inf(y)) {
         g1jq sum, dif;
-        if (g1jq_addsub(g1jq_unpack(x), g1jq_unpack(y), sum, dif)) {
+        if (KZG_LIKELY(g1jq_addsub(g1jq_unpack(x), g1jq_unpack(y), sum, dif))) {
             g1j o0; o0.x = packq(sum.x); o0.y = packq(sum.y); o0.z = packq(sum.z);
             row[i0] = o0;
             if (j) {
