@@ -475,6 +475,17 @@ template <bool SPLIT> __global__ __launch_bounds__(FB_ACC_BLOCK, FB_ACC_WAVES) v
         }
         raw = scalar_bits(k, w0 * c, c) + carry;
         if (raw > D) { carry = 1; mag = (1u << c) - raw; ng = 1; } else { carry = 0; mag = raw; ng = 0; }
+#ifdef KZG_WALK_NO_PREFETCH                                   // A/B builds: gather at the point of use (no register-held next entry)
+#pragma nounroll
+        for (uint32_t w = w0; w < w1; w++) {
+            const uint32_t cmag = mag, cng = ng;
+            g1a q = table[((uint64_t)w * table_n + i) * D + (cmag ? cmag - 1 : 0)];
+            if (w + 1 < w1) {
+                raw = scalar_bits(k, (w + 1) * c, c) + carry;
+                if (raw > D) { carry = 1; mag = (1u << c) - raw; ng = 1; } else { carry = 0; mag = raw; ng = 0; }
+            }
+            if (cmag) {
+#else
         g1a qn = table[((uint64_t)w0 * table_n + i) * D + (mag ? mag - 1 : 0)];
 #pragma nounroll
         for (uint32_t w = w0; w < w1; w++) {
@@ -486,6 +497,7 @@ template <bool SPLIT> __global__ __launch_bounds__(FB_ACC_BLOCK, FB_ACC_WAVES) v
                 qn = table[((uint64_t)(w + 1) * table_n + i) * D + (mag ? mag - 1 : 0)];
             }
             if (cmag) {
+#endif
                 if (cng) q.y = neg<FpP>(q.y);
                 acc.add(q);
             }
