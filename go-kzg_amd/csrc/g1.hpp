@@ -887,10 +887,10 @@ template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_wnaf_loop_aq
 // table for the multiplications below (co-Z chain); `dz`: 7 field elements of scratch.  false: a difference of the chain vanished (P of
 // order < 16, never in G1) -- the callers then take the generic path for the whole product.
 KZG_HD bool g1_wnaf_table(const g1jq &pq, g1aq *tbl, fq *dz) {
-#ifdef KZG_WNAF_TABLE_INLINE                                // A/B builds: the chain's products inlined (+0.3 % measured: not worth the code)
-    return g1_wnaf_table_affine_coz<true>(pq, tbl, dz);
-#else
+#ifdef KZG_WNAF_TABLE_NOINLINE                              // A/B builds: the chain's products as calls (-0.2 .. -0.6 % FK20 measured)
     return g1_wnaf_table_affine_coz<false>(pq, tbl, dz);
+#else
+    return g1_wnaf_table_affine_coz<true>(pq, tbl, dz);
 #endif
 }
 template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_mul_glv_wnaf_aq_q(const g1jq &pq, const fr &kk, g1aq *tbl, fq *dz, int8_t *d1, int8_t *d2, int stride, g1jq &out, g1j &packed) {
