@@ -199,7 +199,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=512, help="blobs per step per GPU")
+    ap.add_argument("--batch", type=int, default=4096, help="blobs per step per GPU (round 1: 512; see batch_sweep)")
     ap.add_argument("--fk20-batch", type=int, default=1024)
     ap.add_argument("--fk20-multi-batch", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -299,18 +299,20 @@ def main():
     secs = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, barrier, max_over_ranks)
     value = B * world * args.steps / secs
 
-    # SURVEY.md 8(d) config 2 also names the batch sizes 1, 64 and 1024: the same step at those sizes (secondary figures)
+    # SURVEY.md 8(d) config 2 also names the batch sizes 1, 64 and 1024: the same step at those sizes and at round 1's 512 (secondary
+    # figures; the headline's step is `--batch` blobs: the end of a launch -- block trees, one inversion per blob -- is amortised over more
+    # work the larger the step)
     batch_sweep = {}
     if not args.no_fk20:
-        big = mont_blobs(1 + rank * 1024, 1024)
+        big = mont_blobs(1 + rank * 2048, 2048)
         d_big = torch.from_numpy(big.view(np.int64)).cuda()
-        d_big_out = torch.zeros((1024, 18), dtype=torch.int64, device="cuda")
-        for bs in (1, 64, 1024):
+        d_big_out = torch.zeros((2048, 18), dtype=torch.int64, device="cuda")
+        for bs in (1, 64, 512, 1024, 2048):
             def sweep_step(bs=bs):
                 st = lib.kzg_hip_commit_to_poly_batch_dev(ks.h, d_big.data_ptr(), N_COEFF, bs, d_big_out.data_ptr(), stream)
                 if st:
                     raise RuntimeError("commit_to_poly_batch_dev status %d" % st)
-            reps = 20 if bs < 1024 else 5
+            reps = 20 if bs < 1024 else 8
             ssecs = timed_steps(sweep_step, reps, 2, torch.cuda.synchronize, barrier, max_over_ranks)
             batch_sweep[str(bs)] = {"commitments_per_s": bs * world * reps / ssecs, "ms_per_step": ssecs / reps * 1e3}
         del d_big, d_big_out
@@ -333,10 +335,13 @@ def main():
         alg_bytes = B * BYTES_PER_COMMIT + BYTES_SETUP
         ach = alg_bytes / avg_s * 1e-9
         tab_c, tab_w, tab_bytes = ks.table_info()
-        traffic, pm, pm_ok = None, pmc.get("k_fb_accumulate", pmc), False
-        try:   # HBM bytes per launch from the committed PMC passes (profiles/), only when the workload matches that measurement
-            if pm["kernel"] == "k_" + dominant.decode() and pm["batch"] == B and pm["n"] == N_COEFF and pm["table_c"] == tab_c:
-                traffic = pm["fetch_bytes_per_launch"] + pm["write_bytes_per_launch"]
+        traffic, pm, pm_ok, pm_sc = None, pmc.get("k_fb_accumulate", pmc), False, 1.0
+        try:   # HBM bytes per launch from the committed PMC passes (profiles/), only when the workload matches that measurement; the counter
+            # passes ran 512-blob launches: the work per blob is identical at every batch of 512 and more (one workgroup per blob), so the
+            # per-launch counts scale with the batch (stated in traffic_source)
+            if pm["kernel"] == "k_" + dominant.decode() and pm["n"] == N_COEFF and pm["table_c"] == tab_c and B >= pm["batch"] and B % pm["batch"] == 0:
+                pm_sc = B / pm["batch"]
+                traffic = (pm["fetch_bytes_per_launch"] + pm["write_bytes_per_launch"]) * pm_sc
                 pm_ok = True
         except (KeyError, TypeError):
             pass
@@ -344,7 +349,7 @@ def main():
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_s * 1e3,
                     "algorithmic_bytes_per_launch": alg_bytes,
                     "table": {"window_bits": tab_c, "windows": tab_w, "GB": tab_bytes / 1e9},
-                    "traffic_source": pmc.get("_file") if pm_ok else None,
+                    "traffic_source": (pmc.get("_file") if pm_sc == 1.0 else "%s (counters of the %d-blob launch x %g)" % (pmc.get("_file"), pm["batch"], pm_sc)) if pm_ok else None,
                     "note": "integer-issue-bound kernel (see mac / issue); traffic (PMC passes committed under profiles/) exceeds the algorithmic bytes by design: fixed-base table gathers trade HBM bandwidth for integer work (DESIGN.md 4)"}
 
         if tab_w:
@@ -360,9 +365,10 @@ def main():
                                "note": "peak = kzg_hip_calibrate on this GPU in this run (tools/microbench.hip loops); the guide's SIMD-32 figure "
                                        "(one wave64 VALU instruction per 2 cycles) holds for v_add_u32 / v_mov, the 64-bit multiply-add issues at ~5.3 cycles"}
             if pm_ok and "valu_insts_per_launch" in pm:
-                other = pm["valu_insts_per_launch"] * 64.0 - mads
+                valu = pm["valu_insts_per_launch"] * pm_sc
+                other = valu * 64.0 - mads
                 model_s = mads / cal_mad + max(other, 0.0) / cal_add
-                roofline["issue"] = {"valu_wave_insts_per_launch": pm["valu_insts_per_launch"], "mad_share_of_insts": mads / 64.0 / pm["valu_insts_per_launch"],
+                roofline["issue"] = {"valu_wave_insts_per_launch": valu, "mad_share_of_insts": mads / 64.0 / valu,
                                      "issue_model_ms": model_s * 1e3, "frac_of_launch_explained": model_s / avg_s,
                                      "note": "mads / measured mad rate + other VALU / measured add rate; the rest is dependency / memory stalls at 2 waves per SIMD"}
 
@@ -396,7 +402,8 @@ def main():
             ks.bench_drop_in(host_blobs, 8, 4)
             for T in (1, 8, 64, 256):
                 rate_, outs = ks.bench_drop_in(host_blobs, T, 200 if T == 1 else 60)
-                drop_in["threads"][str(T)] = {"commitments_per_s": rate_, "frac_of_device_resident_batch": rate_ / (value / world)}
+                drop_in["threads"][str(T)] = {"commitments_per_s": rate_, "frac_of_device_resident_batch": rate_ / (value / world),
+                                              "frac_of_512_blob_resident_rate": rate_ / (batch_sweep["512"]["commitments_per_s"] / world)}
             want0 = d_out[(T - 1 + 59) % 64].cpu().numpy().view(np.uint64).reshape(3, 6)      # thread T-1's last call used blob (T-1 + 59) % 64
             drop_in["bit_exact_vs_batched_path"] = bool(np.array_equal(outs[T - 1], want0))
             prate_, _ = ks.bench_drop_in(host_blobs, 64, 40, op=1)
@@ -414,7 +421,8 @@ def main():
                 reps = 10 if bs < 512 else 3
                 lsecs = timed_steps(lc_step, reps, 1, torch.cuda.synchronize, barrier, max_over_ranks)
                 lincomb["batch"][str(bs)] = {"msm_per_s": bs * world * reps / lsecs, "ms_per_step": lsecs / reps * 1e3}
-            lincomb["matches_fixed_base_commitments"] = bool(torch.equal(d_lc_out[:B], d_out[:B])) if B <= 512 else None
+            nchk = min(B, 512)                                   # the last lincomb step used the first 512 blobs
+            lincomb["matches_fixed_base_commitments"] = bool(torch.equal(d_lc_out[:nchk], d_out[:nchk]))
 
             # --- single-call latencies through the host-buffer entry points (ms)
             # median of the timed calls (a one-off ~50 ms host / driver hiccup somewhere in this block was seen to land in one of the ten

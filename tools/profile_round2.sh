@@ -6,8 +6,8 @@ tag=${1:-r02}
 R=$(pwd); out=$R/gpurun_out/prof_$tag; rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 BENCH_FK="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --fk20-multi-batch 0 --fk20-batch 512"   # FK20 step: 512 polynomials
-BENCH_FB="python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-fk20"                               # commitment step only: every launch has 512 blobs
-rocprofv3 --kernel-trace --stats -d $out/trace -o $tag -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --fk20-batch 512 --fk20-multi-batch 256 > $out/trace_bench.json 2> $out/trace_err.txt
+BENCH_FB="python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-fk20 --batch 512"                               # commitment step only: every launch has 512 blobs
+rocprofv3 --kernel-trace --stats -d $out/trace -o $tag -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --batch 512 --fk20-batch 512 --fk20-multi-batch 256 > $out/trace_bench.json 2> $out/trace_err.txt
 db=$(find $out/trace -name "*.db" | head -1)
 python $R/tools/rocprof_summary.py $db $out/kernel_stats.md > /dev/null
 for ctr in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVES; do
