@@ -34,7 +34,8 @@ for k, a in acc.items():
 PY
  done
 done
-cd $R && python bench.py --steps 10 --warmup 3 2>/dev/null | tail -1 > $out/bench_line.json
+# the un-profiled line at the SAME launch shapes as the counter passes (512 blobs / 512 polynomials per step; bench.py's defaults are larger)
+cd $R && python bench.py --steps 10 --warmup 3 --batch 512 --fk20-batch 512 --fk20-multi-batch 256 2>/dev/null | tail -1 > $out/bench_line.json
 rm -rf $out/trace/*/*.db $out/pmc_*/*agent_info.csv $out/pmc_*/*kernel_trace.csv $out/pmc_*/*counter_collection.csv 2>/dev/null
 cat $out/pmc_rows.jsonl
 du -sh $out
