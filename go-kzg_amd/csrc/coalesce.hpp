@@ -10,7 +10,7 @@
 //   leader:         waits until every reserved row is filled, then runs the batch on the buffer's own stream (inputs read from
 //                   pinned memory, batched kernels, one D2H) and wakes the batch's callers.
 //
-// One batch is in flight up to ~96 concurrent callers, up to MAX_EXEC (on separate streams) beyond: the end of a batch (reduction
+// One batch is in flight up to ~48 concurrent callers, up to MAX_EXEC (on separate streams) beyond: the end of a batch (reduction
 // trees, one inversion per polynomial) is latency-bound and uses a fraction of the CUs, so with hundreds of callers the next batch's
 // table walk overlaps it.  The elected leader holds its buffer open for at most `window` microseconds until it has its share
 // (concurrency / batches in flight) of the recent callers; a steady lone caller never waits: nothing is added to its latency.
@@ -36,6 +36,10 @@
 #include <linux/futex.h>
 #include <sys/syscall.h>
 #include <unistd.h>
+
+#ifndef KZG_COALESCE_CALLERS_PER_BATCH
+#define KZG_COALESCE_CALLERS_PER_BATCH 48   // concurrent callers per batch in flight (96 until the small-batch walk got cheaper: 48 measured +2 % at 64 callers, +10 % for proofs)
+#endif
 
 namespace kzg {
 
@@ -147,12 +151,12 @@ class coalescer {
                 const uint64_t decayed = peak_ - (peak_ + 3) / 4;          // rounds up: 3 -> 2 -> 1 -> 0 (a lone caller must end at a target of 1)
                 peak_ = inside_max_ > decayed ? inside_max_ : decayed;
                 inside_max_ = inside_.load(std::memory_order_relaxed);
-                // Batches in flight: ONE up to ~96 concurrent callers (a table walk over fewer than ~50 polynomials leaves lanes idle
+                // Batches in flight: ONE up to ~48 concurrent callers (96 when this was measured) (a table walk over fewer than ~50 polynomials leaves lanes idle
                 // and pays its reduction tree in full, so two half-size walks take 1.3 times one full-size walk: measured 44.6 k/s
                 // against 38.2 k/s with 64 callers), a second and third one beyond, where a batch is large enough to walk
                 // efficiently and the host side of a batch (hundreds of wake-ups and 128 KiB row copies) is worth overlapping
                 // (256 callers: 55.8 k/s with three against 44.0 k/s with one).
-                exec_limit_ = (int)(1 + peak_ / 96);
+                exec_limit_ = (int)(1 + peak_ / KZG_COALESCE_CALLERS_PER_BATCH);
                 if (exec_limit_ > max_exec_) exec_limit_ = max_exec_;
                 uint64_t target = (peak_ + exec_limit_ - 1) / exec_limit_;
                 if (target > max_batch_) target = max_batch_;
