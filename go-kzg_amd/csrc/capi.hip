@@ -409,6 +409,7 @@ struct kzg_hip_points {
     kzg_hip_fft *fs = nullptr;
     uint64_t n = 0;
     g1a *d_tab = nullptr;          // [P_0 .. P_{n-1} | 2^64 P_0 .. 2^64 P_{n-1}], affine, (0, 0) = inf
+    std::unique_ptr<coalescer> co; // concurrent one-MSM calls (bls.LinCombG1 from many goroutines) merge into batched launches
 };
 __global__ __launch_bounds__(128, 2) void k_points_shift64(const g1a *pts, uint64_t n, g1j *out) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
@@ -424,6 +425,7 @@ void kzg_hip_points_free(kzg_hip_points *pts) {
     if (!pts) return;
     hipSetDevice(pts->fs->device);
     hipDeviceSynchronize();
+    pts->co.reset();
     hipFree(pts->d_tab);
     (void)hipGetLastError();
     delete pts;
@@ -454,11 +456,11 @@ int kzg_hip_points_new(kzg_hip_fft *fs, const void *points_g1, uint64_t n, kzg_h
 }
 uint64_t kzg_hip_points_count(const kzg_hip_points *pts) { return pts ? pts->n : 0; }
 // batch MSMs against points[:n]: scalars in rows of n; out = batch normalised Kilic images (device)
-static int lincomb_points_rows(kzg_hip_points *pts, hipStream_t s, const fr *d_sc, uint64_t n, uint64_t batch, g1j *d_out) {
+static int lincomb_points_rows(kzg_hip_points *pts, hipStream_t s, const fr *d_sc, uint64_t n, uint64_t batch, g1j *d_out, uint64_t sc_stride = 0) {
     msm_plan p = classic_plan(pts->n, true);
     dtmp<uint8_t> d_ws(s);
     CHK(d_ws.alloc(msm_workspace_bytes(p, n, batch)));
-    launch_msm(s, p, pts->d_tab, d_sc, n, n, batch, d_ws.p, d_out, true);
+    launch_msm(s, p, pts->d_tab, d_sc, sc_stride ? sc_stride : n, n, batch, d_ws.p, d_out, true);
     HIPCHK(hipGetLastError());
     return KZG_HIP_OK;
 }
@@ -486,7 +488,9 @@ int kzg_hip_lincomb_points_batch(kzg_hip_points *pts, const void *scalars_fr, ui
     HIPCHK(hipStreamSynchronize(s));
     return KZG_HIP_OK;
 }
+static int lincomb_points_coalesced(kzg_hip_points *pts, const void *scalars_fr, uint64_t n, void *out_g1);   // below, with the other coalesced entries
 int kzg_hip_lincomb_points(kzg_hip_points *pts, const void *scalars_fr, uint64_t n, void *out_g1) {
+    if (pts && scalars_fr && out_g1 && n && n <= pts->n) return lincomb_points_coalesced(pts, scalars_fr, n, out_g1);
     return kzg_hip_lincomb_points_batch(pts, scalars_fr, n, 1, out_g1);
 }
 
@@ -840,6 +844,41 @@ int kzg_hip_commit_to_poly(kzg_hip_kzg *ks, const void *coeffs_fr, uint64_t n, v
         return KZG_HIP_OK;
     };
     return co->submit(coeffs_fr, n * sizeof(fr), n, 0, out_g1, sizeof(g1j), exec, KZG_HIP_ERR_HIP);
+    KZG_CATCH
+}
+
+// bls.LinCombG1 on a cached point set, ONE linear combination per call (bls/bls_kilic.go:132-150; what eth.PolynomialToKZGCommitment and
+// CommitToEvalPoly call from many goroutines): concurrent calls on a handle run as one batched bucket MSM.  Uniform rows are read in
+// place from the pinned staging buffer; ragged ones are compacted and zero-filled on the device (a zero scalar adds nothing).
+static int lincomb_points_coalesced(kzg_hip_points *pts, const void *scalars_fr, uint64_t n, void *out_g1) {
+    if (!coalescing_enabled()) return kzg_hip_lincomb_points_batch(pts, scalars_fr, n, 1, out_g1);
+    KZG_TRY
+    coalescer *co = get_coalescer(pts->fs, pts->co, pts->n * sizeof(fr), sizeof(g1j));
+    auto exec = [pts, co](coalesce_buf &b, uint64_t batch) -> int {
+        hipSetDevice(pts->fs->device);
+        hipStream_t s = b.stream;
+        uint64_t n_max = 0;
+        for (uint64_t i = 0; i < batch; i++) n_max = b.h_meta[i].n > n_max ? b.h_meta[i].n : n_max;
+        bool uniform = true;
+        for (uint64_t i = 0; i < batch && uniform; i++) uniform = b.h_meta[i].n == n_max;
+        dtmp<fr> d_rows(s); dtmp<uint64_t> d_meta(s);
+        void *dp_out = nullptr;                                                    // results go straight into the pinned output rows
+        HIPCHK(hipHostGetDevicePointer(&dp_out, b.h_out, 0));
+        const fr *d_src; uint64_t stride;
+        if (uniform) {
+            void *dp = nullptr;
+            HIPCHK(hipHostGetDevicePointer(&dp, b.h_in, 0));
+            d_src = (const fr *)dp; stride = co->in_row_bytes() / sizeof(fr);
+        } else {
+            CHK(d_rows.alloc(batch * n_max)); CHK(d_meta.alloc(2 * batch));
+            CHK(coalesce_upload_rows(b, batch, co->in_row_bytes(), n_max, d_rows.p, d_meta.p));
+            d_src = d_rows.p; stride = n_max;
+        }
+        CHK(lincomb_points_rows(pts, s, d_src, n_max, batch, (g1j *)dp_out, stride));
+        HIPCHK(hipStreamSynchronize(s));
+        return KZG_HIP_OK;
+    };
+    return co->submit(scalars_fr, n * sizeof(fr), n, 0, out_g1, sizeof(g1j), exec, KZG_HIP_ERR_HIP);
     KZG_CATCH
 }
 

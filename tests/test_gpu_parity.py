@@ -314,6 +314,26 @@ def test_lincomb_edge_scalars_and_cached_points(kz, fs16, setup_1337):
     assert comp_hex(got[:1])[0] == DERIVED["F_blob_seed1"]["commit_eth_bitrev_lagrange"]
     assert_points_equal(got[3], ko.lincomb_g1(lag, blobs[3]))
     assert np.array_equal(lag_set.lin_comb(blobs[2]), got[2])
+    # bls.LinCombG1 is ONE linear combination per call: 24 concurrent callers (ragged lengths among them) share batched bucket MSMs
+    import threading
+    lens = [4096 if i % 3 else 4096 - 7 * i - 1 for i in range(24)]
+    want = [lag_set.lin_comb_batch(blobs[i % 4][None, :lens[i]])[0] for i in range(24)]
+    res, errs = [None] * 24, []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                res[i] = lag_set.lin_comb(blobs[i % 4][:lens[i]])
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(24)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs[:2]
+    for i in range(24):
+        assert np.array_equal(res[i], want[i]), i
+    assert_points_equal(res[1], ko.lincomb_g1(lag[:lens[1]], blobs[1][:lens[1]]))
+    assert_points_equal(res[3], ko.lincomb_g1(lag[:lens[3]], blobs[3][:lens[3]]))
     lag_set.close(); fs12.close()
 
 
