@@ -421,6 +421,22 @@ def main():
                 reps = 10 if bs < 512 else 3
                 lsecs = timed_steps(lc_step, reps, 1, torch.cuda.synchronize, barrier, max_over_ranks)
                 lincomb["batch"][str(bs)] = {"msm_per_s": bs * world * reps / lsecs, "ms_per_step": lsecs / reps * 1e3}
+            # one linear combination per call (bls.LinCombG1's shape) from 64 host threads: coalesced into batched bucket MSMs
+            import threading
+            lc_T, lc_per = 64, 30
+            lc_gate = threading.Barrier(lc_T + 1)
+            def lc_worker(i):
+                lc_gate.wait()
+                for r in range(lc_per):
+                    pts.lin_comb(blobs_h[(i + r) % 64])
+            for _ in range(5):
+                pts.lin_comb(blobs_h[0])
+            lc_ths = [threading.Thread(target=lc_worker, args=(i,)) for i in range(lc_T)]
+            [t.start() for t in lc_ths]
+            lc_gate.wait()
+            lc_t0 = time.perf_counter()
+            [t.join() for t in lc_ths]
+            lincomb["one_call_at_a_time_from_64_threads_per_s"] = lc_T * lc_per / (time.perf_counter() - lc_t0)
             nchk = min(B, 512)                                   # the last lincomb step used the first 512 blobs
             lincomb["matches_fixed_base_commitments"] = bool(torch.equal(d_lc_out[:nchk], d_out[:nchk]))
 
