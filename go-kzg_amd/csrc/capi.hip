@@ -9,6 +9,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -97,6 +98,7 @@ struct kzg_hip_kzg {
     hipStream_t copy_stream = nullptr;   // uploads of the host-buffer batch entry point, overlapped with the walk of the previous chunk
     hipEvent_t copy_done[2] = {nullptr, nullptr};
     std::unique_ptr<coalescer> co_commit, co_proof;   // merge concurrent one-polynomial calls into batched launches (coalesce.hpp)
+    std::shared_mutex tab_mu;      // table lifetime: coalesced batches walk d_fixed outside the handle mutex (shared), kzg_hip_kzg_set_table_budget_gb frees it (unique)
 };
 struct fk20_core {
     kzg_hip_kzg *ks = nullptr;
@@ -720,6 +722,7 @@ static int commit_rows(kzg_hip_kzg *ks, hipStream_t s, const fr *d_sc, uint64_t 
 }
 int kzg_hip_kzg_set_table_budget_gb(kzg_hip_kzg *ks, double gb) {
     if (!ks || !(gb >= 0.0)) return KZG_HIP_ERR_BAD_ARG;
+    std::unique_lock<std::shared_mutex> tl(ks->tab_mu);        // waits for coalesced batches that are walking the current table
     dev_guard g(ks->fs);
     if (ks->d_fixed) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(ks->d_fixed)); ks->d_fixed = nullptr; }
     ks->fixed_plan = msm_plan{};
@@ -804,6 +807,7 @@ int kzg_hip_commit_to_poly(kzg_hip_kzg *ks, const void *coeffs_fr, uint64_t n, v
     auto exec = [ks, co](coalesce_buf &b, uint64_t batch) -> int {
         hipSetDevice(ks->fs->device);
         hipStream_t s = b.stream;
+        std::shared_lock<std::shared_mutex> tl(ks->tab_mu);                         // the table stays until this batch has drained
         { dev_guard g(ks->fs); CHK(ensure_fixed_table(ks, s)); }                    // the lazy table build is the only shared mutation
         uint64_t n_max = 0;
         for (uint64_t i = 0; i < batch; i++) n_max = b.h_meta[i].n > n_max ? b.h_meta[i].n : n_max;
@@ -923,6 +927,7 @@ int kzg_hip_compute_proof_single(kzg_hip_kzg *ks, const void *poly_fr, uint64_t 
     auto exec = [ks, co](coalesce_buf &b, uint64_t batch) -> int {
         hipSetDevice(ks->fs->device);
         hipStream_t s = b.stream;
+        std::shared_lock<std::shared_mutex> tl(ks->tab_mu);
         { dev_guard g(ks->fs); CHK(ensure_fixed_table(ks, s)); }
         uint64_t n_max = 0;
         for (uint64_t i = 0; i < batch; i++) n_max = b.h_meta[i].n > n_max ? b.h_meta[i].n : n_max;
@@ -1433,6 +1438,7 @@ int kzg_hip_eth_blob_to_kzg_commitment_batch(kzg_hip_eth *eth, const void *blobs
         auto exec = [eth, n](coalesce_buf &b, uint64_t rows) -> int {
             hipSetDevice(eth->fs->device);
             hipStream_t s = b.stream;
+            std::shared_lock<std::shared_mutex> tl(eth->ks->tab_mu);
             { dev_guard g(eth->fs); CHK(ensure_fixed_table(eth->ks, s)); }
             dtmp<uint8_t> d_c(s); dtmp<fr> d_poly(s); dtmp<g1j> d_out(s); dtmp<uint32_t> d_bad(s);
             CHK(d_c.alloc(rows * 48)); CHK(d_poly.alloc(rows * n)); CHK(d_out.alloc(rows)); CHK(d_bad.alloc(rows));

@@ -852,6 +852,42 @@ def test_coalescer_with_callers_joining_and_leaving(kz, ks4096):
     assert not bad, bad[:5]
 
 
+@pytest.mark.timeout(300)
+def test_table_budget_changes_while_coalesced_commitments_run(kz, setup_1337):
+    """kzg_hip_kzg_set_table_budget_gb frees the fixed-base table; coalesced batches walk it outside the handle mutex.  The table's
+    lifetime lock must make the two safe together: 8 threads keep committing while the budget flips between two table sizes."""
+    import threading
+    fs = kz.FFTSettings(12)
+    ks = kz.KZGSettings(fs, setup_1337)
+    ks.set_table_budget_gb(1.0)
+    blobs = np.stack([ko.synthetic_blob(1500 + i) for i in range(4)])
+    want = ks.commit_to_poly_batch(blobs)
+    stop, bad, errs = threading.Event(), [], []
+
+    def work(i):
+        try:
+            r = 0
+            while not stop.is_set():
+                j = (i + r) % 4
+                if not np.array_equal(ks.commit_to_poly(blobs[j]), want[j]):
+                    bad.append((i, r))
+                r += 1
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    [t.start() for t in ts]
+    try:
+        for k in range(6):
+            ks.set_table_budget_gb(3.0 if k % 2 == 0 else 1.0)
+            assert np.array_equal(ks.commit_to_poly(blobs[0]), want[0])
+    finally:
+        stop.set()
+        [t.join() for t in ts]
+    assert not errs, errs[:2]
+    assert not bad, bad[:5]
+    ks.close(); fs.close()
+
+
 def test_lone_caller_pays_no_gather_window_after_a_burst(kz, ks4096):
     """coalesce.hpp: the gather target of a batch leader follows the recent concurrency and must decay back to ONE caller -- a lone
     caller after a burst of 16 threads would otherwise wait the 150 us window on every call (regression: the decay stalled at 3)."""
