@@ -2,7 +2,9 @@
 """bench.py -- headline benchmark of the commitment / proof hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1: either under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...: RANK /
+    WORLD_SIZE come from the environment), or bare -- `python bench.py --gpus N` with no WORLD_SIZE in the environment starts its own N
+    ranks (one per GPU, torch.distributed.run on 127.0.0.1 with a free port) and prints their ONE JSON line.
 
 Workload (BASELINE.json configs[1]): KZGSettings.CommitToPoly on 4096-coefficient blobs against the 4096-point
 monomial setup of eth/trusted_setup.json (s = 1337; rebuilt from tests/golden/trusted_setup_g1.bin through the
@@ -194,6 +196,39 @@ def cpu_baseline(seconds_budget=6.0):
             "reference_published": "BENCH.md Kilic column, Ryzen 9 5950X, 1 thread: see reference_benchmarks"}
 
 
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run (one process per GPU,
+    rendezvous on 127.0.0.1 with a kernel-chosen port), pass their stderr through, and print exactly ONE line on stdout: rank 0's
+    JSON line.  Anything else a rank or the launcher wrote to stdout goes to stderr.  Returns the exit code for sys.exit."""
+    import signal
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KZG_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("[bench.py] no WORLD_SIZE in the environment: launching %d ranks: %s\n" % (n_ranks, " ".join(cmd)))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, _ = proc.communicate()
+    except BaseException:
+        os.killpg(proc.pid, signal.SIGKILL)                  # the launcher AND its ranks (own session), nothing else
+        proc.wait()
+        raise
+    lines = [l for l in out.splitlines() if l.startswith('{"metric"')]
+    for l in out.splitlines():
+        if not l.startswith('{"metric"'):
+            sys.stderr.write(l + "\n")
+    if proc.returncode != 0 or len(lines) != 1:
+        sys.stderr.write("[bench.py] the %d-rank run ended with exit code %d and %d JSON lines\n" % (n_ranks, proc.returncode, len(lines)))
+        return proc.returncode or 1
+    print(lines[0])
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -209,6 +244,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip table_sweep / drop_in / lincomb / latency (profiling runs)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     rank, world, local = dist_env()
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -220,8 +257,6 @@ def main():
     import torch
     import gokzg_amd as kz
 
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available() or kz.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: the HIP path is the only path")
     local = local % max(1, torch.cuda.device_count())        # (test hook: several ranks on one GPU with KZG_BENCH_BACKEND=gloo)
@@ -295,6 +330,19 @@ def main():
 
     tc_, tw_, tb_ = ks.table_info()   # every rank builds its own table; an allocation failure degrades to a smaller window (capi.hip)
     sys.stderr.write("[rank %d/%d, device %d] commitment table: %d-bit windows x %d, %.1f GB\n" % (rank, world, local, tc_, tw_, tb_ / 1e9))
+    rccl = None
+    if use_dist:
+        # who is in the job: every rank contributes (rank, device index, table window bits, windows, table bytes) through the SAME
+        # collective library the data path would use (one all-gather of 5 x int64); rank 0 reports what it saw
+        mine = torch.tensor([rank, local, tc_, tw_, tb_], dtype=torch.int64, device="cuda")
+        seen = torch.empty((world, 5), dtype=torch.int64, device="cuda")
+        dist.all_gather_into_tensor(seen, mine)
+        seen = seen.cpu().tolist()
+        rccl = {"backend": dist.get_backend(), "library": "RCCL (torch.distributed 'nccl' on ROCm)" if dist.get_backend() == "nccl" else "gloo (test transport: several ranks on one GPU)",
+                "world_size": world, "ranks_seen": [r[0] for r in seen], "devices": [r[1] for r in seen],
+                "self_launched": bool(os.environ.get("KZG_BENCH_SELF_LAUNCHED")),
+                "tables_per_rank": [{"rank": r[0], "window_bits": r[2], "windows": r[3], "GB": r[4] / 1e9} for r in seen],
+                "all_gather_proofs_ms": None, "sharded_one_polynomial_ms": None}
     lib.kzg_hip_prof_reset(fs.h, 0)
     secs = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, barrier, max_over_ranks)
     value = B * world * args.steps / secs
@@ -568,6 +616,8 @@ def main():
                     ok_ = bool(gathered.shape[0] == world * cnt_ and torch.equal(gathered[rank * cnt_:(rank + 1) * cnt_], part))
                     fk20["all_gather_proofs"] = {"ms": gsecs / 5 * 1e3, "bytes_per_rank": int(part.numel() * 8), "ranks": world,
                                                  "GB_s_out_per_rank": part.numel() * 8 * (world - 1) / (gsecs / 5) * 1e-9, "own_slice_intact": ok_}
+                    rccl["all_gather_proofs_ms"] = gsecs / 5 * 1e3
+                    rccl["all_gather_proofs_bytes_per_rank"] = int(part.numel() * 8)
                 except Exception as e:                           # noqa: BLE001
                     fk20["all_gather_proofs"] = {"error": "%s: %s" % (type(e).__name__, e)}
             fk.close()
@@ -621,6 +671,9 @@ def main():
                     ssecs = timed_steps(lambda: mg.da_using_fk20_multi_sharded(be, one, 32768, 4096), 3, 1, torch.cuda.synchronize, barrier, max_over_ranks)
                     fk20m["sharded_one_polynomial"] = {"ms": ssecs / 3 * 1e3, "ranks": world, "matches_unsharded": same,
                                                        "collective": "all_gather of 4096 x 144 B point slices (RCCL)" if use_dist else "none (1 rank)"}
+                    if rccl is not None:
+                        rccl["sharded_one_polynomial_ms"] = ssecs / 3 * 1e3
+                        rccl["sharded_one_polynomial_matches_unsharded"] = same
                 except Exception as e:                           # noqa: BLE001
                     fk20m["sharded_one_polynomial"] = {"error": "%s: %s" % (type(e).__name__, e)}
             fkm.close(); ks16.close(); fs16.close()
@@ -678,7 +731,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "CommitToPoly, 4096-coeff blobs, eth/trusted_setup.json monomial setup (s=1337), %d blobs/step/GPU resident in HBM, fixed-base table budget %g GB (opt-in; library default 64 GB, see table_sweep)" % (B, args.table_gb),
                        "global_batch": B * world, "parallelism": "dp%d (independent blobs, no data-path collective)" % world},
-            "roofline": roofline, "roofline_fk20": roofline_fk20, "cpu_baseline": base, "batch_sweep": batch_sweep, "table_sweep": table_sweep, "drop_in": drop_in,
+            "rccl": rccl, "roofline": roofline, "roofline_fk20": roofline_fk20, "cpu_baseline": base, "batch_sweep": batch_sweep, "table_sweep": table_sweep, "drop_in": drop_in,
             "lincomb": lincomb, "latency": latency, "fk20": fk20, "fk20_multi": fk20m, "reference_benchmarks": ref_benches, "secondary_error": secondary_error,
         }))
     if use_dist:

@@ -128,7 +128,7 @@ def test_timed_steps_world_size_2_gloo():
 
 @pytest.mark.gpu
 def test_bench_two_ranks_under_torch_distributed_run():
-    """bench.py exactly as the driver launches it for N > 1 (python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N),
+    """bench.py under an external launcher for N > 1 (python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N),
     with two ranks on the ONE GPU of the test box: gloo moves the bytes (RCCL refuses two ranks on a device), everything else -- rank
     sharding of the blobs, barrier + max-over-ranks timing, the all-gather of proofs, the sharded FK20Multi with its byte comparison,
     the single JSON line from rank 0 -- is the N > 1 code path.  Small tables so that two ranks fit one device."""
@@ -159,6 +159,62 @@ def test_bench_two_ranks_under_torch_distributed_run():
     assert d["fk20"]["all_gather_proofs"]["ranks"] == 2
     assert d["fk20_multi"]["self_check_byte_pin"] is True
     assert d["fk20_multi"]["sharded_one_polynomial"]["matches_unsharded"] is True, d["fk20_multi"]["sharded_one_polynomial"]
+
+
+@pytest.mark.gpu
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2 ...` with NO launcher around it and no WORLD_SIZE in the environment (the shape of the driver's command
+    line): bench.py starts its own two ranks, and the ONE line on stdout is rank 0's, carrying the `rccl` object (backend, ranks seen
+    through an all-gather, per-rank table shape, the proof all-gather and the sharded polynomial).  Two ranks on the one test GPU, so the
+    transport is gloo (KZG_BENCH_BACKEND); on an N-GPU node the same path runs on RCCL."""
+    import json
+    import signal
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(KZG_BENCH_BACKEND="gloo", KZG_HIP_FK20_FB_BUDGET_GB="3")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "64", "--fk20-batch", "8",
+           "--fk20-multi-batch", "2", "--table-gb", "4"]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = proc.communicate(timeout=600)
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, signal.SIGKILL)
+        out, err = proc.communicate()
+        raise AssertionError("self-launched bench.py did not finish in 600 s: " + err[-2000:])
+    assert proc.returncode == 0, err[-3000:]
+    lines = out.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), out[-2000:]      # stdout is exactly the JSON line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["global_batch"] == 128
+    r = d["rccl"]
+    assert r["backend"] == "gloo" and r["self_launched"] is True and r["world_size"] == 2 and r["ranks_seen"] == [0, 1]
+    assert [t["rank"] for t in r["tables_per_rank"]] == [0, 1] and all(t["windows"] > 0 for t in r["tables_per_rank"])
+    assert r["all_gather_proofs_ms"] > 0 and r["sharded_one_polynomial_ms"] > 0 and r["sharded_one_polynomial_matches_unsharded"] is True
+    assert d["fk20"]["self_check_byte_pin"] is True and d["fk20_multi"]["self_check_byte_pin"] is True
+
+
+def test_self_launch_plumbing_without_a_gpu():
+    """CPU box: `bench.py --gpus 2` still goes through its own launcher; both ranks refuse to run without a gfx950 device (no CPU
+    fallback), the parent reports the failure with a non-zero exit code and prints NO JSON line."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by test_bench_self_launches_its_ranks")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0
+    assert res.stdout.strip() == ""
+    assert "launching 2 ranks" in res.stderr and "needs an MI355X" in res.stderr
+    assert "--nproc-per-node 2" in res.stderr and "127.0.0.1" in res.stderr
+
+
+def test_bench_single_gpu_invocation_does_not_self_launch():
+    """--gpus 1 (the default) never goes through the launcher"""
+    import bench
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'if args.gpus > 1 and "WORLD_SIZE" not in os.environ:' in src
+    assert callable(bench.self_launch)
 
 
 @pytest.mark.gpu
