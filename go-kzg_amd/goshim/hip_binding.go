@@ -5,7 +5,8 @@
 //
 // NOT COMPILED IN THE BUILD IMAGE (it has no Go toolchain); kept paper-thin on purpose: every behaviour is
 // implemented and tested at the C ABI (tests/test_gpu_parity.py).  Drop these files into the go-kzg package
-// directory and build with `-tags kzg_hip`; the four method files they replace carry `//go:build !kzg_hip`
+// directory and build with `-tags kzg_hip` and CGO_CFLAGS=-I<repo>/include CGO_LDFLAGS="-L<repo>/go-kzg_amd
+// -Wl,-rpath,<repo>/go-kzg_amd" (no ${SRCDIR}-relative paths here: the file is meant to be copied); the four method files they replace carry `//go:build !kzg_hip`
 // (see INTEGRATION.md).  The default Kilic backend stays in place for everything else (G2, pairings, per-op
 // bls.* calls, tests), so bls.Fr / bls.G1Point keep their memory images: Fr = [4]uint64 Montgomery,
 // G1Point = [3][6]uint64 Jacobian Montgomery (bls/bignum_kilic.go:21-23, bls/bls_kilic.go:30-35), which is
@@ -13,8 +14,7 @@
 package kzg
 
 /*
-#cgo CFLAGS: -I${SRCDIR}/../../include
-#cgo LDFLAGS: -L${SRCDIR}/.. -lkzg_hip -Wl,-rpath,${SRCDIR}/..
+#cgo LDFLAGS: -lkzg_hip
 #include "kzg_hip.h"
 */
 import "C"
@@ -44,7 +44,9 @@ var (
 )
 
 // CloseHip releases the device side of the settings object now (idempotent; the finalizer does the same at collection).
+// Order: close dependents first (FK20 settings, then KZGSettings, then FFTSettings) -- a kzg handle refers to its fft handle.
 func (fs *FFTSettings) CloseHip() {
+	runtime.SetFinalizer(fs, nil) // hip() sets it again if the object is used after an explicit close
 	hipMu.Lock()
 	h := hipFFT[uintptr(unsafe.Pointer(fs))]
 	delete(hipFFT, uintptr(unsafe.Pointer(fs)))
@@ -54,6 +56,7 @@ func (fs *FFTSettings) CloseHip() {
 	}
 }
 func (ks *KZGSettings) CloseHip() {
+	runtime.SetFinalizer(ks, nil) // hip() sets it again if the object is used after an explicit close
 	hipMu.Lock()
 	h := hipKZG[uintptr(unsafe.Pointer(ks))]
 	delete(hipKZG, uintptr(unsafe.Pointer(ks)))
@@ -63,6 +66,7 @@ func (ks *KZGSettings) CloseHip() {
 	}
 }
 func (fk *FK20SingleSettings) CloseHip() {
+	runtime.SetFinalizer(fk, nil) // hip() sets it again if the object is used after an explicit close
 	hipMu.Lock()
 	h := hipFK20S[uintptr(unsafe.Pointer(fk))]
 	delete(hipFK20S, uintptr(unsafe.Pointer(fk)))
@@ -72,6 +76,7 @@ func (fk *FK20SingleSettings) CloseHip() {
 	}
 }
 func (fk *FK20MultiSettings) CloseHip() {
+	runtime.SetFinalizer(fk, nil) // hip() sets it again if the object is used after an explicit close
 	hipMu.Lock()
 	h := hipFK20M[uintptr(unsafe.Pointer(fk))]
 	delete(hipFK20M, uintptr(unsafe.Pointer(fk)))

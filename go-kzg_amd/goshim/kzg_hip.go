@@ -19,6 +19,7 @@ func unsafePointerG1(p *bls.G1Point) unsafe.Pointer { return unsafe.Pointer(p) }
 
 // CommitToPoly replaces kzg_single_proofs.go:17-19.
 func (ks *KZGSettings) CommitToPoly(coeffs []bls.Fr) *bls.G1Point {
+	defer runtime.KeepAlive(ks) // the finalizer must not free the device handle under a running call
 	out := new(bls.G1Point)
 	hipMust(C.kzg_hip_commit_to_poly(ks.hip(), frPtr(coeffs), C.uint64_t(len(coeffs)), unsafePointerG1(out)))
 	return out
@@ -26,6 +27,7 @@ func (ks *KZGSettings) CommitToPoly(coeffs []bls.Fr) *bls.G1Point {
 
 // CommitToPolyBatch is new API surface: many blobs per launch is what fills 256 CUs.
 func (ks *KZGSettings) CommitToPolyBatch(coeffs [][]bls.Fr) []bls.G1Point {
+	defer runtime.KeepAlive(ks) // the finalizer must not free the device handle under a running call
 	if len(coeffs) == 0 {
 		return nil
 	}
@@ -44,6 +46,7 @@ func (ks *KZGSettings) CommitToPolyBatch(coeffs [][]bls.Fr) []bls.G1Point {
 
 // ComputeProofSingle replaces kzg_single_proofs.go:36-54 (x is a uint64 there too).
 func (ks *KZGSettings) ComputeProofSingle(poly []bls.Fr, x uint64) *bls.G1Point {
+	defer runtime.KeepAlive(ks) // the finalizer must not free the device handle under a running call
 	out := new(bls.G1Point)
 	hipMust(C.kzg_hip_compute_proof_single(ks.hip(), frPtr(poly), C.uint64_t(len(poly)), C.uint64_t(x), unsafePointerG1(out)))
 	return out
@@ -51,6 +54,7 @@ func (ks *KZGSettings) ComputeProofSingle(poly []bls.Fr, x uint64) *bls.G1Point 
 
 // ComputeProofSingleBatch is new API surface (kzg_hip_compute_proof_single_batch): polys[b] evaluated at xs[b].
 func (ks *KZGSettings) ComputeProofSingleBatch(polys [][]bls.Fr, xs []uint64) []bls.G1Point {
+	defer runtime.KeepAlive(ks) // the finalizer must not free the device handle under a running call
 	if len(polys) == 0 {
 		return nil
 	}
@@ -73,6 +77,7 @@ func (ks *KZGSettings) ComputeProofSingleBatch(polys [][]bls.Fr, xs []uint64) []
 // SetTableBudgetGB opts this settings object into a bigger (or smaller) fixed-base commitment table than the 64 GB default;
 // 210 selects the 16-bit-window table (206 GB, 16 additions per coefficient).  Call before the first commitment.
 func (ks *KZGSettings) SetTableBudgetGB(gb float64) {
+	defer runtime.KeepAlive(ks) // the finalizer must not free the device handle under a running call
 	hipMust(C.kzg_hip_kzg_set_table_budget_gb(ks.hip(), C.double(gb)))
 }
 
@@ -81,6 +86,7 @@ func (ks *KZGSettings) SetTableBudgetGB(gb float64) {
 type G1Points struct{ h *C.kzg_hip_points }
 
 func (fs *FFTSettings) NewG1Points(points []bls.G1Point) *G1Points {
+	defer runtime.KeepAlive(fs) // the finalizer must not free the device handle under a running call
 	p := &G1Points{}
 	hipMust(C.kzg_hip_points_new(fs.hip(), g1Ptr(points), C.uint64_t(len(points)), &p.h))
 	runtime.SetFinalizer(p, (*G1Points).Close)
@@ -95,6 +101,7 @@ func (p *G1Points) Close() {
 
 // LinComb == bls.LinCombG1(points[:len(factors)], factors)
 func (p *G1Points) LinComb(factors []bls.Fr) *bls.G1Point {
+	defer runtime.KeepAlive(p) // the finalizer must not free the device handle under a running call
 	out := new(bls.G1Point)
 	hipMust(C.kzg_hip_lincomb_points(p.h, frPtr(factors), C.uint64_t(len(factors)), unsafePointerG1(out)))
 	return out
@@ -104,6 +111,7 @@ func (p *G1Points) LinComb(factors []bls.Fr) *bls.G1Point {
 // would call this instead of json.Unmarshal for SetupG1 / SetupLagrange; SetupG2 stays with encoding/json + Kilic).  Hex decoding
 // happens in the library, decompression and the subgroup check on the device.  Panics like init() does on a malformed document.
 func (fs *FFTSettings) LoadTrustedSetupJSON(text []byte) (setupG1, setupLagrange []bls.G1Point) {
+	defer runtime.KeepAlive(fs) // the finalizer must not free the device handle under a running call
 	if len(text) == 0 {
 		panic("kzg_hip: empty trusted setup")
 	}
@@ -122,6 +130,7 @@ func (fs *FFTSettings) LoadTrustedSetupJSON(text []byte) (setupG1, setupLagrange
 
 // ToeplitzPart2 replaces fk20_single.go:59-77.
 func (ks *KZGSettings) ToeplitzPart2(toeplitzCoeffs []bls.Fr, xExtFFT []bls.G1Point) (hExtFFT []bls.G1Point) {
+	defer runtime.KeepAlive(ks) // the finalizer must not free the device handle under a running call
 	if uint64(len(toeplitzCoeffs)) != uint64(len(xExtFFT)) {
 		panic("expected toeplitz coeffs to match xExtFFT length")
 	}
@@ -132,6 +141,7 @@ func (ks *KZGSettings) ToeplitzPart2(toeplitzCoeffs []bls.Fr, xExtFFT []bls.G1Po
 
 // ToeplitzPart3 replaces fk20_single.go:80-87.
 func (ks *KZGSettings) ToeplitzPart3(hExtFFT []bls.G1Point) []bls.G1Point {
+	defer runtime.KeepAlive(ks) // the finalizer must not free the device handle under a running call
 	out := make([]bls.G1Point, len(hExtFFT)/2)
 	hipMust(C.kzg_hip_toeplitz_part3(ks.hip(), g1Ptr(hExtFFT), C.uint64_t(len(hExtFFT)), g1Ptr(out)))
 	return out
@@ -154,6 +164,7 @@ func (fk *FK20SingleSettings) hip() *C.kzg_hip_fk20s {
 
 // FK20Single replaces fk20_single.go:122-134.
 func (fk *FK20SingleSettings) FK20Single(polynomial []bls.Fr) []bls.G1Point {
+	defer runtime.KeepAlive(fk) // the finalizer must not free the device handle under a running call
 	out := make([]bls.G1Point, len(polynomial))
 	hipMust(C.kzg_hip_fk20_single(fk.hip(), frPtr(polynomial), C.uint64_t(len(polynomial)), g1Ptr(out)))
 	return out
@@ -161,6 +172,7 @@ func (fk *FK20SingleSettings) FK20Single(polynomial []bls.Fr) []bls.G1Point {
 
 // FK20SingleDAOptimized replaces fk20_single.go:139-172.
 func (fk *FK20SingleSettings) FK20SingleDAOptimized(polynomial []bls.Fr) []bls.G1Point {
+	defer runtime.KeepAlive(fk) // the finalizer must not free the device handle under a running call
 	out := make([]bls.G1Point, len(polynomial))
 	hipMust(C.kzg_hip_fk20_single_da_optimized(fk.hip(), frPtr(polynomial), C.uint64_t(len(polynomial)), g1Ptr(out)))
 	return out
@@ -168,6 +180,7 @@ func (fk *FK20SingleSettings) FK20SingleDAOptimized(polynomial []bls.Fr) []bls.G
 
 // DAUsingFK20 replaces fk20_single.go:176-196.
 func (fk *FK20SingleSettings) DAUsingFK20(polynomial []bls.Fr) []bls.G1Point {
+	defer runtime.KeepAlive(fk) // the finalizer must not free the device handle under a running call
 	out := make([]bls.G1Point, 2*len(polynomial))
 	hipMust(C.kzg_hip_da_using_fk20(fk.hip(), frPtr(polynomial), C.uint64_t(len(polynomial)), g1Ptr(out)))
 	return out
@@ -190,6 +203,7 @@ func (fk *FK20MultiSettings) hip() *C.kzg_hip_fk20m {
 
 // FK20Multi replaces fk20_multi.go:25-52.
 func (fk *FK20MultiSettings) FK20Multi(polynomial []bls.Fr) []bls.G1Point {
+	defer runtime.KeepAlive(fk) // the finalizer must not free the device handle under a running call
 	out := make([]bls.G1Point, uint64(len(polynomial))/fk.chunkLen)
 	hipMust(C.kzg_hip_fk20_multi(fk.hip(), frPtr(polynomial), C.uint64_t(len(polynomial)), g1Ptr(out)))
 	return out
@@ -197,6 +211,7 @@ func (fk *FK20MultiSettings) FK20Multi(polynomial []bls.Fr) []bls.G1Point {
 
 // FK20MultiDAOptimized replaces fk20_multi.go:58-109.
 func (fk *FK20MultiSettings) FK20MultiDAOptimized(polynomial []bls.Fr) []bls.G1Point {
+	defer runtime.KeepAlive(fk) // the finalizer must not free the device handle under a running call
 	out := make([]bls.G1Point, uint64(len(polynomial))/fk.chunkLen)
 	hipMust(C.kzg_hip_fk20_multi_da_optimized(fk.hip(), frPtr(polynomial), C.uint64_t(len(polynomial)), g1Ptr(out)))
 	return out
@@ -204,6 +219,7 @@ func (fk *FK20MultiSettings) FK20MultiDAOptimized(polynomial []bls.Fr) []bls.G1P
 
 // DAUsingFK20Multi replaces fk20_multi.go:113-133.
 func (fk *FK20MultiSettings) DAUsingFK20Multi(polynomial []bls.Fr) []bls.G1Point {
+	defer runtime.KeepAlive(fk) // the finalizer must not free the device handle under a running call
 	out := make([]bls.G1Point, 2*uint64(len(polynomial))/fk.chunkLen)
 	hipMust(C.kzg_hip_da_using_fk20_multi(fk.hip(), frPtr(polynomial), C.uint64_t(len(polynomial)), g1Ptr(out)))
 	return out

@@ -47,3 +47,46 @@ def test_product_does_not_touch_the_oracle():
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "koracle" not in txt and "kzg_oracle" not in txt and "pyref" not in txt, os.path.join(dirpath, f)
     assert "oracle" not in open(os.path.join(ROOT, "include", "kzg_hip.h")).read()
+
+
+# ---- a compiled C consumer of the boundary, bound the way cgo would bind it (tests/host/cabi_consumer.c) ----
+def _build_consumer():
+    import subprocess
+    import gokzg_amd
+    bdir = os.path.join(ROOT, "tests", "host", "_build")
+    os.makedirs(bdir, exist_ok=True)
+    exe = os.path.join(bdir, "cabi_consumer")
+    libdir = os.path.dirname(gokzg_amd.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "host", "cabi_consumer.c"), "-L", libdir, "-lkzg_hip", "-Wl,-rpath," + libdir, "-o", exe])
+    return exe
+
+
+def test_header_is_strict_c99(tmp_path):
+    """include/kzg_hip.h on its own, as a cgo preamble would include it"""
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "kzg_hip.h"\nint main(void) { return KZG_HIP_OK; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)])
+
+
+def test_c_consumer_builds_and_refuses_without_a_device():
+    import subprocess
+    import gokzg_amd
+    if gokzg_amd.device_count() > 0:
+        pytest.skip("a GPU is present: test_c_consumer_runs_the_vectors covers it")
+    res = subprocess.run([_build_consumer()], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 77, res.stdout + res.stderr            # 77 = "no device, and the library said so"
+    assert "status 7 (want 7)" in res.stdout
+
+
+@pytest.mark.gpu
+def test_c_consumer_runs_the_vectors():
+    """settings -> vectors A, B, C -> status codes 1..6 -> frees, from a C99 program that links -lkzg_hip"""
+    import subprocess
+    res = subprocess.run([_build_consumer()], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "PASSED: 0 failure(s)" in res.stdout and "FAIL " not in res.stdout
+    for what in ("vector A", "vector B", "vector C: proof 18", "status 1 (want 1)", "status 2 (want 2)", "status 3 (want 3)", "status 4 (want 4)",
+                 "status 5 (want 5)", "status 6 (want 6)"):
+        assert what in res.stdout, what
