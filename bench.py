@@ -335,9 +335,9 @@ def main():
         # who is in the job: every rank contributes (rank, device index, table window bits, windows, table bytes) through the SAME
         # collective library the data path would use (one all-gather of 5 x int64); rank 0 reports what it saw
         mine = torch.tensor([rank, local, tc_, tw_, tb_], dtype=torch.int64, device="cuda")
-        seen = torch.empty((world, 5), dtype=torch.int64, device="cuda")
+        seen = torch.empty(world * 5, dtype=torch.int64, device="cuda")     # flat: gloo's all-gather wants output == world x input, 1-D
         dist.all_gather_into_tensor(seen, mine)
-        seen = seen.cpu().tolist()
+        seen = seen.view(world, 5).cpu().tolist()
         rccl = {"backend": dist.get_backend(), "library": "RCCL (torch.distributed 'nccl' on ROCm)" if dist.get_backend() == "nccl" else "gloo (test transport: several ranks on one GPU)",
                 "world_size": world, "ranks_seen": [r[0] for r in seen], "devices": [r[1] for r in seen],
                 "self_launched": bool(os.environ.get("KZG_BENCH_SELF_LAUNCHED")),
