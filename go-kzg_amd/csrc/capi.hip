@@ -3,6 +3,7 @@
 // There is deliberately NO CPU fallback: without a gfx950 device every constructor returns KZG_HIP_ERR_NO_DEVICE.
 #include "../../include/kzg_hip.h"
 #include "internal.hpp"
+#include "fr_fft4096.hpp"
 #include "coalesce.hpp"
 
 #include <algorithm>
@@ -83,6 +84,7 @@ struct kzg_hip_fft {
     std::vector<fr> h_expanded, h_reversed;
     fr *d_expanded = nullptr, *d_reversed = nullptr;
     fr *d_inv_pow2 = nullptr;   // (2^k)^-1, k = 0..63 (Montgomery)
+    uint32_t *d_tw4096[2] = {nullptr, nullptr};   // twiddle files of the radix-4 4096-point transform, forward / inverse (fr_fft4096.hpp); null below scale 12
     fr *d_glv_expanded = nullptr, *d_glv_reversed = nullptr;   // twiddles as GLV pairs for the G1 FFT (g1_mul_glv)
     int8_t *d_wnaf_expanded = nullptr, *d_wnaf_reversed = nullptr;   // ... and their width-5 NAF digit strings (KZG_WNAF_ROW bytes per twiddle)
     std::mutex mu;
@@ -221,6 +223,14 @@ int kzg_hip_fft_settings_new(int device, unsigned max_scale, kzg_hip_fft **out) 
     for (int i = 1; i < 64; i++) invs[i] = mul(invs[i - 1], half);
     HIPCHK(hipMalloc((void **)&fs->d_inv_pow2, sizeof invs));
     HIPCHK(hipMemcpy(fs->d_inv_pow2, invs, sizeof invs, hipMemcpyHostToDevice));
+    if (fs->W >= fr4::N) {
+        std::vector<uint32_t> tw(fr4::TW_WORDS);
+        for (int dir = 0; dir < 2; dir++) {
+            fr4::build_twiddles(dir ? fs->h_reversed.data() : fs->h_expanded.data(), fs->W, tw.data());
+            HIPCHK(hipMalloc((void **)&fs->d_tw4096[dir], tw.size() * 4));
+            HIPCHK(hipMemcpy(fs->d_tw4096[dir], tw.data(), tw.size() * 4, hipMemcpyHostToDevice));
+        }
+    }
     *out = own.release();
     return KZG_HIP_OK;
     KZG_CATCH
@@ -229,7 +239,7 @@ void kzg_hip_fft_settings_free(kzg_hip_fft *fs) {
     if (!fs) return;
     hipSetDevice(fs->device);
     if (fs->stream) hipStreamSynchronize(fs->stream);
-    hipFree(fs->d_expanded); hipFree(fs->d_reversed); hipFree(fs->d_inv_pow2); hipFree(fs->d_glv_expanded); hipFree(fs->d_glv_reversed); hipFree(fs->d_wnaf_expanded); hipFree(fs->d_wnaf_reversed);
+    hipFree(fs->d_expanded); hipFree(fs->d_reversed); hipFree(fs->d_inv_pow2); hipFree(fs->d_tw4096[0]); hipFree(fs->d_tw4096[1]); hipFree(fs->d_glv_expanded); hipFree(fs->d_glv_reversed); hipFree(fs->d_wnaf_expanded); hipFree(fs->d_wnaf_reversed);
     if (fs->stream) hipStreamDestroy(fs->stream);
     (void)hipGetLastError();
     delete fs;
@@ -243,7 +253,8 @@ int kzg_hip_fft_roots(const kzg_hip_fft *fs, int reversed, void *out_fr) {
 
 // device-side (I)FFT over F_r on resident rows
 static void fr_fft_rows(kzg_hip_fft *fs, hipStream_t s, const fr *d_in, uint64_t in_stride, uint64_t n_in, fr *d_out, uint64_t n, uint64_t batch, int inv) {
-    launch_fr_fft(s, d_in, in_stride, n_in, d_out, n, batch, inv ? fs->d_reversed : fs->d_expanded, fs->W, inv ? fs->d_inv_pow2 + ilog2(n) : nullptr);
+    launch_fr_fft(s, d_in, in_stride, n_in, d_out, n, batch, inv ? fs->d_reversed : fs->d_expanded, fs->W, inv ? fs->d_inv_pow2 + ilog2(n) : nullptr,
+                  fs->d_tw4096[inv ? 1 : 0]);
 }
 
 static int fft_fr_impl(kzg_hip_fft *fs, const void *vals, uint64_t n_in, uint64_t n, uint64_t batch, int inv, void *out) {

@@ -3,6 +3,9 @@
 // poly.go:14-40 of the reference.  Whole transforms of <= 4096 points live in LDS (4096 x 32 B = 128 KiB of
 // the CU's 160 KiB), limb-major so that consecutive lanes hit consecutive banks.
 #include "internal.hpp"
+#include "fr_fft4096.hpp"
+#include <stdlib.h>
+#include <string.h>
 
 namespace kzg {
 
@@ -77,6 +80,30 @@ __global__ __launch_bounds__(1024) void k_fr_fft_tile(const fr *in, uint64_t in_
     }
 }
 
+// 4096-point transform in six radix-4 passes on lazy 29-bit limbs (fr_fft4096.hpp): the hot size (scale-12 FFT, the Toeplitz
+// coefficient transforms of FK20 at scale 12 and of FK20Multi at scale 16 / chunk 16).  One workgroup per transform; 146 KiB of LDS.
+template <bool SCALE>
+__global__ __launch_bounds__(1024) void k_fr_fft4096_r4(const fr *in, uint64_t in_stride, uint64_t n_in, fr *out, const uint32_t *__restrict__ tw,
+                                                        const fr *scale) {
+    extern __shared__ uint32_t smem[];
+    const uint32_t t = threadIdx.x, a = __builtin_amdgcn_readfirstlane(t >> 6), b = t & 63u;
+    const fr *src = in + (uint64_t)blockIdx.x * in_stride;
+    fr *dst = out + (uint64_t)blockIdx.x * fr4::N;
+    fr4::pass_first(t, src, n_in, smem, tw);
+    __syncthreads();
+    fr4::pass_lo<4>(a, b, smem, tw);
+    __syncthreads();
+    fr4::pass_lo<16>(a, b, smem, tw);
+    __syncthreads();
+    fr4::pass_hi<64>(t, smem, tw);
+    __syncthreads();
+    fr4::pass_hi<256>(t, smem, tw);
+    __syncthreads();
+    frl sc = frl_zero();
+    if (SCALE) sc = frl_const_from_kilic(*scale);
+    fr4::pass_last<SCALE>(t, smem, tw, sc, dst);
+}
+
 __global__ void k_fr_bitrev_copy(const fr *in, uint64_t in_stride, uint64_t n_in, fr *out, uint32_t logn, uint64_t total) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= total) return;
@@ -101,9 +128,20 @@ __global__ void k_fr_fft_stage_glob(fr *data, uint32_t logn, uint64_t m, const f
 static uint32_t ilog2(uint64_t v) { uint32_t r = 0; while ((1ull << r) < v) r++; return r; }
 
 void launch_fr_fft(hipStream_t s, const fr *in, uint64_t in_stride, uint64_t n_in, fr *out, uint64_t n, uint64_t batch, const fr *roots,
-                   uint64_t W, const fr *scale) {
+                   uint64_t W, const fr *scale, const uint32_t *tw4096) {
     if (n == 0 || batch == 0) return;
     uint32_t logn = ilog2(n);
+    static const bool radix2_forced = [] { const char *e = getenv("KZG_HIP_FR_FFT"); return e && !strcmp(e, "radix2"); }();   // A/B and test hook
+    if (n == fr4::N && tw4096 && !radix2_forced) {
+        if (scale) {
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fr_fft4096_r4<true>), hipFuncAttributeMaxDynamicSharedMemorySize, fr4::LDS_BYTES);
+            hipLaunchKernelGGL(k_fr_fft4096_r4<true>, dim3((uint32_t)batch), dim3(1024), fr4::LDS_BYTES, s, in, in_stride, n_in, out, tw4096, scale);
+        } else {
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fr_fft4096_r4<false>), hipFuncAttributeMaxDynamicSharedMemorySize, fr4::LDS_BYTES);
+            hipLaunchKernelGGL(k_fr_fft4096_r4<false>, dim3((uint32_t)batch), dim3(1024), fr4::LDS_BYTES, s, in, in_stride, n_in, out, tw4096, scale);
+        }
+        return;
+    }
     if (n <= FR_TILE) {
         uint32_t T = (uint32_t)(n / 2 < 64 ? 64 : (n / 2 > 1024 ? 1024 : n / 2));
         size_t sh = (size_t)n * 32;

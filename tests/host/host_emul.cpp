@@ -3,6 +3,8 @@
 // TEST INFRASTRUCTURE: built by tests/test_host_arith.py into tests/host/_build/, never shipped.
 #include "field.hpp"
 #include "g1.hpp"
+#include "fr_fft4096.hpp"
+#include <vector>
 #include <string.h>
 using namespace kzg;
 // n pseudo-random (and bit-pattern-structured) elements: inv(x) * x == one and inv(x) == inv_fermat(x) on every 16th; returns mismatches
@@ -27,6 +29,40 @@ template <class F> static uint64_t inv_stress(uint64_t n, uint64_t seed) {
 }
 
 extern "C" {
+// the radix-4 4096-point transform of k_fr_fft4096_r4, lane by lane and pass by pass (a barrier between passes == finishing the loop over
+// the lanes): roots = W + 1 Kilic images (expanded or reversed), scale = null or the Kilic image of 1/n.  Also reports the largest raw limb
+// seen in LDS (the header promises < 6 * 2^29).
+uint32_t he_fr_fft4096(const fr *in, uint64_t n_in, fr *out, const fr *roots, uint64_t W, const fr *scale) {
+    std::vector<uint32_t> tw(fr4::TW_WORDS), lds(9 * fr4::NPAD, 0);
+    fr4::build_twiddles(roots, W, tw.data());
+    uint32_t worst = 0;
+    auto scan = [&]() { for (uint32_t v : lds) if (v > worst) worst = v; };
+    for (uint32_t t = 0; t < 1024; t++) fr4::pass_first(t, in, n_in, lds.data(), tw.data());
+    scan();
+    for (uint32_t t = 0; t < 1024; t++) fr4::pass_lo<4>(t >> 6, t & 63, lds.data(), tw.data());
+    scan();
+    for (uint32_t t = 0; t < 1024; t++) fr4::pass_lo<16>(t >> 6, t & 63, lds.data(), tw.data());
+    scan();
+    for (uint32_t t = 0; t < 1024; t++) fr4::pass_hi<64>(t, lds.data(), tw.data());
+    scan();
+    for (uint32_t t = 0; t < 1024; t++) fr4::pass_hi<256>(t, lds.data(), tw.data());
+    scan();
+    frl sc = frl_zero();
+    if (scale) sc = frl_const_from_kilic(*scale);
+    for (uint32_t t = 0; t < 1024; t++) { if (scale) fr4::pass_last<true>(t, lds.data(), tw.data(), sc, out); else fr4::pass_last<false>(t, lds.data(), tw.data(), sc, out); }
+    return worst;
+}
+// frl_canon on x = a + k r (a canonical, k < 63) presented with raw limbs; frl_mul(a, const(b)) canonicalised == mul(a, b)
+void he_frl_canon_of_multiple(fr *o, const fr *a, uint32_t k) {
+    frl x = frl_unpack(*a);
+    for (uint32_t i = 0; i < k; i++) { for (int j = 0; j < 9; j++) x.l[j] += frl_p29(j); if (i % 4 == 3) frl_sweep(x); }   // raw limbs < 6 * 2^29
+    *o = frl_canon(x);
+}
+void he_frl_mul(fr *o, const fr *a, const fr *b, uint32_t k) {   // a presented as a + k r with raw limbs, k <= 5
+    frl x = frl_unpack(*a);
+    for (uint32_t i = 0; i < k; i++) for (int j = 0; j < 9; j++) x.l[j] += frl_p29(j);
+    *o = frl_canon_lt2r(frl_mul(x, frl_const_from_kilic(*b)));
+}
 void he_fr_mul(fr *o, const fr *a, const fr *b) { *o = mul(*a, *b); }
 void he_fr_add(fr *o, const fr *a, const fr *b) { *o = add(*a, *b); }
 void he_fr_sub(fr *o, const fr *a, const fr *b) { *o = sub(*a, *b); }

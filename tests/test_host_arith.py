@@ -18,7 +18,7 @@ OUT = os.path.join(HERE, "host", "_build", "libhost_emul.so")
 def he():
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     inc = os.path.join(ROOT, "go-kzg_amd", "csrc")
-    deps = [SRC, os.path.join(inc, "field.hpp"), os.path.join(inc, "g1.hpp")]
+    deps = [SRC] + [os.path.join(inc, h) for h in ("field.hpp", "g1.hpp", "fr_lazy.hpp", "fr_fft4096.hpp")]
     if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", inc, "-o", OUT, SRC])
     return C.CDLL(OUT)
@@ -308,3 +308,49 @@ def test_glv_split_signed_for_variable_scalars(he):
         assert (s1 * k1 + s2 * k2 * lam - v) % r == 0, hex(v)
         assert k1 <= lam // 2 + 1 and k2 < (1 << 127) and k1 < (1 << 127), hex(v)
         assert (k1 >> 120) < 127 and (k2 >> 120) < 127, hex(v)       # top signed window: raw + carry <= 128, no carry out
+
+
+# ---- lazy 29-bit F_r arithmetic and the radix-4 4096-point transform built on it (fr_lazy.hpp, fr_fft4096.hpp) ----
+def test_frl_mul_and_canon(he):
+    rng = np.random.default_rng(29)
+    a, b = rand_fr(rng, 96), rand_fr(rng, 96)
+    edge = ko.fr_from_ints([0, 1, ko.R_MOD - 1, 2, ko.R_MOD - 2, (1 << 232) - 1, 1 << 232])
+    a[:7], b[7:14] = edge, edge
+    L = ko.lib()
+    he.he_frl_canon_of_multiple.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    he.he_frl_mul.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    for i in range(96):
+        for k in (0, 1, 2, 17, 38, 62):
+            got = ko.fr_empty(1)
+            he.he_frl_canon_of_multiple(p(got), p(a[i]), k)
+            assert np.array_equal(got, a[i:i + 1]), (i, k)
+        want = ko.fr_empty(1)
+        L.ko_fr_mul(p(want), p(a[i]), p(b[i]))
+        for k in (0, 1, 5):
+            got = ko.fr_empty(1)
+            he.he_frl_mul(p(got), p(a[i]), p(b[i]), k)
+            assert np.array_equal(got, want), (i, k)
+
+
+@pytest.mark.parametrize("n_in,inv", [(4096, False), (4096, True), (2048, False), (1, False), (0, False), (4095, True)])
+def test_fr_fft4096_radix4_emulation_matches_oracle(he, n_in, inv):
+    """the passes of k_fr_fft4096_r4 run lane by lane on the host == the oracle's recursive radix-2 FFT (fft_fr.go:30-105), bit for bit;
+    raw limbs in LDS stay below 6 * 2^29"""
+    rng = np.random.default_rng(4096 + n_in + inv)
+    fs = ko.FFTSettings(13)                                   # W = 8192: the twiddle file strides through a wider root table
+    vals = rand_fr(rng, 4096)
+    if n_in >= 8:
+        vals[:3] = ko.fr_from_ints([0, ko.R_MOD - 1, 1])
+    padded = vals.copy()
+    padded[n_in:] = 0
+    want = fs.fft(padded, inv=inv)
+    roots = fs.reverse_roots() if inv else fs.expanded_roots()
+    out = ko.fr_empty(4096)
+    scale = None
+    if inv:
+        scale = ko.fr_from_ints([pow(4096, -1, ko.R_MOD)])
+    he.he_fr_fft4096.restype = C.c_uint32
+    he.he_fr_fft4096.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    worst = he.he_fr_fft4096(p(np.ascontiguousarray(vals[:max(n_in, 1)])), n_in, p(out), p(roots), 8192, p(scale) if inv else None)
+    assert np.array_equal(out, want)
+    assert worst < 6 * 2**29
