@@ -4,6 +4,7 @@
 #include "../../include/kzg_hip.h"
 #include "internal.hpp"
 #include "fr_fft4096.hpp"
+#include "fr_das2048.hpp"
 #include "coalesce.hpp"
 
 #include <algorithm>
@@ -84,6 +85,7 @@ struct kzg_hip_fft {
     std::vector<fr> h_expanded, h_reversed;
     fr *d_expanded = nullptr, *d_reversed = nullptr;
     fr *d_inv_pow2 = nullptr;   // (2^k)^-1, k = 0..63 (Montgomery)
+    uint32_t *d_tw_das2048 = nullptr;              // twiddle file of the lazy-limb DASFFTExtension(2048) (fr_das2048.hpp); null below scale 12
     uint32_t *d_tw4096[2] = {nullptr, nullptr};   // twiddle files of the radix-4 4096-point transform, forward / inverse (fr_fft4096.hpp); null below scale 12
     fr *d_glv_expanded = nullptr, *d_glv_reversed = nullptr;   // twiddles as GLV pairs for the G1 FFT (g1_mul_glv)
     int8_t *d_wnaf_expanded = nullptr, *d_wnaf_reversed = nullptr;   // ... and their width-5 NAF digit strings (KZG_WNAF_ROW bytes per twiddle)
@@ -230,6 +232,10 @@ int kzg_hip_fft_settings_new(int device, unsigned max_scale, kzg_hip_fft **out) 
             HIPCHK(hipMalloc((void **)&fs->d_tw4096[dir], tw.size() * 4));
             HIPCHK(hipMemcpy(fs->d_tw4096[dir], tw.data(), tw.size() * 4, hipMemcpyHostToDevice));
         }
+        std::vector<uint32_t> td(das2k::TW_WORDS);
+        das2k::build_twiddles(fs->h_expanded.data(), fs->h_reversed.data(), fs->W, td.data());
+        HIPCHK(hipMalloc((void **)&fs->d_tw_das2048, td.size() * 4));
+        HIPCHK(hipMemcpy(fs->d_tw_das2048, td.data(), td.size() * 4, hipMemcpyHostToDevice));
     }
     *out = own.release();
     return KZG_HIP_OK;
@@ -239,7 +245,7 @@ void kzg_hip_fft_settings_free(kzg_hip_fft *fs) {
     if (!fs) return;
     hipSetDevice(fs->device);
     if (fs->stream) hipStreamSynchronize(fs->stream);
-    hipFree(fs->d_expanded); hipFree(fs->d_reversed); hipFree(fs->d_inv_pow2); hipFree(fs->d_tw4096[0]); hipFree(fs->d_tw4096[1]); hipFree(fs->d_glv_expanded); hipFree(fs->d_glv_reversed); hipFree(fs->d_wnaf_expanded); hipFree(fs->d_wnaf_reversed);
+    hipFree(fs->d_expanded); hipFree(fs->d_reversed); hipFree(fs->d_inv_pow2); hipFree(fs->d_tw4096[0]); hipFree(fs->d_tw4096[1]); hipFree(fs->d_tw_das2048); hipFree(fs->d_glv_expanded); hipFree(fs->d_glv_reversed); hipFree(fs->d_wnaf_expanded); hipFree(fs->d_wnaf_reversed);
     if (fs->stream) hipStreamDestroy(fs->stream);
     (void)hipGetLastError();
     delete fs;
@@ -357,7 +363,7 @@ int kzg_hip_das_fft_extension_batch(kzg_hip_fft *fs, void *vals_fr, uint64_t n, 
     dtmp<fr> d(s);
     CHK(d.alloc(n * batch));
     HIPCHK(hipMemcpyAsync(d.p, vals_fr, n * batch * sizeof(fr), hipMemcpyHostToDevice, s));
-    launch_das_ext(s, d.p, n, batch, fs->d_expanded, fs->d_reversed, fs->W, fs->d_inv_pow2 + ilog2(n));
+    launch_das_ext(s, d.p, n, batch, fs->d_expanded, fs->d_reversed, fs->W, fs->d_inv_pow2 + ilog2(n), fs->d_tw_das2048);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(vals_fr, d.p, n * batch * sizeof(fr), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -397,7 +403,7 @@ int kzg_hip_das_fft_extension_batch_dev(kzg_hip_fft *fs, void *d_vals_fr, uint64
     if (n < 2 || !is_pow2(n)) return KZG_HIP_ERR_BAD_ARG;
     if (!batch) return KZG_HIP_OK;
     dev_guard g(fs);
-    launch_das_ext((hipStream_t)stream, (fr *)d_vals_fr, n, batch, fs->d_expanded, fs->d_reversed, fs->W, fs->d_inv_pow2 + ilog2(n));
+    launch_das_ext((hipStream_t)stream, (fr *)d_vals_fr, n, batch, fs->d_expanded, fs->d_reversed, fs->W, fs->d_inv_pow2 + ilog2(n), fs->d_tw_das2048);
     HIPCHK(hipGetLastError());
     return KZG_HIP_OK;
 }

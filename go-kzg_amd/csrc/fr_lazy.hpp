@@ -24,9 +24,10 @@ KZG_HD uint32_t frl_p29(int i) {          // r in 9 limbs of 29 bits
     const uint32_t t[9] = {0x00000001u, 0x1ffffff8u, 0x1f96ffbfu, 0x1b4805ffu, 0x1d80553bu, 0x0c0404d0u, 0x1520cce7u, 0x0a6533afu, 0x0073eda7u};
     return t[i];
 }
-// limb i of M r, spread so that every limb but the top is >= 2^29 - 1 (the limbs still sum to M r): a + spread - b has
-// no negative limb when b is normalised (limbs < 2^29) and b < (M - 1) r + (a bit): see frl_sub
-template <int M> KZG_HD uint32_t frl_spread(int i) {
+// limb i of M r, spread so that every limb but the top is >= K (2^29 - 1) (the limbs still sum to M r): a + spread - b has no
+// negative limb when the limbs of b are <= K (2^29 - 1) (K = 1: b normalised; K = 2: b a raw sum of two normalised values) and
+// b < (M - 1) r: see frl_sub
+template <int M, int K = 1> KZG_HD uint32_t frl_spread(int i) {
     uint64_t c = 0; uint32_t v = 0;
 #pragma unroll
     for (int k = 0; k <= 8; k++) {
@@ -35,9 +36,9 @@ template <int M> KZG_HD uint32_t frl_spread(int i) {
         c = (k < 8) ? (t >> 29) : 0;
         if (k == i) v = limb;
     }
-    if (i == 0) return v + (1u << 29);
-    if (i < 8) return v + (1u << 29) - 1u;
-    return v - 1u;
+    if (i == 0) return v + (uint32_t)K * (1u << 29);
+    if (i < 8) return v + (uint32_t)K * ((1u << 29) - 1u);
+    return v - (uint32_t)K;
 }
 
 KZG_HD frl frl_unpack(const fr &a) {      // canonical 8 x 32 -> 9 x 29, normalised
@@ -70,12 +71,12 @@ KZG_HD frl frl_add(const frl &a, const frl &b) {         // raw: limbs add
     for (int i = 0; i < 9; i++) o.l[i] = a.l[i] + b.l[i];
     return o;
 }
-// a - b + M r, raw.  Needs b NORMALISED with b < (M - 1) r + 2^232 (so that its top limb is <= that of the spread); a raw.
-// Limbs grow by < 2^30; the bound grows by M.
-template <int M> KZG_HD frl frl_sub(const frl &a, const frl &b) {
+// a - b + M r, raw.  Needs the limbs of b <= K (2^29 - 1) and b < (M - 1) r (so that its top limb is <= that of the spread); a raw.
+// Limbs grow by < (K + 1) 2^29; the bound grows by M.
+template <int M, int K = 1> KZG_HD frl frl_sub(const frl &a, const frl &b) {
     frl o;
 #pragma unroll
-    for (int i = 0; i < 9; i++) o.l[i] = a.l[i] + frl_spread<M>(i) - b.l[i];
+    for (int i = 0; i < 9; i++) o.l[i] = a.l[i] + frl_spread<M, K>(i) - b.l[i];
     return o;
 }
 // Montgomery product on 29-bit limbs: r = A B / 2^261 mod r, NORMALISED, value < A B / 2^261 + r.
@@ -101,6 +102,22 @@ KZG_HD frl frl_mul(const frl &A, const frl &B) {
 #pragma unroll
     for (int j = 0; j < 8; j++) { uint64_t x = acc[j] + c; o.l[j] = (uint32_t)x & FRL_MASK; c = x >> 29; }
     o.l[8] = (uint32_t)(acc[8] + c);
+    return o;
+}
+// partial reduction: any raw value with bound <= 63 -> normalised, < 1.13 r (same quotient estimate as frl_canon, in limb form)
+KZG_HD frl frl_reduce(const frl &araw) {
+    frl a = araw;
+    frl_sweep(a);
+    const uint32_t q = (uint32_t)(((uint64_t)a.l[8] * 0x235u) >> 32);
+    frl o; uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 9; j++) {                          // a - q r, limb-wise with a lent 2^29 per limb (wraps correctly mod 2^32 at the top)
+        c += (uint64_t)q * frl_p29(j);
+        const uint32_t lend = j == 0 ? (1u << 29) : (j < 8 ? (1u << 29) - 1u : 0u - 1u);
+        o.l[j] = a.l[j] + lend - ((uint32_t)c & FRL_MASK);
+        c >>= 29;
+    }
+    frl_sweep(o);
     return o;
 }
 // 9 x 29 normalised, value < 2^256 -> 8 x 32

@@ -16,8 +16,9 @@ namespace kzg {
 void launch_fr_fft(hipStream_t s, const fr *in, uint64_t in_stride, uint64_t n_in, fr *out, uint64_t n, uint64_t batch,
                    const fr *roots, uint64_t W, const fr *scale, const uint32_t *tw4096 = nullptr);
 // DASFFTExtension (das_extension.go:7-84), in place on batch rows of n values.
+//   tw2048 != nullptr and n == 2048: the lazy-limb kernel with that twiddle file (fr_das2048.hpp, built from the same two tables)
 void launch_das_ext(hipStream_t s, fr *vals, uint64_t n, uint64_t batch, const fr *expanded, const fr *reversed, uint64_t W,
-                    const fr *inv_n);
+                    const fr *inv_n, const uint32_t *tw2048 = nullptr);
 // toeplitzCoeffsStepStrided (fk20_single.go:89-103): out[b][file][0..2k) from poly[b][0..n), optionally scaled.
 void launch_toeplitz_coeffs(hipStream_t s, const fr *poly, uint64_t poly_stride, uint64_t n, uint64_t l, uint64_t batch, fr *out,
                             const fr *scale);

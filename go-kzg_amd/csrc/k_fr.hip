@@ -4,6 +4,7 @@
 // the CU's 160 KiB), limb-major so that consecutive lanes hit consecutive banks.
 #include "internal.hpp"
 #include "fr_fft4096.hpp"
+#include "fr_das2048.hpp"
 #include <stdlib.h>
 #include <string.h>
 
@@ -207,6 +208,34 @@ __global__ __launch_bounds__(1024) void k_das_ext_lds(fr *vals, uint32_t logn, c
     fr sc = *inv_n;
     for (uint32_t i = tid; i < n; i += T) row[i] = mul(v.get(i), sc);
 }
+
+// DASFFTExtension of 2048 values in eleven passes on lazy 29-bit limbs (fr_das2048.hpp); one workgroup of 512 lanes per row, two rows per CU
+__global__ __launch_bounds__(512, 4) void k_das_ext2048_r4(fr *vals, const uint32_t *__restrict__ tw, const fr *inv_n) {
+    extern __shared__ uint32_t smem[];
+    const uint32_t t = threadIdx.x, a = __builtin_amdgcn_readfirstlane(t >> 6), b = t & 63u;
+    fr *row = vals + (uint64_t)blockIdx.x * das2k::N;
+    das2k::pass_down_first(t, row, smem, tw);
+    __syncthreads();
+    das2k::pass_down_wide<128>(t, smem, tw);
+    __syncthreads();
+    das2k::pass_down_wide<32>(t, smem, tw);
+    __syncthreads();
+    das2k::pass_down_narrow<8>(a, b, smem, tw);
+    __syncthreads();
+    das2k::pass_down_narrow<2>(a, b, smem, tw);
+    __syncthreads();
+    das2k::pass_middle(a, b, smem, tw);
+    __syncthreads();
+    das2k::pass_up_narrow<2>(a, b, smem, tw);
+    __syncthreads();
+    das2k::pass_up_narrow<8>(a, b, smem, tw);
+    __syncthreads();
+    das2k::pass_up_wide<32>(t, smem, tw);
+    __syncthreads();
+    das2k::pass_up_wide<128>(t, smem, tw);
+    __syncthreads();
+    das2k::pass_up_last(t, smem, tw, frl_const_from_kilic(*inv_n), row);
+}
 __global__ void k_das_stage_glob(fr *vals, uint32_t logn, uint64_t h, int up, const fr *tbl, uint64_t total) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= total) return;
@@ -219,8 +248,16 @@ __global__ void k_fr_scale(fr *vals, const fr *sc, uint64_t total) {
     if (t >= total) return;
     vals[t] = mul(vals[t], *sc);
 }
-void launch_das_ext(hipStream_t s, fr *vals, uint64_t n, uint64_t batch, const fr *expanded, const fr *reversed, uint64_t W, const fr *inv_n) {
+void launch_das_ext(hipStream_t s, fr *vals, uint64_t n, uint64_t batch, const fr *expanded, const fr *reversed, uint64_t W, const fr *inv_n,
+                    const uint32_t *tw2048) {
     (void)W;
+    if (!n || !batch) return;
+    static const bool radix2_forced = [] { const char *e = getenv("KZG_HIP_FR_FFT"); return e && !strcmp(e, "radix2"); }();
+    if (n == das2k::N && tw2048 && !radix2_forced) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_das_ext2048_r4), hipFuncAttributeMaxDynamicSharedMemorySize, das2k::LDS_BYTES);
+        hipLaunchKernelGGL(k_das_ext2048_r4, dim3((uint32_t)batch), dim3(das2k::THREADS), das2k::LDS_BYTES, s, vals, tw2048, inv_n);
+        return;
+    }
     uint32_t logn = ilog2(n);
     if (n <= FR_TILE) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_das_ext_lds), hipFuncAttributeMaxDynamicSharedMemorySize, FR_TILE * 32);

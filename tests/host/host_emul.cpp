@@ -4,6 +4,7 @@
 #include "field.hpp"
 #include "g1.hpp"
 #include "fr_fft4096.hpp"
+#include "fr_das2048.hpp"
 #include <vector>
 #include <string.h>
 using namespace kzg;
@@ -51,6 +52,42 @@ uint32_t he_fr_fft4096(const fr *in, uint64_t n_in, fr *out, const fr *roots, ui
     if (scale) sc = frl_const_from_kilic(*scale);
     for (uint32_t t = 0; t < 1024; t++) { if (scale) fr4::pass_last<true>(t, lds.data(), tw.data(), sc, out); else fr4::pass_last<false>(t, lds.data(), tw.data(), sc, out); }
     return worst;
+}
+// the eleven passes of k_das_ext2048_r4 lane by lane (in place on vals[2048]); returns the largest raw limb seen in LDS
+uint32_t he_das_ext2048(fr *vals, const fr *expanded, const fr *reversed, uint64_t W, const fr *inv_n) {
+    std::vector<uint32_t> tw(das2k::TW_WORDS), lds(9 * das2k::NPAD, 0);
+    das2k::build_twiddles(expanded, reversed, W, tw.data());
+    uint32_t worst = 0;
+    auto scan = [&]() { for (uint32_t v : lds) if (v > worst) worst = v; };
+    uint32_t *s = lds.data(); const uint32_t *w = tw.data();
+    for (uint32_t t = 0; t < 512; t++) das2k::pass_down_first(t, vals, s, w);
+    scan();
+    for (uint32_t t = 0; t < 512; t++) das2k::pass_down_wide<128>(t, s, w);
+    scan();
+    for (uint32_t t = 0; t < 512; t++) das2k::pass_down_wide<32>(t, s, w);
+    scan();
+    for (uint32_t t = 0; t < 512; t++) das2k::pass_down_narrow<8>(t >> 6, t & 63, s, w);
+    scan();
+    for (uint32_t t = 0; t < 512; t++) das2k::pass_down_narrow<2>(t >> 6, t & 63, s, w);
+    scan();
+    for (uint32_t t = 0; t < 512; t++) das2k::pass_middle(t >> 6, t & 63, s, w);
+    scan();
+    for (uint32_t t = 0; t < 512; t++) das2k::pass_up_narrow<2>(t >> 6, t & 63, s, w);
+    scan();
+    for (uint32_t t = 0; t < 512; t++) das2k::pass_up_narrow<8>(t >> 6, t & 63, s, w);
+    scan();
+    for (uint32_t t = 0; t < 512; t++) das2k::pass_up_wide<32>(t, s, w);
+    scan();
+    for (uint32_t t = 0; t < 512; t++) das2k::pass_up_wide<128>(t, s, w);
+    scan();
+    const frl sc = frl_const_from_kilic(*inv_n);
+    for (uint32_t t = 0; t < 512; t++) das2k::pass_up_last(t, s, w, sc, vals);
+    return worst;
+}
+void he_frl_reduce(fr *o, const fr *a, uint32_t k) {             // frl_reduce(a + k r) is congruent to a and below 2 r
+    frl x = frl_unpack(*a);
+    for (uint32_t i = 0; i < k; i++) { for (int j = 0; j < 9; j++) x.l[j] += frl_p29(j); if (i % 4 == 3) frl_sweep(x); }
+    *o = frl_canon_lt2r(frl_reduce(x));
 }
 // frl_canon on x = a + k r (a canonical, k < 63) presented with raw limbs; frl_mul(a, const(b)) canonicalised == mul(a, b)
 void he_frl_canon_of_multiple(fr *o, const fr *a, uint32_t k) {

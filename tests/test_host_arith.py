@@ -18,7 +18,7 @@ OUT = os.path.join(HERE, "host", "_build", "libhost_emul.so")
 def he():
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     inc = os.path.join(ROOT, "go-kzg_amd", "csrc")
-    deps = [SRC] + [os.path.join(inc, h) for h in ("field.hpp", "g1.hpp", "fr_lazy.hpp", "fr_fft4096.hpp")]
+    deps = [SRC] + [os.path.join(inc, h) for h in ("field.hpp", "g1.hpp", "fr_lazy.hpp", "fr_fft4096.hpp", "fr_das2048.hpp")]
     if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", inc, "-o", OUT, SRC])
     return C.CDLL(OUT)
@@ -319,11 +319,14 @@ def test_frl_mul_and_canon(he):
     L = ko.lib()
     he.he_frl_canon_of_multiple.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     he.he_frl_mul.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    he.he_frl_reduce.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     for i in range(96):
         for k in (0, 1, 2, 17, 38, 62):
             got = ko.fr_empty(1)
             he.he_frl_canon_of_multiple(p(got), p(a[i]), k)
             assert np.array_equal(got, a[i:i + 1]), (i, k)
+            he.he_frl_reduce(p(got), p(a[i]), k)
+            assert np.array_equal(got, a[i:i + 1]), ("reduce", i, k)
         want = ko.fr_empty(1)
         L.ko_fr_mul(p(want), p(a[i]), p(b[i]))
         for k in (0, 1, 5):
@@ -353,4 +356,22 @@ def test_fr_fft4096_radix4_emulation_matches_oracle(he, n_in, inv):
     he.he_fr_fft4096.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     worst = he.he_fr_fft4096(p(np.ascontiguousarray(vals[:max(n_in, 1)])), n_in, p(out), p(roots), 8192, p(scale) if inv else None)
     assert np.array_equal(out, want)
+    assert worst < 6 * 2**29
+
+
+@pytest.mark.parametrize("scale", [12, 13])
+def test_das_ext2048_lazy_emulation_matches_oracle(he, scale):
+    """the passes of k_das_ext2048_r4 on the host == the oracle's recursive dASFFTExtension (das_extension.go:7-84) bit for bit, with the
+    exact-width domain (scale 12) and with a wider one (scale 13: the reference walks the full-width tables without rescaling the indices)"""
+    rng = np.random.default_rng(2048 + scale)
+    fs = ko.FFTSettings(scale)
+    vals = rand_fr(rng, 2048)
+    vals[:3] = ko.fr_from_ints([0, ko.R_MOD - 1, 1])
+    want = fs.das_fft_extension(vals.copy())
+    got = vals.copy()
+    inv_n = ko.fr_from_ints([pow(2048, -1, ko.R_MOD)])
+    he.he_das_ext2048.restype = C.c_uint32
+    he.he_das_ext2048.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    worst = he.he_das_ext2048(p(got), p(fs.expanded_roots()), p(fs.reverse_roots()), 1 << scale, p(inv_n))
+    assert np.array_equal(got, want)
     assert worst < 6 * 2**29
