@@ -104,6 +104,9 @@ def lib():
         "kzg_hip_eth_settings_new": (i32, [vp, vp, u64, pp]), "kzg_hip_eth_settings_free": (None, [vp]),
         "kzg_hip_eth_blob_to_kzg_commitment_batch": (i32, [vp, vp, u64, vp, vp]),
         "kzg_hip_eth_compute_kzg_proof": (i32, [vp, vp, u64, vp, vp, vp]),
+        "kzg_hip_eth_compute_kzg_proof_batch": (i32, [vp, vp, u64, u64, vp, vp, vp, vp]),
+        "kzg_hip_eth_compute_kzg_proof_batch_dev": (i32, [vp, vp, u64, u64, vp, vp, vp, vp, vp]),
+        "kzg_hip_bench_drop_in_eth_proof": (i32, [vp, vp, u64, u64, u32, u32, vp, C.POINTER(C.c_double)]),
         "kzg_hip_zero_poly_via_multiplication": (i32, [vp, vp, u64, u64, vp, vp]),
         "kzg_hip_recover_poly_from_samples": (i32, [vp, vp, vp, u64, vp]),
         "kzg_hip_calibrate": (i32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -566,3 +569,22 @@ class EthSettings:
             raise KzgError(st, "invalid z challenge")
         _chk(st)
         return out, y[0]
+
+    def compute_kzg_proof_batch(self, polynomials, zs):
+        """eth.ComputeKZGProof over rows (kzg_hip_eth_compute_kzg_proof_batch): ((batch, 48) uint8 proofs, (batch, 4) ys, ok flags); ok[b] is False
+        where zs[b] lies in the domain (the reference's "invalid z challenge")"""
+        polys = np.ascontiguousarray(polynomials, dtype=np.uint64).reshape(-1, self.n, 4)
+        zs = np.ascontiguousarray(zs, dtype=np.uint64).reshape(-1, 4)
+        b = polys.shape[0]
+        if zs.shape[0] != b:
+            raise KzgError(ERR_LEN_MISMATCH, "one z per polynomial")
+        out, ys, ok = np.zeros((b, 48), dtype=np.uint8), fr_empty(b), np.zeros(b, dtype=np.uint8)
+        _chk(lib().kzg_hip_eth_compute_kzg_proof_batch(self.h, _p(polys), self.n, b, _p(zs), _p(out), _p(ys), _p(ok)))
+        return out, ys, ok.astype(bool)
+
+    def bench_drop_in_proof(self, polys, threads, calls):
+        """`threads` native host threads x `calls` blocking eth.ComputeKZGProof calls: (calls per second, each thread's last proof)"""
+        polys = np.ascontiguousarray(polys, dtype=np.uint64)
+        out, secs = np.zeros((threads, 48), dtype=np.uint8), C.c_double(0)
+        _chk(lib().kzg_hip_bench_drop_in_eth_proof(self.h, _p(polys), polys.shape[1], polys.shape[0], threads, calls, _p(out), C.byref(secs)))
+        return threads * calls / secs.value, out

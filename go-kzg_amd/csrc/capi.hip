@@ -120,6 +120,13 @@ struct dev_guard {
     explicit dev_guard(kzg_hip_fft *f) : fs(f), lk(f->mu) { hipSetDevice(f->device); }
 };
 
+// coalesced executors enqueue kernels that read and write a batch's PINNED rows in place: whatever way the executor returns (an error
+// status after some kernels were already enqueued included), the stream has drained before the rows are handed back to their callers
+struct drain_on_exit {
+    hipStream_t s;
+    explicit drain_on_exit(hipStream_t st) : s(st) {}
+    ~drain_on_exit() { (void)hipStreamSynchronize(s); }
+};
 // stream-ordered temporary
 template <class T> struct dtmp {
     T *p = nullptr; hipStream_t s;
@@ -824,6 +831,7 @@ int kzg_hip_commit_to_poly(kzg_hip_kzg *ks, const void *coeffs_fr, uint64_t n, v
     auto exec = [ks, co](coalesce_buf &b, uint64_t batch) -> int {
         hipSetDevice(ks->fs->device);
         hipStream_t s = b.stream;
+        drain_on_exit drain(s);
         std::shared_lock<std::shared_mutex> tl(ks->tab_mu);                         // the table stays until this batch has drained
         { dev_guard g(ks->fs); CHK(ensure_fixed_table(ks, s)); }                    // the lazy table build is the only shared mutation
         uint64_t n_max = 0;
@@ -878,6 +886,7 @@ static int lincomb_points_coalesced(kzg_hip_points *pts, const void *scalars_fr,
     auto exec = [pts, co](coalesce_buf &b, uint64_t batch) -> int {
         hipSetDevice(pts->fs->device);
         hipStream_t s = b.stream;
+        drain_on_exit drain(s);
         uint64_t n_max = 0;
         for (uint64_t i = 0; i < batch; i++) n_max = b.h_meta[i].n > n_max ? b.h_meta[i].n : n_max;
         bool uniform = true;
@@ -944,6 +953,7 @@ int kzg_hip_compute_proof_single(kzg_hip_kzg *ks, const void *poly_fr, uint64_t 
     auto exec = [ks, co](coalesce_buf &b, uint64_t batch) -> int {
         hipSetDevice(ks->fs->device);
         hipStream_t s = b.stream;
+        drain_on_exit drain(s);
         std::shared_lock<std::shared_mutex> tl(ks->tab_mu);
         { dev_guard g(ks->fs); CHK(ensure_fixed_table(ks, s)); }
         uint64_t n_max = 0;
@@ -1223,6 +1233,7 @@ static int fk20_da_coalesced(fk20_core *c, const void *poly_fr, uint64_t n, void
     auto exec = [c, co, n, on](coalesce_buf &b, uint64_t batch) -> int {
         hipSetDevice(c->ks->fs->device);
         hipStream_t s = b.stream;
+        drain_on_exit drain(s);
         dtmp<fr> d_poly(s); dtmp<g1j> d_out(s);
         CHK(d_poly.alloc(batch * n)); CHK(d_out.alloc(batch * on));
         HIPCHK(hipMemcpyAsync(d_poly.p, b.h_in, batch * co->in_row_bytes(), hipMemcpyHostToDevice, s));
@@ -1399,6 +1410,7 @@ struct kzg_hip_eth {
     uint64_t n = 0;
     fr *d_domain = nullptr;        // DomainFr: w^bitrev(i) (eth/globals.go:61-66)
     std::unique_ptr<coalescer> co_blob;   // concurrent one-blob BlobToKZGCommitment calls (eth/eth.go:145-151) merge into batched launches
+    std::unique_ptr<coalescer> co_proof;  // concurrent ComputeKZGProof calls (eth/helpers.go:179-203)
 };
 
 int kzg_hip_eth_settings_new(kzg_hip_fft *fs, const void *lagrange_g1, uint64_t n, kzg_hip_eth **out) {
@@ -1436,7 +1448,7 @@ void kzg_hip_eth_settings_free(kzg_hip_eth *eth) {
     if (!eth) return;
     hipSetDevice(eth->fs->device);
     hipDeviceSynchronize();
-    eth->co_blob.reset();
+    eth->co_blob.reset(); eth->co_proof.reset();
     kzg_hip_kzg_settings_free(eth->ks);   // drains the device first
     hipFree(eth->d_domain);
     (void)hipGetLastError();
@@ -1455,6 +1467,7 @@ int kzg_hip_eth_blob_to_kzg_commitment_batch(kzg_hip_eth *eth, const void *blobs
         auto exec = [eth, n](coalesce_buf &b, uint64_t rows) -> int {
             hipSetDevice(eth->fs->device);
             hipStream_t s = b.stream;
+            drain_on_exit drain(s);
             std::shared_lock<std::shared_mutex> tl(eth->ks->tab_mu);
             { dev_guard g(eth->fs); CHK(ensure_fixed_table(eth->ks, s)); }
             dtmp<uint8_t> d_c(s); dtmp<fr> d_poly(s); dtmp<g1j> d_out(s); dtmp<uint32_t> d_bad(s);
@@ -1503,29 +1516,103 @@ int kzg_hip_eth_blob_to_kzg_commitment_batch(kzg_hip_eth *eth, const void *blobs
     return KZG_HIP_OK;
     KZG_CATCH
 }
+// ComputeKZGProof over resident rows (eth/helpers.go:179-203): quotients in evaluation form, their commitment over the Lagrange setup, 48-byte
+// compression.  No host round trip in between: a row whose z lies in the domain gets bad[row] = 1 and a zero quotient.
+static int eth_proof_rows(kzg_hip_eth *eth, hipStream_t s, const fr *d_poly, uint64_t poly_stride, const fr *d_z, uint64_t z_stride, uint64_t batch, uint8_t *d_out48,
+                          fr *d_y, uint32_t *d_bad) {
+    const uint64_t n = eth->n;
+    dtmp<fr> d_q(s); dtmp<g1j> d_out(s);
+    CHK(d_q.alloc(batch * n)); CHK(d_out.alloc(batch));
+    HIPCHK(hipMemsetAsync(d_bad, 0, batch * 4, s));
+    launch_eth_quotient(s, d_poly, poly_stride, eth->d_domain, n, batch, d_z, z_stride, eth->fs->d_inv_pow2 + ilog2(n), d_q.p, d_y, d_bad);
+    CHK(commit_rows(eth->ks, s, d_q.p, n, batch, d_out.p));                      // bls.LinCombG1(kzgSetupLagrange, quotient), eth/helpers.go:199
+    launch_g1_from_kilic(s, d_out.p, batch);
+    launch_g1_compress(s, d_out.p, d_out48, batch);
+    HIPCHK(hipGetLastError());
+    return KZG_HIP_OK;
+}
+int kzg_hip_eth_compute_kzg_proof_batch_dev(kzg_hip_eth *eth, const void *d_polys_fr, uint64_t n, uint64_t batch, const void *d_zs_fr, void *d_out48, void *d_ys_fr,
+                                            void *d_bad_u32, void *stream) {
+    if (!eth || !d_out48 || !d_bad_u32) return KZG_HIP_ERR_BAD_ARG;
+    if (n != eth->n) return KZG_HIP_ERR_LEN_MISMATCH;
+    if (!batch) return KZG_HIP_OK;
+    if (!d_polys_fr || !d_zs_fr) return KZG_HIP_ERR_BAD_ARG;
+    KZG_TRY
+    hipStream_t s = (hipStream_t)stream;
+    std::shared_lock<std::shared_mutex> tl(eth->ks->tab_mu);
+    { dev_guard g(eth->fs); CHK(ensure_fixed_table(eth->ks, s)); }
+    dtmp<fr> d_y(s);
+    fr *yp = (fr *)d_ys_fr;
+    if (!yp) { CHK(d_y.alloc(batch)); yp = d_y.p; }
+    return eth_proof_rows(eth, s, (const fr *)d_polys_fr, n, (const fr *)d_zs_fr, 1, batch, (uint8_t *)d_out48, yp, (uint32_t *)d_bad_u32);
+    KZG_CATCH
+}
+int kzg_hip_eth_compute_kzg_proof_batch(kzg_hip_eth *eth, const void *polys_fr, uint64_t n, uint64_t batch, const void *zs_fr, void *out48, void *ys_fr, uint8_t *ok) {
+    if (!eth || !out48 || !ok) return KZG_HIP_ERR_BAD_ARG;
+    if (n != eth->n) return KZG_HIP_ERR_LEN_MISMATCH;                            // "polynomial has invalid length", eth/helpers.go:186-188
+    if (!batch) return KZG_HIP_OK;
+    if (!polys_fr || !zs_fr) return KZG_HIP_ERR_BAD_ARG;
+    KZG_TRY
+    dev_guard g(eth->fs);
+    hipStream_t s = eth->fs->stream;
+    dtmp<fr> d_poly(s), d_z(s), d_y(s); dtmp<uint8_t> d_c(s); dtmp<uint32_t> d_bad(s);
+    CHK(d_poly.alloc(batch * n)); CHK(d_z.alloc(batch)); CHK(d_y.alloc(batch)); CHK(d_c.alloc(batch * 48)); CHK(d_bad.alloc(batch));
+    HIPCHK(hipMemcpyAsync(d_poly.p, polys_fr, batch * n * sizeof(fr), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_z.p, zs_fr, batch * sizeof(fr), hipMemcpyHostToDevice, s));
+    CHK(ensure_fixed_table(eth->ks, s));
+    CHK(eth_proof_rows(eth, s, d_poly.p, n, d_z.p, 1, batch, d_c.p, d_y.p, d_bad.p));
+    std::vector<uint32_t> bad(batch);
+    HIPCHK(hipMemcpyAsync(bad.data(), d_bad.p, batch * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out48, d_c.p, batch * 48, hipMemcpyDeviceToHost, s));
+    if (ys_fr) HIPCHK(hipMemcpyAsync(ys_fr, d_y.p, batch * sizeof(fr), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (uint64_t b = 0; b < batch; b++) {
+        ok[b] = bad[b] ? 0 : 1;
+        if (bad[b]) { memset((uint8_t *)out48 + 48 * b, 0, 48); if (ys_fr) memset((uint8_t *)ys_fr + 32 * b, 0, 32); }
+    }
+    return KZG_HIP_OK;
+    KZG_CATCH
+}
 int kzg_hip_eth_compute_kzg_proof(kzg_hip_eth *eth, const void *poly_fr, uint64_t n, const void *z_fr, void *out48, void *y_fr) {
     if (!eth || !poly_fr || !z_fr || !out48) return KZG_HIP_ERR_BAD_ARG;
     if (n != eth->n) return KZG_HIP_ERR_LEN_MISMATCH;                            // "polynomial has invalid length", eth/helpers.go:186-188
-    dev_guard g(eth->fs);
-    hipStream_t s = eth->fs->stream;
-    dtmp<fr> d_poly(s), d_q(s), d_z(s); dtmp<g1j> d_out(s); dtmp<uint8_t> d_c(s); dtmp<uint32_t> d_flag(s);
-    CHK(d_poly.alloc(n)); CHK(d_q.alloc(n)); CHK(d_z.alloc(2)); CHK(d_out.alloc(1)); CHK(d_c.alloc(48)); CHK(d_flag.alloc(1));
-    HIPCHK(hipMemsetAsync(d_flag.p, 0, 4, s));
-    HIPCHK(hipMemcpyAsync(d_poly.p, poly_fr, n * sizeof(fr), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(d_z.p, z_fr, sizeof(fr), hipMemcpyHostToDevice, s));
-    launch_eth_quotient(s, d_poly.p, eth->d_domain, n, d_z.p, eth->fs->d_inv_pow2 + ilog2(n), d_q.p, d_z.p + 1, d_flag.p);
-    uint32_t flag = 0;
-    HIPCHK(hipMemcpyAsync(&flag, d_flag.p, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    if (flag) return KZG_HIP_ERR_BAD_ARG;                                        // "invalid z challenge", eth/helpers.go:190-192
-    CHK(commit_rows(eth->ks, s, d_q.p, n, 1, d_out.p));                          // eth/helpers.go:199
-    launch_g1_from_kilic(s, d_out.p, 1);
-    launch_g1_compress(s, d_out.p, d_c.p, 1);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out48, d_c.p, 48, hipMemcpyDeviceToHost, s));
-    if (y_fr) HIPCHK(hipMemcpyAsync(y_fr, d_z.p + 1, sizeof(fr), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    KZG_TRY
+    uint8_t row[128];
+    if (!coalescing_enabled()) {
+        uint8_t ok = 0;
+        CHK(kzg_hip_eth_compute_kzg_proof_batch(eth, poly_fr, n, 1, z_fr, row, row + 48, &ok));
+        if (!ok) return KZG_HIP_ERR_BAD_ARG;
+    } else {
+        // eth.ComputeKZGProof takes ONE polynomial per call: concurrent callers share batched launches.  A request's row is its polynomial
+        // followed by z (read in place from the pinned staging buffer); a result row is 48 proof bytes | y | the "invalid z" flag.
+        coalescer *co = get_coalescer(eth->fs, eth->co_proof, (n + 1) * sizeof(fr), 128);
+        auto exec = [eth, n, co](coalesce_buf &b, uint64_t rows) -> int {
+            hipSetDevice(eth->fs->device);
+            hipStream_t s = b.stream;
+            drain_on_exit drain(s);
+            std::shared_lock<std::shared_mutex> tl(eth->ks->tab_mu);
+            { dev_guard g(eth->fs); CHK(ensure_fixed_table(eth->ks, s)); }
+            dtmp<uint8_t> d_c(s); dtmp<fr> d_y(s); dtmp<uint32_t> d_bad(s);
+            CHK(d_c.alloc(rows * 48)); CHK(d_y.alloc(rows)); CHK(d_bad.alloc(rows));
+            void *dp_in = nullptr;
+            HIPCHK(hipHostGetDevicePointer(&dp_in, b.h_in, 0));
+            const uint64_t stride = co->in_row_bytes() / sizeof(fr);
+            CHK(eth_proof_rows(eth, s, (const fr *)dp_in, stride, (const fr *)dp_in + n, stride, rows, d_c.p, d_y.p, d_bad.p));
+            HIPCHK(hipMemcpy2DAsync(b.h_out, 128, d_c.p, 48, 48, rows, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpy2DAsync(b.h_out + 48, 128, d_y.p, 32, 32, rows, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpy2DAsync(b.h_out + 80, 128, d_bad.p, 4, 4, rows, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            return KZG_HIP_OK;
+        };
+        int st = co->submit(poly_fr, n * sizeof(fr), n, 0, row, 128, exec, KZG_HIP_ERR_HIP, z_fr, sizeof(fr));
+        if (st != KZG_HIP_OK) return st;
+        uint32_t bad; memcpy(&bad, row + 80, 4);
+        if (bad) return KZG_HIP_ERR_BAD_ARG;                                     // "invalid z challenge", eth/helpers.go:190-192
+    }
+    memcpy(out48, row, 48);
+    if (y_fr) memcpy(y_fr, row + 48, sizeof(fr));
     return KZG_HIP_OK;
+    KZG_CATCH
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1639,6 +1726,32 @@ int kzg_hip_bench_drop_in(kzg_hip_kzg *ks, int op, const void *blobs_fr, uint64_
                 const uint8_t *in = (const uint8_t *)blobs_fr + ((uint64_t)(t + c) % nblobs) * n * sizeof(fr);
                 int st = op == 0 ? kzg_hip_commit_to_poly(ks, in, n, (uint8_t *)out_g1 + (size_t)t * sizeof(g1j))
                                  : kzg_hip_compute_proof_single(ks, in, n, 17 + t, (uint8_t *)out_g1 + (size_t)t * sizeof(g1j));
+                if (st) { status[t] = st; break; }
+            }
+        });
+    std::chrono::steady_clock::time_point t0;
+    { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return arrived == threads; }); go = true; t0 = std::chrono::steady_clock::now(); cv.notify_all(); }
+    for (auto &th : ts) th.join();
+    *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (int st : status) if (st) return st;
+    return KZG_HIP_OK;
+    KZG_CATCH
+}
+// the same for eth.ComputeKZGProof (eth/helpers.go:179-203): polys = npolys x n Fr (evaluation form), z = 5 + thread (outside the domain);
+// out: threads x 48 bytes
+int kzg_hip_bench_drop_in_eth_proof(kzg_hip_eth *eth, const void *polys_fr, uint64_t n, uint64_t npolys, unsigned threads, unsigned calls, void *out48, double *seconds) {
+    if (!eth || !polys_fr || !out48 || !seconds || !threads || !calls || !npolys) return KZG_HIP_ERR_BAD_ARG;
+    KZG_TRY
+    std::vector<std::thread> ts;
+    std::vector<int> status(threads, 0);
+    std::mutex mu; std::condition_variable cv; unsigned arrived = 0; bool go = false;
+    for (unsigned t = 0; t < threads; t++)
+        ts.emplace_back([&, t] {
+            const fr z = fr_from_u64(5 + t);
+            { std::unique_lock<std::mutex> lk(mu); arrived++; cv.notify_all(); cv.wait(lk, [&] { return go; }); }
+            for (unsigned c = 0; c < calls; c++) {
+                const uint8_t *in = (const uint8_t *)polys_fr + ((uint64_t)(t + c) % npolys) * n * sizeof(fr);
+                int st = kzg_hip_eth_compute_kzg_proof(eth, in, n, &z, (uint8_t *)out48 + (size_t)t * 48, nullptr);
                 if (st) { status[t] = st; break; }
             }
         });

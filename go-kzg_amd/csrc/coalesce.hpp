@@ -103,7 +103,9 @@ class coalescer {
     // one request: `in` holds in_bytes (<= in_row_bytes), the result (out_bytes <= out_row_bytes) is written to `out`.
     // Wake-ups are targeted: a futex word per buffer for its callers, one condition variable for the (single) gathering leader and
     // one for callers that found every buffer busy.
-    int submit(const void *in, size_t in_bytes, uint64_t n, uint64_t arg, void *out, size_t out_bytes, const exec_fn &exec, int alloc_error_status) {
+    // (in2: an optional second input, copied behind the first one in the request's row -- ComputeKZGProof's z after its polynomial)
+    int submit(const void *in, size_t in_bytes, uint64_t n, uint64_t arg, void *out, size_t out_bytes, const exec_fn &exec, int alloc_error_status,
+               const void *in2 = nullptr, size_t in2_bytes = 0) {
         hipSetDevice(device_);                   // caller threads (goroutine-backed OS threads) start on device 0
         std::unique_lock<std::mutex> lk(mu_);
         const uint64_t in_now0 = inside_.fetch_add(1, std::memory_order_relaxed) + 1;
@@ -135,6 +137,7 @@ class coalescer {
         if (gathering_ == bi && b.rows.size() >= b.target) cv_leader_.notify_all();   // the leader holding this buffer open has its share
         lk.unlock();
         memcpy(b.h_in + row * in_row_, in, in_bytes);                      // parallel across callers
+        if (in2_bytes) memcpy(b.h_in + row * in_row_ + in_bytes, in2, in2_bytes);
         lk.lock();
         b.ready++;
         if (b.state.load(std::memory_order_relaxed) == coalesce_buf::CLOSED && b.ready == b.rows.size()) cv_leader_.notify_all();   // its leader waits for the last row

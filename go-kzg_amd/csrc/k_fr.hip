@@ -413,21 +413,52 @@ void launch_fr_bitrev_gather(hipStream_t s, const fr *in, fr *out, uint64_t n) {
     if (!n) return;
     hipLaunchKernelGGL(k_fr_bitrev_gather, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, in, out, ilog2(n), n);
 }
-// ComputeKZGProof's field part (eth/helpers.go:179-198) with bls.EvaluatePolyInEvaluationForm (bls/globals.go:106-153):
+// ComputeKZGProof's field part (eth/helpers.go:179-198) with bls.EvaluatePolyInEvaluationForm (bls/globals.go:106-153), one workgroup per
+// (polynomial, z) row of a batch:
 //   y = (z^n - 1) / n * sum_i p_i w_i / (z - w_i);   q_i = (p_i - y) / (w_i - z).
-// One workgroup; every lane inverts its own denominators (Fermat), LDS tree for the sum.  flag |= 1 if z is in the domain.
-__global__ __launch_bounds__(1024) void k_eth_quotient(const fr *poly, const fr *domain, uint64_t n, const fr *zp, const fr *inv_n, fr *q, fr *y_out,
-                                                       uint32_t *flag) {
+// Every lane inverts the PRODUCT of its (up to four) denominators once (binary GCD) and unwinds it (Montgomery's trick: the reference's
+// BatchInvModFr, per lane); LDS tree for the sum.  A row whose z is in the domain ("invalid z challenge", :190-192) sets flag[row] and gets
+// a zero quotient (its proof is never looked at) -- no host round trip between this kernel and the commitment of the quotients.
+__global__ __launch_bounds__(1024) void k_eth_quotient(const fr *poly_all, uint64_t poly_stride, const fr *domain, uint64_t n, const fr *z_all, uint64_t z_stride,
+                                                       const fr *inv_n, fr *q_all, fr *y_all, uint32_t *flag_all) {
     __shared__ fr red[1024];
+    __shared__ uint32_t bad;
     const uint32_t tid = threadIdx.x;
-    const fr z = *zp;
+    const uint64_t row = blockIdx.x;
+    const fr *poly = poly_all + row * poly_stride;
+    fr *q = q_all + row * n;
+    const fr z = z_all[row * z_stride];
+    if (tid == 0) bad = 0;
+    __syncthreads();
     fr part = zero<FrP>();
-    for (uint64_t i = tid; i < n; i += 1024) {
-        fr d = sub(z, domain[i]);
-        if (is_zero<FrP>(d)) { atomicOr(flag, 1u); continue; }
-        fr di = inv<FrP>(d);
-        q[i] = di;                                             // stash 1 / (z - w_i)
-        part = add(part, mul(mul(poly[i], domain[i]), di));
+    for (uint64_t base = 0; base < n; base += 4096) {
+        fr d[4], pv[4], pre[4];
+        uint32_t cnt = 0, hit = 0;
+        fr acc = one<FrP>();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint64_t i = base + tid + 1024u * k;
+            if (i < n) {
+                d[k] = sub(z, domain[i]);
+                pv[k] = poly[i];
+                if (is_zero<FrP>(d[k])) { hit = 1; d[k] = one<FrP>(); }
+                pre[k] = acc;
+                acc = mul(acc, d[k]);
+                cnt = k + 1;
+            }
+        }
+        if (hit) atomicOr(&bad, 1u);
+        fr ia = inv<FrP>(acc);
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+            if ((uint32_t)k < cnt) {
+                const uint64_t i = base + tid + 1024u * k;
+                const fr di = mul(ia, pre[k]);                     // 1 / (z - w_i)
+                ia = mul(ia, d[k]);
+                q[i] = di;                                         // stash it; second use below, after y is known
+                part = add(part, mul(mul(pv[k], domain[i]), di));
+            }
+        }
     }
     red[tid] = part;
     __syncthreads();
@@ -437,15 +468,18 @@ __global__ __launch_bounds__(1024) void k_eth_quotient(const fr *poly, const fr 
     }
     fr zn = z;                                                  // z^n, n a power of two
     for (uint64_t m = 1; m < n; m <<= 1) zn = sqr(zn);
-    fr y = mul(mul(red[0], sub(zn, one<FrP>())), *inv_n);
-    if (tid == 0) *y_out = y;
+    const fr y = mul(mul(red[0], sub(zn, one<FrP>())), *inv_n);
+    const bool invalid = bad != 0;
+    if (tid == 0) { y_all[row] = invalid ? zero<FrP>() : y; if (invalid) flag_all[row] = 1u; }
     for (uint64_t i = tid; i < n; i += 1024) {
-        fr di = q[i];
-        q[i] = neg<FrP>(mul(sub(poly[i], y), di));              // (p_i - y) / (w_i - z)
+        const fr di = q[i];
+        q[i] = invalid ? zero<FrP>() : neg<FrP>(mul(sub(poly[i], y), di));   // (p_i - y) / (w_i - z)
     }
 }
-void launch_eth_quotient(hipStream_t s, const fr *poly, const fr *domain, uint64_t n, const fr *z, const fr *inv_n, fr *q, fr *y_out, uint32_t *flag) {
-    hipLaunchKernelGGL(k_eth_quotient, dim3(1), dim3(1024), 0, s, poly, domain, n, z, inv_n, q, y_out, flag);
+void launch_eth_quotient(hipStream_t s, const fr *poly, uint64_t poly_stride, const fr *domain, uint64_t n, uint64_t batch, const fr *z, uint64_t z_stride,
+                         const fr *inv_n, fr *q, fr *y_out, uint32_t *flag) {
+    if (!batch) return;
+    hipLaunchKernelGGL(k_eth_quotient, dim3((uint32_t)batch), dim3(1024), 0, s, poly, poly_stride, domain, n, z, z_stride, inv_n, q, y_out, flag);
 }
 
 // CheckProofMulti's coefficient scaling (kzg_multi_proofs.go:55-66): c_i <- c_i / x^i.  Lane i computes x^-i by

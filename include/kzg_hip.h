@@ -184,6 +184,15 @@ int kzg_hip_eth_blob_to_kzg_commitment_batch(kzg_hip_eth *eth, const void *blobs
 /* ComputeKZGProof (eth/helpers.go:179-203): polynomial in evaluation form (n Fr), z; writes the 48-byte proof and (optionally) y.
  * KZG_HIP_ERR_LEN_MISMATCH: "polynomial has invalid length"; KZG_HIP_ERR_BAD_ARG: "invalid z challenge" (z in the domain). */
 int kzg_hip_eth_compute_kzg_proof(kzg_hip_eth *eth, const void *poly_fr, uint64_t n, const void *z_fr, void *out48, void *y_fr);
+/* (one polynomial per call, like the reference: concurrent calls on a handle are coalesced into batched launches.)
+ * The same over `batch` rows (polys_fr: batch x n Fr, zs_fr: batch Fr): out48[b] / ys_fr[b] (optional) and ok[b] = 1, or ok[b] = 0 with
+ * out48[b] and ys_fr[b] zeroed where zs[b] lies in the domain (the reference's "invalid z challenge" for that row).  One launch chain for
+ * the whole batch, no host round trip between the quotients and their commitment. */
+int kzg_hip_eth_compute_kzg_proof_batch(kzg_hip_eth *eth, const void *polys_fr, uint64_t n, uint64_t batch, const void *zs_fr, void *out48, void *ys_fr, uint8_t *ok);
+/* device-resident form: every pointer is device memory, work is enqueued on `stream`; d_bad_u32[b] != 0 marks an invalid z (that row's
+ * proof bytes are then those of the point at infinity and must be ignored); d_ys_fr may be null */
+int kzg_hip_eth_compute_kzg_proof_batch_dev(kzg_hip_eth *eth, const void *d_polys_fr, uint64_t n, uint64_t batch, const void *d_zs_fr, void *d_out48, void *d_ys_fr,
+                                            void *d_bad_u32, void *stream);
 
 /* ---- erasure recovery ----
  * FFTSettings.ZeroPolyViaMultiplication (zero_poly.go:116-217): vanishing polynomial of the missing indices of a size-`length`
@@ -206,6 +215,9 @@ int kzg_hip_calibrate(kzg_hip_fft *fs, double *mad_per_s, double *add_per_s, dou
  * points (each thread's last result); *seconds = wall time from the common start to the last return */
 int kzg_hip_bench_drop_in(kzg_hip_kzg *ks, int op, const void *blobs_fr, uint64_t n, uint64_t nblobs, unsigned threads, unsigned calls, void *out_g1,
                           double *seconds);
+/* the same for kzg_hip_eth_compute_kzg_proof: thread t evaluates at z = 5 + t; out48 holds `threads` proofs (each thread's last) */
+int kzg_hip_bench_drop_in_eth_proof(kzg_hip_eth *eth, const void *polys_fr, uint64_t n, uint64_t npolys, unsigned threads, unsigned calls, void *out48,
+                                    double *seconds);
 /* shape of the fixed-base table CommitToPoly walks (built lazily by the first commitment): signed window bits c, window count and
  * bytes of HBM; all zero before the first commitment or when the setup is too small for a table (classic bucket path) */
 int kzg_hip_kzg_table_info(kzg_hip_kzg *ks, uint32_t *window_bits, uint32_t *windows, uint64_t *table_bytes);

@@ -91,6 +91,40 @@ def test_fft_fr_matches_oracle(kz, n):
     fs.close()
 
 
+def test_fr_lazy_kernels_4096_and_das2048(kz):
+    """the radix-4 kernels on lazy 29-bit limbs (k_fr_fft4096_r4, k_das_ext2048_r4): padding (n_in < n), both directions, batches with
+    distinct rows, the exact-width domain and a wider one (the twiddle files stride through the settings' own tables), edge values"""
+    rng = np.random.default_rng(4096)
+    for scale in (12, 14):
+        fs, ofs = kz.FFTSettings(scale), ko.FFTSettings(scale)
+        rows = np.stack([rand_fr(rng, 4096) for _ in range(5)])
+        rows[0, :4] = ko.fr_from_ints([0, ko.R_MOD - 1, 1, ko.R_MOD - 2])
+        rows[1] = ko.fr_from_ints([ko.R_MOD - 1] * 4096)
+        rows[2] = 0
+        for inv in (False, True):
+            got = fs.fft_batch(rows, inv=inv)
+            for b in range(5):
+                assert np.array_equal(got[b], ofs.fft(rows[b], inv)), (scale, inv, b)
+        d = rows[:, :2048].copy()
+        gotd = fs.das_fft_extension_batch(d)
+        for b in range(5):
+            assert np.array_equal(gotd[b], ofs.das_fft_extension(rows[b, :2048].copy())), (scale, b)
+        fs.close()
+
+
+def test_fr_radix2_kernels_in_a_fresh_process():
+    """sizes other than 4096 / 2048 (and tiles of longer transforms) still run the radix-2 kernels; at the hot sizes they are re-run in a
+    child process that forces them (KZG_HIP_FR_FFT=radix2), so both families stay pinned to the oracle and the reference's KATs"""
+    import subprocess
+    import sys
+    if os.environ.get("KZG_HIP_FR_FFT") == "radix2":
+        pytest.skip("already the forced child")
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k",
+                          "fft_fr or das or fr_lazy or vector_C or full_das_flow"],
+                         env=dict(os.environ, KZG_HIP_FR_FFT="radix2"), capture_output=True, text=True, timeout=1200)
+    assert res.returncode == 0, res.stdout[-1500:]
+
+
 def test_fft_fr_batch_and_config1_roundtrip(kz):
     # BASELINE config 1: FFT_Fr scale 12 forward + inverse round trip on blob(seed 12)
     fs, ofs = kz.FFTSettings(12), ko.FFTSettings(12)
@@ -760,6 +794,55 @@ def test_eth_blob_to_kzg_commitment_and_compute_kzg_proof(kz):
     assert not errs, errs[:2]
     for i in range(24):
         assert got[i][1] == bool(want_ok[i]) and got[i][0].tobytes() == want[i].tobytes(), i
+    eth.close(); fs.close()
+
+
+def test_eth_compute_kzg_proof_batch_and_concurrent_callers(kz):
+    """kzg_hip_eth_compute_kzg_proof_batch: every row against the formulas of eth/helpers.go:179-203 evaluated with Python integers and
+    the oracle's MSM over the bit-reversed Lagrange setup, incl. a row whose z lies in the domain (per-row "invalid z challenge", the
+    other rows unaffected) and z = 0; then the one-polynomial entry from 20 threads (coalesced) against the batch, the invalid row
+    raising for its caller only"""
+    import threading
+    fs = kz.FFTSettings(12)
+    lag = ko.g1_decompress(np.frombuffer(open(os.path.join(GOLDEN, "trusted_setup_g1_lagrange.bin"), "rb").read(), dtype=np.uint8))
+    eth = kz.EthSettings(fs, lag)
+    R = ko.R_MOD
+    pfs = pyref.FFTSettings(12)
+    dom = [pfs.expanded[pyref.rev_bits(i, 12)] for i in range(4096)]
+    lag_br = ko.reverse_bit_order(lag)
+    polys_i = [ko.fr_to_ints(ko.synthetic_blob(300 + b)) for b in range(5)]
+    zs_i = [0x1234567890abcdef % R, dom[1234], 0, R - 1, 7]              # row 1: z in the domain; row 3: z = -1 = w^(n/2) is in the domain too
+    polys = np.stack([ko.fr_from_ints(p_) for p_ in polys_i])
+    zs = ko.fr_from_ints(zs_i)
+    proofs, ys, ok = eth.compute_kzg_proof_batch(polys, zs)
+    assert list(ok) == [True, False, True, False, True]
+    for b in range(5):
+        if not ok[b]:
+            assert not proofs[b].any() and not ys[b].any()
+            continue
+        coeffs = pfs.fft(pyref.bitrev(polys_i[b]), inv=True)
+        y_ref = pyref.eval_poly(coeffs, zs_i[b])
+        q = [(p_ - y_ref) * pow(w - zs_i[b], -1, R) % R for p_, w in zip(polys_i[b], dom)]
+        assert ko.fr_to_ints(ys[b:b + 1])[0] == y_ref, b
+        assert proofs[b].tobytes().hex() == comp_hex(ko.lincomb_g1(lag_br, ko.fr_from_ints(q)))[0], b
+    # one polynomial per call from 20 threads: rows 0..4 repeated, four callers hold an invalid z
+    got, errs = [None] * 20, [None] * 20
+
+    def work(i):
+        try:
+            for _ in range(3):
+                got[i] = eth.compute_kzg_proof(polys[i % 5], zs[i % 5:i % 5 + 1])
+        except kz.KzgError as e:
+            errs[i] = e
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(20)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for i in range(20):
+        b = i % 5
+        if ok[b]:
+            assert errs[i] is None and got[i][0].tobytes() == proofs[b].tobytes() and np.array_equal(got[i][1], ys[b]), i
+        else:
+            assert errs[i] is not None and "invalid z challenge" in str(errs[i]), i
     eth.close(); fs.close()
 
 
