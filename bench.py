@@ -153,6 +153,36 @@ def _cpu_worker(seconds_budget):
     return n, time.perf_counter() - t0
 
 
+def _port_vs_published():
+    """the oracle port timed on the three transforms the reference PUBLISHES numbers for (BENCH.md, Kilic column, Ryzen 9 5950X, 1 thread),
+    so that a reader can rescale the port's commitments/s: ratio = port time / published time (> 1: the port is slower than Go + Kilic's
+    assembly on that CPU).  FFT over G1 is estimated from the oracle's scalar multiplication: 12 x 2048 butterflies, each one MulG1
+    (fft_g1.go:44-55 multiplies every butterfly) -- timing a whole transform would take a minute of the bench."""
+    from oracle import koracle as ko
+    fs = ko.FFTSettings(12)
+    blob = ko.synthetic_blob(12)
+
+    def per_call(fn, min_s=1.0):
+        fn()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < min_s:
+            fn()
+            n += 1
+        return (time.perf_counter() - t0) / n
+    t_fft = per_call(lambda: fs.fft(blob))
+    half = blob[:2048].copy()
+    t_das = per_call(lambda: fs.das_fft_extension(half.copy()))
+    gen = ko.g1_generator()
+    ks_ = [ko.fr_from_ints([int.from_bytes(os.urandom(32), "little") % R_MOD])[0] for _ in range(8)]
+    it = iter(range(1 << 30))
+    t_mul = per_call(lambda: ko.g1_mul(gen, ks_[next(it) % 8]), 1.5)
+    pub = {"fft_fr_scale12_ns": 1911871, "das_fft_extension_scale12_ns": 1169011, "fft_g1_scale12_ns": 3745748396}
+    mine = {"fft_fr_scale12_ns": t_fft * 1e9, "das_fft_extension_scale12_ns": t_das * 1e9, "fft_g1_scale12_ns": 12 * 2048 * t_mul * 1e9}
+    return {"port_ns": mine, "published_ns": pub, "port_over_published": {k: mine[k] / pub[k] for k in pub},
+            "sources": "BENCH.md:43 (FFT over F_r), :31 (DAS FFT extension), :55 (FFT over G1), scale 12",
+            "mul_g1_port_us": t_mul * 1e6, "fft_g1_is_estimate": "12 x 2048 x MulG1 of the port (additions not counted)"}
+
+
 def cpu_baseline(seconds_budget=6.0):
     """oracle (kind 'port'): Kilic-style bls.LinCombG1 on 4096 points.  `value` = ONE thread (the reference is single-threaded);
     `all_cores` = one blob per core on every host core (the metric is a per-second throughput).  Must run before the
@@ -182,6 +212,10 @@ def cpu_baseline(seconds_budget=6.0):
         except (OSError, subprocess.SubprocessError):
             go_version = "present, `go version` failed"
     n1, dt1 = _cpu_worker(seconds_budget)
+    try:
+        calib = _port_vs_published()
+    except Exception as e:                                  # noqa: BLE001
+        calib = {"error": "%s: %s" % (type(e).__name__, e)}
     t0 = time.perf_counter()
     with mp.get_context("fork").Pool(cores) as pool:
         res = pool.map(_cpu_worker, [seconds_budget] * cores)
@@ -193,7 +227,8 @@ def cpu_baseline(seconds_budget=6.0):
             "all_cores": {"value": sum(r[0] / r[1] for r in res), "unit": "commitments/s", "cores": cores,
                           "sample": "%d x LinCombG1(n=4096), one blob per core on %d processes, %.1f s wall" % (total, cores, wall)},
             "go_toolchain": go_version or "absent (`go`: command not found): the Go/Kilic reference cannot be timed on this host (BASELINE.md 3)",
-            "reference_published": "BENCH.md Kilic column, Ryzen 9 5950X, 1 thread: see reference_benchmarks"}
+            "port_vs_published": calib,
+            "reference_published": "BENCH.md Kilic column, Ryzen 9 5950X, 1 thread: see reference_benchmarks and port_vs_published"}
 
 
 def self_launch(n_ranks):
@@ -438,6 +473,34 @@ def main():
                 tsecs = timed_steps(step, 5, 1, torch.cuda.synchronize, barrier, max_over_ranks)
                 c_, w_, b_ = ks.table_info()
                 table_sweep["%g" % gb] = {"commitments_per_s": B * world * 5 / tsecs, "window_bits": c_, "windows": w_, "table_GB": b_ / 1e9}
+            # --- eth.ComputeKZGProof (eth/helpers.go:179-203) while the monomial settings hold the library-default 64 GB table, so that the
+            # eth settings get their own default table beside it (the co-residence the default budget is chosen for)
+            eth_proof = None
+            try:
+                lag_raw = np.frombuffer(open(os.path.join(ROOT, "tests", "golden", "trusted_setup_g1_lagrange.bin"), "rb").read(), dtype=np.uint8)
+                eth = kz.EthSettings(fs, fs.from_compressed_g1(lag_raw))
+                EB = min(512, B)
+                d_z = torch.from_numpy(fs.fr_from_32(splitmix_blobs_le32(77, 1, EB).reshape(-1, 32))[0].view(np.int64)).cuda()
+                d_p48 = torch.zeros((EB, 48), dtype=torch.uint8, device="cuda")
+                d_bad = torch.zeros(EB, dtype=torch.int32, device="cuda")
+
+                def eth_step():
+                    st = lib.kzg_hip_eth_compute_kzg_proof_batch_dev(eth.h, d_blobs.data_ptr(), N_COEFF, EB, d_z.data_ptr(), d_p48.data_ptr(), None, d_bad.data_ptr(), stream)
+                    if st:
+                        raise RuntimeError("eth_compute_kzg_proof_batch_dev status %d %s" % (st, lib.kzg_hip_last_error().decode()))
+                eth_step()
+                torch.cuda.synchronize()
+                esecs = timed_steps(eth_step, 5, 1, torch.cuda.synchronize, barrier, max_over_ranks)
+                eth.bench_drop_in_proof(blobs_h[:64], 8, 4)
+                erates = {}
+                for T in (1, 8, 64):
+                    erates[str(T)] = eth.bench_drop_in_proof(blobs_h[:64], T, 100 if T == 1 else 40)[0]
+                eth_proof = {"entry": "kzg_hip_eth_compute_kzg_proof (host buffers, blocking, one polynomial per call; coalesced in the library)",
+                             "device_resident_batch_%d_per_s" % EB: EB * 5 / esecs, "invalid_rows_in_batch": int((d_bad != 0).sum().item()),
+                             "threads_per_s": erates, "monomial_table_GB_beside_it": table_sweep["64"]["table_GB"]}
+                eth.close()
+            except Exception as e:                              # noqa: BLE001
+                eth_proof = {"error": "%s: %s" % (type(e).__name__, e)}
             ks.set_table_budget_gb(args.table_gb)
             step()
             torch.cuda.synchronize()
@@ -456,6 +519,7 @@ def main():
             drop_in["bit_exact_vs_batched_path"] = bool(np.array_equal(outs[T - 1], want0))
             prate_, _ = ks.bench_drop_in(host_blobs, 64, 40, op=1)
             drop_in["compute_proof_single_64_threads_per_s"] = prate_
+            drop_in["eth_compute_kzg_proof"] = eth_proof
 
             # --- variable-base bls.LinCombG1 on a cached point set (the seam eth/helpers.go:99,159,199 and CommitToEvalPoly go through)
             pts = kz.G1Points(fs, setup)
