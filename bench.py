@@ -316,7 +316,7 @@ def main():
     golden = os.path.join(ROOT, "tests", "golden")
     pins = json.load(open(os.path.join(golden, "fk20_pins.json")))
     pmc = {}
-    for name in ("r02_pmc.json", "r01_pmc_traffic.json"):   # counters of the committed rocprofv3 passes (tools/profile_round.sh)
+    for name in ("r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):   # counters of the committed rocprofv3 passes (tools/profile_round.sh)
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             pmc["_file"] = "profiles/" + name
@@ -658,7 +658,7 @@ def main():
                                  "frac": alg / kern_s * 1e-9 / HBM_PEAK_GBS, "launches_per_step": int(cnt2.value), "avg_launch_ms": tot2.value / cnt2.value,
                                  "kernel_ms_per_all_proofs": tot2.value / FB, "algorithmic_bytes_per_step": alg,
                                  "traffic": (pf.get("fetch_bytes_per_step", 0) + pf.get("write_bytes_per_step", 0)) * psc if psc else None,
-                                 "traffic_source": ("%s (counters of the %d-polynomial step x %g)" % (pmc.get("_file"), pf["batch"], psc)) if psc else None,
+                                 "traffic_source": ((pmc.get("_file") + " (same launch shape)") if psc == 1 else "%s (counters of the %d-polynomial step x %g)" % (pmc.get("_file"), pf["batch"], psc)) if psc else None,
                                  "share_of_step": kern_s / (fsecs / fsteps), "table_walk_ms_per_step": tot3.value if cnt3.value else None,
                                  "mac": {"mads_per_all_proofs": mads_unit, "achieved_Tmad_s": FB * mads_unit / kern_s * 1e-12, "measured_peak_Tmad_s": cal_mad * 1e-12,
                                          "frac": FB * mads_unit / kern_s / cal_mad},
@@ -775,10 +775,43 @@ def main():
                 if st:
                     raise RuntimeError("fft_g1_batch_dev status %d" % st)
 
+            lib.kzg_hip_prof_reset(fs.h, 1)
             r_fr, r_das, r_g1 = rate(fr_step, FB, 5), rate(das_step, FB, 5), rate(g1_step, GB, 2)
+            torch.cuda.synchronize()
+
+            def fr_roofline(prof_name, pmc_key, kernel, alg_bytes_unit, mads_unit, what):
+                """HBM roofline of an LDS-resident F_r transform kernel (bytes in + bytes out per transform), its multiply-add rate
+                against the v_mad_u64_u32 rate measured in this run, and the committed counter pass of the same launch shape"""
+                t_, c_ = C.c_double(0), C.c_uint64(0)
+                lib.kzg_hip_prof_read(fs.h, prof_name, C.byref(t_), C.byref(c_))
+                if not c_.value:
+                    return None
+                avg = t_.value / c_.value * 1e-3
+                pk = pmc.get(pmc_key, {})
+                same = pk.get("batch") == FB
+                out = {"bound": "hbm", "kernel": kernel, "achieved": FB * alg_bytes_unit / avg * 1e-9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": FB * alg_bytes_unit / avg * 1e-9 / HBM_PEAK_GBS, "avg_launch_ms": avg * 1e3, "launches_timed": int(c_.value), "per_launch": what,
+                       "algorithmic_bytes_per_launch": FB * alg_bytes_unit,
+                       "traffic": (pk["fetch_bytes_per_launch"] + pk["write_bytes_per_launch"]) if same else None,
+                       "traffic_source": (pmc.get("_file") + " (same launch shape; FETCH_SIZE x 2 per the guide's correction for wide coalesced reads)") if same else None,
+                       "mac": {"mads_per_launch": FB * mads_unit, "achieved_Tmad_s": FB * mads_unit / avg * 1e-12, "measured_peak_Tmad_s": cal_mad * 1e-12,
+                               "frac": FB * mads_unit / avg / cal_mad}}
+                if same:
+                    valu = pk["valu_insts_per_launch"]
+                    model = FB * mads_unit / cal_mad + max(valu * 64.0 - FB * mads_unit, 0.0) / cal_add
+                    out["issue"] = {"valu_wave_insts_per_launch": valu, "mad_share_of_insts": FB * mads_unit / 64.0 / valu, "issue_model_ms": model * 1e3,
+                                    "frac_of_launch_explained": model / avg, "lds_bank_conflict_share": pk["lds_bank_conflict"] / max(pk["lds_idx_active"], 1.0),
+                                    "wave_cycles_split": {"active": pk["sq_active_inst_any"] / pk["sq_wave_cycles"], "issue_stall": pk["sq_wait_inst_any"] / pk["sq_wave_cycles"],
+                                                          "parked_waitcnt_or_barrier": pk["sq_wait_any"] / pk["sq_wave_cycles"]}}
+                return out
+            # multiply-adds per transform: 1024 lanes x (21 products of 153 + 4 canonicalisations of 8); per extension: 512 lanes x (46 products of 153)
+            roofline_fft_fr = fr_roofline(b"fr_fft4096", "k_fr_fft4096_r4", "k_fr_fft4096_r4", 2 * 4096 * 32, 1024 * (21 * 153 + 4 * 8), "%d forward transforms of 4096 points" % FB)
+            roofline_das = fr_roofline(b"das_ext2048", "k_das_ext2048_r4", "k_das_ext2048_r4", 2 * 2048 * 32, 512 * (46 * 153 + 5 * 9), "%d extensions of 2048 values" % FB)
+            lib.kzg_hip_prof_reset(fs.h, 0)
             ref_benches = {
                 "fft_fr_scale12_per_s": {"value": r_fr, "reference_published": 1e9 / 1911871, "source": "BENCH.md:43 (Kilic, 5950X, 1 thread)", "batch": FB},
                 "das_fft_extension_scale12_per_s": {"value": r_das, "reference_published": 1e9 / 1169011, "source": "BENCH.md:31", "batch": FB},
+                "roofline_fft_fr": roofline_fft_fr, "roofline_das_ext": roofline_das,
                 "fft_g1_scale12_per_s": {"value": r_g1, "reference_published": 1e9 / 3745748396, "source": "BENCH.md:55", "batch": GB},
             }
 

@@ -134,6 +134,7 @@ void launch_fr_fft(hipStream_t s, const fr *in, uint64_t in_stride, uint64_t n_i
     uint32_t logn = ilog2(n);
     static const bool radix2_forced = [] { const char *e = getenv("KZG_HIP_FR_FFT"); return e && !strcmp(e, "radix2"); }();   // A/B and test hook
     if (n == fr4::N && tw4096 && !radix2_forced) {
+        prof_begin(s, "fr_fft4096");
         if (scale) {
             hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fr_fft4096_r4<true>), hipFuncAttributeMaxDynamicSharedMemorySize, fr4::LDS_BYTES);
             hipLaunchKernelGGL(k_fr_fft4096_r4<true>, dim3((uint32_t)batch), dim3(1024), fr4::LDS_BYTES, s, in, in_stride, n_in, out, tw4096, scale);
@@ -141,6 +142,7 @@ void launch_fr_fft(hipStream_t s, const fr *in, uint64_t in_stride, uint64_t n_i
             hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fr_fft4096_r4<false>), hipFuncAttributeMaxDynamicSharedMemorySize, fr4::LDS_BYTES);
             hipLaunchKernelGGL(k_fr_fft4096_r4<false>, dim3((uint32_t)batch), dim3(1024), fr4::LDS_BYTES, s, in, in_stride, n_in, out, tw4096, scale);
         }
+        prof_end(s, "fr_fft4096");
         return;
     }
     if (n <= FR_TILE) {
@@ -255,7 +257,9 @@ void launch_das_ext(hipStream_t s, fr *vals, uint64_t n, uint64_t batch, const f
     static const bool radix2_forced = [] { const char *e = getenv("KZG_HIP_FR_FFT"); return e && !strcmp(e, "radix2"); }();
     if (n == das2k::N && tw2048 && !radix2_forced) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_das_ext2048_r4), hipFuncAttributeMaxDynamicSharedMemorySize, das2k::LDS_BYTES);
+        prof_begin(s, "das_ext2048");
         hipLaunchKernelGGL(k_das_ext2048_r4, dim3((uint32_t)batch), dim3(das2k::THREADS), das2k::LDS_BYTES, s, vals, tw2048, inv_n);
+        prof_end(s, "das_ext2048");
         return;
     }
     uint32_t logn = ilog2(n);
