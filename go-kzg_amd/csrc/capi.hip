@@ -90,6 +90,7 @@ struct kzg_hip_fft {
     fr *d_glv_expanded = nullptr, *d_glv_reversed = nullptr;   // twiddles as GLV pairs for the G1 FFT (g1_mul_glv)
     int8_t *d_wnaf_expanded = nullptr, *d_wnaf_reversed = nullptr;   // ... and their width-5 NAF digit strings (KZG_WNAF_ROW bytes per twiddle)
     std::mutex mu;
+    std::mutex pool_mu; std::condition_variable pool_cv; std::vector<hipStream_t> pool_idle; int pool_total = 0;   // stream_lease
 };
 struct kzg_hip_kzg {
     kzg_hip_fft *fs = nullptr;
@@ -120,6 +121,36 @@ struct dev_guard {
     explicit dev_guard(kzg_hip_fft *f) : fs(f), lk(f->mu) { hipSetDevice(f->device); }
 };
 
+// selects the handle's device for the calling thread (goroutine-backed OS threads start on device 0); no lock: for entry points that only
+// read the settings' immutable tables and order their work on a caller-supplied stream
+struct dev_select { explicit dev_select(kzg_hip_fft *f) { hipSetDevice(f->device); } };
+// A stream of the handle's pool for one host-buffer call (FFT, FFTG1, DASFFTExtension, uncached LinCombG1, conversions, recovery): these only
+// read immutable settings tables and allocate their temporaries stream-ordered, so calls from different threads need no common lock and no
+// common stream.  Up to POOL_MAX streams per handle, created on demand; further callers wait for one to come back.  If no stream can be
+// created at all the call falls back to the handle's stream under its mutex.
+struct stream_lease {
+    static constexpr int POOL_MAX = 16;
+    kzg_hip_fft *fs; hipStream_t s = nullptr; std::unique_lock<std::mutex> fallback;
+    explicit stream_lease(kzg_hip_fft *f) : fs(f) {
+        hipSetDevice(f->device);
+        std::unique_lock<std::mutex> lk(f->pool_mu);
+        for (;;) {
+            if (!f->pool_idle.empty()) { s = f->pool_idle.back(); f->pool_idle.pop_back(); return; }
+            if (f->pool_total < POOL_MAX) {
+                if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess) { f->pool_total++; return; }
+                (void)hipGetLastError(); s = nullptr;
+                if (f->pool_total == 0) { lk.unlock(); fallback = std::unique_lock<std::mutex>(f->mu); s = f->stream; return; }
+            }
+            f->pool_cv.wait(lk);
+        }
+    }
+    ~stream_lease() {
+        if (fallback.owns_lock()) return;
+        std::lock_guard<std::mutex> lk(fs->pool_mu);
+        fs->pool_idle.push_back(s);
+        fs->pool_cv.notify_one();
+    }
+};
 // coalesced executors enqueue kernels that read and write a batch's PINNED rows in place: whatever way the executor returns (an error
 // status after some kernels were already enqueued included), the stream has drained before the rows are handed back to their callers
 struct drain_on_exit {
@@ -254,6 +285,7 @@ void kzg_hip_fft_settings_free(kzg_hip_fft *fs) {
     if (fs->stream) hipStreamSynchronize(fs->stream);
     hipFree(fs->d_expanded); hipFree(fs->d_reversed); hipFree(fs->d_inv_pow2); hipFree(fs->d_tw4096[0]); hipFree(fs->d_tw4096[1]); hipFree(fs->d_tw_das2048); hipFree(fs->d_glv_expanded); hipFree(fs->d_glv_reversed); hipFree(fs->d_wnaf_expanded); hipFree(fs->d_wnaf_reversed);
     if (fs->stream) hipStreamDestroy(fs->stream);
+    for (hipStream_t ps : fs->pool_idle) { hipStreamSynchronize(ps); hipStreamDestroy(ps); }
     (void)hipGetLastError();
     delete fs;
 }
@@ -271,8 +303,8 @@ static void fr_fft_rows(kzg_hip_fft *fs, hipStream_t s, const fr *d_in, uint64_t
 }
 
 static int fft_fr_impl(kzg_hip_fft *fs, const void *vals, uint64_t n_in, uint64_t n, uint64_t batch, int inv, void *out) {
-    dev_guard g(fs);
-    hipStream_t s = fs->stream;
+    stream_lease lease(fs);     // its own stream: host-buffer calls from many threads run side by side
+    hipStream_t s = lease.s;
     dtmp<fr> d_in(s), d_out(s);
     CHK(d_in.alloc(n_in * batch)); CHK(d_out.alloc(n * batch));
     if (n_in) HIPCHK(hipMemcpyAsync(d_in.p, vals, n_in * batch * sizeof(fr), hipMemcpyHostToDevice, s));
@@ -315,8 +347,7 @@ int kzg_hip_fft_fr_batch(kzg_hip_fft *fs, const void *vals_fr, uint64_t n, uint6
 // 12 ms per transform against 19 ms for the 12 launches of the radix-2 network, which are one scalar-multiplication latency each);
 // 0 = the radix-2 network (larger batches fill the chip per stage).  KZG_HIP_G1_FFT = "direct" / "radix2" forces a path (A/B runs).
 static uint32_t g1_fft_direct_logr(uint64_t n, uint64_t batch) {
-    static int forced = -1;
-    if (forced < 0) { const char *e = getenv("KZG_HIP_G1_FFT"); forced = !e ? 0 : (e[0] == 'd' ? 1 : 2); }
+    static const int forced = [] { const char *e = getenv("KZG_HIP_G1_FFT"); return !e ? 0 : (e[0] == 'd' ? 1 : 2); }();   // (initialised once, thread-safe)
     if (forced) return forced == 1 ? 4u : 0u;
     if (n < 2) return 0;
     if (n * batch <= 8192) return 4;
@@ -345,8 +376,8 @@ int kzg_hip_fft_g1(kzg_hip_fft *fs, const void *vals_g1, uint64_t n, int inv, vo
     if (n > fs->W) return KZG_HIP_ERR_TOO_WIDE;          // fft_g1.go:60-62
     if (!is_pow2(n)) return KZG_HIP_ERR_NOT_POW2;        // fft_g1.go:63-65
     if (n == 0 || !vals_g1 || !out_g1) return KZG_HIP_ERR_BAD_ARG;   // n == 0: the reference divides by zero (fft_g1.go:76)
-    dev_guard g(fs);
-    hipStream_t s = fs->stream;
+    stream_lease lease(fs);     // its own stream: host-buffer calls from many threads run side by side
+    hipStream_t s = lease.s;
     dtmp<g1j> d_in(s), d_data(s);
     CHK(d_in.alloc(n)); CHK(d_data.alloc(n));
     HIPCHK(hipMemcpyAsync(d_in.p, vals_g1, n * sizeof(g1j), hipMemcpyHostToDevice, s));
@@ -365,8 +396,8 @@ int kzg_hip_das_fft_extension_batch(kzg_hip_fft *fs, void *vals_fr, uint64_t n, 
     if (n * 2 > fs->W) return KZG_HIP_ERR_TOO_WIDE;      // panic das_extension.go:72-74
     if (n < 2 || !is_pow2(n)) return KZG_HIP_ERR_BAD_ARG; // "bad usage" das_extension.go:22-24
     if (!batch) return KZG_HIP_OK;
-    dev_guard g(fs);
-    hipStream_t s = fs->stream;
+    stream_lease lease(fs);     // its own stream: host-buffer calls from many threads run side by side
+    hipStream_t s = lease.s;
     dtmp<fr> d(s);
     CHK(d.alloc(n * batch));
     HIPCHK(hipMemcpyAsync(d.p, vals_fr, n * batch * sizeof(fr), hipMemcpyHostToDevice, s));
@@ -382,7 +413,7 @@ int kzg_hip_fft_fr_batch_dev(kzg_hip_fft *fs, const void *d_vals_fr, uint64_t n,
     if (!is_pow2(n)) return KZG_HIP_ERR_NOT_POW2;
     if (n == 0 || batch == 0) return KZG_HIP_OK;
     if (!d_vals_fr || !d_out_fr) return KZG_HIP_ERR_BAD_ARG;
-    dev_guard g(fs);
+    dev_select sel(fs);       // the caller's stream orders the work; settings tables are read-only
     fr_fft_rows(fs, (hipStream_t)stream, (const fr *)d_vals_fr, n, n, (fr *)d_out_fr, n, batch, inv);
     HIPCHK(hipGetLastError());
     return KZG_HIP_OK;
@@ -393,7 +424,7 @@ int kzg_hip_fft_g1_batch_dev(kzg_hip_fft *fs, const void *d_vals_g1, uint64_t n,
     if (!is_pow2(n)) return KZG_HIP_ERR_NOT_POW2;
     if (n == 0 || !d_vals_g1 || !d_out_g1) return KZG_HIP_ERR_BAD_ARG;
     if (!batch) return KZG_HIP_OK;
-    dev_guard g(fs);
+    dev_select sel(fs);       // the caller's stream orders the work; settings tables are read-only
     hipStream_t s = (hipStream_t)stream;
     dtmp<g1j> d_in(s), d_data(s);
     CHK(d_in.alloc(n * batch)); CHK(d_data.alloc(n * batch));
@@ -409,7 +440,7 @@ int kzg_hip_das_fft_extension_batch_dev(kzg_hip_fft *fs, void *d_vals_fr, uint64
     if (n * 2 > fs->W) return KZG_HIP_ERR_TOO_WIDE;
     if (n < 2 || !is_pow2(n)) return KZG_HIP_ERR_BAD_ARG;
     if (!batch) return KZG_HIP_OK;
-    dev_guard g(fs);
+    dev_select sel(fs);       // the caller's stream orders the work; settings tables are read-only
     launch_das_ext((hipStream_t)stream, (fr *)d_vals_fr, n, batch, fs->d_expanded, fs->d_reversed, fs->W, fs->d_inv_pow2 + ilog2(n), fs->d_tw_das2048);
     HIPCHK(hipGetLastError());
     return KZG_HIP_OK;
@@ -484,6 +515,7 @@ uint64_t kzg_hip_points_count(const kzg_hip_points *pts) { return pts ? pts->n :
 // batch MSMs against points[:n]: scalars in rows of n; out = batch normalised Kilic images (device)
 static int lincomb_points_rows(kzg_hip_points *pts, hipStream_t s, const fr *d_sc, uint64_t n, uint64_t batch, g1j *d_out, uint64_t sc_stride = 0) {
     msm_plan p = classic_plan(pts->n, true);
+    if (!msm_index_range_ok(p, n)) return KZG_HIP_ERR_TOO_WIDE;      // the packed bucket entries would wrap
     dtmp<uint8_t> d_ws(s);
     CHK(d_ws.alloc(msm_workspace_bytes(p, n, batch)));
     launch_msm(s, p, pts->d_tab, d_sc, sc_stride ? sc_stride : n, n, batch, d_ws.p, d_out, true);
@@ -504,8 +536,8 @@ int kzg_hip_lincomb_points_batch(kzg_hip_points *pts, const void *scalars_fr, ui
     if (!batch) return KZG_HIP_OK;
     if (n == 0) { for (uint64_t b = 0; b < batch; b++) set_inf_image((uint8_t *)out_g1 + b * sizeof(g1j)); return KZG_HIP_OK; }   // bls/bls_test.go:69-78
     if (!scalars_fr) return KZG_HIP_ERR_BAD_ARG;
-    dev_guard g(pts->fs);
-    hipStream_t s = pts->fs->stream;
+    stream_lease lease(pts->fs);     // its own stream: host-buffer calls from many threads run side by side
+    hipStream_t s = lease.s;
     dtmp<fr> d_sc(s); dtmp<g1j> d_out(s);
     CHK(d_sc.alloc(n * batch)); CHK(d_out.alloc(batch));
     HIPCHK(hipMemcpyAsync(d_sc.p, scalars_fr, n * batch * sizeof(fr), hipMemcpyHostToDevice, s));
@@ -524,9 +556,10 @@ int kzg_hip_lincomb_g1(kzg_hip_fft *fs, const void *points_g1, const void *scala
     if (!fs || !out_g1) return KZG_HIP_ERR_BAD_ARG;
     if (n == 0) { set_inf_image(out_g1); return KZG_HIP_OK; }   // bls/bls_test.go:69-78
     if (!points_g1 || !scalars_fr) return KZG_HIP_ERR_BAD_ARG;
-    dev_guard g(fs);
-    hipStream_t s = fs->stream;
+    stream_lease lease(fs);     // its own stream: host-buffer calls from many threads run side by side
+    hipStream_t s = lease.s;
     msm_plan p = classic_plan(n);                               // one-shot points: no 2^64 rows (computing them costs the 64 doublings they save)
+    if (!msm_index_range_ok(p, n)) return KZG_HIP_ERR_TOO_WIDE;
     dtmp<g1j> d_pts(s), d_out(s); dtmp<g1a> d_tab(s); dtmp<fr> d_sc(s); dtmp<uint8_t> d_ws(s);
     CHK(d_pts.alloc(n)); CHK(d_out.alloc(1)); CHK(d_tab.alloc(n)); CHK(d_sc.alloc(n)); CHK(d_ws.alloc(msm_workspace_bytes(p, n, 1)));
     HIPCHK(hipMemcpyAsync(d_pts.p, points_g1, n * sizeof(g1j), hipMemcpyHostToDevice, s));
@@ -544,8 +577,8 @@ int kzg_hip_fr_from_le32(kzg_hip_fft *fs, const void *in_le32, uint64_t n, void 
     if (!fs || (n && (!in_le32 || !out_fr))) return KZG_HIP_ERR_BAD_ARG;
     if (all_ok) *all_ok = 1;
     if (!n) return KZG_HIP_OK;
-    dev_guard g(fs);
-    hipStream_t s = fs->stream;
+    stream_lease lease(fs);     // its own stream: host-buffer calls from many threads run side by side
+    hipStream_t s = lease.s;
     dtmp<uint8_t> d_in(s); dtmp<fr> d_out(s); dtmp<uint32_t> d_bad(s);
     CHK(d_in.alloc(32 * n)); CHK(d_out.alloc(n)); CHK(d_bad.alloc(1));
     HIPCHK(hipMemsetAsync(d_bad.p, 0, 4, s));
@@ -562,8 +595,8 @@ int kzg_hip_fr_from_le32(kzg_hip_fft *fs, const void *in_le32, uint64_t n, void 
 int kzg_hip_fr_to_le32(kzg_hip_fft *fs, const void *in_fr, uint64_t n, void *out_le32) {
     if (!fs || (n && (!in_fr || !out_le32))) return KZG_HIP_ERR_BAD_ARG;
     if (!n) return KZG_HIP_OK;
-    dev_guard g(fs);
-    hipStream_t s = fs->stream;
+    stream_lease lease(fs);     // its own stream: host-buffer calls from many threads run side by side
+    hipStream_t s = lease.s;
     dtmp<uint8_t> d_out(s); dtmp<fr> d_in(s);
     CHK(d_in.alloc(n)); CHK(d_out.alloc(32 * n));
     HIPCHK(hipMemcpyAsync(d_in.p, in_fr, n * sizeof(fr), hipMemcpyHostToDevice, s));
@@ -576,8 +609,8 @@ int kzg_hip_fr_to_le32(kzg_hip_fft *fs, const void *in_fr, uint64_t n, void *out
 int kzg_hip_g1_to_compressed(kzg_hip_fft *fs, const void *points_g1, uint64_t n, void *out48) {
     if (!fs || (n && (!points_g1 || !out48))) return KZG_HIP_ERR_BAD_ARG;
     if (!n) return KZG_HIP_OK;
-    dev_guard g(fs);
-    hipStream_t s = fs->stream;
+    stream_lease lease(fs);     // its own stream: host-buffer calls from many threads run side by side
+    hipStream_t s = lease.s;
     dtmp<g1j> d_pts(s); dtmp<uint8_t> d_out(s);
     CHK(d_pts.alloc(n)); CHK(d_out.alloc(48 * n));
     HIPCHK(hipMemcpyAsync(d_pts.p, points_g1, n * sizeof(g1j), hipMemcpyHostToDevice, s));
@@ -591,8 +624,8 @@ int kzg_hip_g1_to_compressed(kzg_hip_fft *fs, const void *points_g1, uint64_t n,
 int kzg_hip_g1_from_compressed(kzg_hip_fft *fs, const void *in48, uint64_t n, void *out_g1) {
     if (!fs || (n && (!in48 || !out_g1))) return KZG_HIP_ERR_BAD_ARG;
     if (!n) return KZG_HIP_OK;
-    dev_guard g(fs);
-    hipStream_t s = fs->stream;
+    stream_lease lease(fs);     // its own stream: host-buffer calls from many threads run side by side
+    hipStream_t s = lease.s;
     dtmp<g1j> d_pts(s); dtmp<uint8_t> d_in(s); dtmp<uint32_t> d_flag(s);
     CHK(d_pts.alloc(n)); CHK(d_in.alloc(48 * n)); CHK(d_flag.alloc(1));
     HIPCHK(hipMemsetAsync(d_flag.p, 0, 4, s));
@@ -608,8 +641,8 @@ int kzg_hip_g1_from_compressed(kzg_hip_fft *fs, const void *in48, uint64_t n, vo
 int kzg_hip_g1_mul_vec(kzg_hip_fft *fs, const void *points_g1, const void *scalars_fr, uint64_t n, void *out_g1) {
     if (!fs || (n && (!points_g1 || !scalars_fr || !out_g1))) return KZG_HIP_ERR_BAD_ARG;
     if (!n) return KZG_HIP_OK;
-    dev_guard g(fs);
-    hipStream_t s = fs->stream;
+    stream_lease lease(fs);     // its own stream: host-buffer calls from many threads run side by side
+    hipStream_t s = lease.s;
     dtmp<g1j> d_pts(s), d_out(s); dtmp<fr> d_sc(s);
     CHK(d_pts.alloc(n)); CHK(d_out.alloc(n)); CHK(d_sc.alloc(n));
     HIPCHK(hipMemcpyAsync(d_pts.p, points_g1, n * sizeof(g1j), hipMemcpyHostToDevice, s));
@@ -705,8 +738,11 @@ static uint32_t fb_windows(uint32_t c) {
 // Measured, n = 4096, 512 blobs per launch: c = 11 (10 GB) ~39k, c = 13 (32 GB) ~55k, c = 14 (61 GB) ~77k, c = 16 (206 GB,
 // 16 windows) ~88k commitments/s (bench.py table_sweep).  If the allocation fails (another process on the GPU, fragmentation)
 // the next smaller window is tried, and finally the bucket path, which needs no table: a commitment never fails for lack of HBM.
-static int ensure_fixed_table(kzg_hip_kzg *ks, hipStream_t s) {
+// The build runs on the HANDLE's stream and only that stream is waited for (by the host thread that found no table): a caller's stream
+// passed to a _dev entry point is never synchronised here -- its work already enqueued keeps running under the build.  Callers hold fs->mu.
+static int ensure_fixed_table(kzg_hip_kzg *ks, hipStream_t) {
     if (ks->d_fixed || ks->fixed_plan.c == 0xffffffffu) return KZG_HIP_OK;
+    hipStream_t s = ks->fs->stream;
     double budget_gb = ks->budget_gb >= 0.0 ? ks->budget_gb : table_budget_gb("KZG_HIP_FB_BUDGET_GB", 64.0, 24.0);
     if (ks->n_setup < 64) { ks->fixed_plan.c = 0xffffffffu; return KZG_HIP_OK; }   // classic path only
     for (uint32_t c = 16; c >= 5; c--) {
@@ -736,6 +772,7 @@ static int commit_rows(kzg_hip_kzg *ks, hipStream_t s, const fr *d_sc, uint64_t 
     bool fixed = ks->d_fixed != nullptr;
     if (!sc_stride) sc_stride = n;
     msm_plan p = fixed ? ks->fixed_plan : classic_plan(ks->n_setup);
+    if (!fixed && !msm_index_range_ok(p, n)) return KZG_HIP_ERR_TOO_WIDE;
     size_t ws_main = fixed ? fb_partials_bytes(n, batch) : msm_workspace_bytes(p, n, batch);
     dtmp<uint8_t> d_ws(s);
     CHK(d_ws.alloc(ws_main));
@@ -800,9 +837,8 @@ int kzg_hip_commit_to_poly_batch(kzg_hip_kzg *ks, const void *coeffs_fr, uint64_
 }
 // ---- one-polynomial calls: concurrent callers on a handle are merged into batched launches (coalesce.hpp) ----
 static bool coalescing_enabled() {
-    static int on = -1;
-    if (on < 0) { const char *e = getenv("KZG_HIP_COALESCE"); on = (e && e[0] == '0') ? 0 : 1; }
-    return on != 0;
+    static const bool on = [] { const char *e = getenv("KZG_HIP_COALESCE"); return !(e && e[0] == '0'); }();
+    return on;
 }
 // rows per staging buffer: as many as fit 32 MiB of pinned memory per direction, within [4, 256]
 static uint64_t coalesce_rows(size_t in_row, size_t out_row) {
@@ -1004,8 +1040,8 @@ int kzg_hip_toeplitz_part2(kzg_hip_kzg *ks, const void *coeffs_fr, const void *x
     kzg_hip_fft *fs = ks->fs;
     if (n > fs->W) return KZG_HIP_ERR_TOO_WIDE;              // FFT error -> panic, fk20_single.go:63-66
     if (!is_pow2(n) || n == 0) return KZG_HIP_ERR_LEN_MISMATCH;   // padded FFT length != len(xExtFFT): index panic in the reference
-    dev_guard g(fs);
-    hipStream_t s = fs->stream;
+    stream_lease lease(fs);     // its own stream: host-buffer calls from many threads run side by side
+    hipStream_t s = lease.s;
     dtmp<fr> d_c(s), d_cf(s); dtmp<g1j> d_x(s), d_h(s);
     CHK(d_c.alloc(n)); CHK(d_cf.alloc(n)); CHK(d_x.alloc(n)); CHK(d_h.alloc(n));
     HIPCHK(hipMemcpyAsync(d_c.p, coeffs_fr, n * sizeof(fr), hipMemcpyHostToDevice, s));
@@ -1121,8 +1157,7 @@ static int fk20_finish(fk20_core *c, hipStream_t s, const g1j *d_hext, uint64_t 
 // forward (decimation-in-time) transform reads: 10 instead of 12 multiplying stages for the inverse transform and no reordering
 // passes.  Same group elements as the plain pipeline; outputs are normalised, so the bytes are identical (tests compare both).
 static bool fk20_fused_ok(const fk20_core *c, uint64_t batch, int da) {
-    static int off = -1;
-    if (off < 0) { const char *e = getenv("KZG_HIP_FK20_FUSE"); off = (e && e[0] == '0') ? 1 : 0; }
+    static const bool off = [] { const char *e = getenv("KZG_HIP_FK20_FUSE"); return e && e[0] == '0'; }();
     const uint64_t k2 = 2 * c->k;
     return !off && da && c->l == 1 && c->d_files_fb && k2 >= 8 && !g1_fft_direct_mode(k2, batch);
 }
@@ -1348,8 +1383,8 @@ int kzg_hip_zero_poly_via_multiplication(kzg_hip_fft *fs, const uint64_t *missin
     if (!is_pow2(length)) return KZG_HIP_ERR_NOT_POW2;       // "length not a power of two" :123-125
     if (n_missing >= length) return KZG_HIP_ERR_BAD_ARG;     // "expected output smaller or equal to input length" :205-207
     for (uint64_t i = 0; i < n_missing; i++) if (missing_indices[i] >= length) return KZG_HIP_ERR_BAD_ARG;
-    dev_guard g(fs);
-    hipStream_t s = fs->stream;
+    stream_lease lease(fs);     // its own stream: host-buffer calls from many threads run side by side
+    hipStream_t s = lease.s;
     dtmp<uint64_t> d_m(s); dtmp<fr> d_e(s), d_p(s);
     CHK(d_m.alloc(n_missing)); CHK(d_e.alloc(length)); CHK(d_p.alloc(length));
     HIPCHK(hipMemcpyAsync(d_m.p, missing_indices, n_missing * 8, hipMemcpyHostToDevice, s));
@@ -1368,8 +1403,8 @@ int kzg_hip_recover_poly_from_samples(kzg_hip_fft *fs, const void *samples_fr, c
     for (uint64_t i = 0; i < n; i++) if (!present[i]) missing.push_back(i);   // recover_from_samples.go:44-49
     if (missing.size() >= n) return KZG_HIP_ERR_BAD_ARG;
     if (missing.empty()) { memcpy(out_fr, samples_fr, n * sizeof(fr)); return KZG_HIP_OK; }   // zero poly == 0: nothing to divide by; data complete
-    dev_guard g(fs);
-    hipStream_t s = fs->stream;
+    stream_lease lease(fs);     // its own stream: host-buffer calls from many threads run side by side
+    hipStream_t s = lease.s;
     dtmp<uint64_t> d_m(s); dtmp<uint8_t> d_pr(s); dtmp<uint32_t> d_flag(s);
     dtmp<fr> d_s(s), d_ze(s), d_zp(s), d_a(s), d_b(s), d_c(s), d_f(s);
     CHK(d_m.alloc(missing.size())); CHK(d_pr.alloc(n)); CHK(d_flag.alloc(1)); CHK(d_s.alloc(n)); CHK(d_ze.alloc(n)); CHK(d_zp.alloc(n));

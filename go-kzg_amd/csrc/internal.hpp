@@ -81,6 +81,8 @@ struct msm_plan {
     uint32_t fixed;    // 1: plan of a fixed-base table (k_fb_*), 0: bucket MSM
     uint64_t table_n;  // points per row of the table
 };
+// the bucket pipeline packs (point index << 2 | half | sign) into 32 bits and counts entries (32 per scalar) in 32 bits: both must fit
+inline bool msm_index_range_ok(const msm_plan &p, uint64_t n) { return n < (1ull << 27) && 2 * p.table_n < (1ull << 30); }
 size_t msm_workspace_bytes(const msm_plan &p, uint64_t n, uint64_t batch);
 // batch MSMs over the same affine points, scalars in rows of sc_stride: out[b] = sum_i scalars[b][i] * P_i, NORMALISED (Z = one),
 // as Kilic images when to_kilic

@@ -228,8 +228,7 @@ void launch_g1_fft_stage(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, u
     // (n / 2 / m) * batch consecutive lanes: a multiple of 64 means every wave is uniform; >= 256 means at most a quarter of the
     // waves straddle two twiddles.  Otherwise (late stages of small batches: a single 4096-point transform has 64 different
     // twiddles per wave in its last stage, measured 21 ms against 2.3 ms) the regular signed-window schedule runs instead.
-    static int forced = -2;
-    if (forced == -2) { const char *e = getenv("KZG_HIP_G1_MUL"); forced = !e ? -1 : e[0] == 'r' ? 0 : e[0] == 'w' ? 4 : -1; }
+    static const int forced = [] { const char *e = getenv("KZG_HIP_G1_MUL"); return !e ? -1 : e[0] == 'r' ? 0 : e[0] == 'w' ? 4 : -1; }();
     const uint64_t per_twiddle = (n / 2 / m) * batch;
     const int mode = forced >= 0 ? forced : ((per_twiddle % 64 == 0 || per_twiddle >= 256) ? 4 : 0);
     const dim3 grid((uint32_t)((total + G1_BLOCK - 1) / G1_BLOCK)), block(G1_BLOCK);

@@ -14,6 +14,7 @@
 // Bucket contents are summed in a data-dependent order; the group law is commutative and the result is
 // normalised afterwards, so the output bytes do not depend on that order.
 #include "internal.hpp"
+#include <atomic>
 
 namespace kzg {
 
@@ -729,17 +730,20 @@ void launch_fb_mul_vec(hipStream_t s, const g1a *table, uint64_t table_n, uint32
 static uint32_t fb_blocks_per_blob(uint64_t n, uint64_t batch, uint32_t *wsplit = nullptr) {
     // 131072 lanes = 2048 wavefronts = exactly the resident capacity at 2 waves per SIMD: ONE round.  Measured (512 blobs):
     // 131072 lanes 5.7 ms, 262144 lanes (two rounds) 6.4 ms, 98304 / 65536 lanes 10.4 ms.  KZG_HIP_FB_LANES overrides.
-    static uint64_t lanes = 0;
-    if (!lanes) {
-        const char *e = getenv("KZG_HIP_FB_LANES");
-        if (e) lanes = strtoull(e, nullptr, 10);
-        else {                                               // CUs x 4 SIMDs x 2 resident waves x 64 lanes (256 CUs: 131072)
-            int dev = 0, cus = 256;
-            if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            lanes = (uint64_t)(cus > 0 ? cus : 256) * 4 * 2 * 64;
-        }
-        if (lanes < FB_ACC_BLOCK) lanes = FB_ACC_BLOCK;
+    // (thread-safe: coalescer leaders on several host threads get here at once; one value per device)
+    static const uint64_t forced_lanes = [] { const char *e = getenv("KZG_HIP_FB_LANES"); return e ? strtoull(e, nullptr, 10) : 0ull; }();
+    static std::atomic<uint64_t> lanes_of_device[16];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::atomic<uint64_t> &slot = lanes_of_device[dev >= 0 && dev < 16 ? dev : 0];
+    uint64_t lanes = forced_lanes ? forced_lanes : slot.load(std::memory_order_relaxed);
+    if (!lanes) {                                            // CUs x 4 SIMDs x 2 resident waves x 64 lanes (256 CUs: 131072)
+        int cus = 256;
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        lanes = (uint64_t)(cus > 0 ? cus : 256) * 4 * 2 * 64;
+        slot.store(lanes, std::memory_order_relaxed);        // (a racing thread computes the same value)
     }
+    if (lanes < FB_ACC_BLOCK) lanes = FB_ACC_BLOCK;
     uint64_t target = lanes / FB_ACC_BLOCK;
     uint64_t bpb = target / (batch ? batch : 1);
     // small batches: up to 8 lanes per point (each takes a share of the windows) while the launch stays within one round of lanes

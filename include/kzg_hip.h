@@ -13,11 +13,13 @@
  * comparison with any correct backend is meaningful.  Callers own all buffers; the library keeps no
  * caller pointer after a call returns (cgo rule).  All calls are blocking and thread-safe per handle.
  * Concurrent ONE-polynomial calls on a handle (kzg_hip_commit_to_poly, _compute_proof_single, _da_using_fk20, _da_using_fk20_multi,
- * _lincomb_points, _eth_blob_to_kzg_commitment_batch with batch == 1) are merged into batched launches (go-kzg_amd/csrc/coalesce.hpp; KZG_HIP_COALESCE=0
+ * _lincomb_points, _eth_blob_to_kzg_commitment_batch with batch == 1, _eth_compute_kzg_proof) are merged into batched launches (go-kzg_amd/csrc/coalesce.hpp; KZG_HIP_COALESCE=0
  * turns that off); a lone caller is not delayed.
  *
  * Functions ending in _dev take DEVICE pointers (HBM-resident inputs/outputs) and a hipStream_t passed
- * as void*; they enqueue work and return without synchronising.
+ * as void*; they enqueue work and return without synchronising the caller's stream.  (The FIRST commitment on a settings object builds
+ * its fixed-base table: that call blocks its host thread until the build -- on the handle's own stream -- is done; the caller's stream is
+ * not drained.)
  */
 #ifndef KZG_HIP_H
 #define KZG_HIP_H
