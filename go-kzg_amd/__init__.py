@@ -106,6 +106,7 @@ def lib():
         "kzg_hip_eth_compute_kzg_proof": (i32, [vp, vp, u64, vp, vp, vp]),
         "kzg_hip_eth_compute_kzg_proof_batch": (i32, [vp, vp, u64, u64, vp, vp, vp, vp]),
         "kzg_hip_eth_compute_kzg_proof_batch_dev": (i32, [vp, vp, u64, u64, vp, vp, vp, vp, vp]),
+        "kzg_hip_bench_threads_fft_fr": (i32, [vp, vp, u64, u64, u32, u32, vp, C.POINTER(C.c_double)]),
         "kzg_hip_bench_drop_in_eth_proof": (i32, [vp, vp, u64, u64, u32, u32, vp, C.POINTER(C.c_double)]),
         "kzg_hip_zero_poly_via_multiplication": (i32, [vp, vp, u64, u64, vp, vp]),
         "kzg_hip_recover_poly_from_samples": (i32, [vp, vp, vp, u64, vp]),
@@ -269,6 +270,13 @@ class FFTSettings:
             raise KzgError(st, "failed to reconstruct data correctly")
         _chk(st, error_ok=True)
         return out
+
+    def bench_threads_fft(self, rows, threads, calls):
+        """`threads` native host threads x `calls` blocking FFT calls on host buffers (kzg_hip_bench_threads_fft_fr): (calls per second, last results)"""
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        out, secs = np.zeros((threads, rows.shape[1], 4), dtype=np.uint64), C.c_double(0)
+        _chk(lib().kzg_hip_bench_threads_fft_fr(self.h, _p(rows), rows.shape[1], rows.shape[0], threads, calls, _p(out), C.byref(secs)))
+        return threads * calls / secs.value, out
 
     # ---- bls.* batch helpers that need a device context ----
     def lin_comb_g1(self, numbers, factors):

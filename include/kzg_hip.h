@@ -220,6 +220,9 @@ int kzg_hip_bench_drop_in(kzg_hip_kzg *ks, int op, const void *blobs_fr, uint64_
 /* the same for kzg_hip_eth_compute_kzg_proof: thread t evaluates at z = 5 + t; out48 holds `threads` proofs (each thread's last) */
 int kzg_hip_bench_drop_in_eth_proof(kzg_hip_eth *eth, const void *polys_fr, uint64_t n, uint64_t npolys, unsigned threads, unsigned calls, void *out48,
                                     double *seconds);
+/* and for kzg_hip_fft_fr on host buffers (thread t transforms row t % nrows of vals_fr, nrows x n Fr; out_fr: threads x n Fr): the
+ * per-handle stream pool at work */
+int kzg_hip_bench_threads_fft_fr(kzg_hip_fft *fs, const void *vals_fr, uint64_t n, uint64_t nrows, unsigned threads, unsigned calls, void *out_fr, double *seconds);
 /* shape of the fixed-base table CommitToPoly walks (built lazily by the first commitment): signed window bits c, window count and
  * bytes of HBM; all zero before the first commitment or when the setup is too small for a table (classic bucket path) */
 int kzg_hip_kzg_table_info(kzg_hip_kzg *ks, uint32_t *window_bits, uint32_t *windows, uint64_t *table_bytes);

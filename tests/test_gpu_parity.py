@@ -851,7 +851,6 @@ def test_host_buffer_calls_from_many_threads_use_the_stream_pool(kz):
     stream under the handle mutex: 16 threads get bit-identical results, and their FFT_Fr(4096) calls overlap (aggregate rate well above one
     thread's; the measured ratio is printed for DESIGN.md)"""
     import threading
-    import time
     fs, ofs = kz.FFTSettings(12), ko.FFTSettings(12)
     rng = np.random.default_rng(16)
     T = 16
@@ -868,9 +867,9 @@ def test_host_buffer_calls_from_many_threads_use_the_stream_pool(kz):
                 assert np.array_equal(fs.fft(vals[i % 4]), want[i % 4])
                 assert np.array_equal(fs.fft(fs.fft(vals[i]), inv=True), vals[i])
                 if i % 4 == 0:
-                    assert ko.g1_equal(fs.fft_g1(pts), want_g1).all()
+                    assert ko.g1_equal(fs.fft_g1(pts), want_g1)
                 if i % 4 == 1:
-                    assert ko.g1_equal(fs.lin_comb_g1(pts, vals[0][:64]).reshape(1, 3, 6), want_lc.reshape(1, 3, 6)).all()
+                    assert ko.g1_equal(fs.lin_comb_g1(pts, vals[0][:64]).reshape(1, 3, 6), want_lc.reshape(1, 3, 6))
                 if i % 4 == 2:
                     assert np.array_equal(fs.das_fft_extension(vals[i][:2048].copy()), ofs.das_fft_extension(vals[i][:2048].copy()))
         except Exception as e:  # noqa: BLE001
@@ -880,19 +879,14 @@ def test_host_buffer_calls_from_many_threads_use_the_stream_pool(kz):
     [t.join() for t in ts]
     assert not errs, errs[:3]
 
-    def rate(nthreads, calls=150):
-        def work(i):
-            for _ in range(calls):
-                fs.fft(vals[i])
-        ts_ = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
-        t0 = time.perf_counter()
-        [t.start() for t in ts_]
-        [t.join() for t in ts_]
-        return nthreads * calls / (time.perf_counter() - t0)
-    rate(2, 20)
-    r1, r16 = rate(1), rate(16)
+    rows = np.stack(vals)
+    fs.bench_threads_fft(rows, 2, 20)
+    r1, _ = fs.bench_threads_fft(rows, 1, 400)
+    r16, outs = fs.bench_threads_fft(rows, 16, 200)              # native threads: the interpreter lock would cap Python threads near 25k calls/s
     print("FFT_Fr(4096) host-buffer calls/s: 1 thread %.0f, 16 threads %.0f (x%.1f)" % (r1, r16, r16 / r1))
-    assert r16 > 2.5 * r1
+    for i in range(4):
+        assert np.array_equal(outs[i], want[i])
+    assert r16 > 3 * r1                                       # x5.4 with the 8 hardware queues the library asks for, x3.9 with ROCm's default 4
     fs.close()
 
 
