@@ -185,11 +185,10 @@ template <class T> struct dtmp {
     ~dtmp() { if (p) hipFreeAsync(p, s); }
 };
 
-// ROCm maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): kernels of streams that share a queue run one after the
-// other.  The library keeps up to 16 pool streams + 3 coalescer streams per handle busy, so it asks for 8 queues -- unless the variable is
-// already set, and only effective when this library is loaded before the process's first HIP call (measured, 16 host threads of FFT_Fr(4096)
-// on host buffers: x3.9 of one thread with 4 queues, x5.4 with 8, x5.6 with 16).
-__attribute__((constructor)) static void kzg_hip_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// (ROCm maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues, default 4: kernels of streams that share a queue run one after
+// the other.  Measured with 16 host threads of FFT_Fr(4096) on host buffers: x3.9 of one thread with 4 queues, x5.4 with 8, x5.6 with 16 --
+// but with 8 queues a LONE coalesced CommitToPoly takes 1.5 ms instead of 0.41 (the batch stream and the handle stream land on different
+// queues), so the library leaves the runtime's default alone; a caller that runs many host-buffer transforms side by side can set it.)
 
 extern "C" {
 

@@ -36,6 +36,39 @@ __device__ __forceinline__ void fb_partial_load(const fb_partial &p, g1xq &v) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Wave-level exchange for the reduction trees (the "wavefront shuffles" of the north star): lane i receives what lane i + DELTA of the
+// SAME wavefront holds -- DPP row shifts (v_mov_b32 row_shl) inside a row of 16 lanes, ds_bpermute_b32 (the LDS crossbar, no LDS memory)
+// across rows; 53 moves per lazy XYZZ point, no LDS round trip, no workgroup barrier.  ROW = true (tree levels: only lanes i < DELTA <= 32
+// use the result, so a DPP shift never has to leave its row of 16); ROW = false (scans: every lane i with i + DELTA < 64 uses it):
+// ds_bpermute at every distance.  Lanes whose source falls outside receive an unspecified value.
+// KZG_NO_WAVE_SHUFFLE restores the LDS + __syncthreads exchange of round 2 (A/B builds, profiles/r03_wave_shuffle_ab.md); the bucket
+// scan of k_msm_reduce keeps the LDS form by default (KZG_MSM_REDUCE_SHUFFLE selects the shuffle form: measured 3 % slower).
+// ---------------------------------------------------------------------------------------------------------
+template <uint32_t DELTA, bool ROW> __device__ __forceinline__ uint32_t lane_down(uint32_t v) {
+    if constexpr (ROW && DELTA < 16) return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x100 + DELTA, 0xf, 0xf, false);   // row_shl:DELTA
+    else return (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((threadIdx.x & 63u) + DELTA) & 63u) << 2), (int)v);
+}
+template <uint32_t DELTA, bool ROW> __device__ __forceinline__ void point_down(g1xq &o, uint32_t &oinf, const g1xq &v, uint32_t vinf) {
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+        o.x.l[i] = lane_down<DELTA, ROW>(v.x.l[i]); o.y.l[i] = lane_down<DELTA, ROW>(v.y.l[i]);
+        o.zz.l[i] = lane_down<DELTA, ROW>(v.zz.l[i]); o.zzz.l[i] = lane_down<DELTA, ROW>(v.zzz.l[i]);
+    }
+    oinf = lane_down<DELTA, ROW>(vinf);
+}
+// off in {1, 2, 4, 8, 16, 32}; wave-uniform
+template <bool ROW = true> __device__ __forceinline__ void point_down_any(g1xq &o, uint32_t &oinf, const g1xq &v, uint32_t vinf, uint32_t off) {
+    switch (off) {
+    case 1: point_down<1, ROW>(o, oinf, v, vinf); break;
+    case 2: point_down<2, ROW>(o, oinf, v, vinf); break;
+    case 4: point_down<4, ROW>(o, oinf, v, vinf); break;
+    case 8: point_down<8, ROW>(o, oinf, v, vinf); break;
+    case 16: point_down<16, ROW>(o, oinf, v, vinf); break;
+    default: point_down<32, ROW>(o, oinf, v, vinf); break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Variable-base MSM (bls.LinCombG1 on caller-supplied points, bls/bls_kilic.go:132-150): Pippenger buckets over the GLV halves.
 //   k_i P_i = s1 |k1| P_i + s2 |k2| phi(P_i), |k1|, |k2| < 2^126.5 (glv_split_signed): 16 signed 8-bit windows per half, no carry
 //   out of the top one.  ngroups = 16: one bucket group per window (120 doublings in the final Horner);  ngroups = 8: the table
@@ -173,6 +206,7 @@ __global__ __launch_bounds__(MSM_NB) void k_msm_reduce(uint8_t *ws, size_t per_b
     const fb_partial *buckets = (const fb_partial *)(ws + b * per_blob + buckets_off) + (uint64_t)g * MSM_NB;
     g1x_acc acc; acc.inf = buckets[d].inf != 0;
     if (!acc.inf) fb_partial_load(buckets[d], acc.v);
+#if defined(KZG_NO_WAVE_SHUFFLE) || !defined(KZG_MSM_REDUCE_SHUFFLE)   // measured: the shuffle form below is 3 % SLOWER for a lone LinCombG1 (profiles/r03_wave_shuffle_ab.md)
     fb_partial_store(buf[d], acc);
     __syncthreads();
 #pragma nounroll
@@ -192,6 +226,33 @@ __global__ __launch_bounds__(MSM_NB) void k_msm_reduce(uint8_t *ws, size_t per_b
         }
         __syncthreads();
     }
+#else
+    // The 128 buckets of a group sit on two wavefronts.  Suffix scan INSIDE each wavefront by lane shuffles (6 steps, no LDS, no barrier),
+    // then the lower wavefront adds the upper one's total (its lane 0) -- the one exchange through LDS; the tree sum likewise: 6 shuffle
+    // levels per wavefront, then lane 0 adds the other wavefront's sum.  16 dependent additions as before, 2 barriers instead of 42.
+    const uint32_t lane = d & 63u;
+    if (acc.inf) acc.v = g1xq_from_affine(g1a_inf());      // defined limbs for the shuffles
+#pragma nounroll
+    for (uint32_t off = 1; off < 64; off <<= 1) {
+        g1xq v; uint32_t vi;
+        point_down_any<false>(v, vi, acc.v, acc.inf ? 1u : 0u, off);
+        if (lane + off < 64) g1x_acc_merge(acc, v, vi != 0);
+    }
+    if (d == 64) fb_partial_store(buf[0], acc);            // T_64 = the sum of the upper 64 buckets
+    __syncthreads();
+    if (d < 64) { g1xq v; fb_partial_load(buf[0], v); g1x_acc_merge(acc, v, buf[0].inf != 0); }
+    // acc = T_d (suffix sums); the answer is their sum
+#pragma nounroll
+    for (uint32_t off = 32; off >= 1; off >>= 1) {
+        g1xq v; uint32_t vi;
+        point_down_any(v, vi, acc.v, acc.inf ? 1u : 0u, off);
+        if (lane < off) g1x_acc_merge(acc, v, vi != 0);
+    }
+    __syncthreads();                                       // buf[0] has been read by everyone
+    if (d == 64) fb_partial_store(buf[0], acc);
+    __syncthreads();
+    if (d == 0) { g1xq v; fb_partial_load(buf[0], v); g1x_acc_merge(acc, v, buf[0].inf != 0); }
+#endif
     if (d == 0) fb_partial_store(((fb_partial *)(ws + b * per_blob + gsum_off))[g], acc);
 }
 
@@ -427,13 +488,20 @@ __device__ __forceinline__ void fb_block_reduce_coop(g1x_acc &acc, fb_partial *b
     }
 #pragma nounroll
     for (uint32_t off = 32; off >= 1; off >>= 1) {
+        const bool have = c.col < off;
+#ifdef KZG_NO_WAVE_SHUFFLE
         if (c.wave == 0) fb_partial_store(buf[c.col], col);   // the replicas are identical: one wave publishes the columns
         __syncthreads();
-        const bool have = c.col < off;
         const uint32_t src = have ? c.col + off : c.col;
         g1xq w; fb_partial_load(buf[src], w);
         const bool winf = !have || buf[src].inf != 0;
         __syncthreads();
+#else
+        // every wave holds all 64 columns (identical replicas): column c + off comes from lane c + off of the SAME wave
+        g1xq w; uint32_t wi;
+        point_down_any(w, wi, col.v, col.inf ? 1u : 0u, off);
+        const bool winf = !have || wi != 0;
+#endif
         coop_acc_add(col, w, winf, c);
     }
     acc = col;                                             // column 0 (of every wave) holds the block's sum
@@ -533,13 +601,19 @@ __global__ __launch_bounds__(256) void k_fb_finish(const fb_partial *partials, u
     while (off < live) off *= 2;                          // smallest power of two >= live
 #pragma nounroll
     for (off >>= 1; off >= 1; off >>= 1) {
+        const bool have = col < off && col + off < live;
+#ifdef KZG_NO_WAVE_SHUFFLE
         if (c.wave == 0) fb_partial_store(buf[col], acc);  // the replicas are identical: one wave publishes the columns
         __syncthreads();
-        const bool have = col < off && col + off < live;
         const uint32_t src = have ? col + off : col;
         g1xq w; fb_partial_load(buf[src], w);
         const bool winf = !have || buf[src].inf != 0;
         __syncthreads();                                   // everyone has read before the next level overwrites
+#else
+        g1xq w; uint32_t wi;                               // column col + off lives in lane col + off of the same wave (replicas)
+        point_down_any(w, wi, acc.v, acc.inf ? 1u : 0u, off);
+        const bool winf = !have || wi != 0;
+#endif
         coop_acc_add(acc, w, winf, c);
     }
     if (c.wave == 0 && col == 0) {

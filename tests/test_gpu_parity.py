@@ -886,7 +886,7 @@ def test_host_buffer_calls_from_many_threads_use_the_stream_pool(kz):
     print("FFT_Fr(4096) host-buffer calls/s: 1 thread %.0f, 16 threads %.0f (x%.1f)" % (r1, r16, r16 / r1))
     for i in range(4):
         assert np.array_equal(outs[i], want[i])
-    assert r16 > 3 * r1                                       # x5.4 with the 8 hardware queues the library asks for, x3.9 with ROCm's default 4
+    assert r16 > 2.5 * r1                                     # x3.9 with ROCm's default 4 hardware queues per process, x5.4 with GPU_MAX_HW_QUEUES=8
     fs.close()
 
 
