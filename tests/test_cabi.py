@@ -90,3 +90,49 @@ def test_c_consumer_runs_the_vectors():
     for what in ("vector A", "vector B", "vector C: proof 18", "status 1 (want 1)", "status 2 (want 2)", "status 3 (want 3)", "status 4 (want 4)",
                  "status 5 (want 5)", "status 6 (want 6)"):
         assert what in res.stdout, what
+
+
+# ---- the C++ mirror of the Go API (include/kzg_hip.hpp) and the reference's tests re-stated against it (tests/host/go_mirror_test.cpp) ----
+def _build_go_mirror():
+    import subprocess
+    import gokzg_amd
+    bdir = os.path.join(ROOT, "tests", "host", "_build")
+    os.makedirs(bdir, exist_ok=True)
+    exe = os.path.join(bdir, "go_mirror_test")
+    libdir = os.path.dirname(gokzg_amd.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "host", "go_mirror_test.cpp"), "-L", libdir, "-lkzg_hip", "-Wl,-rpath," + libdir, "-o", exe])
+    import json
+    g = os.path.join(ROOT, "tests", "golden")
+    kats, der = json.load(open(os.path.join(g, "reference_kats.json"))), json.load(open(os.path.join(g, "derived_vectors.json")))
+    c = der["C_da_using_fk20_scale5"]
+    idx = sorted(int(k) for k in c if k.isdigit())
+    lines = ["test_inv_fft " + " ".join(kats["test_inv_fft"]["expected"]), "test_das_fft_extension " + " ".join(kats["test_das_fft_extension"]["expected"]),
+             "A_commit " + der["A_commit_test_poly"], "B_proof " + der["B_proof_single_x17"], "C_idx " + " ".join(str(i) for i in idx),
+             "C_val " + " ".join(c[str(i)] for i in idx)]
+    kat = os.path.join(bdir, "go_mirror_kats.txt")
+    open(kat, "w").write("\n".join(lines) + "\n")
+    return exe, kat
+
+
+def test_cpp_mirror_builds_and_refuses_without_a_device():
+    import subprocess
+    import gokzg_amd
+    exe, kat = _build_go_mirror()                                   # -Wall -Wextra -Werror: the header-only mirror compiles clean
+    if gokzg_amd.device_count() > 0:
+        pytest.skip("a GPU is present: test_cpp_mirror_runs_the_reference_tests covers it")
+    res = subprocess.run([exe, kat], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 77, res.stdout + res.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_runs_the_reference_tests():
+    """TestFFTRoundtrip, TestInvFFT, TestDASFFTExtension, TestParametrizedDASFFTExtension, TestKZGSettings_*, TestFFTSettings_RecoverPolyFromSamples_Simple
+    and the error / panic behaviour, from compiled C++ written against the Go-shaped mirror of the API"""
+    import subprocess
+    exe, kat = _build_go_mirror()
+    res = subprocess.run([exe, kat], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "PASSED: 0 failure(s)" in res.stdout and "FAIL" not in res.stdout
+    for name in ("TestInvFFT", "TestDASFFTExtension", "TestKZGSettings_DAUsingFK20", "TestErrorsAndPanics"):
+        assert "ok   " + name in res.stdout, name
