@@ -89,6 +89,7 @@ struct kzg_hip_fft {
     uint32_t *d_tw4096[2] = {nullptr, nullptr};   // twiddle files of the radix-4 4096-point transform, forward / inverse (fr_fft4096.hpp); null below scale 12
     fr *d_glv_expanded = nullptr, *d_glv_reversed = nullptr;   // twiddles as GLV pairs for the G1 FFT (g1_mul_glv)
     int8_t *d_wnaf_expanded = nullptr, *d_wnaf_reversed = nullptr;   // ... and their width-5 NAF digit strings (KZG_WNAF_ROW bytes per twiddle)
+    uint8_t *h_stage = nullptr; size_t h_stage_cap = 0;   // pinned staging for large results of calls that hold `mu` (d2h_staged)
     std::mutex mu;
     struct pool_slot { hipStream_t s = nullptr; uint8_t *h_pin = nullptr; size_t pin_cap = 0; };   // a stream + its pinned staging area (stream_lease)
     std::mutex pool_mu; std::condition_variable pool_cv; std::vector<pool_slot> pool_idle; int pool_total = 0;
@@ -166,6 +167,32 @@ struct stream_lease {
         fs->pool_cv.notify_one();
     }
 };
+// Device -> pageable host memory for a call that holds fs->mu: through the handle's pinned staging area (grown on demand, at most 16 MiB) and a
+// host memcpy.  hipMemcpyAsync into pageable memory changes mechanism above ~4 MiB (the runtime pins the destination on the fly): the 4.7 MB
+// of proofs of an 8-polynomial DAUsingFK20 batch took 5 ms longer than the 4.1 MB of a 7-polynomial one.  Synchronises the stream.
+static int d2h_staged(kzg_hip_fft *fs, hipStream_t s, void *host_dst, const void *dev_src, size_t bytes) {
+    if (bytes > (16u << 20) || bytes < (1u << 20)) {   // larger results: the runtime's own pinning is cheaper than a second pass over the bytes
+        HIPCHK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return KZG_HIP_OK;
+    }
+    if (fs->h_stage_cap < bytes) {
+        if (fs->h_stage) { hipHostFree(fs->h_stage); fs->h_stage = nullptr; fs->h_stage_cap = 0; }
+        size_t cap = 8u << 20;
+        while (cap < bytes) cap <<= 1;
+        if (hipHostMalloc((void **)&fs->h_stage, cap, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError(); fs->h_stage = nullptr;
+            HIPCHK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            return KZG_HIP_OK;
+        }
+        fs->h_stage_cap = cap;
+    }
+    HIPCHK(hipMemcpyAsync(fs->h_stage, dev_src, bytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    memcpy(host_dst, fs->h_stage, bytes);
+    return KZG_HIP_OK;
+}
 // coalesced executors enqueue kernels that read and write a batch's PINNED rows in place: whatever way the executor returns (an error
 // status after some kernels were already enqueued included), the stream has drained before the rows are handed back to their callers
 struct drain_on_exit {
@@ -305,6 +332,7 @@ void kzg_hip_fft_settings_free(kzg_hip_fft *fs) {
     if (fs->stream) hipStreamSynchronize(fs->stream);
     hipFree(fs->d_expanded); hipFree(fs->d_reversed); hipFree(fs->d_inv_pow2); hipFree(fs->d_tw4096[0]); hipFree(fs->d_tw4096[1]); hipFree(fs->d_tw_das2048); hipFree(fs->d_glv_expanded); hipFree(fs->d_glv_reversed); hipFree(fs->d_wnaf_expanded); hipFree(fs->d_wnaf_reversed);
     if (fs->stream) hipStreamDestroy(fs->stream);
+    if (fs->h_stage) hipHostFree(fs->h_stage);
     for (auto &ps : fs->pool_idle) { hipStreamSynchronize(ps.s); hipStreamDestroy(ps.s); if (ps.h_pin) hipHostFree(ps.h_pin); }
     (void)hipGetLastError();
     delete fs;
@@ -382,7 +410,7 @@ static uint32_t g1_fft_direct_logr(uint64_t n, uint64_t batch) {
     if (forced) return forced == 1 ? 4u : 0u;
     if (n < 2) return 0;
     if (n * batch <= 8192) return 4;
-    if (n * batch <= 16384) return 3;
+    if (n * batch <= 16384 && !g1_quad_enabled()) return 3;   // 3-4 transforms: the radix-2 network with four lanes per butterfly is faster (23.6 vs 30.5 ms per FK20 batch of 4)
     return 0;
 }
 static bool g1_fft_direct_mode(uint64_t n, uint64_t batch) { return g1_fft_direct_logr(n, batch) != 0; }
@@ -1244,9 +1272,7 @@ static int fk20_run_host(fk20_core *c, const void *poly_fr, uint64_t row_len, ui
         if (flag) return KZG_HIP_ERR_UPPER_HALF;
     }
     CHK(fk20_run_dev(c, s, d_poly.p, row_len, n, batch, da, bit_reverse, d_out.p));
-    HIPCHK(hipMemcpyAsync(out_g1, d_out.p, batch * on * sizeof(g1j), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    return KZG_HIP_OK;
+    return d2h_staged(c->ks->fs, s, out_g1, d_out.p, batch * on * sizeof(g1j));
 }
 
 int kzg_hip_fk20_single_settings_new(kzg_hip_kzg *ks, uint64_t n2, kzg_hip_fk20s **out) {

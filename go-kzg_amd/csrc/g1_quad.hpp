@@ -1,0 +1,126 @@
+// g1_quad.hpp -- QUAD-COOPERATIVE scalar multiplication: four adjacent lanes of one wavefront work on ONE multiplication.
+//
+// For launches with fewer butterflies than a quarter of the resident lanes (a G1 transform stage of at most 8 polynomials of 4096 points: 16 384
+// butterflies on a chip that holds 65 536 lanes at one wavefront per SIMD) the stage time is the LATENCY of one scalar multiplication on one
+// lane: ~1 370 dependent F_p products.  The products inside a group operation are mostly independent of each other: an XYZZ doubling is 9
+// products in 3 dependency levels, an XYZZ + affine addition 10 products in 4.  Here the four lanes of a quad hold replicas of the running
+// point and each computes ONE product of a level -- all lanes execute the same instruction stream (one 13-limb product), only their operands
+// differ (selected by the lane's role, v_cndmask) -- and the results are exchanged with DPP quad_perm broadcasts (v_mov_b32 ... quad_perm:[r,r,r,r],
+// 13 moves per value): no LDS, no barrier, no divergence.  128 doublings + 66 additions = 648 levels instead of ~1 370 products on the chain.
+// Replaces the per-butterfly bls.MulG1 of fft_g1.go:49 for those launches; the schedule (signed odd digits of the two GLV halves on the affine
+// co-Z table) and all values are those of g1_mul_glv_regular_aq, so the results are the same group elements.
+// The table construction and everything outside the digit loop is computed redundantly by the four lanes.
+#pragma once
+#include "g1.hpp"
+
+namespace kzg {
+
+#if defined(__HIPCC__)
+template <int R> __device__ __forceinline__ fq quad_bcast(const fq &v) {          // every lane of the quad receives lane R's value
+    fq o;
+#pragma unroll
+    for (int i = 0; i < 13; i++) o.l[i] = (uint32_t)__builtin_amdgcn_update_dpp((int)v.l[i], (int)v.l[i], R * 0x55, 0xf, 0xf, false);
+    return o;
+}
+__device__ __forceinline__ fq quad_sel(uint32_t role, const fq &a0, const fq &a1, const fq &a2, const fq &a3) {
+    fq o;
+#pragma unroll
+    for (int i = 0; i < 13; i++) { const uint32_t lo = role & 1u ? a1.l[i] : a0.l[i], hi = role & 1u ? a3.l[i] : a2.l[i]; o.l[i] = role & 2u ? hi : lo; }
+    return o;
+}
+__device__ __forceinline__ fq quad_sel2(uint32_t role, const fq &a0, const fq &a1) {   // roles 2, 3 repeat 0, 1 (idle lanes of a two-product level)
+    fq o;
+#pragma unroll
+    for (int i = 0; i < 13; i++) o.l[i] = role & 1u ? a1.l[i] : a0.l[i];
+    return o;
+}
+// p <- 2 p (dbl-2008-s-1, a = 0), bounds (X, Y, ZZ, ZZZ) <= (11, 5, 2, 2) in and out -- the levels of coop_xyzz_dbl (k_msm.hip):
+//   U = 2 Y;  L1: V = U^2, XX = X^2;  M = 3 XX;  L2: W = U V, S = X V, ZZ' = V ZZ, MM = M^2;  X' = MM - 2 S;
+//   L3: T1 = M (S - X'), T2 = W Y, ZZZ' = W ZZZ;  Y' = T1 - T2
+__device__ __forceinline__ void quad_xyzz_dbl(g1xq &p, uint32_t role) {
+    const fq u = addq(p.y, p.y);                                               // 10
+    fq mine = sqrq_inl(quad_sel2(role, u, p.x));
+    const fq v = quad_bcast<0>(mine), xx = quad_bcast<1>(mine);
+    const fq m = addq(addq(xx, xx), xx);                                       // 6
+    mine = mulq_inl(quad_sel(role, u, p.x, v, m), quad_sel(role, v, v, p.zz, m));
+    const fq w = quad_bcast<0>(mine), s_ = quad_bcast<1>(mine), zz3 = quad_bcast<2>(mine), mm = quad_bcast<3>(mine);
+    const fq x3 = subq<5>(mm, addq(s_, s_));                                   // 7
+    mine = mulq_inl(quad_sel(role, m, w, w, w), quad_sel(role, subq<8>(s_, x3), p.y, p.zzz, p.zzz));
+    const fq t1 = quad_bcast<0>(mine), t2 = quad_bcast<1>(mine), zzz3 = quad_bcast<2>(mine);
+    p.x = x3; p.y = subq<3>(t1, t2); p.zz = zz3; p.zzz = zzz3;              // (7, 5, 2, 2)
+}
+// p <- p + (x2, y2) for an affine point with bounds (2, 3) (madd-2008-s), accumulator bounds as above.  Returns false -- p untouched -- when
+// P == +-Q (the caller takes the generic path); the verdict is the same on the four lanes.
+//   L1: U2 = x2 ZZ, S2 = y2 ZZZ;  P = U2 - X (14), R = S2 - Y (8);  L2: PP = P^2, RR = R^2;  L3: PPP = P PP, Q = X PP, ZZ' = ZZ PP;
+//   X3 = RR - PPP - 2 Q (11);  L4: T1 = R (Q - X3), T2 = (6 p - Y) PPP, ZZZ' = ZZZ PPP;  Y3 = T1 + T2 (4)
+__device__ __forceinline__ bool quad_xyzz_madd(g1xq &p, const fq &x2, const fq &y2, uint32_t role) {
+    fq mine = mulq_inl(quad_sel2(role, x2, y2), quad_sel2(role, p.zz, p.zzz));
+    const fq u2 = quad_bcast<0>(mine), s2 = quad_bcast<1>(mine);
+    const fq pp_ = subq<12>(u2, p.x), r = subq<6>(s2, p.y);
+    mine = sqrq_inl(quad_sel2(role, pp_, r));
+    const fq pp = quad_bcast<0>(mine), rr = quad_bcast<1>(mine);
+    if (KZG_UNLIKELY(is_zero_mod_p_q(pp))) return false;
+    mine = mulq_inl(quad_sel(role, pp_, p.x, p.zz, p.zz), pp);
+    const fq ppp = quad_bcast<0>(mine), q_ = quad_bcast<1>(mine), zz3 = quad_bcast<2>(mine);
+    const fq x3 = subq<3>(subq<3>(subq<3>(rr, ppp), q_), q_);
+    fq zero_q;
+#pragma unroll
+    for (int i = 0; i < 13; i++) zero_q.l[i] = 0;
+    mine = mulq_inl(quad_sel(role, r, subq<6>(zero_q, p.y), p.zzz, p.zzz), quad_sel(role, subq<12>(q_, x3), ppp, ppp, ppp));
+    const fq t1 = quad_bcast<0>(mine), t2 = quad_bcast<1>(mine), zzz3 = quad_bcast<2>(mine);
+    p.x = x3; p.y = addq(t1, t2); p.zz = zz3; p.zzz = zzz3;
+    return true;
+}
+// the table entry (+-)(phi?) tbl[i] as the operands of quad_xyzz_madd
+__device__ __forceinline__ void quad_entry(const g1aq *t, bool ng, bool phi, fq &x2, fq &y2) {
+    x2 = phi ? t->bx : t->x;
+    y2 = t->y;
+    if (ng) { fq zero_q;
+#pragma unroll
+        for (int i = 0; i < 13; i++) zero_q.l[i] = 0;
+        y2 = subq<3>(zero_q, y2); }
+}
+// The regular odd-digit GLV multiplication of g1_mul_glv_regular_aq (same digits, same table, same return contract: 1 = `out` holds the product
+// as a lazy Jacobian image, 0 = infinity, 2 = `packed` holds it), with the digit loop on a quad.  All four lanes of the quad pass the same
+// arguments and receive the same result.
+__device__ __forceinline__ int g1_mul_glv_regular_quad(const g1jq &pq, const glv_halves &h, g1aq *tbl, fq *dz, g1jq &out, g1j &packed, uint32_t role) {
+    const bool on1 = (h.k1[0] | h.k1[1] | h.k1[2] | h.k1[3]) != 0, on2 = (h.k2[0] | h.k2[1] | h.k2[2] | h.k2[3]) != 0;
+    if (!on1 && !on2) return 0;
+    if (!g1_wnaf_table(pq, tbl, dz)) { g1j pc = g1jq_pack(pq); glv_halves hc = h; g1_mul_glv_signed_cold(&packed, &pc, &hc); return 2; }
+    const bool n1 = h.neg1 != 0, n2 = h.neg2 != 0;
+    uint32_t a0 = h.k1[0] | 1u, a1 = h.k1[1], a2 = h.k1[2], a3 = h.k1[3], a4 = 0;
+    uint32_t b0 = h.k2[0] | 1u, b1 = h.k2[1], b2 = h.k2[2], b3 = h.k2[3], b4 = 0;
+    g1xq acc;
+    fq x2, y2;
+    bool degenerate = false;
+    quad_entry(&tbl[0], on1 ? n1 : n2, !on1, x2, y2);                          // top digits: +1 for each live half
+    acc.x = x2; acc.y = y2; acc.zz = unpackq(one<FpP>()); acc.zzz = acc.zz;
+    if (on1 && on2) { quad_entry(&tbl[0], n2, true, x2, y2); degenerate = !quad_xyzz_madd(acc, x2, y2, role); }
+#pragma nounroll
+    for (int i = 31; i >= 0 && !degenerate; i--) {
+#pragma nounroll
+        for (int t = 0; t < 4; t++) quad_xyzz_dbl(acc, role);
+        const int da = (int)((((a4 & 1u) << 4) | (a3 >> 28)) | 1u) - 16, db = (int)((((b4 & 1u) << 4) | (b3 >> 28)) | 1u) - 16;
+        a4 = a3 >> 28; a3 = (a3 << 4) | (a2 >> 28); a2 = (a2 << 4) | (a1 >> 28); a1 = (a1 << 4) | (a0 >> 28); a0 <<= 4;
+        b4 = b3 >> 28; b3 = (b3 << 4) | (b2 >> 28); b2 = (b2 << 4) | (b1 >> 28); b1 = (b1 << 4) | (b0 >> 28); b0 <<= 4;
+        if (on1) {
+            quad_entry(&tbl[((da < 0 ? -da : da) - 1) >> 1], (da < 0) != n1, false, x2, y2);
+            degenerate = !quad_xyzz_madd(acc, x2, y2, role);
+        }
+        if (on2 && !degenerate) {
+            quad_entry(&tbl[((db < 0 ? -db : db) - 1) >> 1], (db < 0) != n2, true, x2, y2);
+            degenerate = !quad_xyzz_madd(acc, x2, y2, role);
+        }
+    }
+    // even halves were recoded as |k| + 1: take the extra (+-)P / (+-)phi(P) off again
+    if (on1 && !(h.k1[0] & 1u) && !degenerate) { quad_entry(&tbl[0], !n1, false, x2, y2); degenerate = !quad_xyzz_madd(acc, x2, y2, role); }
+    if (on2 && !(h.k2[0] & 1u) && !degenerate) { quad_entry(&tbl[0], !n2, true, x2, y2); degenerate = !quad_xyzz_madd(acc, x2, y2, role); }
+    if (degenerate) { g1j pc = g1jq_pack(pq); glv_halves hc = h; g1_mul_glv_signed_cold(&packed, &pc, &hc); return 2; }   // (a degenerate addition never ends at infinity silently)
+    // XYZZ -> the Jacobian image (X ZZ, Y ZZZ, ZZ): two more products, one level
+    fq mine = mulq_inl(quad_sel2(role, acc.x, acc.y), quad_sel2(role, acc.zz, acc.zzz));
+    out.x = quad_bcast<0>(mine); out.y = quad_bcast<1>(mine); out.z = acc.zz;
+    return 1;
+}
+#endif
+
+}  // namespace kzg

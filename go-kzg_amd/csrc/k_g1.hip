@@ -3,6 +3,8 @@
 // fk20_single.go:72-74 (ToeplitzPart2), fk20_multi.go:86-89 and bls.To/FromCompressedG1 (bls/bls_kilic.go:114-121).
 #define KZG_MULQ_NOINLINE 1   // many mulq call sites in this translation unit: keep the product out of line (I-cache)
 #include "internal.hpp"
+#include "g1_quad.hpp"
+#include <stdlib.h>
 
 namespace kzg {
 
@@ -153,6 +155,97 @@ template <int MODE, bool PRE = false> __global__ __launch_bounds__(G1_BLOCK, 2) 
     row[i0] = g1_add(x, y);
     row[i1] = g1_add(x, g1_neg(y));
 }
+// The same stages with FOUR lanes per butterfly (g1_quad.hpp): for launches that would leave most SIMDs empty (at most 16 384 butterflies: up to 8
+// polynomials of 4096 points), where the stage time is the latency of one scalar multiplication on one lane.  The quad shares the digit loop of
+// the multiplication (648 dependency levels of one product each instead of ~1 370 sequential products); loads, the table, the shared
+// (x + y, x - y) formulas and the packing are computed redundantly by the four lanes, lane 0 of the quad stores.  Regular odd-digit schedule
+// (lanes of a wavefront may hold different twiddles).  DIF = false: (x, y) -> (x + w y, x - w y); DIF = true: (x, y) -> (x + y, (x - y) w).
+template <bool DIF> __global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_fft_stage_quad(g1j *data, uint32_t logn, uint64_t m, const fr *roots, uint64_t W, uint64_t total, uint64_t batch) {
+    const uint64_t t4 = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    const uint32_t role = (uint32_t)(t4 & 3u);
+    const uint64_t t = t4 >> 2;
+    if (t >= total) return;
+    const uint64_t half = 1ull << (logn - 1), groups = half / m;
+    const uint64_t j = t / (groups * batch), rem = t % (groups * batch), b = rem / groups, g = rem % groups;   // twiddle-major, as in k_g1_fft_stage
+    g1j *row = data + (b << logn);
+    const uint64_t i0 = g * 2 * m + j, i1 = i0 + m;
+    g1j y = row[i1];
+    g1j x = row[i0];
+    glv_halves h;
+    {
+        const fr kk = roots[j * (W / (2 * m))];             // (k1, k2) GLV pair, both halves non-negative
+#pragma unroll
+        for (int i = 0; i < 4; i++) { h.k1[i] = kk.l[i]; h.k2[i] = kk.l[4 + i]; }
+        h.neg1 = h.neg2 = 0;
+    }
+    g1aq tbl[8]; fq dz[7]; g1j packed;
+    if (!DIF) {
+        g1jq yq; int st = is_inf(y) ? 0 : 1;
+        if (st == 1) {
+            if (j) {
+                st = g1_mul_glv_regular_quad(g1jq_unpack(y), h, tbl, dz, yq, packed, role);
+                if (st == 2) y = packed; else if (st == 0) y = g1_inf();
+            } else yq = g1jq_unpack(y);
+        }
+        if (st == 1 && !is_inf(x)) {
+            g1jq sum, dif;
+            if (KZG_LIKELY(g1jq_addsub(g1jq_unpack(x), yq, sum, dif))) {
+                if (role == 0) {
+                    fp z3 = packq(sum.z);
+                    g1j o0, o1;
+                    o0.x = packq(sum.x); o0.y = packq(sum.y); o0.z = z3;
+                    o1.x = packq(dif.x); o1.y = packq(dif.y); o1.z = z3;
+                    row[i0] = o0; row[i1] = o1;
+                }
+                return;
+            }
+        }
+        if (st == 1) y = g1jq_pack(yq);
+        if (role == 0) { row[i0] = g1_add(x, y); row[i1] = g1_add(x, g1_neg(y)); }
+    } else {
+        if (!is_inf(x) && !is_inf(y)) {
+            g1jq sum, dif;
+            if (KZG_LIKELY(g1jq_addsub(g1jq_unpack(x), g1jq_unpack(y), sum, dif))) {
+                g1j o0; o0.x = packq(sum.x); o0.y = packq(sum.y); o0.z = packq(sum.z);
+                g1j o1;
+                if (j) {
+                    g1jq dq;
+                    const int st = g1_mul_glv_regular_quad(dif, h, tbl, dz, dq, packed, role);
+                    o1 = st == 1 ? g1jq_pack(dq) : st == 2 ? packed : g1_inf();
+                } else { o1.x = packq(dif.x); o1.y = packq(dif.y); o1.z = o0.z; }
+                if (role == 0) { row[i0] = o0; row[i1] = o1; }
+                return;
+            }
+        }
+        g1j s_ = g1_add(x, y), d_ = g1_add(x, g1_neg(y));   // an infinite operand or x == +-y: generic complete formulas
+        if (j && !is_inf(d_)) {
+            g1jq dq;
+            const int st = g1_mul_glv_regular_quad(g1jq_unpack(d_), h, tbl, dz, dq, packed, role);
+            d_ = st == 1 ? g1jq_pack(dq) : st == 2 ? packed : g1_inf();
+        }
+        if (role == 0) { row[i0] = s_; row[i1] = d_; }
+    }
+}
+// 4 lanes per butterfly while the quadrupled launch still fits one wavefront per SIMD (65 536 lanes on 256 CUs); KZG_HIP_G1_QUAD = 0 / 1: never / always
+static int g1_quad_forced() {
+    static const int forced = [] { const char *e = getenv("KZG_HIP_G1_QUAD"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
+    return forced;
+}
+bool g1_quad_enabled() { return g1_quad_forced() != 0; }
+static bool g1_stage_quad(uint64_t butterflies) {
+    if (g1_quad_forced() >= 0) return g1_quad_forced() == 1;
+    return butterflies * 4 <= 65536;
+}
+// these launches are at most one 256-lane workgroup per CU: 96 KiB of unused dynamic LDS keeps the dispatcher from putting two on one CU (two
+// wavefronts on a SIMD take 1.76x as long as one) while another CU stays empty
+static size_t g1_quad_lds(uint64_t butterflies) {
+    static const bool once = [] {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_g1_fft_stage_quad<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_g1_fft_stage_quad<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        return true; }();
+    (void)once;
+    return butterflies * 4 <= 65536 ? 96 * 1024 : 0;
+}
 // The twiddles' precomputed width-5 NAF digit strings (264 bytes per twiddle in HBM) replace the per-butterfly recoding only where a
 // row is shared by many lanes (>= 512: measured +2.3 % on the 512-polynomial FK20 step); with one wavefront per twiddle every row is a
 // cold read and the recoding in registers is faster (measured -4 % on 64 transforms when the rows were always used).
@@ -205,6 +298,11 @@ void launch_g1_fft_stage_dif(hipStream_t s, g1j *data, uint64_t n, uint64_t batc
     uint64_t total = n / 2 * batch;
     if (!total) return;
     prof_begin(s, "g1_fft_stage");
+    if (g1_stage_quad(total)) {
+        hipLaunchKernelGGL(k_g1_fft_stage_quad<true>, dim3((uint32_t)((4 * total + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), g1_quad_lds(total), s, data, ilog2g(n), m, roots, W, total, batch);
+        prof_end(s, "g1_fft_stage");
+        return;
+    }
     const dim3 grid((uint32_t)((total + G1_BLOCK - 1) / G1_BLOCK)), block(G1_BLOCK);
     if (g1_wnaf_rows_pay(n, batch, m)) hipLaunchKernelGGL(k_g1_fft_stage_dif<true>, grid, block, 0, s, data, ilog2g(n), m, roots, wnaf, W, total, batch);
     else hipLaunchKernelGGL(k_g1_fft_stage_dif<false>, grid, block, 0, s, data, ilog2g(n), m, roots, wnaf, W, total, batch);
@@ -228,6 +326,11 @@ void launch_g1_fft_stage(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, u
     // (n / 2 / m) * batch consecutive lanes: a multiple of 64 means every wave is uniform; >= 256 means at most a quarter of the
     // waves straddle two twiddles.  Otherwise (late stages of small batches: a single 4096-point transform has 64 different
     // twiddles per wave in its last stage, measured 21 ms against 2.3 ms) the regular signed-window schedule runs instead.
+    if (g1_stage_quad(total)) {
+        hipLaunchKernelGGL(k_g1_fft_stage_quad<false>, dim3((uint32_t)((4 * total + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), g1_quad_lds(total), s, data, ilog2g(n), m, roots, W, total, batch);
+        prof_end(s, "g1_fft_stage");
+        return;
+    }
     static const int forced = [] { const char *e = getenv("KZG_HIP_G1_MUL"); return !e ? -1 : e[0] == 'r' ? 0 : e[0] == 'w' ? 4 : -1; }();
     const uint64_t per_twiddle = (n / 2 / m) * batch;
     const int mode = forced >= 0 ? forced : ((per_twiddle % 64 == 0 || per_twiddle >= 256) ? 4 : 0);

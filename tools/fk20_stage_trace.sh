@@ -14,7 +14,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 gk = "Grid_Size" if "Grid_Size" in rows[0] else ("Grid_Size_X" if "Grid_Size_X" in rows[0] else None)
 if gk is None:
     print(sorted(rows[0].keys())); sys.exit(0)
-st = [r for r in rows if "k_g1_fft_stage" in r["Kernel_Name"] and int(r[gk]) == b * 2048]   # exactly this step's launches (the bench also runs 64 plain transforms)
+st = [r for r in rows if "k_g1_fft_stage" in r["Kernel_Name"] and int(r[gk]) in (b * 2048, 4 * b * 2048)]   # exactly this step's launches (the bench also runs 64 plain transforms)
 last = st[-22:]
 d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in last]
 gaps = [(int(last[i + 1]["Start_Timestamp"]) - int(last[i]["End_Timestamp"])) / 1e6 for i in range(len(last) - 1)]
