@@ -409,8 +409,11 @@ static uint32_t g1_fft_direct_logr(uint64_t n, uint64_t batch) {
     static const int forced = [] { const char *e = getenv("KZG_HIP_G1_FFT"); return !e ? 0 : (e[0] == 'd' ? 1 : 2); }();   // (initialised once, thread-safe)
     if (forced) return forced == 1 ? 4u : 0u;
     if (n < 2) return 0;
+    // with four lanes per butterfly (g1_quad.hpp) the radix-2 network beats the direct passes from two transforms on (DAUsingFK20 on 2 / 4 polynomials:
+    // 20.8 / 21.0 ms against 23.3 / 30.5 ms); a lone transform stays direct (15.1 ms against 20.7 ms)
+    if (g1_quad_enabled()) return n * batch <= 4096 ? 4 : 0;
     if (n * batch <= 8192) return 4;
-    if (n * batch <= 16384 && !g1_quad_enabled()) return 3;   // 3-4 transforms: the radix-2 network with four lanes per butterfly is faster (23.6 vs 30.5 ms per FK20 batch of 4)
+    if (n * batch <= 16384) return 3;
     return 0;
 }
 static bool g1_fft_direct_mode(uint64_t n, uint64_t batch) { return g1_fft_direct_logr(n, batch) != 0; }

@@ -121,6 +121,48 @@ __device__ __forceinline__ int g1_mul_glv_regular_quad(const g1jq &pq, const glv
     out.x = quad_bcast<0>(mine); out.y = quad_bcast<1>(mine); out.z = acc.zz;
     return 1;
 }
+// The width-5 NAF schedule of g1_wnaf_loop_aq on a quad, digits from the twiddle's precomputed row (KZG_WNAF_ROW bytes: 132 for k1 -- digit i at
+// [i], the length at [131] -- then 132 for k2): 128 doublings + ~43 additions = ~556 levels.  For launches whose wavefronts hold ONE twiddle (the
+// zero-digit runs are data-dependent branches).  Same return contract.
+__device__ __forceinline__ int g1_mul_glv_wnaf_quad(const g1jq &pq, const fr &kk, g1aq *tbl, fq *dz, const int8_t *dg, g1jq &out, g1j &packed, uint32_t role) {
+    if (!g1_wnaf_table(pq, tbl, dz)) { g1j pc = g1jq_pack(pq); fr kc = kk; g1_mul_glv_cold(&packed, &pc, &kc); return 2; }
+    const int8_t *d1 = dg, *d2 = dg + 132;
+    const int n1 = (int)(uint8_t)dg[131], n2 = (int)(uint8_t)dg[132 + 131];
+    int j = (n1 > n2 ? n1 : n2) - 1;
+    if (j < 0) return 0;
+    g1xq acc; fq x2, y2;
+    bool degenerate = false;
+    {
+        const int a = d1[j], b = d2[j];
+        const int first = a ? a : b;
+        quad_entry(&tbl[((first < 0 ? -first : first) - 1) >> 1], first < 0, a == 0, x2, y2);
+        acc.x = x2; acc.y = y2; acc.zz = unpackq(one<FpP>()); acc.zzz = acc.zz;
+        if (a && b) { quad_entry(&tbl[((b < 0 ? -b : b) - 1) >> 1], b < 0, true, x2, y2); degenerate = !quad_xyzz_madd(acc, x2, y2, role); }
+        j--;
+    }
+    int pend = 0;
+#pragma nounroll
+    for (; j >= 0 && !degenerate; j--) {
+        const int a = d1[j], b = d2[j];
+        pend++;
+        if (!(a | b)) continue;
+#pragma nounroll
+        for (; pend > 0; pend--) quad_xyzz_dbl(acc, role);
+#pragma nounroll
+        for (int half = 0; half < 2; half++) {
+            const int dgt = half ? b : a;
+            if (!dgt || degenerate) continue;
+            quad_entry(&tbl[((dgt < 0 ? -dgt : dgt) - 1) >> 1], dgt < 0, half != 0, x2, y2);
+            degenerate = !quad_xyzz_madd(acc, x2, y2, role);
+        }
+    }
+    if (degenerate) { g1j pc = g1jq_pack(pq); fr kc = kk; g1_mul_glv_cold(&packed, &pc, &kc); return 2; }
+#pragma nounroll
+    for (; pend > 0; pend--) quad_xyzz_dbl(acc, role);
+    fq mine = mulq_inl(quad_sel2(role, acc.x, acc.y), quad_sel2(role, acc.zz, acc.zzz));
+    out.x = quad_bcast<0>(mine); out.y = quad_bcast<1>(mine); out.z = acc.zz;
+    return 1;
+}
 #endif
 
 }  // namespace kzg

@@ -160,7 +160,8 @@ template <int MODE, bool PRE = false> __global__ __launch_bounds__(G1_BLOCK, 2) 
 // the multiplication (648 dependency levels of one product each instead of ~1 370 sequential products); loads, the table, the shared
 // (x + y, x - y) formulas and the packing are computed redundantly by the four lanes, lane 0 of the quad stores.  Regular odd-digit schedule
 // (lanes of a wavefront may hold different twiddles).  DIF = false: (x, y) -> (x + w y, x - w y); DIF = true: (x, y) -> (x + y, (x - y) w).
-template <bool DIF> __global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_fft_stage_quad(g1j *data, uint32_t logn, uint64_t m, const fr *roots, uint64_t W, uint64_t total, uint64_t batch) {
+// WNAF: the width-5 NAF digit rows of the twiddles (wave-uniform launches) instead of the regular odd-digit schedule.
+template <bool DIF, bool WNAF> __global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_fft_stage_quad(g1j *data, uint32_t logn, uint64_t m, const fr *roots, const int8_t *wnaf, uint64_t W, uint64_t total, uint64_t batch) {
     const uint64_t t4 = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     const uint32_t role = (uint32_t)(t4 & 3u);
     const uint64_t t = t4 >> 2;
@@ -171,19 +172,19 @@ template <bool DIF> __global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_fft_stag
     const uint64_t i0 = g * 2 * m + j, i1 = i0 + m;
     g1j y = row[i1];
     g1j x = row[i0];
+    const uint64_t ti = j * (W / (2 * m));
+    const fr kk = roots[ti];                                // (k1, k2) GLV pair, both halves non-negative
     glv_halves h;
-    {
-        const fr kk = roots[j * (W / (2 * m))];             // (k1, k2) GLV pair, both halves non-negative
 #pragma unroll
-        for (int i = 0; i < 4; i++) { h.k1[i] = kk.l[i]; h.k2[i] = kk.l[4 + i]; }
-        h.neg1 = h.neg2 = 0;
-    }
+    for (int i = 0; i < 4; i++) { h.k1[i] = kk.l[i]; h.k2[i] = kk.l[4 + i]; }
+    h.neg1 = h.neg2 = 0;
     g1aq tbl[8]; fq dz[7]; g1j packed;
+#define QMUL(pq, res) (WNAF ? g1_mul_glv_wnaf_quad((pq), kk, tbl, dz, wnaf + ti * KZG_WNAF_ROW, (res), packed, role) : g1_mul_glv_regular_quad((pq), h, tbl, dz, (res), packed, role))
     if (!DIF) {
         g1jq yq; int st = is_inf(y) ? 0 : 1;
         if (st == 1) {
             if (j) {
-                st = g1_mul_glv_regular_quad(g1jq_unpack(y), h, tbl, dz, yq, packed, role);
+                st = QMUL(g1jq_unpack(y), yq);
                 if (st == 2) y = packed; else if (st == 0) y = g1_inf();
             } else yq = g1jq_unpack(y);
         }
@@ -210,7 +211,7 @@ template <bool DIF> __global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_fft_stag
                 g1j o1;
                 if (j) {
                     g1jq dq;
-                    const int st = g1_mul_glv_regular_quad(dif, h, tbl, dz, dq, packed, role);
+                    const int st = QMUL(dif, dq);
                     o1 = st == 1 ? g1jq_pack(dq) : st == 2 ? packed : g1_inf();
                 } else { o1.x = packq(dif.x); o1.y = packq(dif.y); o1.z = o0.z; }
                 if (role == 0) { row[i0] = o0; row[i1] = o1; }
@@ -220,28 +221,37 @@ template <bool DIF> __global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_fft_stag
         g1j s_ = g1_add(x, y), d_ = g1_add(x, g1_neg(y));   // an infinite operand or x == +-y: generic complete formulas
         if (j && !is_inf(d_)) {
             g1jq dq;
-            const int st = g1_mul_glv_regular_quad(g1jq_unpack(d_), h, tbl, dz, dq, packed, role);
+            const int st = QMUL(g1jq_unpack(d_), dq);
             d_ = st == 1 ? g1jq_pack(dq) : st == 2 ? packed : g1_inf();
         }
         if (role == 0) { row[i0] = s_; row[i1] = d_; }
     }
 }
+#undef QMUL
 // 4 lanes per butterfly while the quadrupled launch still fits one wavefront per SIMD (65 536 lanes on 256 CUs); KZG_HIP_G1_QUAD = 0 / 1: never / always
 static int g1_quad_forced() {
     static const int forced = [] { const char *e = getenv("KZG_HIP_G1_QUAD"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
     return forced;
 }
 bool g1_quad_enabled() { return g1_quad_forced() != 0; }
-static bool g1_stage_quad(uint64_t butterflies) {
+// `uniform`: every wavefront of the one-lane-per-butterfly launch would hold ONE twiddle (the width-5 NAF schedule needs that; otherwise the regular
+// schedule runs, which the quad form beats up to two wavefronts per SIMD: 9-16 polynomials)
+static bool g1_stage_quad(uint64_t butterflies, bool uniform = true) {
     if (g1_quad_forced() >= 0) return g1_quad_forced() == 1;
-    return butterflies * 4 <= 65536;
+    return butterflies * 4 <= (uniform ? 65536u : 131072u);
 }
 // these launches are at most one 256-lane workgroup per CU: 96 KiB of unused dynamic LDS keeps the dispatcher from putting two on one CU (two
 // wavefronts on a SIMD take 1.76x as long as one) while another CU stays empty
+static bool g1_quad_wnaf(uint64_t n, uint64_t batch, uint64_t m) {
+    static const bool off = [] { const char *e = getenv("KZG_HIP_G1_MUL"); return e && e[0] == 'r'; }();
+    return !off && ((n / 2 / m) * batch * 4) % 64 == 0;
+}
 static size_t g1_quad_lds(uint64_t butterflies) {
     static const bool once = [] {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_g1_fft_stage_quad<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_g1_fft_stage_quad<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_g1_fft_stage_quad<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_g1_fft_stage_quad<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_g1_fft_stage_quad<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_g1_fft_stage_quad<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         return true; }();
     (void)once;
     return butterflies * 4 <= 65536 ? 96 * 1024 : 0;
@@ -298,8 +308,12 @@ void launch_g1_fft_stage_dif(hipStream_t s, g1j *data, uint64_t n, uint64_t batc
     uint64_t total = n / 2 * batch;
     if (!total) return;
     prof_begin(s, "g1_fft_stage");
-    if (g1_stage_quad(total)) {
-        hipLaunchKernelGGL(k_g1_fft_stage_quad<true>, dim3((uint32_t)((4 * total + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), g1_quad_lds(total), s, data, ilog2g(n), m, roots, W, total, batch);
+    const uint64_t per_tw = (n / 2 / m) * batch;
+    if (g1_stage_quad(total, per_tw % 64 == 0 || per_tw >= 256)) {
+        // the irregular width-5 NAF schedule where every wavefront holds one twiddle (4 lanes x (n / 2 / m) batch butterflies per twiddle), else the regular one
+        const dim3 qg((uint32_t)((4 * total + G1_BLOCK - 1) / G1_BLOCK));
+        if (g1_quad_wnaf(n, batch, m)) hipLaunchKernelGGL((k_g1_fft_stage_quad<true, true>), qg, dim3(G1_BLOCK), g1_quad_lds(total), s, data, ilog2g(n), m, roots, wnaf, W, total, batch);
+        else hipLaunchKernelGGL((k_g1_fft_stage_quad<true, false>), qg, dim3(G1_BLOCK), g1_quad_lds(total), s, data, ilog2g(n), m, roots, wnaf, W, total, batch);
         prof_end(s, "g1_fft_stage");
         return;
     }
@@ -326,14 +340,16 @@ void launch_g1_fft_stage(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, u
     // (n / 2 / m) * batch consecutive lanes: a multiple of 64 means every wave is uniform; >= 256 means at most a quarter of the
     // waves straddle two twiddles.  Otherwise (late stages of small batches: a single 4096-point transform has 64 different
     // twiddles per wave in its last stage, measured 21 ms against 2.3 ms) the regular signed-window schedule runs instead.
-    if (g1_stage_quad(total)) {
-        hipLaunchKernelGGL(k_g1_fft_stage_quad<false>, dim3((uint32_t)((4 * total + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), g1_quad_lds(total), s, data, ilog2g(n), m, roots, W, total, batch);
-        prof_end(s, "g1_fft_stage");
-        return;
-    }
     static const int forced = [] { const char *e = getenv("KZG_HIP_G1_MUL"); return !e ? -1 : e[0] == 'r' ? 0 : e[0] == 'w' ? 4 : -1; }();
     const uint64_t per_twiddle = (n / 2 / m) * batch;
     const int mode = forced >= 0 ? forced : ((per_twiddle % 64 == 0 || per_twiddle >= 256) ? 4 : 0);
+    if (g1_stage_quad(total, mode == 4)) {
+        const dim3 qg((uint32_t)((4 * total + G1_BLOCK - 1) / G1_BLOCK));
+        if (g1_quad_wnaf(n, batch, m)) hipLaunchKernelGGL((k_g1_fft_stage_quad<false, true>), qg, dim3(G1_BLOCK), g1_quad_lds(total), s, data, ilog2g(n), m, roots, wnaf, W, total, batch);
+        else hipLaunchKernelGGL((k_g1_fft_stage_quad<false, false>), qg, dim3(G1_BLOCK), g1_quad_lds(total), s, data, ilog2g(n), m, roots, wnaf, W, total, batch);
+        prof_end(s, "g1_fft_stage");
+        return;
+    }
     const dim3 grid((uint32_t)((total + G1_BLOCK - 1) / G1_BLOCK)), block(G1_BLOCK);
     const uint32_t logn = ilog2g(n);
     switch (mode) {
