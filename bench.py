@@ -612,6 +612,17 @@ def main():
                     fk.da_using_fk20(polys_h[0])
                     ts.append((time.perf_counter() - t0) * 1e3)
                 fk20["DAUsingFK20_single_call_ms"] = float(np.median(ts))      # median of 5 calls, like the `latency` block
+                # a few polynomials per host-buffer call (four lanes per butterfly up to 8 polynomials: go-kzg_amd/csrc/g1_quad.hpp)
+                small = {}
+                for nb in (2, 8, 32):
+                    if nb > polys_h.shape[0]:
+                        continue
+                    fk.da_using_fk20_batch(polys_h[:nb])
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        fk.da_using_fk20_batch(polys_h[:nb])
+                    small[str(nb)] = (time.perf_counter() - t0) / 3 * 1e3
+                fk20["DAUsingFK20_host_batch_ms"] = small
                 # the reference's API is one polynomial per call (fk20_single.go:176-196): 64 host threads calling it concurrently are merged
                 # into batched launches by the library (Python threads here: ctypes releases the GIL for the ~50 ms a call blocks)
                 import threading
