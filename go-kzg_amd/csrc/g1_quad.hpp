@@ -71,6 +71,35 @@ __device__ __forceinline__ bool quad_xyzz_madd(g1xq &p, const fq &x2, const fq &
     p.x = x3; p.y = addq(t1, t2); p.zz = zz3; p.zzz = zzz3;
     return true;
 }
+// a <- a + b for two XYZZ points (add-2008-s), bounds as in g1xq_add_fast / coop_xyzz_add (k_msm.hip): both operands (11, 5, 2, 2), result the same.
+// Returns false (a untouched) when the operands are equal or opposite.
+//   L1: U1 = X1 ZZ2, U2 = X2 ZZ1, S1 = Y1 ZZZ2, S2 = Y2 ZZZ1;  P = U2 - U1 (5), R = S2 - S1 (5);  L2: PP = P^2, RR = R^2, ZZ12 = ZZ1 ZZ2, ZZZ12 = ZZZ1 ZZZ2;
+//   L3: PPP = P PP, Q = U1 PP, ZZ3 = ZZ12 PP;  X3 = RR - PPP - 2 Q (11);  L4: T1 = R (Q - X3), T2 = S1 PPP, ZZZ3 = ZZZ12 PPP;  Y3 = T1 - T2 (5)
+__device__ __forceinline__ bool quad_xyzz_add(g1xq &a, const g1xq &b, uint32_t role) {
+    fq mine = mulq_inl(quad_sel(role, a.x, b.x, a.y, b.y), quad_sel(role, b.zz, a.zz, b.zzz, a.zzz));
+    const fq u1 = quad_bcast<0>(mine), u2 = quad_bcast<1>(mine), s1 = quad_bcast<2>(mine), s2 = quad_bcast<3>(mine);
+    const fq pp_ = subq<3>(u2, u1), r = subq<3>(s2, s1);
+    mine = mulq_inl(quad_sel(role, pp_, r, a.zz, a.zzz), quad_sel(role, pp_, r, b.zz, b.zzz));
+    const fq pp = quad_bcast<0>(mine), rr = quad_bcast<1>(mine), zz12 = quad_bcast<2>(mine), zzz12 = quad_bcast<3>(mine);
+    if (KZG_UNLIKELY(is_zero_mod_p_q(pp))) return false;
+    mine = mulq_inl(quad_sel(role, pp_, u1, zz12, zz12), pp);
+    const fq ppp = quad_bcast<0>(mine), q_ = quad_bcast<1>(mine), zz3 = quad_bcast<2>(mine);
+    const fq x3 = subq<3>(subq<3>(subq<3>(rr, ppp), q_), q_);
+    mine = mulq_inl(quad_sel(role, r, s1, zzz12, zzz12), quad_sel(role, subq<12>(q_, x3), ppp, ppp, ppp));
+    const fq t1 = quad_bcast<0>(mine), t2 = quad_bcast<1>(mine), zzz3 = quad_bcast<2>(mine);
+    a.x = x3; a.y = subq<3>(t1, t2); a.zz = zz3; a.zzz = zzz3;
+    return true;
+}
+// acc += w for the replicated accumulators of a quad (infinity flags beside the limbs); equal / opposite operands take the generic complete
+// formulas, identically on the four lanes.  Lanes with nothing to add (winf) still run the levels on whatever `w` holds and drop the result.
+__device__ __forceinline__ void quad_acc_add(g1x_acc &acc, const g1xq &w, bool winf, uint32_t role) {
+    g1xq sum = acc.v;
+    const bool ok = quad_xyzz_add(sum, w, role);
+    if (winf) return;
+    if (acc.inf) { acc.v = w; acc.inf = false; }
+    else if (ok) acc.v = sum;
+    else g1x_acc_merge(acc, w, false);
+}
 // the table entry (+-)(phi?) tbl[i] as the operands of quad_xyzz_madd
 __device__ __forceinline__ void quad_entry(const g1aq *t, bool ng, bool phi, fq &x2, fq &y2) {
     x2 = phi ? t->bx : t->x;

@@ -14,6 +14,7 @@
 // Bucket contents are summed in a data-dependent order; the group law is commutative and the result is
 // normalised afterwards, so the output bytes do not depend on that order.
 #include "internal.hpp"
+#include "g1_quad.hpp"
 #include <atomic>
 
 namespace kzg {
@@ -343,6 +344,7 @@ __device__ __forceinline__ void coop_acc_add(g1x_acc &acc, const g1xq &w, bool w
 
 // Horner over the window groups (8 doublings per group), then normalise and convert.  The doublings are the critical path of a
 // lone MSM (120 for 16 groups, 56 for 8): workgroup = 4 cooperating waves, lane column = blob (64 blobs per workgroup).
+#ifdef KZG_COMBINE_WAVE_COOP                                 // round 2's form: four WAVEFRONTS per blob column, exchange through LDS (A/B builds)
 __global__ __launch_bounds__(256) void k_msm_combine(uint8_t *ws, size_t per_blob, size_t gsum_off, uint32_t ngroups, uint64_t batch, g1j *out, int to_kilic) {
     __shared__ coop_lds lds;
     coop_ctx c; c.L = &lds; c.wave = threadIdx.x >> 6; c.col = threadIdx.x & 63u; c.set = 0;
@@ -375,6 +377,41 @@ __global__ __launch_bounds__(256) void k_msm_combine(uint8_t *ws, size_t per_blo
         out[b] = to_kilic ? g1_to_kilic(r) : r;
     }
 }
+#else
+// Quad form (g1_quad.hpp): the four LANES of a quad hold the replicas and exchange the products of a level by DPP broadcasts -- no LDS, no barrier
+// (a level 1.3 us instead of 1.84).  64 blobs per 256-lane workgroup, as before.
+__global__ __launch_bounds__(256) void k_msm_combine(uint8_t *ws, size_t per_blob, size_t gsum_off, uint32_t ngroups, uint64_t batch, g1j *out, int to_kilic) {
+    const uint32_t role = threadIdx.x & 3u;
+    const uint64_t b = blockIdx.x * 64ull + (threadIdx.x >> 2);
+    const bool live = b < batch;
+    const fb_partial *gsum = (const fb_partial *)(ws + (live ? b : 0) * per_blob + gsum_off);
+    g1x_acc acc; acc.init();
+    acc.v = g1xq_from_affine(g1a_inf());                   // defined limbs while the accumulator is still empty (results are discarded)
+#pragma nounroll
+    for (uint32_t g = ngroups; g-- > 0;) {
+#pragma nounroll
+        for (uint32_t j = 0; j < 8; j++) {                 // every lane runs the doubling, empty accumulators ignore it
+            g1xq d = acc.v;
+            quad_xyzz_dbl(d, role);
+            if (!acc.inf) acc.v = d;
+        }
+        const bool winf = !live || gsum[g].inf != 0;
+        g1xq w;
+        if (winf) w = acc.v; else fb_partial_load(gsum[g], w);
+        quad_acc_add(acc, w, winf, role);
+    }
+    if (live && role == 0) {
+        g1j r;
+        if (acc.inf) r = g1_inf();
+        else {   // x = X / ZZ, y = Y / ZZZ with one inversion
+            g1x px = g1xq_pack(acc.v);
+            fp i = inv<FpP>(mul(px.zz, px.zzz));
+            r.x = mul(px.x, mul(i, px.zzz)); r.y = mul(px.y, mul(i, px.zz)); r.z = one<FpP>();
+        }
+        out[b] = to_kilic ? g1_to_kilic(r) : r;
+    }
+}
+#endif
 
 void launch_msm(hipStream_t s, const msm_plan &p, const g1a *table, const fr *scalars, uint64_t sc_stride, uint64_t n, uint64_t batch, void *workspace, g1j *out,
                 bool to_kilic) {
