@@ -524,15 +524,27 @@ def main():
             # --- variable-base bls.LinCombG1 on a cached point set (the seam eth/helpers.go:99,159,199 and CommitToEvalPoly go through)
             pts = kz.G1Points(fs, setup)
             d_lc_out = torch.zeros((512, 18), dtype=torch.int64, device="cuda")
-            lincomb = {"kernel_chain": "k_msm_sort / accumulate / reduce / combine (GLV halves, signed 8-bit windows, 2^64 rows cached)", "n": N_COEFF, "batch": {}}
-            for bs in (1, 64, 512):
-                def lc_step(bs=bs):
-                    st = lib.kzg_hip_lincomb_points_batch_dev(pts.h, d_blobs.data_ptr(), N_COEFF, bs, d_lc_out.data_ptr(), stream)
-                    if st:
-                        raise RuntimeError("lincomb_points_batch_dev status %d" % st)
-                reps = 10 if bs < 512 else 3
-                lsecs = timed_steps(lc_step, reps, 1, torch.cuda.synchronize, barrier, max_over_ranks)
-                lincomb["batch"][str(bs)] = {"msm_per_s": bs * world * reps / lsecs, "ms_per_step": lsecs / reps * 1e3}
+            lincomb = {"n": N_COEFF, "batch": {}, "bucket_pipeline_batch": {},
+                       "kernel_chain": "a cached set walks its own fixed-base table (k_fb_accumulate; default budget min(32 GB, free HBM - 24 GB): 13-bit windows for 4096 points); "
+                                       "bucket_pipeline_batch = the same set with the table budget at 0: k_msm_sort / accumulate / reduce / combine (GLV halves, signed 8-bit "
+                                       "windows, 2^64 rows cached), which is also what caller-supplied points take (latency.LinCombG1_4096_one_shot_ms)"}
+
+            def lc_rates(key):
+                for bs in (1, 64, 512):
+                    def lc_step(bs=bs):
+                        st = lib.kzg_hip_lincomb_points_batch_dev(pts.h, d_blobs.data_ptr(), N_COEFF, bs, d_lc_out.data_ptr(), stream)
+                        if st:
+                            raise RuntimeError("lincomb_points_batch_dev status %d" % st)
+                    lc_step()
+                    torch.cuda.synchronize()
+                    reps = 10 if bs < 512 else 3
+                    lsecs = timed_steps(lc_step, reps, 1, torch.cuda.synchronize, barrier, max_over_ranks)
+                    lincomb[key][str(bs)] = {"msm_per_s": bs * world * reps / lsecs, "ms_per_step": lsecs / reps * 1e3}
+            pts.set_table_budget_gb(0)
+            lc_rates("bucket_pipeline_batch")
+            pts.set_table_budget_gb(32)
+            lc_rates("batch")
+            lincomb["table"] = "budget 32 GB"
             # one linear combination per call (bls.LinCombG1's shape) from 64 host threads: coalesced into batched bucket MSMs
             import threading
             lc_T, lc_per = 64, 30

@@ -75,6 +75,7 @@ def lib():
         "kzg_hip_fr_from_le32": (i32, [vp, vp, u64, vp, C.POINTER(i32)]), "kzg_hip_fr_to_le32": (i32, [vp, vp, u64, vp]),
         "kzg_hip_lincomb_g1": (i32, [vp, vp, vp, u64, vp]),
         "kzg_hip_points_new": (i32, [vp, vp, u64, pp]), "kzg_hip_points_free": (None, [vp]), "kzg_hip_points_count": (u64, [vp]),
+        "kzg_hip_points_set_table_budget_gb": (i32, [vp, C.c_double]),
         "kzg_hip_lincomb_points": (i32, [vp, vp, u64, vp]), "kzg_hip_lincomb_points_batch": (i32, [vp, vp, u64, u64, vp]),
         "kzg_hip_lincomb_points_batch_dev": (i32, [vp, vp, u64, u64, vp, vp]), "kzg_hip_g1_to_compressed": (i32, [vp, vp, u64, vp]),
         "kzg_hip_g1_from_compressed": (i32, [vp, vp, u64, vp]), "kzg_hip_g1_mul_vec": (i32, [vp, vp, vp, u64, vp]),
@@ -357,6 +358,10 @@ class G1Points:
         if getattr(self, "h", None):
             lib().kzg_hip_points_free(self.h)
             self.h = None
+
+    def set_table_budget_gb(self, gb):
+        """HBM budget of the set's fixed-base table (0: bucket pipeline only); see kzg_hip_points_set_table_budget_gb"""
+        _chk(lib().kzg_hip_points_set_table_budget_gb(self.h, float(gb)))
 
     def lin_comb(self, factors):
         """bls.LinCombG1(points[:len(factors)], factors)"""

@@ -534,10 +534,16 @@ static void set_inf_image(void *out_g1) { g1j z = g1_to_kilic(g1_inf()); memcpy(
 // the IFFT of the setup) and eth/helpers.go:99,159,199 (the Lagrange setup) multiply the SAME points by fresh scalars every call.
 // The handle keeps them in HBM as affine device-internal images together with 2^64 P_i, which folds the 16 windows of each GLV
 // half onto 8 bucket groups: 56 instead of 120 doublings on the critical path of a lone MSM.
+static int kzg_settings_build(kzg_hip_fft *fs, const void *points_g1, uint64_t n, kzg_hip_kzg **out);
+static int ensure_fixed_table(kzg_hip_kzg *ks, hipStream_t);
+static int commit_rows(kzg_hip_kzg *ks, hipStream_t s, const fr *d_sc, uint64_t n, uint64_t batch, g1j *d_out, uint64_t sc_stride = 0);
+static double table_budget_gb(const char *env, double cap_gb, double headroom_gb);
 struct kzg_hip_points {
     kzg_hip_fft *fs = nullptr;
     uint64_t n = 0;
-    g1a *d_tab = nullptr;          // [P_0 .. P_{n-1} | 2^64 P_0 .. 2^64 P_{n-1}], affine, (0, 0) = inf
+    g1a *d_tab = nullptr;          // [P_0 .. P_{n-1} | 2^64 P_0 .. 2^64 P_{n-1}], affine, (0, 0) = inf: the bucket pipeline's rows
+    kzg_hip_kzg *ks = nullptr;     // the same points as a settings object: its fixed-base table (built lazily within the set's budget) turns a
+                                   // linear combination on the cached set into the table walk of CommitToPoly; null below 64 points
     std::unique_ptr<coalescer> co; // concurrent one-MSM calls (bls.LinCombG1 from many goroutines) merge into batched launches
 };
 __global__ __launch_bounds__(128, 2) void k_points_shift64(const g1a *pts, uint64_t n, g1j *out) {
@@ -555,6 +561,7 @@ void kzg_hip_points_free(kzg_hip_points *pts) {
     hipSetDevice(pts->fs->device);
     hipDeviceSynchronize();
     pts->co.reset();
+    if (pts->ks) kzg_hip_kzg_settings_free(pts->ks);
     hipFree(pts->d_tab);
     (void)hipGetLastError();
     delete pts;
@@ -563,11 +570,11 @@ int kzg_hip_points_new(kzg_hip_fft *fs, const void *points_g1, uint64_t n, kzg_h
     if (!fs || !out || (n && !points_g1)) return KZG_HIP_ERR_BAD_ARG;
     *out = nullptr;
     KZG_TRY
-    dev_guard g(fs);
-    hipStream_t s = fs->stream;
     std::unique_ptr<kzg_hip_points, void (*)(kzg_hip_points *)> own(new kzg_hip_points, kzg_hip_points_free);
     own->fs = fs; own->n = n;
     if (n) {
+        dev_guard g(fs);
+        hipStream_t s = fs->stream;
         dtmp<g1j> d_raw(s), d_hi(s);
         CHK(d_raw.alloc(n)); CHK(d_hi.alloc(n));
         HIPCHK(hipMalloc((void **)&own->d_tab, 2 * n * sizeof(g1a)));
@@ -579,13 +586,29 @@ int kzg_hip_points_new(kzg_hip_fft *fs, const void *points_g1, uint64_t n, kzg_h
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(s));
     }
+    if (n >= 64) {   // (takes the handle mutex itself)
+        CHK(kzg_settings_build(fs, points_g1, n, &own->ks));
+        // budget of the set's fixed-base table: KZG_HIP_POINTS_FB_BUDGET_GB, else min(32 GB, free HBM - 24 GB) at creation (4096 points: 13-bit windows,
+        // 20 of them, 32 GB); 0 keeps the set on the bucket pipeline.  kzg_hip_points_set_table_budget_gb changes it per set.
+        own->ks->budget_gb = table_budget_gb("KZG_HIP_POINTS_FB_BUDGET_GB", 32.0, 24.0);
+    }
     *out = own.release();
     return KZG_HIP_OK;
     KZG_CATCH
 }
+int kzg_hip_points_set_table_budget_gb(kzg_hip_points *pts, double gb) {
+    if (!pts) return KZG_HIP_ERR_BAD_ARG;
+    if (!pts->ks) return KZG_HIP_OK;
+    return kzg_hip_kzg_set_table_budget_gb(pts->ks, gb);
+}
 uint64_t kzg_hip_points_count(const kzg_hip_points *pts) { return pts ? pts->n : 0; }
 // batch MSMs against points[:n]: scalars in rows of n; out = batch normalised Kilic images (device)
 static int lincomb_points_rows(kzg_hip_points *pts, hipStream_t s, const fr *d_sc, uint64_t n, uint64_t batch, g1j *d_out, uint64_t sc_stride = 0) {
+    if (pts->ks) {   // the cached set's fixed-base table, when its budget allows one: n x windows mixed additions per combination, no sort, no buckets
+        { dev_guard g(pts->fs); CHK(ensure_fixed_table(pts->ks, s)); }
+        std::shared_lock<std::shared_mutex> tl(pts->ks->tab_mu);
+        if (pts->ks->d_fixed) return commit_rows(pts->ks, s, d_sc, n, batch, d_out, sc_stride ? sc_stride : n);
+    }
     msm_plan p = classic_plan(pts->n, true);
     if (!msm_index_range_ok(p, n)) return KZG_HIP_ERR_TOO_WIDE;      // the packed bucket entries would wrap
     dtmp<uint8_t> d_ws(s);
@@ -839,7 +862,7 @@ static int ensure_fixed_table(kzg_hip_kzg *ks, hipStream_t) {
 // MSM of `batch` resident scalar rows against SecretG1[:n]; out = batch normalised points (device).  The partial-sum / bucket
 // workspace is allocated per call, stream-ordered on the launch stream (hipMallocAsync pool: no device synchronisation after the
 // first use), so concurrent callers on different streams never share scratch memory.
-static int commit_rows(kzg_hip_kzg *ks, hipStream_t s, const fr *d_sc, uint64_t n, uint64_t batch, g1j *d_out, uint64_t sc_stride = 0) {
+static int commit_rows(kzg_hip_kzg *ks, hipStream_t s, const fr *d_sc, uint64_t n, uint64_t batch, g1j *d_out, uint64_t sc_stride) {
     CHK(ensure_fixed_table(ks, s));
     bool fixed = ks->d_fixed != nullptr;
     if (!sc_stride) sc_stride = n;

@@ -92,6 +92,9 @@ int kzg_hip_lincomb_g1(kzg_hip_fft *fs, const void *points_g1, const void *scala
 typedef struct kzg_hip_points kzg_hip_points;
 int kzg_hip_points_new(kzg_hip_fft *fs, const void *points_g1, uint64_t n, kzg_hip_points **out);
 void kzg_hip_points_free(kzg_hip_points *pts);
+/* A cached set of >= 64 points also gets a fixed-base table like a KZGSettings object (built by its first combination): budget in GB, default
+ * KZG_HIP_POINTS_FB_BUDGET_GB or min(32 GB, free HBM - 24 GB) at creation; 0 keeps the set on the bucket pipeline.  Results are identical. */
+int kzg_hip_points_set_table_budget_gb(kzg_hip_points *pts, double gb);
 uint64_t kzg_hip_points_count(const kzg_hip_points *pts);
 int kzg_hip_lincomb_points(kzg_hip_points *pts, const void *scalars_fr, uint64_t n, void *out_g1);
 int kzg_hip_lincomb_points_batch(kzg_hip_points *pts, const void *scalars_fr, uint64_t n, uint64_t batch, void *out_g1);

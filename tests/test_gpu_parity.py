@@ -338,6 +338,12 @@ def test_lincomb_edge_scalars_and_cached_points(kz, fs16, setup_1337):
     assert np.array_equal(cached.lin_comb(ko.fr_empty(0)), ko.g1_zero()[0])
     with pytest.raises(kz.KzgPanic):
         cached.lin_comb(rand_fr(rng, n + 1))
+    # a cached set walks its own fixed-base table by default; budget 0 sends the same set through the bucket pipeline: identical bytes
+    cached.set_table_budget_gb(0)
+    assert_points_equal(cached.lin_comb(scal), want)
+    assert np.array_equal(cached.lin_comb_batch(batch), got)
+    for m in (1, 21, 299):
+        assert_points_equal(cached.lin_comb(scal[:m]), ko.lincomb_g1(pts[:m], scal[:m]))
     cached.close()
     # full size: CommitToEvalPoly's use (kzg_single_proofs.go:12-14) with the Lagrange setup as the cached set == vector F (eth form)
     lag = ko.reverse_bit_order(ko.g1_decompress(np.frombuffer(open(os.path.join(GOLDEN, "trusted_setup_g1_lagrange.bin"), "rb").read(), dtype=np.uint8)))
@@ -348,6 +354,10 @@ def test_lincomb_edge_scalars_and_cached_points(kz, fs16, setup_1337):
     assert comp_hex(got[:1])[0] == DERIVED["F_blob_seed1"]["commit_eth_bitrev_lagrange"]
     assert_points_equal(got[3], ko.lincomb_g1(lag, blobs[3]))
     assert np.array_equal(lag_set.lin_comb(blobs[2]), got[2])
+    lag_set.set_table_budget_gb(0)                            # bucket pipeline at full size
+    assert np.array_equal(lag_set.lin_comb_batch(blobs), got)
+    lag_set.set_table_budget_gb(8)                            # and a smaller table than the default
+    assert np.array_equal(lag_set.lin_comb_batch(blobs), got)
     # bls.LinCombG1 is ONE linear combination per call: 24 concurrent callers (ragged lengths among them) share batched bucket MSMs
     import threading
     lens = [4096 if i % 3 else 4096 - 7 * i - 1 for i in range(24)]
