@@ -99,6 +99,12 @@ func (p *G1Points) Close() {
 	}
 }
 
+// SetTableBudgetGB: HBM budget of this set's fixed-base table (default min(32 GB, free - 24 GB); 0 keeps the set on the bucket pipeline)
+func (p *G1Points) SetTableBudgetGB(gb float64) {
+	defer runtime.KeepAlive(p)
+	hipMust(C.kzg_hip_points_set_table_budget_gb(p.h, C.double(gb)))
+}
+
 // LinComb == bls.LinCombG1(points[:len(factors)], factors)
 func (p *G1Points) LinComb(factors []bls.Fr) *bls.G1Point {
 	defer runtime.KeepAlive(p) // the finalizer must not free the device handle under a running call
