@@ -512,16 +512,49 @@ void launch_fr_scale_by_inv_powers(hipStream_t s, fr *c, const fr *x, uint64_t n
 // missing-root loads are wave-uniform -- and gets the coefficients with one inverse FFT.  O(n m) Fr products: 5e8 at
 // scale 15 with half the samples missing, a few ms on the chip against 172 ms for the reference's tree (BENCH.md).
 // ---------------------------------------------------------------------------------------------------------
-__global__ void k_zero_eval_direct(const fr *expanded, uint64_t stride, const uint64_t *missing, uint64_t n_missing, uint64_t length, fr *zero_eval) {
-    uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    if (k >= length) return;
-    fr x = expanded[k * stride], acc = one<FrP>();
-    for (uint64_t i = 0; i < n_missing; i++) acc = mul(acc, sub(x, expanded[missing[i] * stride]));
-    zero_eval[k] = acc;
+// The product chain runs on lazy 29-bit limbs (fr_lazy.hpp): frl_mul divides by 2^261 while both operands are Kilic images (2^256), so every step
+// leaves a stray 2^-5; `corr` = the Kilic image of 2^(5 n_missing) (computed on the host) takes all of them out in one last product.  A step is one
+// lazy subtraction + 153 multiply-adds instead of a canonical subtraction + the 170-multiply-add product with its packing: 1.5x.
+// A point's chain is cut into `segs` pieces, one wavefront of the workgroup each (the missing root of a step stays wave-uniform), multiplied
+// together through LDS at the end: 65 536 points alone are one wavefront per SIMD, and a lone wavefront waits on its own dependent products.
+__global__ void __launch_bounds__(1024) k_zero_eval_direct(const fr *expanded, uint64_t stride, const uint64_t *missing, uint64_t n_missing, uint64_t length,
+                                                           fr *zero_eval, fr corr) {
+    extern __shared__ uint32_t zsh[];                                     // [segs - 1][9][64]
+    const uint32_t lane = threadIdx.x & 63, seg = threadIdx.x >> 6, segs = blockDim.x >> 6;
+    uint64_t k = blockIdx.x * 64ull + lane;
+    if (k >= length) k = length - 1;                                      // idle lanes repeat the last point: every lane reaches the barrier
+    const uint64_t per = (n_missing + segs - 1) / segs, lo = seg * per, hi = lo + per < n_missing ? lo + per : n_missing;
+    const frl x = frl_unpack(expanded[k * stride]);
+    frl acc = frl_unpack(one<FrP>());
+#pragma nounroll
+    for (uint64_t i = lo; i < hi; i++) {
+        const frl m = frl_unpack(expanded[missing[i] * stride]);          // wave-uniform
+        acc = frl_mul(frl_sub<2>(x, m), acc);                               // raw difference (bound 3) x normalised running product (bound < 2)
+    }
+    if (seg) {
+#pragma unroll
+        for (int j = 0; j < 9; j++) zsh[((seg - 1) * 9 + j) * 64 + lane] = acc.l[j];
+    }
+    __syncthreads();
+    if (seg) return;
+    for (uint32_t sgm = 1; sgm < segs; sgm++) {
+        frl o;
+#pragma unroll
+        for (int j = 0; j < 9; j++) o.l[j] = zsh[((sgm - 1) * 9 + j) * 64 + lane];
+        acc = frl_mul(o, acc);
+    }
+    if (blockIdx.x * 64ull + lane < length) zero_eval[k] = frl_canon_lt2r(frl_mul(acc, frl_const_from_kilic(corr)));
 }
 void launch_zero_eval_direct(hipStream_t s, const fr *expanded, uint64_t stride, const uint64_t *missing, uint64_t n_missing, uint64_t length, fr *zero_eval) {
     if (!length) return;
-    hipLaunchKernelGGL(k_zero_eval_direct, dim3((uint32_t)((length + 63) / 64)), dim3(64), 0, s, expanded, stride, missing, n_missing, length, zero_eval);
+    uint32_t segs = 1;                                                    // aim at 4 wavefronts per SIMD (4096 on the chip)
+    while (segs < 16 && length * segs < 262144 && 2ull * segs <= n_missing) segs *= 2;
+    // every product of two Kilic images on the lazy limbs leaves 2^-5: n_missing chain steps (a segment with fewer steps than `per` simply has
+    // fewer) + segs - 1 to join the segments
+    fr corr = one<FrP>(), pw = fr_from_u64(32);                           // 2^(5 (n_missing + segs - 1)), by square-and-multiply on the host
+    for (uint64_t e = n_missing + segs - 1; e; e >>= 1) { if (e & 1) corr = mul(corr, pw); pw = mul(pw, pw); }
+    hipLaunchKernelGGL(k_zero_eval_direct, dim3((uint32_t)((length + 63) / 64)), dim3(64 * segs), (segs - 1) * 9 * 64 * 4, s, expanded, stride, missing,
+                       n_missing, length, zero_eval, corr);
 }
 // poly[i] *= base^i  (ShiftPoly / UnshiftPoly, recover_from_samples.go:9-40, with base = 5^-1 / 5)
 __global__ void k_fr_scale_by_powers(fr *poly, const fr *base, uint64_t n) {
