@@ -24,7 +24,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KZG_HIP_LIB") or os.path.join(_HERE, "libkzg_hip.so")   # KZG_HIP_LIB: another build of the same library (A/B runs)
 
-OK, ERR_TOO_WIDE, ERR_NOT_POW2, ERR_LEN_MISMATCH, ERR_UPPER_HALF, ERR_BAD_ARG, ERR_BAD_POINT, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_RECOVERY = range(11)
+OK, ERR_TOO_WIDE, ERR_NOT_POW2, ERR_LEN_MISMATCH, ERR_UPPER_HALF, ERR_BAD_ARG, ERR_BAD_POINT, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_RECOVERY, ERR_BAD_BLOB = range(12)
 
 
 class KzgError(Exception):
@@ -107,6 +107,9 @@ def lib():
         "kzg_hip_eth_compute_kzg_proof": (i32, [vp, vp, u64, vp, vp, vp]),
         "kzg_hip_eth_compute_kzg_proof_batch": (i32, [vp, vp, u64, u64, vp, vp, vp, vp]),
         "kzg_hip_eth_compute_kzg_proof_batch_dev": (i32, [vp, vp, u64, u64, vp, vp, vp, vp, vp]),
+        "kzg_hip_eth_compute_aggregate_kzg_proof": (i32, [vp, vp, u64, vp, vp]),
+        "kzg_hip_eth_compute_aggregated_poly_and_commitment": (i32, [vp, vp, vp, u64, vp, vp, vp, vp]),
+        "kzg_hip_test_sha256": (None, [vp, u64, vp]),
         "kzg_hip_bench_threads_fft_fr": (i32, [vp, vp, u64, u64, u32, u32, vp, C.POINTER(C.c_double)]),
         "kzg_hip_bench_drop_in_eth_proof": (i32, [vp, vp, u64, u64, u32, u32, vp, C.POINTER(C.c_double)]),
         "kzg_hip_zero_poly_via_multiplication": (i32, [vp, vp, u64, u64, vp, vp]),
@@ -596,6 +599,37 @@ class EthSettings:
         out, ys, ok = np.zeros((b, 48), dtype=np.uint8), fr_empty(b), np.zeros(b, dtype=np.uint8)
         _chk(lib().kzg_hip_eth_compute_kzg_proof_batch(self.h, _p(polys), self.n, b, _p(zs), _p(out), _p(ys), _p(ok)))
         return out, ys, ok.astype(bool)
+
+    def compute_aggregate_kzg_proof(self, blobs):
+        """eth.ComputeAggregateKZGProof (eth/eth.go:175-182) on (batch, n, 32) uint8 blobs (batch may be 0): (proof48, (batch, 48) commitments);
+        KzgError "could not convert blobs to polynomials" / "invalid z challenge" like the reference"""
+        blobs = np.ascontiguousarray(blobs, dtype=np.uint8).reshape(-1, self.n, 32)
+        b = blobs.shape[0]
+        proof, comm = np.zeros(48, dtype=np.uint8), np.zeros((b, 48), dtype=np.uint8)
+        st = lib().kzg_hip_eth_compute_aggregate_kzg_proof(self.h, _p(blobs), b, _p(proof), _p(comm))
+        if st == ERR_BAD_BLOB:
+            raise KzgError(st, "could not convert blobs to polynomials")
+        if st == ERR_BAD_ARG:
+            raise KzgError(st, "invalid z challenge")
+        _chk(st)
+        return proof, comm
+
+    def compute_aggregated_poly_and_commitment(self, blobs, commitments):
+        """The prover-side pieces of eth.VerifyAggregateKZGProof (eth/eth.go:155-172): (aggregated polynomial (n, 4), aggregated commitment
+        G1 image (18,), z (4,), y (4,)); the pairing of VerifyKZGProofFromPoints stays with the caller"""
+        blobs = np.ascontiguousarray(blobs, dtype=np.uint8).reshape(-1, self.n, 32)
+        comm = np.ascontiguousarray(commitments, dtype=np.uint8).reshape(-1, 48)
+        b = blobs.shape[0]
+        if comm.shape[0] != b:
+            raise KzgError(ERR_LEN_MISMATCH, "one commitment per blob")
+        poly, c, z, y = fr_empty(self.n), g1_empty(1), fr_empty(1), fr_empty(1)
+        st = lib().kzg_hip_eth_compute_aggregated_poly_and_commitment(self.h, _p(blobs), _p(comm), b, _p(poly), _p(c), _p(z), _p(y))
+        if st == ERR_BAD_BLOB:
+            raise KzgError(st, "could not convert blobs to polynomials")
+        if st == ERR_BAD_POINT:
+            raise KzgError(st, "invalid commitment")
+        _chk(st)
+        return poly, c[0], z[0], y[0]
 
     def bench_drop_in_proof(self, polys, threads, calls):
         """`threads` native host threads x `calls` blocking eth.ComputeKZGProof calls: (calls per second, each thread's last proof)"""

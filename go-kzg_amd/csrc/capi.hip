@@ -6,6 +6,7 @@
 #include "fr_fft4096.hpp"
 #include "fr_das2048.hpp"
 #include "coalesce.hpp"
+#include "sha256.hpp"
 
 #include <algorithm>
 #include <map>
@@ -1741,6 +1742,162 @@ int kzg_hip_eth_compute_kzg_proof(kzg_hip_eth *eth, const void *poly_fr, uint64_
     if (y_fr) memcpy(y_fr, row + 48, sizeof(fr));
     return KZG_HIP_OK;
     KZG_CATCH
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// eth.ComputeAggregateKZGProof / the prover-side pieces of eth.VerifyAggregateKZGProof (eth/eth.go:155-182, eth/helpers.go:137-176,215-260):
+// the block-level caller of the commitment path.  Device: blobs -> polynomials -> commitments -> aggregated polynomial -> proof; host: the
+// Fiat-Shamir transcript (one SHA-256 chain over every blob of the block), hashed while the device commits.
+// ---------------------------------------------------------------------------------------------------------
+// hashToBLSField (eth/helpers.go:113-133): SHA-256, digest read as a little-endian integer, reduced mod r
+static fr hash_to_bls_field(const uint8_t *input, size_t len) {
+    sha256 h;
+    h.update(input, len);
+    uint8_t d[32];
+    h.final(d);
+    uint64_t v[4], m[4];
+    memcpy(v, d, 32);
+    for (int i = 0; i < 4; i++) m[i] = (uint64_t)FrP::mod(2 * i) | (uint64_t)FrP::mod(2 * i + 1) << 32;
+    for (int k = 0; k < 3; k++) {                                   // 2^256 < 3 r
+        bool ge = true;
+        for (int i = 3; i >= 0; i--) { if (v[i] != m[i]) { ge = v[i] > m[i]; break; } }
+        if (!ge) break;
+        unsigned __int128 br = 0;
+        for (int i = 0; i < 4; i++) { unsigned __int128 t = (unsigned __int128)v[i] - m[i] - (uint64_t)br; v[i] = (uint64_t)t; br = (t >> 64) & 1; }
+    }
+    fr c;
+    memcpy(c.l, v, 32);
+    return to_mont<FrP>(c);
+}
+// ComputeAggregatedPolyAndCommitment (eth/helpers.go:137-162) up to the aggregated polynomial: BlobsToPolynomials (:275-285), the commitments
+// (taken from `comm_in`, or PolynomialToKZGCommitment of every blob, :166-169, into `comm`), ComputeChallenges (:215-232), bls.PolyLinComb.
+// Leaves polynomials, powers (device + host) and the aggregated polynomial resident; z_out = the evaluation challenge.
+static int eth_aggregate(kzg_hip_eth *eth, hipStream_t s, const uint8_t *blobs, const uint8_t *comm_in, uint64_t batch, dtmp<fr> &d_poly, dtmp<fr> &d_agg,
+                         dtmp<fr> &d_pow, std::vector<fr> &pw, std::vector<uint8_t> &comm, fr &z_out) {
+    const uint64_t n = eth->n;
+    CHK(d_agg.alloc(n));
+    std::vector<uint32_t> bad(batch);
+    drain_on_exit drain(s);                                          // an error return must not leave a copy into `bad` in flight
+    dtmp<uint8_t> d_in(s), d_c(s); dtmp<g1j> d_out(s); dtmp<uint32_t> d_bad(s);
+    if (batch) {
+        CHK(d_in.alloc(batch * n * 32)); CHK(d_poly.alloc(batch * n)); CHK(d_bad.alloc(batch)); CHK(d_pow.alloc(batch));
+        HIPCHK(hipMemsetAsync(d_bad.p, 0, batch * 4, s));
+        HIPCHK(hipMemcpyAsync(d_in.p, blobs, batch * n * 32, hipMemcpyHostToDevice, s));
+        launch_fr_from_le32(s, d_in.p, d_poly.p, n, batch, d_bad.p);
+        HIPCHK(hipMemcpyAsync(bad.data(), d_bad.p, batch * 4, hipMemcpyDeviceToHost, s));
+        if (!comm_in) {
+            comm.resize(batch * 48);
+            CHK(d_c.alloc(batch * 48)); CHK(d_out.alloc(batch));
+            CHK(commit_rows(eth->ks, s, d_poly.p, n, batch, d_out.p));
+            launch_g1_from_kilic(s, d_out.p, batch);
+            launch_g1_compress(s, d_out.p, d_c.p, batch);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(comm.data(), d_c.p, batch * 48, hipMemcpyDeviceToHost, s));
+        }
+    }
+    // hashPolysComms (eth/helpers.go:235-260), while the device works: FrTo32 of a valid element is the blob's own 32 bytes
+    sha256 h;
+    h.update("FSBLOBVERIFY_V1_", 16);
+    h.update_u64_le(n);                                              // FieldElementsPerBlob
+    h.update_u64_le(batch);
+    if (batch) h.update(blobs, batch * n * 32);
+    HIPCHK(hipStreamSynchronize(s));
+    for (uint64_t b = 0; b < batch; b++) if (bad[b]) return KZG_HIP_ERR_BAD_BLOB;   // "could not convert blobs to polynomials"
+    if (batch) h.update(comm_in ? comm_in : comm.data(), batch * 48);
+    uint8_t tr[33];
+    h.final(tr);
+    tr[32] = 0;
+    const fr r_chal = hash_to_bls_field(tr, 33);                     // linCombChallenge
+    tr[32] = 1;
+    z_out = hash_to_bls_field(tr, 33);                               // evalChallenge
+    pw.resize(batch);                                                // ComputePowers (eth/helpers.go:87-96)
+    fr cur = one<FrP>();
+    for (uint64_t i = 0; i < batch; i++) { pw[i] = cur; cur = mul(cur, r_chal); }
+    if (batch) {
+        HIPCHK(hipMemcpyAsync(d_pow.p, pw.data(), batch * sizeof(fr), hipMemcpyHostToDevice, s));
+        launch_poly_lincomb(s, d_poly.p, n, d_pow.p, batch, n, d_agg.p);
+        HIPCHK(hipGetLastError());
+    } else {
+        HIPCHK(hipMemsetAsync(d_agg.p, 0, n * sizeof(fr), s));       // PolyLinComb of no vector: zeros (bls/globals.go:157-159)
+    }
+    return KZG_HIP_OK;
+}
+int kzg_hip_eth_compute_aggregate_kzg_proof(kzg_hip_eth *eth, const void *blobs_le32, uint64_t batch, void *out_proof48, void *out_commitments48) {
+    if (!eth || !out_proof48 || (batch && !blobs_le32)) return KZG_HIP_ERR_BAD_ARG;
+    KZG_TRY
+    dev_guard g(eth->fs);
+    hipStream_t s = eth->fs->stream;
+    std::vector<fr> pw; std::vector<uint8_t> comm; fr z;
+    uint32_t bad = 0;
+    uint8_t proof[48];
+    drain_on_exit drain(s);                                          // declared after the host buffers the stream copies from / into
+    CHK(ensure_fixed_table(eth->ks, s));
+    dtmp<fr> d_poly(s), d_agg(s), d_pow(s), d_z(s), d_y(s); dtmp<uint8_t> d_c(s); dtmp<uint32_t> d_bad(s);
+    CHK(eth_aggregate(eth, s, (const uint8_t *)blobs_le32, nullptr, batch, d_poly, d_agg, d_pow, pw, comm, z));
+    CHK(d_z.alloc(1)); CHK(d_y.alloc(1)); CHK(d_c.alloc(48)); CHK(d_bad.alloc(1));
+    HIPCHK(hipMemcpyAsync(d_z.p, &z, sizeof(fr), hipMemcpyHostToDevice, s));
+    CHK(eth_proof_rows(eth, s, d_agg.p, eth->n, d_z.p, 1, 1, d_c.p, d_y.p, d_bad.p));   // ComputeKZGProof(aggregatedPoly, evaluationChallenge), eth/helpers.go:175
+    HIPCHK(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(proof, d_c.p, 48, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (bad) return KZG_HIP_ERR_BAD_ARG;                             // "invalid z challenge"
+    memcpy(out_proof48, proof, 48);
+    if (out_commitments48 && batch) memcpy(out_commitments48, comm.data(), batch * 48);
+    return KZG_HIP_OK;
+    KZG_CATCH
+}
+int kzg_hip_eth_compute_aggregated_poly_and_commitment(kzg_hip_eth *eth, const void *blobs_le32, const void *commitments48, uint64_t batch, void *out_poly_fr,
+                                                       void *out_commitment_g1, void *out_z_fr, void *out_y_fr) {
+    if (!eth || !out_commitment_g1 || !out_z_fr || (batch && (!blobs_le32 || !commitments48))) return KZG_HIP_ERR_BAD_ARG;
+    KZG_TRY
+    dev_guard g(eth->fs);
+    hipStream_t s = eth->fs->stream;
+    const uint64_t n = eth->n;
+    std::vector<fr> pw; std::vector<uint8_t> comm; fr z, y;
+    g1j agg_c;
+    uint32_t flag[2] = {0, 0};
+    drain_on_exit drain(s);                                          // declared after the host buffers the stream copies from / into
+    dtmp<fr> d_poly(s), d_agg(s), d_pow(s), d_z(s), d_y(s), d_q(s); dtmp<uint32_t> d_flag(s);
+    CHK(eth_aggregate(eth, s, (const uint8_t *)blobs_le32, (const uint8_t *)commitments48, batch, d_poly, d_agg, d_pow, pw, comm, z));
+    // aggregatedCommitmentG1 = LinCombG1(FromCompressedG1(commitments), powers), eth/helpers.go:149-160
+    set_inf_image(&agg_c);
+    CHK(d_flag.alloc(2));
+    HIPCHK(hipMemsetAsync(d_flag.p, 0, 8, s));
+    dtmp<g1j> d_pts(s), d_out(s); dtmp<g1a> d_tab(s); dtmp<uint8_t> d_cin(s), d_ws(s);
+    if (batch) {
+        msm_plan p = classic_plan(batch);
+        if (!msm_index_range_ok(p, batch)) return KZG_HIP_ERR_TOO_WIDE;
+        CHK(d_pts.alloc(batch)); CHK(d_out.alloc(1)); CHK(d_tab.alloc(batch)); CHK(d_cin.alloc(batch * 48)); CHK(d_ws.alloc(msm_workspace_bytes(p, batch, 1)));
+        HIPCHK(hipMemcpyAsync(d_cin.p, commitments48, batch * 48, hipMemcpyHostToDevice, s));
+        launch_g1_decompress(s, d_cin.p, d_pts.p, batch, d_flag.p);
+        launch_g1_from_kilic(s, d_pts.p, batch);
+        launch_g1_to_affine(s, d_pts.p, d_tab.p, batch);
+        launch_msm(s, p, d_tab.p, d_pow.p, batch, batch, 1, d_ws.p, d_out.p, true);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&agg_c, d_out.p, sizeof(g1j), hipMemcpyDeviceToHost, s));
+    }
+    // y = EvaluatePolynomialInEvaluationForm(aggregatedPoly, evaluationChallenge) (eth/eth.go:166): the quotient kernel's first half
+    CHK(d_z.alloc(1)); CHK(d_y.alloc(1)); CHK(d_q.alloc(n));
+    HIPCHK(hipMemcpyAsync(d_z.p, &z, sizeof(fr), hipMemcpyHostToDevice, s));
+    launch_eth_quotient(s, d_agg.p, n, eth->d_domain, n, 1, d_z.p, 1, eth->fs->d_inv_pow2 + ilog2(n), d_q.p, d_y.p, d_flag.p + 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(flag, d_flag.p, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&y, d_y.p, sizeof(fr), hipMemcpyDeviceToHost, s));
+    if (out_poly_fr) HIPCHK(hipMemcpyAsync(out_poly_fr, d_agg.p, n * sizeof(fr), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (flag[0]) return KZG_HIP_ERR_BAD_POINT;                       // FromCompressedG1 failed, eth/helpers.go:153-156
+    if (flag[1]) return KZG_HIP_ERR_BAD_ARG;                         // evaluation challenge inside the domain (probability 2^-243): the barycentric formula divides by zero
+    memcpy(out_commitment_g1, &agg_c, sizeof(g1j));
+    memcpy(out_z_fr, &z, sizeof(fr));
+    if (out_y_fr) memcpy(out_y_fr, &y, sizeof(fr));
+    return KZG_HIP_OK;
+    KZG_CATCH
+}
+// test hook: SHA-256 of a host buffer through the transcript's implementation (needs no device)
+void kzg_hip_test_sha256(const void *data, uint64_t len, void *out32) {
+    sha256 h;
+    h.update(data, len);
+    h.final((uint8_t *)out32);
 }
 
 // ---------------------------------------------------------------------------------------------------------

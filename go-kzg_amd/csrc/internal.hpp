@@ -36,6 +36,7 @@ void launch_fr_from_le32(hipStream_t s, const uint8_t *in, fr *out, uint64_t per
 void launch_fr_to_le32(hipStream_t s, const fr *in, uint8_t *out, uint64_t n);
 void launch_fr_bitrev_gather(hipStream_t s, const fr *in, fr *out, uint64_t n);
 // rows of (polynomial, z): q[row] = quotient, y_out[row] = p(z), flag[row] = 1 where z is in the domain (that row's quotient is zero)
+void launch_poly_lincomb(hipStream_t s, const fr *vectors, uint64_t stride, const fr *scalars, uint64_t count, uint64_t n, fr *out);   // bls.PolyLinComb
 void launch_eth_quotient(hipStream_t s, const fr *poly, uint64_t poly_stride, const fr *domain, uint64_t n, uint64_t batch, const fr *z, uint64_t z_stride,
                          const fr *inv_n, fr *q, fr *y_out, uint32_t *flag);
 

@@ -486,6 +486,20 @@ void launch_eth_quotient(hipStream_t s, const fr *poly, uint64_t poly_stride, co
     hipLaunchKernelGGL(k_eth_quotient, dim3((uint32_t)batch), dim3(1024), 0, s, poly, poly_stride, domain, n, z, z_stride, inv_n, q, y_out, flag);
 }
 
+// bls.PolyLinComb (bls/globals.go:155-178) over resident rows: out[i] = sum_j scalars[j] * vectors[j][i]; a lane per coefficient, the scalars
+// wave-uniform.  No vector -> zeros (:157-159).
+__global__ void k_poly_lincomb(const fr *vectors, uint64_t stride, const fr *scalars, uint64_t count, uint64_t n, fr *out) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    fr acc = zero<FrP>();
+    for (uint64_t j = 0; j < count; j++) acc = add(acc, mul(scalars[j], vectors[j * stride + t]));
+    out[t] = acc;
+}
+void launch_poly_lincomb(hipStream_t s, const fr *vectors, uint64_t stride, const fr *scalars, uint64_t count, uint64_t n, fr *out) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_poly_lincomb, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, s, vectors, stride, scalars, count, n, out);
+}
+
 // CheckProofMulti's coefficient scaling (kzg_multi_proofs.go:55-66): c_i <- c_i / x^i.  Lane i computes x^-i by
 // square-and-multiply on the once-inverted x (the reference inverts x^i afresh for every i).
 __global__ void k_fr_scale_by_inv_powers(fr *c, const fr *x, uint64_t n, fr *xpow_n) {

@@ -42,6 +42,7 @@ extern "C" {
 #define KZG_HIP_ERR_HIP 8           /* HIP runtime error, see kzg_hip_last_error() */
 #define KZG_HIP_ERR_UNSUPPORTED 9
 #define KZG_HIP_ERR_RECOVERY 10      /* "failed to reconstruct data correctly" (recover_from_samples.go:103-107) */
+#define KZG_HIP_ERR_BAD_BLOB 11      /* "could not convert blobs to polynomials" (eth/eth.go:156-159,176-179): a field element >= r */
 
 typedef struct kzg_hip_fft kzg_hip_fft;                 /* *kzg.FFTSettings         fft.go:34-42   */
 typedef struct kzg_hip_kzg kzg_hip_kzg;                 /* *kzg.KZGSettings         kzg.go:11-19   */
@@ -198,6 +199,23 @@ int kzg_hip_eth_compute_kzg_proof_batch(kzg_hip_eth *eth, const void *polys_fr, 
  * proof bytes are then those of the point at infinity and must be ignored); d_ys_fr may be null */
 int kzg_hip_eth_compute_kzg_proof_batch_dev(kzg_hip_eth *eth, const void *d_polys_fr, uint64_t n, uint64_t batch, const void *d_zs_fr, void *d_out48, void *d_ys_fr,
                                             void *d_bad_u32, void *stream);
+
+/* eth.ComputeAggregateKZGProof (eth/eth.go:175-182 -> ComputeAggregateKZGProofFromPolynomials, eth/helpers.go:165-176): the blobs of one block
+ * (batch x n x 32 little-endian bytes; batch == 0 is valid: the proof of the zero polynomial) -> the 48-byte aggregated proof.  On the device: the
+ * polynomials, their commitments, the aggregated polynomial (bls.PolyLinComb) and its proof at the evaluation challenge; on the host, while the
+ * device commits: the Fiat-Shamir transcript (hashPolysComms / hashToBLSField: one SHA-256 chain over all blobs).  out_commitments48 (optional,
+ * batch x 48) receives the blobs' commitments, which the caller needs for the block anyway.
+ * KZG_HIP_ERR_BAD_BLOB: "could not convert blobs to polynomials"; KZG_HIP_ERR_BAD_ARG: "invalid z challenge". */
+int kzg_hip_eth_compute_aggregate_kzg_proof(kzg_hip_eth *eth, const void *blobs_le32, uint64_t batch, void *out_proof48, void *out_commitments48);
+/* The prover-side pieces of eth.VerifyAggregateKZGProof (eth/eth.go:155-172): ComputeAggregatedPolyAndCommitment (eth/helpers.go:137-162) over the
+ * blobs and the EXPECTED commitments (batch x 48), then y = EvaluatePolynomialInEvaluationForm(aggregatedPoly, z).  Writes the aggregated
+ * commitment (one G1 Kilic image), z, y (optional) and the aggregated polynomial (n Fr, optional); the pairing check of
+ * VerifyKZGProofFromPoints (eth/helpers.go:55-68) stays with the caller.  KZG_HIP_ERR_BAD_BLOB as above; KZG_HIP_ERR_BAD_POINT: a commitment does
+ * not decode (:153-156); KZG_HIP_ERR_BAD_ARG: z inside the domain (the reference's barycentric formula divides by zero there). */
+int kzg_hip_eth_compute_aggregated_poly_and_commitment(kzg_hip_eth *eth, const void *blobs_le32, const void *commitments48, uint64_t batch, void *out_poly_fr,
+                                                       void *out_commitment_g1, void *out_z_fr, void *out_y_fr);
+/* test hook: SHA-256 of a host buffer through the transcript's implementation (x86 SHA extensions or the portable loop; no device needed) */
+void kzg_hip_test_sha256(const void *data, uint64_t len, void *out32);
 
 /* ---- erasure recovery ----
  * FFTSettings.ZeroPolyViaMultiplication (zero_poly.go:116-217): vanishing polynomial of the missing indices of a size-`length`

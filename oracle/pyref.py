@@ -261,3 +261,59 @@ def coset_proof_dlog(poly, s, x, l):
         rem[i] = 0
     I = rem[:l]
     return (eval_poly(poly, s) - eval_poly(I, s)) * pow(pow(s, l, R) - xl, -1, R) % R
+
+
+# ---------------- eth/ aggregate proofs: Fiat-Shamir transcript and aggregation (eth/helpers.go) ----------------
+import hashlib  # noqa: E402
+
+FIAT_SHAMIR_PROTOCOL_DOMAIN = b"FSBLOBVERIFY_V1_"  # eth/helpers.go:18
+
+
+def hash_to_bls_field(data):
+    """hashToBLSField (eth/helpers.go:113-133): SHA-256, digest as a little-endian integer, mod r."""
+    return int.from_bytes(hashlib.sha256(data).digest(), "little") % R
+
+
+def hash_polys_comms(polys, comms, field_elements_per_blob=4096):
+    """hashPolysComms (eth/helpers.go:235-260): polys = lists of ints, comms = 48-byte strings."""
+    h = hashlib.sha256()
+    h.update(FIAT_SHAMIR_PROTOCOL_DOMAIN)
+    h.update(field_elements_per_blob.to_bytes(8, "little"))
+    h.update(len(polys).to_bytes(8, "little"))
+    for poly in polys:
+        for fe in poly:
+            h.update(fe.to_bytes(32, "little"))  # bls.FrTo32
+    for c in comms:
+        h.update(bytes(c))
+    return h.digest()
+
+
+def compute_challenges(polys, comms, field_elements_per_blob=4096):
+    """ComputeChallenges (eth/helpers.go:215-232): (powers of the linear-combination challenge, evaluation challenge)."""
+    digest = hash_polys_comms(polys, comms, field_elements_per_blob)
+    r = hash_to_bls_field(digest + b"\x00")
+    z = hash_to_bls_field(digest + b"\x01")
+    powers, cur = [], 1
+    for _ in polys:  # ComputePowers, eth/helpers.go:87-96
+        powers.append(cur)
+        cur = cur * r % R
+    return powers, z
+
+
+def compute_aggregated_poly(polys, comms, field_elements_per_blob=4096):
+    """ComputeAggregatedPolyAndCommitment (eth/helpers.go:137-162) without the G1 part: (aggregated polynomial, powers, z);
+    bls.PolyLinComb (bls/globals.go:155-178) of no vector is the zero vector."""
+    powers, z = compute_challenges(polys, comms, field_elements_per_blob)
+    agg = [0] * field_elements_per_blob
+    for s_, poly in zip(powers, polys):
+        agg = [(a + s_ * v) % R for a, v in zip(agg, poly)]
+    return agg, powers, z
+
+
+def eval_in_evaluation_form(poly, x, domain):
+    """bls.EvaluatePolyInEvaluationForm (bls/globals.go:106-153), x outside the domain."""
+    n = len(poly)
+    acc = 0
+    for p_, w in zip(poly, domain):
+        acc = (acc + p_ * w % R * pow(x - w, -1, R)) % R
+    return acc * ((pow(x, n, R) - 1) * pow(n, -1, R) % R) % R

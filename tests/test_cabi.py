@@ -49,6 +49,30 @@ def test_product_does_not_touch_the_oracle():
     assert "oracle" not in open(os.path.join(ROOT, "include", "kzg_hip.h")).read()
 
 
+def test_transcript_sha256_matches_hashlib_on_both_code_paths():
+    """the SHA-256 behind eth.ComputeAggregateKZGProof's Fiat-Shamir transcript (go-kzg_amd/csrc/sha256.cpp): x86 SHA extensions where the CPU
+    has them and the portable loop (forced with KZG_HIP_SHA256=portable in a child process), every length around the padding boundaries"""
+    import subprocess
+    import sys
+    prog = (
+        "import ctypes, hashlib, random, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import gokzg_amd\n"
+        "L = ctypes.CDLL(gokzg_amd.LIB_PATH)\n"
+        "L.kzg_hip_test_sha256.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p]\n"
+        "L.kzg_hip_test_sha256.restype = None\n"
+        "random.seed(7)\n"
+        "for n in list(range(0, 260)) + [4096, 131072 + 16 + 16, 3 * 131072 + 177]:\n"
+        "    d = random.randbytes(n)\n"
+        "    out = ctypes.create_string_buffer(32)\n"
+        "    L.kzg_hip_test_sha256(d, n, out)\n"
+        "    assert out.raw == hashlib.sha256(d).digest(), n\n"
+        "print('ok')\n") % ROOT
+    for mode in ("", "portable"):
+        env = dict(os.environ, KZG_HIP_SHA256=mode)
+        assert subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=120).stdout.strip() == "ok", mode
+
+
 # ---- a compiled C consumer of the boundary, bound the way cgo would bind it (tests/host/cabi_consumer.c) ----
 def _build_consumer():
     import subprocess

@@ -856,6 +856,55 @@ def test_eth_compute_kzg_proof_batch_and_concurrent_callers(kz):
     eth.close(); fs.close()
 
 
+def test_eth_compute_aggregate_kzg_proof(kz):
+    """eth.ComputeAggregateKZGProof (eth/eth.go:175-182) and the prover-side pieces of VerifyAggregateKZGProof (:155-172) against the restatement of
+    eth/helpers.go:113-176,215-260 in oracle/pyref.py (hashlib transcript, Python-integer aggregation) + the oracle's MSM, and against the
+    pairing-free identity with s = 1337; blocks of 3, 1 and 0 blobs; an invalid field element; an undecodable commitment"""
+    fs = kz.FFTSettings(12)
+    lag = ko.g1_decompress(np.frombuffer(open(os.path.join(GOLDEN, "trusted_setup_g1_lagrange.bin"), "rb").read(), dtype=np.uint8))
+    eth = kz.EthSettings(fs, lag)
+    R = ko.R_MOD
+    pfs = pyref.FFTSettings(12)
+    dom = [pfs.expanded[pyref.rev_bits(i, 12)] for i in range(4096)]
+    lag_br = ko.reverse_bit_order(lag)
+    polys_i = [ko.fr_to_ints(ko.synthetic_blob(700 + b)) for b in range(3)]
+    polys_i[1][17] = R - 1                                           # the largest valid element
+    blobs = np.stack([np.frombuffer(b"".join(v.to_bytes(32, "little") for v in p_), dtype=np.uint8).reshape(4096, 32) for p_ in polys_i])
+    for count in (3, 1, 0):
+        proof, comm = eth.compute_aggregate_kzg_proof(blobs[:count])
+        want_comm, ok = eth.blob_to_kzg_commitment_batch(blobs[:count]) if count else (np.zeros((0, 48), dtype=np.uint8), np.zeros(0, dtype=bool))
+        assert ok.all() and comm.tobytes() == want_comm.tobytes()
+        agg, powers, z = pyref.compute_aggregated_poly(polys_i[:count], [c.tobytes() for c in comm])
+        y_ref = pyref.eval_in_evaluation_form(agg, z, dom)
+        q = [(p_ - y_ref) * pow(w - z, -1, R) % R for p_, w in zip(agg, dom)]
+        assert proof.tobytes().hex() == comp_hex(ko.lincomb_g1(lag_br, ko.fr_from_ints(q)))[0], count
+        coeffs = pfs.fft(pyref.bitrev(agg), inv=True)
+        assert pyref.eval_poly(coeffs, z) == y_ref
+        d = (pyref.eval_poly(coeffs, 1337) - y_ref) * pow(1337 - z, -1, R) % R       # pairing-free VerifyKZGProof with the setup's secret
+        assert proof.tobytes().hex() == comp_hex(ko.g1_mul(ko.g1_generator(), ko.fr_from_ints([d])[0]))[0], count
+        if count == 0:
+            assert proof.tobytes().hex() == "c0" + "00" * 47                              # the zero polynomial's proof: the point at infinity
+        # the verifier's side on the same block
+        poly, c_agg, z_got, y_got = eth.compute_aggregated_poly_and_commitment(blobs[:count], comm)
+        assert ko.fr_to_ints(poly) == agg and ko.fr_to_ints(z_got.reshape(1, 4))[0] == z and ko.fr_to_ints(y_got.reshape(1, 4))[0] == y_ref
+        want_c = ko.lincomb_g1(ko.g1_decompress(comm.reshape(-1)), ko.fr_from_ints(powers)) if count else ko.g1_zero(1)
+        assert comp_hex(c_agg.reshape(1, -1)) == comp_hex(want_c), count
+        # the aggregated commitment commits to the aggregated polynomial
+        assert comp_hex(c_agg.reshape(1, -1)) == comp_hex(ko.lincomb_g1(lag_br, ko.fr_from_ints(agg)))
+    bad = blobs.copy()
+    bad[2, 4095] = np.frombuffer(R.to_bytes(32, "little"), dtype=np.uint8)
+    with pytest.raises(kz.KzgError, match="could not convert blobs"):
+        eth.compute_aggregate_kzg_proof(bad)
+    _, comm = eth.compute_aggregate_kzg_proof(blobs)
+    with pytest.raises(kz.KzgError, match="could not convert blobs"):
+        eth.compute_aggregated_poly_and_commitment(bad, comm)
+    broken = comm.copy()
+    broken[1, 47] ^= 1                                               # x no longer on the curve (or not in the subgroup)
+    with pytest.raises(kz.KzgError, match="invalid commitment"):
+        eth.compute_aggregated_poly_and_commitment(blobs, broken)
+    eth.close(); fs.close()
+
+
 def test_host_buffer_calls_from_many_threads_use_the_stream_pool(kz):
     """FFT / FFTG1 / DASFFTExtension / uncached LinCombG1 on host buffers lease a stream of the handle's pool instead of serialising on one
     stream under the handle mutex: 16 threads get bit-identical results, and their FFT_Fr(4096) calls overlap (aggregate rate well above one
