@@ -498,6 +498,17 @@ def main():
                 eth_proof = {"entry": "kzg_hip_eth_compute_kzg_proof (host buffers, blocking, one polynomial per call; coalesced in the library)",
                              "device_resident_batch_%d_per_s" % EB: EB * 5 / esecs, "invalid_rows_in_batch": int((d_bad != 0).sum().item()),
                              "threads_per_s": erates, "monomial_table_GB_beside_it": table_sweep["64"]["table_GB"]}
+                # eth.ComputeAggregateKZGProof (eth/eth.go:175-182): the blobs of one block from host buffers -> commitments + aggregated proof,
+                # the SHA-256 transcript hashed on the host while the device commits
+                agg = {}
+                blob_bytes = splitmix_blobs_le32(99, 16, N_COEFF)
+                for nb in (1, 4, 16):
+                    eth.compute_aggregate_kzg_proof(blob_bytes[:nb])
+                    t0_ = time.perf_counter()
+                    for _ in range(10):
+                        eth.compute_aggregate_kzg_proof(blob_bytes[:nb])
+                    agg["%d_blobs_ms" % nb] = (time.perf_counter() - t0_) / 10 * 1e3
+                eth_proof["compute_aggregate_kzg_proof_host_buffers"] = agg
                 eth.close()
             except Exception as e:                              # noqa: BLE001
                 eth_proof = {"error": "%s: %s" % (type(e).__name__, e)}

@@ -110,6 +110,8 @@ def lib():
         "kzg_hip_eth_compute_aggregate_kzg_proof": (i32, [vp, vp, u64, vp, vp]),
         "kzg_hip_eth_compute_aggregated_poly_and_commitment": (i32, [vp, vp, vp, u64, vp, vp, vp, vp]),
         "kzg_hip_test_sha256": (None, [vp, u64, vp]),
+        "kzg_hip_evaluate_poly_in_evaluation_form": (i32, [vp, vp, u64, vp, u32, vp]),
+        "kzg_hip_eth_evaluate_polynomial_in_evaluation_form": (i32, [vp, vp, u64, vp, vp]),
         "kzg_hip_bench_threads_fft_fr": (i32, [vp, vp, u64, u64, u32, u32, vp, C.POINTER(C.c_double)]),
         "kzg_hip_bench_drop_in_eth_proof": (i32, [vp, vp, u64, u64, u32, u32, vp, C.POINTER(C.c_double)]),
         "kzg_hip_zero_poly_via_multiplication": (i32, [vp, vp, u64, u64, vp, vp]),
@@ -227,6 +229,15 @@ class FFTSettings:
         out = g1_empty(vals.shape[0])
         _chk(lib().kzg_hip_fft_g1(self.h, _p(vals), vals.shape[0], int(inv), _p(out)), error_ok=True)
         return out
+
+    def evaluate_poly_in_evaluation_form(self, poly, x, scale=0):
+        """bls.EvaluatePolyInEvaluationForm(y, poly, x, fs.ExpandedRootsOfUnity[:fs.MaxWidth], scale) (bls/globals.go:106-153)"""
+        poly, x, y = _fr(poly), _fr(x), fr_empty(1)
+        st = lib().kzg_hip_evaluate_poly_in_evaluation_form(self.h, _p(poly), poly.shape[0], _p(x), scale, _p(y))
+        if st == ERR_BAD_ARG:
+            raise KzgError(st, "x is in the domain")
+        _chk(st)
+        return y[0]
 
     def das_fft_extension(self, vals):
         """FFTSettings.DASFFTExtension (das_extension.go:71-84); returns the odd values (the reference writes in place)"""
@@ -599,6 +610,15 @@ class EthSettings:
         out, ys, ok = np.zeros((b, 48), dtype=np.uint8), fr_empty(b), np.zeros(b, dtype=np.uint8)
         _chk(lib().kzg_hip_eth_compute_kzg_proof_batch(self.h, _p(polys), self.n, b, _p(zs), _p(out), _p(ys), _p(ok)))
         return out, ys, ok.astype(bool)
+
+    def evaluate_polynomial_in_evaluation_form(self, polynomial, x):
+        """eth.EvaluatePolynomialInEvaluationForm (eth/helpers.go:207-211)"""
+        poly, x, y = _fr(polynomial), _fr(x), fr_empty(1)
+        st = lib().kzg_hip_eth_evaluate_polynomial_in_evaluation_form(self.h, _p(poly), poly.shape[0], _p(x), _p(y))
+        if st == ERR_BAD_ARG:
+            raise KzgError(st, "x is in the domain")
+        _chk(st)
+        return y[0]
 
     def compute_aggregate_kzg_proof(self, blobs):
         """eth.ComputeAggregateKZGProof (eth/eth.go:175-182) on (batch, n, 32) uint8 blobs (batch may be 0): (proof48, (batch, 48) commitments);

@@ -1893,6 +1893,41 @@ int kzg_hip_eth_compute_aggregated_poly_and_commitment(kzg_hip_eth *eth, const v
     return KZG_HIP_OK;
     KZG_CATCH
 }
+// bls.EvaluatePolyInEvaluationForm (bls/globals.go:106-153) with rootsOfUnity = the settings' ExpandedRootsOfUnity[:MaxWidth] (the form of
+// fft_fr_test.go:73-99), and eth.EvaluatePolynomialInEvaluationForm (eth/helpers.go:207-211: DomainFr, scale 0): the first half of the quotient kernel
+static int evaluate_in_evaluation_form(kzg_hip_fft *fs, const fr *d_roots, uint64_t root_stride, const void *poly_fr, uint64_t n, const void *x_fr, void *out_y_fr) {
+    stream_lease lease(fs);
+    hipStream_t s = lease.s;
+    fr y; uint32_t flag = 0;
+    drain_on_exit drain(s);
+    dtmp<fr> d_poly(s), d_x(s), d_y(s), d_q(s); dtmp<uint32_t> d_flag(s);
+    CHK(d_poly.alloc(n)); CHK(d_x.alloc(1)); CHK(d_y.alloc(1)); CHK(d_q.alloc(n)); CHK(d_flag.alloc(1));
+    HIPCHK(hipMemsetAsync(d_flag.p, 0, 4, s));
+    HIPCHK(hipMemcpyAsync(d_poly.p, poly_fr, n * sizeof(fr), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_x.p, x_fr, sizeof(fr), hipMemcpyHostToDevice, s));
+    launch_eth_quotient(s, d_poly.p, n, d_roots, n, 1, d_x.p, 1, fs->d_inv_pow2 + ilog2(n), d_q.p, d_y.p, d_flag.p, root_stride);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&y, d_y.p, sizeof(fr), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&flag, d_flag.p, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (flag) return KZG_HIP_ERR_BAD_ARG;                            // x inside the domain: the barycentric formula divides by zero
+    memcpy(out_y_fr, &y, sizeof(fr));
+    return KZG_HIP_OK;
+}
+int kzg_hip_evaluate_poly_in_evaluation_form(kzg_hip_fft *fs, const void *poly_fr, uint64_t n, const void *x_fr, uint32_t scale, void *out_y_fr) {
+    if (!fs || !poly_fr || !x_fr || !out_y_fr) return KZG_HIP_ERR_BAD_ARG;
+    if (scale > 63 || n != fs->W >> scale || !n) return KZG_HIP_ERR_LEN_MISMATCH;   // "expected roots of unity ... to match polynomial size", bls/globals.go:107-109
+    KZG_TRY
+    return evaluate_in_evaluation_form(fs, fs->d_expanded, 1ull << scale, poly_fr, n, x_fr, out_y_fr);
+    KZG_CATCH
+}
+int kzg_hip_eth_evaluate_polynomial_in_evaluation_form(kzg_hip_eth *eth, const void *poly_fr, uint64_t n, const void *x_fr, void *out_y_fr) {
+    if (!eth || !poly_fr || !x_fr || !out_y_fr) return KZG_HIP_ERR_BAD_ARG;
+    if (n != eth->n) return KZG_HIP_ERR_LEN_MISMATCH;
+    KZG_TRY
+    return evaluate_in_evaluation_form(eth->fs, eth->d_domain, 1, poly_fr, n, x_fr, out_y_fr);
+    KZG_CATCH
+}
 // test hook: SHA-256 of a host buffer through the transcript's implementation (needs no device)
 void kzg_hip_test_sha256(const void *data, uint64_t len, void *out32) {
     sha256 h;

@@ -38,7 +38,7 @@ void launch_fr_bitrev_gather(hipStream_t s, const fr *in, fr *out, uint64_t n);
 // rows of (polynomial, z): q[row] = quotient, y_out[row] = p(z), flag[row] = 1 where z is in the domain (that row's quotient is zero)
 void launch_poly_lincomb(hipStream_t s, const fr *vectors, uint64_t stride, const fr *scalars, uint64_t count, uint64_t n, fr *out);   // bls.PolyLinComb
 void launch_eth_quotient(hipStream_t s, const fr *poly, uint64_t poly_stride, const fr *domain, uint64_t n, uint64_t batch, const fr *z, uint64_t z_stride,
-                         const fr *inv_n, fr *q, fr *y_out, uint32_t *flag);
+                         const fr *inv_n, fr *q, fr *y_out, uint32_t *flag, uint64_t dom_stride = 1);
 
 void launch_fr_scale_by_inv_powers(hipStream_t s, fr *c, const fr *x, uint64_t n, fr *xpow_n);   // c_i /= x^i; *xpow_n = x^n
 

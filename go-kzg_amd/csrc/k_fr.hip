@@ -423,8 +423,8 @@ void launch_fr_bitrev_gather(hipStream_t s, const fr *in, fr *out, uint64_t n) {
 // Every lane inverts the PRODUCT of its (up to four) denominators once (binary GCD) and unwinds it (Montgomery's trick: the reference's
 // BatchInvModFr, per lane); LDS tree for the sum.  A row whose z is in the domain ("invalid z challenge", :190-192) sets flag[row] and gets
 // a zero quotient (its proof is never looked at) -- no host round trip between this kernel and the commitment of the quotients.
-__global__ __launch_bounds__(1024) void k_eth_quotient(const fr *poly_all, uint64_t poly_stride, const fr *domain, uint64_t n, const fr *z_all, uint64_t z_stride,
-                                                       const fr *inv_n, fr *q_all, fr *y_all, uint32_t *flag_all) {
+__global__ __launch_bounds__(1024) void k_eth_quotient(const fr *poly_all, uint64_t poly_stride, const fr *domain, uint64_t dom_stride, uint64_t n, const fr *z_all,
+                                                       uint64_t z_stride, const fr *inv_n, fr *q_all, fr *y_all, uint32_t *flag_all) {
     __shared__ fr red[1024];
     __shared__ uint32_t bad;
     const uint32_t tid = threadIdx.x;
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(1024) void k_eth_quotient(const fr *poly_all, uint6
         for (int k = 0; k < 4; k++) {
             const uint64_t i = base + tid + 1024u * k;
             if (i < n) {
-                d[k] = sub(z, domain[i]);
+                d[k] = sub(z, domain[i * dom_stride]);
                 pv[k] = poly[i];
                 if (is_zero<FrP>(d[k])) { hit = 1; d[k] = one<FrP>(); }
                 pre[k] = acc;
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(1024) void k_eth_quotient(const fr *poly_all, uint6
                 const fr di = mul(ia, pre[k]);                     // 1 / (z - w_i)
                 ia = mul(ia, d[k]);
                 q[i] = di;                                         // stash it; second use below, after y is known
-                part = add(part, mul(mul(pv[k], domain[i]), di));
+                part = add(part, mul(mul(pv[k], domain[i * dom_stride]), di));
             }
         }
     }
@@ -481,9 +481,9 @@ __global__ __launch_bounds__(1024) void k_eth_quotient(const fr *poly_all, uint6
     }
 }
 void launch_eth_quotient(hipStream_t s, const fr *poly, uint64_t poly_stride, const fr *domain, uint64_t n, uint64_t batch, const fr *z, uint64_t z_stride,
-                         const fr *inv_n, fr *q, fr *y_out, uint32_t *flag) {
+                         const fr *inv_n, fr *q, fr *y_out, uint32_t *flag, uint64_t dom_stride) {
     if (!batch) return;
-    hipLaunchKernelGGL(k_eth_quotient, dim3((uint32_t)batch), dim3(1024), 0, s, poly, poly_stride, domain, n, z, z_stride, inv_n, q, y_out, flag);
+    hipLaunchKernelGGL(k_eth_quotient, dim3((uint32_t)batch), dim3(1024), 0, s, poly, poly_stride, domain, dom_stride, n, z, z_stride, inv_n, q, y_out, flag);
 }
 
 // bls.PolyLinComb (bls/globals.go:155-178) over resident rows: out[i] = sum_j scalars[j] * vectors[j][i]; a lane per coefficient, the scalars

@@ -214,6 +214,12 @@ int kzg_hip_eth_compute_aggregate_kzg_proof(kzg_hip_eth *eth, const void *blobs_
  * not decode (:153-156); KZG_HIP_ERR_BAD_ARG: z inside the domain (the reference's barycentric formula divides by zero there). */
 int kzg_hip_eth_compute_aggregated_poly_and_commitment(kzg_hip_eth *eth, const void *blobs_le32, const void *commitments48, uint64_t batch, void *out_poly_fr,
                                                        void *out_commitment_g1, void *out_z_fr, void *out_y_fr);
+/* bls.EvaluatePolyInEvaluationForm(y, poly, x, fs.ExpandedRootsOfUnity[:fs.MaxWidth], scale) (bls/globals.go:106-153, as called in
+ * fft_fr_test.go:73-99): poly[i] = f(w^(i << scale)), n = MaxWidth >> scale (else KZG_HIP_ERR_LEN_MISMATCH: the reference's panic), barycentric
+ * evaluation at x.  KZG_HIP_ERR_BAD_ARG: x is one of the roots (the formula divides by zero). */
+int kzg_hip_evaluate_poly_in_evaluation_form(kzg_hip_fft *fs, const void *poly_fr, uint64_t n, const void *x_fr, uint32_t scale, void *out_y_fr);
+/* eth.EvaluatePolynomialInEvaluationForm (eth/helpers.go:207-211): the same on DomainFr (bit-reversed order) */
+int kzg_hip_eth_evaluate_polynomial_in_evaluation_form(kzg_hip_eth *eth, const void *poly_fr, uint64_t n, const void *x_fr, void *out_y_fr);
 /* test hook: SHA-256 of a host buffer through the transcript's implementation (x86 SHA extensions or the portable loop; no device needed) */
 void kzg_hip_test_sha256(const void *data, uint64_t len, void *out32);
 

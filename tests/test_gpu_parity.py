@@ -856,6 +856,38 @@ def test_eth_compute_kzg_proof_batch_and_concurrent_callers(kz):
     eth.close(); fs.close()
 
 
+def test_evaluate_poly_in_evaluation_form(kz):
+    """TestEvaluatePolyInEvaluationForm (fft_fr_test.go:73-99): coefficients -> FFT -> barycentric evaluation at random x == Horner on the
+    coefficients (bls.EvalPolyAt, restated in pyref.eval_poly); at scale 4 as in the reference and at 4096 points with a strided domain
+    (scale 1 of a 8192-wide settings object); eth's form on the bit-reversed domain; x inside the domain is refused"""
+    R = ko.R_MOD
+    rng = np.random.default_rng(11)
+
+    def rand_ints(k):
+        return [int.from_bytes(rng.bytes(32), "little") % R for _ in range(k)]
+    for max_scale, scale in ((4, 0), (13, 1), (12, 0)):
+        fs = kz.FFTSettings(max_scale)
+        n = (1 << max_scale) >> scale
+        coeffs = rand_ints(n)
+        pfs = pyref.FFTSettings(max_scale - scale)
+        evals = pfs.fft(coeffs)
+        assert ko.fr_to_ints(fs.fft(ko.fr_from_ints(coeffs))) == evals if scale == 0 else True
+        for x in rand_ints(5 if n > 100 else 100) + [0]:
+            y = fs.evaluate_poly_in_evaluation_form(ko.fr_from_ints(evals), ko.fr_from_ints([x]), scale)
+            assert ko.fr_to_ints(y.reshape(1, 4))[0] == pyref.eval_poly(coeffs, x)
+        with pytest.raises(kz.KzgError, match="in the domain"):
+            fs.evaluate_poly_in_evaluation_form(ko.fr_from_ints(evals), ko.fr_from_ints([pfs.expanded[3]]), scale)
+        with pytest.raises(kz.KzgPanic):
+            fs.evaluate_poly_in_evaluation_form(ko.fr_from_ints(evals[: n // 2]), ko.fr_from_ints([5]), scale)
+        if max_scale == 12:
+            lag = ko.g1_decompress(np.frombuffer(open(os.path.join(GOLDEN, "trusted_setup_g1_lagrange.bin"), "rb").read(), dtype=np.uint8))
+            eth = kz.EthSettings(fs, lag)
+            y = eth.evaluate_polynomial_in_evaluation_form(ko.fr_from_ints(pyref.bitrev(evals)), ko.fr_from_ints([12345]))
+            assert ko.fr_to_ints(y.reshape(1, 4))[0] == pyref.eval_poly(coeffs, 12345)
+            eth.close()
+        fs.close()
+
+
 def test_eth_compute_aggregate_kzg_proof(kz):
     """eth.ComputeAggregateKZGProof (eth/eth.go:175-182) and the prover-side pieces of VerifyAggregateKZGProof (:155-172) against the restatement of
     eth/helpers.go:113-176,215-260 in oracle/pyref.py (hashlib transcript, Python-integer aggregation) + the oracle's MSM, and against the
