@@ -7,6 +7,7 @@
 //   Go panic (kzg.go:22-27,44-52,74-91; fk20_*.go; bls_kilic.go:133)  -> kzg::Panic   (status 3-7 and anything else)
 // Memory images are the Kilic backend's: bls.Fr = [4]uint64 Montgomery, bls.G1Point = [3][6]uint64 Jacobian Montgomery; slices are passed as is.
 #pragma once
+#include <array>
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
@@ -199,5 +200,54 @@ class FK20MultiSettings {
   private:
     kzg_hip_fk20m *h_ = nullptr; uint64_t chunk_;
 };
+
+// package eth (eth/globals.go:39-72, eth/eth.go:145-182, eth/helpers.go:179-211): byte-level callers.  Blob = FieldElementsPerBlob x 32 little-endian
+// bytes, KZGCommitment / KZGProof = 48 bytes; `error` returns of the reference are kzg::Error with its texts.
+namespace eth {
+using Blob = std::vector<uint8_t>;
+using Bytes48 = std::array<uint8_t, 48>;
+class Settings {
+  public:
+    // setupG1Lagrange in NATURAL order, as eth/trusted_setup.json stores it (the library applies bitReversalPermutation, eth/globals.go:48)
+    Settings(const FFTSettings *fs, const std::vector<G1Point> &setupG1Lagrange) : n_(setupG1Lagrange.size()) {
+        detail::must(kzg_hip_eth_settings_new(fs->handle(), setupG1Lagrange.data(), n_, &h_));
+    }
+    ~Settings() { kzg_hip_eth_settings_free(h_); }
+    Settings(const Settings &) = delete;
+    Settings &operator=(const Settings &) = delete;
+    std::pair<Bytes48, bool> BlobToKZGCommitment(const Blob &blob) const {                        // eth/eth.go:145-151
+        Bytes48 out{}; uint8_t ok = 0;
+        if (blob.size() != n_ * 32) throw Panic(KZG_HIP_ERR_LEN_MISMATCH, "blob size");
+        detail::must(kzg_hip_eth_blob_to_kzg_commitment_batch(h_, blob.data(), 1, out.data(), &ok));
+        return {out, ok != 0};
+    }
+    Bytes48 ComputeKZGProof(const std::vector<Fr> &polynomial, const Fr &z) const {               // eth/helpers.go:179-203
+        Bytes48 out{};
+        int st = kzg_hip_eth_compute_kzg_proof(h_, polynomial.data(), polynomial.size(), &z, out.data(), nullptr);
+        if (st == KZG_HIP_ERR_LEN_MISMATCH) throw Error(st, "polynomial has invalid length");
+        if (st == KZG_HIP_ERR_BAD_ARG) throw Error(st, "invalid z challenge");
+        detail::must(st);
+        return out;
+    }
+    Fr EvaluatePolynomialInEvaluationForm(const std::vector<Fr> &poly, const Fr &x) const {       // eth/helpers.go:207-211
+        Fr y; detail::must(kzg_hip_eth_evaluate_polynomial_in_evaluation_form(h_, poly.data(), poly.size(), &x, &y)); return y;
+    }
+    Bytes48 ComputeAggregateKZGProof(const std::vector<Blob> &blobs, std::vector<Bytes48> *commitments = nullptr) const {   // eth/eth.go:175-182
+        std::vector<uint8_t> flat;
+        for (const auto &b : blobs) { if (b.size() != n_ * 32) throw Panic(KZG_HIP_ERR_LEN_MISMATCH, "blob size"); flat.insert(flat.end(), b.begin(), b.end()); }
+        Bytes48 out{};
+        std::vector<Bytes48> comm(blobs.size());
+        int st = kzg_hip_eth_compute_aggregate_kzg_proof(h_, flat.data(), blobs.size(), out.data(), comm.data());
+        if (st == KZG_HIP_ERR_BAD_BLOB) throw Error(st, "could not convert blobs to polynomials");
+        if (st == KZG_HIP_ERR_BAD_ARG) throw Error(st, "invalid z challenge");
+        detail::must(st);
+        if (commitments) *commitments = comm;
+        return out;
+    }
+
+  private:
+    kzg_hip_eth *h_ = nullptr; uint64_t n_;
+};
+}  // namespace eth
 
 }  // namespace kzg

@@ -5,6 +5,7 @@
 //   TestKZGSettings_CommitToEvalPoly / _CheckProofSingle   kzg_single_proofs_test.go:11-64   (pairing check -> SURVEY 8c vectors A, B)
 //   TestKZGSettings_DAUsingFK20                        fk20_single_test.go:11-47           (pairing check -> vector C)
 //   TestFFTSettings_RecoverPolyFromSamples_Simple      recover_from_samples_test.go:10-60
+//   package eth (no tests in the reference): ComputeAggregateKZGProof / BlobToKZGCommitment / ComputeKZGProof against oracle values
 //   error behaviour: FFT's `error` values (fft_fr.go:57-59,78-83) and the panics of kzg.go:22-27, fk20_single.go:140-154
 // Expected values come from tests/golden/*.json through a key/value file written by tests/test_cabi.py (argv[1]).
 // TEST INFRASTRUCTURE, built and run by tests/test_cabi.py (-m gpu).
@@ -115,6 +116,37 @@ static void TestFFTSettings_RecoverPolyFromSamples_Simple() {
     auto back = fs.FFT(recovered, true);
     for (uint64_t i = 0; i < fs.MaxWidth; i++) CHECK(EqualFr(back[i], poly[i]), "coeff at index %llu", (unsigned long long)i);
 }
+// package eth has no tests in the reference: the block-level caller against values computed by the oracle (tests/test_cabi.py writes them)
+static eth::Blob mirrorBlob(uint64_t b) {                                             // element i of blob b = i * i + 7 * b + 3 (same formula in test_cabi.py)
+    eth::Blob blob(4096 * 32, 0);
+    for (uint64_t i = 0; i < 4096; i++) { uint64_t v = i * i + 7 * b + 3; std::memcpy(&blob[32 * i], &v, 8); }
+    return blob;
+}
+static void TestEth_ComputeAggregateKZGProof() {
+    FFTSettings fs(12);
+    auto setup = fs.GenerateTestingSetupG1("1337", 4096);                              // eth/trusted_setup.json's secret
+    auto lagrange = fs.FFTG1(setup, true);                                             // setup_G1_lagrange, natural order
+    eth::Settings es(&fs, lagrange);
+    std::vector<eth::Blob> blobs = {mirrorBlob(0), mirrorBlob(1)};
+    std::vector<eth::Bytes48> comms;
+    auto proof = es.ComputeAggregateKZGProof(blobs, &comms);
+    auto hex48 = [](const eth::Bytes48 &b) { return hex(std::vector<uint8_t>(b.begin(), b.end()), 0, 48); };
+    const auto &want = KAT["eth_aggregate"];                                           // commitment 0, commitment 1, proof
+    CHECK(want.size() == 3, "fixture");
+    CHECK(comms.size() == 2 && hex48(comms[0]) == want[0] && hex48(comms[1]) == want[1], "commitments");
+    CHECK(hex48(proof) == want[2], "aggregated proof %s", hex48(proof).c_str());
+    auto c0 = es.BlobToKZGCommitment(blobs[0]);
+    CHECK(c0.second && hex48(c0.first) == want[0], "BlobToKZGCommitment");
+    CHECK(hex48(es.ComputeAggregateKZGProof({})) == "c0" + std::string(94, '0'), "no blobs: the proof of the zero polynomial");
+    auto bad = blobs;
+    std::memset(&bad[1][32 * 100], 0xff, 32);                                          // an element >= r
+    try { es.ComputeAggregateKZGProof(bad); CHECK(false, "expected an error"); }
+    catch (const Error &e) { CHECK(std::string(e.what()) == "could not convert blobs to polynomials", "%s", e.what()); }
+    CHECK(!es.BlobToKZGCommitment(bad[1]).second, "BlobToKZGCommitment of an invalid blob");
+    auto poly = fs.FrFrom32(blobs[0]);
+    try { es.ComputeKZGProof(poly, fs.AsFr(1)); CHECK(false, "expected an error"); }   // 1 = DomainFr[0]
+    catch (const Error &e) { CHECK(std::string(e.what()) == "invalid z challenge", "%s", e.what()); }
+}
 static void TestErrorsAndPanics() {
     FFTSettings fs(4);
     std::vector<Fr> tooMany(17, fs.AsFr(1)), notPow2(12, fs.AsFr(1));
@@ -149,7 +181,8 @@ int main(int argc, char **argv) {
         {"TestParametrizedDASFFTExtension", TestParametrizedDASFFTExtension},
         {"TestKZGSettings_CommitToEvalPoly_and_CheckProofSingle", TestKZGSettings_CommitToEvalPoly_and_CheckProofSingle},
         {"TestKZGSettings_DAUsingFK20", TestKZGSettings_DAUsingFK20},
-        {"TestFFTSettings_RecoverPolyFromSamples_Simple", TestFFTSettings_RecoverPolyFromSamples_Simple}, {"TestErrorsAndPanics", TestErrorsAndPanics}};
+        {"TestFFTSettings_RecoverPolyFromSamples_Simple", TestFFTSettings_RecoverPolyFromSamples_Simple}, {"TestErrorsAndPanics", TestErrorsAndPanics},
+        {"TestEth_ComputeAggregateKZGProof", TestEth_ComputeAggregateKZGProof}};
     for (auto &t : tests) {
         int before = failures;
         try { t.fn(); } catch (const std::exception &e) { failures++; printf("FAIL %s: unexpected %s\n", t.name, e.what()); }

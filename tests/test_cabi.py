@@ -117,6 +117,27 @@ def test_c_consumer_runs_the_vectors():
 
 
 # ---- the C++ mirror of the Go API (include/kzg_hip.hpp) and the reference's tests re-stated against it (tests/host/go_mirror_test.cpp) ----
+def _eth_aggregate_expected():
+    """what eth.ComputeAggregateKZGProof returns for the two blobs of go_mirror_test.cpp (element i of blob b = i * i + 7 * b + 3), from the oracle:
+    commitments (oracle MSM over the bit-reversed Lagrange setup), transcript + aggregation (oracle/pyref.py), proof (oracle MSM)"""
+    import sys
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from oracle import koracle as ko, pyref
+    R = ko.R_MOD
+    lag = ko.g1_decompress(np.frombuffer(open(os.path.join(ROOT, "tests", "golden", "trusted_setup_g1_lagrange.bin"), "rb").read(), dtype=np.uint8))
+    lag_br = ko.reverse_bit_order(lag)
+    polys = [[i * i + 7 * b + 3 for i in range(4096)] for b in range(2)]
+    comms = [ko.g1_compress(ko.lincomb_g1(lag_br, ko.fr_from_ints(p_)))[0].tobytes() for p_ in polys]
+    agg, _, z = pyref.compute_aggregated_poly(polys, comms)
+    pfs = pyref.FFTSettings(12)
+    dom = [pfs.expanded[pyref.rev_bits(i, 12)] for i in range(4096)]
+    y = pyref.eval_in_evaluation_form(agg, z, dom)
+    q = [(p_ - y) * pow(w - z, -1, R) % R for p_, w in zip(agg, dom)]
+    proof = ko.g1_compress(ko.lincomb_g1(lag_br, ko.fr_from_ints(q)))[0].tobytes()
+    return [c.hex() for c in comms] + [proof.hex()]
+
+
 def _build_go_mirror():
     import subprocess
     import gokzg_amd
@@ -134,6 +155,7 @@ def _build_go_mirror():
     lines = ["test_inv_fft " + " ".join(kats["test_inv_fft"]["expected"]), "test_das_fft_extension " + " ".join(kats["test_das_fft_extension"]["expected"]),
              "A_commit " + der["A_commit_test_poly"], "B_proof " + der["B_proof_single_x17"], "C_idx " + " ".join(str(i) for i in idx),
              "C_val " + " ".join(c[str(i)] for i in idx)]
+    lines.append("eth_aggregate " + " ".join(_eth_aggregate_expected()))
     kat = os.path.join(bdir, "go_mirror_kats.txt")
     open(kat, "w").write("\n".join(lines) + "\n")
     return exe, kat
@@ -158,5 +180,5 @@ def test_cpp_mirror_runs_the_reference_tests():
     res = subprocess.run([exe, kat], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "PASSED: 0 failure(s)" in res.stdout and "FAIL" not in res.stdout
-    for name in ("TestInvFFT", "TestDASFFTExtension", "TestKZGSettings_DAUsingFK20", "TestErrorsAndPanics"):
+    for name in ("TestInvFFT", "TestDASFFTExtension", "TestKZGSettings_DAUsingFK20", "TestErrorsAndPanics", "TestEth_ComputeAggregateKZGProof"):
         assert "ok   " + name in res.stdout, name
