@@ -1460,7 +1460,34 @@ int kzg_hip_fk20_multi_finish_dev(kzg_hip_fk20m *fk, const void *d_hext_g1, int 
 // ---------------------------------------------------------------------------------------------------------
 // erasure recovery (row f3)
 // ---------------------------------------------------------------------------------------------------------
+// Small erasure sets: the vanishing polynomial evaluated directly on the domain (k_zero_eval_direct, length x n_missing products), then one inverse
+// transform for the coefficients.  Large ones: the product tree of k_fr.hip (n log^2 n products: 65 536 points with half of them missing are 2^31
+// products directly and ~2^24 through the tree), then one forward transform for the evaluations.  The polynomial is unique (monic, the given roots),
+// so both give the reference's values bit for bit.  KZG_HIP_ZERO_POLY=direct|tree forces one (tests run both).
+static int zero_poly_tree(kzg_hip_fft *fs, hipStream_t s, const uint64_t *d_missing, uint64_t n_missing, uint64_t length, fr *d_eval, fr *d_poly) {
+    uint64_t leaves = 1;
+    while (leaves * ZERO_TREE_LEAF < n_missing) leaves <<= 1;             // <= length / 16: the root has degree <= length
+    const uint64_t dtot = leaves * ZERO_TREE_LEAF, pad = dtot - n_missing;
+    dtmp<fr> d_a(s), d_b(s), d_f(s), d_g(s);
+    CHK(d_a.alloc(dtot)); CHK(d_b.alloc(dtot)); CHK(d_f.alloc(2 * dtot)); CHK(d_g.alloc(dtot));
+    launch_zero_leaves(s, fs->d_expanded, fs->W / length, d_missing, n_missing, leaves, d_a.p);
+    fr *cur = d_a.p, *nxt = d_b.p;
+    for (uint64_t d = ZERO_TREE_LEAF, nodes = leaves; nodes > 1; d <<= 1, nodes >>= 1) {
+        fr_fft_rows(fs, s, cur, d, d, d_f.p, 2 * d, nodes, 0);            // every node's a, zero-extended to 2d values
+        launch_zero_pair_products(s, d_f.p, 2 * d, nodes / 2, d_g.p);
+        fr_fft_rows(fs, s, d_g.p, 2 * d, 2 * d, nxt, 2 * d, nodes / 2, 1);   // a b
+        launch_zero_join(s, nxt, cur, d, nodes / 2);                      // + x^d (a + b)
+        std::swap(cur, nxt);
+    }
+    launch_zero_unpad(s, cur, pad, n_missing, length, d_poly);
+    fr_fft_rows(fs, s, d_poly, length, length, d_eval, length, 1, 0);
+    HIPCHK(hipGetLastError());
+    return KZG_HIP_OK;
+}
 static int zero_poly_dev(kzg_hip_fft *fs, hipStream_t s, const uint64_t *d_missing, uint64_t n_missing, uint64_t length, fr *d_eval, fr *d_poly) {
+    static const int forced = [] { const char *e = getenv("KZG_HIP_ZERO_POLY"); return !e ? 0 : !strcmp(e, "direct") ? 1 : !strcmp(e, "tree") ? 2 : 0; }();
+    // measured crossover (half of the domain missing): 8192 points, where both take 0.7 ms; 32 768 points: 4.9 ms direct, 1.2 ms through the tree
+    if (forced == 2 || (forced == 0 && n_missing >= 1024 && n_missing * length >= (1ull << 26))) return zero_poly_tree(fs, s, d_missing, n_missing, length, d_eval, d_poly);
     launch_zero_eval_direct(s, fs->d_expanded, fs->W / length, d_missing, n_missing, length, d_eval);
     fr_fft_rows(fs, s, d_eval, length, length, d_poly, length, 1, 1);     // coefficients: degree n_missing < length
     HIPCHK(hipGetLastError());

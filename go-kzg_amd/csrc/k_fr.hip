@@ -570,6 +570,63 @@ void launch_zero_eval_direct(hipStream_t s, const fr *expanded, uint64_t stride,
     hipLaunchKernelGGL(k_zero_eval_direct, dim3((uint32_t)((length + 63) / 64)), dim3(64 * segs), (segs - 1) * 9 * 64 * 4, s, expanded, stride, missing,
                        n_missing, length, zero_eval, corr);
 }
+// ---- the vanishing polynomial as a product tree (large erasure sets): monic factors kept as their non-leading part ----
+// A node of degree d is x^d + a(x), deg a < d, stored as the d coefficients of a.  Leaves hold 16 roots; a leaf with fewer (the tail, and the
+// padding up to a power of two of leaves) is filled with roots at 0, i.e. multiplied by x: every node stays monic of its level's degree, and the
+// root is Z(x) x^pad.  Joining two nodes: (x^d + a)(x^d + b) = x^2d + x^d (a + b) + a b, and a b (degree <= 2d - 2) is one cyclic product of
+// size 2d -- two forward transforms, a pointwise product, an inverse transform, all batched over the level.
+constexpr int ZLEAF = 16;
+__global__ void __launch_bounds__(64) k_zero_leaves(const fr *expanded, uint64_t stride, const uint64_t *missing, uint64_t n_missing, uint64_t leaves, fr *a) {
+    __shared__ fr c[ZLEAF + 1][64];                                       // running product, coefficient-major: lane-contiguous rows
+    const uint32_t lane = threadIdx.x;
+    const uint64_t t = blockIdx.x * 64ull + lane;
+    if (t >= leaves) return;
+    const uint64_t lo = t * ZLEAF;
+    c[0][lane] = one<FrP>();
+    for (int i = 0; i < ZLEAF; i++) {                                     // c <- c (x - r_i); beyond the erasure set r = 0: c <- c x
+        const bool real = lo + i < n_missing;
+        const fr r = real ? expanded[missing[lo + i] * stride] : zero<FrP>();
+        c[i + 1][lane] = c[i][lane];                                      // the leading coefficient (1) moves up
+        for (int j = i; j >= 1; j--) c[j][lane] = real ? sub(c[j - 1][lane], mul(r, c[j][lane])) : c[j - 1][lane];
+        c[0][lane] = real ? neg<FrP>(mul(r, c[0][lane])) : zero<FrP>();
+    }
+    for (int j = 0; j < ZLEAF; j++) a[t * ZLEAF + j] = c[j][lane];
+}
+// out[p][k] = f[2p][k] * f[2p + 1][k], rows of m values
+__global__ void k_zero_pair_products(const fr *f, uint64_t m, uint64_t total, fr *out) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const uint64_t p = t / m, k = t - p * m;
+    out[t] = mul(f[2 * p * m + k], f[(2 * p + 1) * m + k]);
+}
+// c[p][k] += a[2p][k - d] + a[2p + 1][k - d] for k >= d (rows of 2d values in c, of d values in a)
+__global__ void k_zero_join(fr *c, const fr *a, uint64_t d, uint64_t total) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const uint64_t p = t / (2 * d), k = t - p * 2 * d;
+    if (k >= d) c[t] = add(c[t], add(a[2 * p * d + k - d], a[(2 * p + 1) * d + k - d]));
+}
+// Z = root / x^pad: poly[k] = root[k + pad] below the degree, 1 at the degree, 0 above
+__global__ void k_zero_unpad(const fr *root, uint64_t pad, uint64_t n_missing, uint64_t length, fr *poly) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= length) return;
+    poly[t] = t < n_missing ? root[t + pad] : (t == n_missing ? one<FrP>() : zero<FrP>());
+}
+void launch_zero_leaves(hipStream_t s, const fr *expanded, uint64_t stride, const uint64_t *missing, uint64_t n_missing, uint64_t leaves, fr *a) {
+    hipLaunchKernelGGL(k_zero_leaves, dim3((uint32_t)((leaves + 63) / 64)), dim3(64), 0, s, expanded, stride, missing, n_missing, leaves, a);
+}
+void launch_zero_pair_products(hipStream_t s, const fr *f, uint64_t m, uint64_t pairs, fr *out) {
+    const uint64_t total = m * pairs;
+    hipLaunchKernelGGL(k_zero_pair_products, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, f, m, total, out);
+}
+void launch_zero_join(hipStream_t s, fr *c, const fr *a, uint64_t d, uint64_t pairs) {
+    const uint64_t total = 2 * d * pairs;
+    hipLaunchKernelGGL(k_zero_join, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, c, a, d, total);
+}
+void launch_zero_unpad(hipStream_t s, const fr *root, uint64_t pad, uint64_t n_missing, uint64_t length, fr *poly) {
+    hipLaunchKernelGGL(k_zero_unpad, dim3((uint32_t)((length + 255) / 256)), dim3(256), 0, s, root, pad, n_missing, length, poly);
+}
+
 // poly[i] *= base^i  (ShiftPoly / UnshiftPoly, recover_from_samples.go:9-40, with base = 5^-1 / 5)
 __global__ void k_fr_scale_by_powers(fr *poly, const fr *base, uint64_t n) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;

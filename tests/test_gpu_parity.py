@@ -1364,6 +1364,37 @@ def test_zero_poly_python_kat_gpu(kz):
     fs.close()
 
 
+def test_zero_poly_ragged_erasure_sets(kz):
+    """erasure counts around the product tree's leaf size (16) and its power-of-two padding, contiguous and scattered, against the oracle's
+    restatement of the reference's algorithm (whichever pipeline the process runs: see the forced children below)"""
+    fs, ofs = kz.FFTSettings(12), ko.FFTSettings(12)
+    rng = np.random.default_rng(99)
+    # (4032 = 64 leaves of 63: the most the reference's own tree handles in a 4096-wide settings object -- one more leaf and its convolutions need
+    # 8192 roots of unity, InplaceFFT fails and ZeroPolyViaMultiplication panics)
+    for cnt in (1, 2, 15, 16, 17, 31, 33, 255, 1000, 2049, 4032):
+        for missing in (list(range(cnt)), sorted(rng.choice(4096, size=cnt, replace=False).tolist())):
+            ze, zp = fs.zero_poly_via_multiplication(missing, 4096)
+            oze, ozp = ofs.zero_poly_via_multiplication(missing, 4096)
+            assert np.array_equal(ze, oze) and np.array_equal(zp, ozp), cnt
+    ze, zp = fs.zero_poly_via_multiplication([3, 4, 5, 9], 16)             # a short domain inside a wide settings object (stride 256)
+    oze, ozp = ofs.zero_poly_via_multiplication([3, 4, 5, 9], 16)
+    assert np.array_equal(ze, oze) and np.array_equal(zp, ozp)
+    fs.close()
+
+
+def test_zero_poly_pipelines_in_fresh_processes():
+    """the vanishing polynomial is evaluated directly for small erasure sets and built as a product tree for large ones (chosen by size, once per
+    process): the KAT, the ragged sets, every oracle comparison and the full DAS flow re-run with each pipeline forced at every size"""
+    import subprocess
+    import sys
+    if os.environ.get("KZG_HIP_ZERO_POLY"):
+        pytest.skip("already a forced child")
+    for mode in ("tree", "direct"):
+        res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", "zero_poly or recover or full_das_flow"],
+                             env=dict(os.environ, KZG_HIP_ZERO_POLY=mode), capture_output=True, text=True, timeout=1200)
+        assert res.returncode == 0, (mode, res.stdout[-1500:])
+
+
 @pytest.mark.parametrize("scale,frac", [(5, 2), (8, 2), (10, 3), (12, 2), (15, 2)])
 def test_zero_poly_and_recover_match_oracle(kz, scale, frac):
     fs, ofs = kz.FFTSettings(scale), ko.FFTSettings(scale)

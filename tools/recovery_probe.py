@@ -3,7 +3,7 @@ import numpy as np
 sys.path.insert(0, "/root/repo")
 import bench
 import gokzg_amd as kz
-for scale in (12, 16):
+for scale in ([int(a) for a in sys.argv[1:]] or (12, 16)):
     n = 1 << scale
     fs = kz.FFTSettings(scale)
     poly, _ = fs.fr_from_32(bench.splitmix_blobs_le32(3, 1, n).reshape(-1, 32))
