@@ -85,6 +85,7 @@ struct kzg_hip_fft {
     uint64_t W = 0;
     std::vector<fr> h_expanded, h_reversed;
     fr *d_expanded = nullptr, *d_reversed = nullptr;
+    fr *d_expanded_l = nullptr, *d_reversed_l = nullptr;   // the same roots as images 2^261 (the constant operand of fr_lazy.hpp's product): k_fr_fft_upper; W > 4096 only
     fr *d_inv_pow2 = nullptr;   // (2^k)^-1, k = 0..63 (Montgomery)
     uint32_t *d_tw_das2048 = nullptr;              // twiddle file of the lazy-limb DASFFTExtension(2048) (fr_das2048.hpp); null below scale 12
     uint32_t *d_tw4096[2] = {nullptr, nullptr};   // twiddle files of the radix-4 4096-point transform, forward / inverse (fr_fft4096.hpp); null below scale 12
@@ -318,6 +319,16 @@ int kzg_hip_fft_settings_new(int device, unsigned max_scale, kzg_hip_fft **out) 
             HIPCHK(hipMalloc((void **)&fs->d_tw4096[dir], tw.size() * 4));
             HIPCHK(hipMemcpy(fs->d_tw4096[dir], tw.data(), tw.size() * 4, hipMemcpyHostToDevice));
         }
+        if (fs->W > fr4::N) {   // transforms above 4096 points: the roots once more, pre-scaled for the lazy-limb product
+            std::vector<fr> le(fs->W + 1), lr(fs->W + 1);
+            const fr k32 = fr_from_u64(32);
+            for (uint64_t i = 0; i <= fs->W; i++) le[i] = mul(fs->h_expanded[i], k32);
+            for (uint64_t i = 0; i <= fs->W; i++) lr[i] = le[fs->W - i];
+            HIPCHK(hipMalloc((void **)&fs->d_expanded_l, bytes));
+            HIPCHK(hipMalloc((void **)&fs->d_reversed_l, bytes));
+            HIPCHK(hipMemcpy(fs->d_expanded_l, le.data(), bytes, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(fs->d_reversed_l, lr.data(), bytes, hipMemcpyHostToDevice));
+        }
         std::vector<uint32_t> td(das2k::TW_WORDS);
         das2k::build_twiddles(fs->h_expanded.data(), fs->h_reversed.data(), fs->W, td.data());
         HIPCHK(hipMalloc((void **)&fs->d_tw_das2048, td.size() * 4));
@@ -331,7 +342,7 @@ void kzg_hip_fft_settings_free(kzg_hip_fft *fs) {
     if (!fs) return;
     hipSetDevice(fs->device);
     if (fs->stream) hipStreamSynchronize(fs->stream);
-    hipFree(fs->d_expanded); hipFree(fs->d_reversed); hipFree(fs->d_inv_pow2); hipFree(fs->d_tw4096[0]); hipFree(fs->d_tw4096[1]); hipFree(fs->d_tw_das2048); hipFree(fs->d_glv_expanded); hipFree(fs->d_glv_reversed); hipFree(fs->d_wnaf_expanded); hipFree(fs->d_wnaf_reversed);
+    hipFree(fs->d_expanded); hipFree(fs->d_reversed); hipFree(fs->d_expanded_l); hipFree(fs->d_reversed_l); hipFree(fs->d_inv_pow2); hipFree(fs->d_tw4096[0]); hipFree(fs->d_tw4096[1]); hipFree(fs->d_tw_das2048); hipFree(fs->d_glv_expanded); hipFree(fs->d_glv_reversed); hipFree(fs->d_wnaf_expanded); hipFree(fs->d_wnaf_reversed);
     if (fs->stream) hipStreamDestroy(fs->stream);
     if (fs->h_stage) hipHostFree(fs->h_stage);
     for (auto &ps : fs->pool_idle) { hipStreamSynchronize(ps.s); hipStreamDestroy(ps.s); if (ps.h_pin) hipHostFree(ps.h_pin); }
@@ -348,7 +359,7 @@ int kzg_hip_fft_roots(const kzg_hip_fft *fs, int reversed, void *out_fr) {
 // device-side (I)FFT over F_r on resident rows
 static void fr_fft_rows(kzg_hip_fft *fs, hipStream_t s, const fr *d_in, uint64_t in_stride, uint64_t n_in, fr *d_out, uint64_t n, uint64_t batch, int inv) {
     launch_fr_fft(s, d_in, in_stride, n_in, d_out, n, batch, inv ? fs->d_reversed : fs->d_expanded, fs->W, inv ? fs->d_inv_pow2 + ilog2(n) : nullptr,
-                  fs->d_tw4096[inv ? 1 : 0]);
+                  fs->d_tw4096[inv ? 1 : 0], inv ? fs->d_reversed_l : fs->d_expanded_l);
 }
 
 static int fft_fr_impl(kzg_hip_fft *fs, const void *vals, uint64_t n_in, uint64_t n, uint64_t batch, int inv, void *out) {

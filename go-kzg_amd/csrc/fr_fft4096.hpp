@@ -61,11 +61,12 @@ KZG_HD void unit(frl &x0, frl &x1, frl &x2, frl &x3, const frl &w1, const frl &w
 }
 
 // pass 1 (stride 1): lane t, natural inputs t + 1024 q (zero beyond n_in) -> positions 4 u + 0..3, u = bitrev10(t)
-KZG_HD void pass_first(uint32_t t, const fr *src, uint64_t n_in, uint32_t *s, const uint32_t *tw) {
+// (es, off: element i of this transform is src[off + i es] -- a row of a longer transform is every es-th element of it: k_fr_fft_upper)
+KZG_HD void pass_first(uint32_t t, const fr *src, uint64_t n_in, uint32_t *s, const uint32_t *tw, uint64_t es = 1, uint64_t off = 0) {
     frl x[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const uint32_t i = t + 1024u * q;
+        const uint64_t i = off + (uint64_t)(t + 1024u * q) * es;
         x[q] = (i < n_in) ? frl_unpack(src[i]) : frl_zero();
     }
     // position offset o holds the natural quarter bitrev2(o): X0 = x[0], X1 = x[2], X2 = x[1], X3 = x[3]; twiddles 1, 1, w_4

@@ -14,7 +14,7 @@ namespace kzg {
 //   scale != nullptr: every output is multiplied by *scale (device pointer; n^-1 for the inverse).
 //   tw4096 != nullptr and n == 4096: the radix-4 kernel on lazy limbs with that twiddle file (fr_fft4096.hpp; same direction as roots)
 void launch_fr_fft(hipStream_t s, const fr *in, uint64_t in_stride, uint64_t n_in, fr *out, uint64_t n, uint64_t batch,
-                   const fr *roots, uint64_t W, const fr *scale, const uint32_t *tw4096 = nullptr);
+                   const fr *roots, uint64_t W, const fr *scale, const uint32_t *tw4096 = nullptr, const fr *roots_l = nullptr);
 // DASFFTExtension (das_extension.go:7-84), in place on batch rows of n values.
 //   tw2048 != nullptr and n == 2048: the lazy-limb kernel with that twiddle file (fr_das2048.hpp, built from the same two tables)
 void launch_das_ext(hipStream_t s, fr *vals, uint64_t n, uint64_t batch, const fr *expanded, const fr *reversed, uint64_t W,

@@ -85,12 +85,16 @@ __global__ __launch_bounds__(1024) void k_fr_fft_tile(const fr *in, uint64_t in_
 // coefficient transforms of FK20 at scale 12 and of FK20Multi at scale 16 / chunk 16).  One workgroup per transform; 146 KiB of LDS.
 template <bool SCALE>
 __global__ __launch_bounds__(1024) void k_fr_fft4096_r4(const fr *in, uint64_t in_stride, uint64_t n_in, fr *out, const uint32_t *__restrict__ tw,
-                                                        const fr *scale) {
+                                                        const fr *scale, uint32_t rows_log) {
     extern __shared__ uint32_t smem[];
     const uint32_t t = threadIdx.x, a = __builtin_amdgcn_readfirstlane(t >> 6), b = t & 63u;
-    const fr *src = in + (uint64_t)blockIdx.x * in_stride;
+    // rows_log = 0: workgroup w transforms row w.  rows_log = k > 0: the workgroups are the 2^k rows of transforms of 2^k * 4096 points --
+    // row a of transform w >> k is its subsequence bitrev_k(a) + 2^k i (what a bit-reversal copy would have put in block a), left in natural
+    // order in block a of the output for the upper stages (k_fr_fft_upper)
+    const uint32_t rows = 1u << rows_log, row = blockIdx.x & (rows - 1);
+    const fr *src = in + (uint64_t)(blockIdx.x >> rows_log) * in_stride;
     fr *dst = out + (uint64_t)blockIdx.x * fr4::N;
-    fr4::pass_first(t, src, n_in, smem, tw);
+    fr4::pass_first(t, src, n_in, smem, tw, rows, rows_log ? bitrev32(row, rows_log) : 0u);
     __syncthreads();
     fr4::pass_lo<4>(a, b, smem, tw);
     __syncthreads();
@@ -103,6 +107,55 @@ __global__ __launch_bounds__(1024) void k_fr_fft4096_r4(const fr *in, uint64_t i
     frl sc = frl_zero();
     if (SCALE) sc = frl_const_from_kilic(*scale);
     fr4::pass_last<SCALE>(t, smem, tw, sc, dst);
+}
+#define LOGR_OF(R) ((R) == 2 ? 1 : (R) == 4 ? 2 : (R) == 8 ? 3 : 4)
+// The stages above 4096 of a transform of R * 4096 points (R = 2, 4, 8, 16), all in one pass over the data: lane k2 holds the R values
+// k2 + 4096 a in registers and runs the log2 R radix-2 stages of half-size m = 4096 2^s on them (fft_fr.go:40-52 with the lazy limbs of
+// fr_lazy.hpp; twiddle w_{2m}^j, j = (a mod 2^s) 4096 + k2, from the settings' roots pre-scaled to the 2^261 image), then canonicalises
+// (SCALE: after the product with 1/n).  Bounds: a stage adds 2 (sum) / 3 (difference) to a bound and 2^29 / 2 * 2^29 to the limbs; from the
+// fourth stage on both operands are swept first, so every product sees limbs < 6 * 2^29 and no limb passes 2^32; final bounds <= 13.
+// (compile-time recursion instead of loops: every index into x[] must be a constant for the array to live in registers, and the
+// unroller gives up on loops whose bodies hold a 153-multiply-add product each)
+template <int R, int S, int B = 0> __device__ __forceinline__ void fr_upper_stage(frl (&x)[R], const fr *__restrict__ roots_l, uint64_t W, uint32_t k2, frl &w) {
+    if constexpr (B < R / 2) {
+        constexpr int jh = B >> (LOGR_OF(R) - 1 - S), hi = B & ((R >> (S + 1)) - 1), a = (hi << (S + 1)) + jh;   // butterflies ordered by twiddle
+        if constexpr (hi == 0) w = frl_unpack(roots_l[((uint64_t)jh * fr4::N + k2) * (W / ((uint64_t)fr4::N << (S + 1)))]);
+        frl x0 = x[a], y = x[a + (1 << S)];
+        if (S >= 3) { frl_sweep(x0); frl_sweep(y); }
+        const frl tq = frl_mul(y, w);
+        x[a] = frl_add(x0, tq);
+        x[a + (1 << S)] = frl_sub<3>(x0, tq);
+        fr_upper_stage<R, S, B + 1>(x, roots_l, W, k2, w);
+    }
+}
+template <int R, int A = 0> __device__ __forceinline__ void fr_upper_load(frl (&x)[R], const fr *base, uint32_t k2) {
+    if constexpr (A < R) { x[A] = frl_unpack(base[(uint64_t)A * fr4::N + k2]); fr_upper_load<R, A + 1>(x, base, k2); }
+}
+template <int R, bool SCALE, int A = 0> __device__ __forceinline__ void fr_upper_store(frl (&x)[R], fr *base, uint32_t k2, const frl &sc) {
+    if constexpr (A < R) {
+        if (SCALE) { frl v = x[A]; frl_sweep(v); base[(uint64_t)A * fr4::N + k2] = frl_canon_lt2r(frl_mul(v, sc)); }
+        else base[(uint64_t)A * fr4::N + k2] = frl_canon(x[A]);
+        fr_upper_store<R, SCALE, A + 1>(x, base, k2, sc);
+    }
+}
+template <int LOGR, bool SCALE>
+__global__ __launch_bounds__(256) void k_fr_fft_upper(fr *data, const fr *__restrict__ roots_l, uint64_t W, const fr *scale) {
+    constexpr int R = 1 << LOGR;
+    const uint32_t k2 = blockIdx.x * 256u + threadIdx.x;
+    fr *base = data + (uint64_t)blockIdx.y * ((uint64_t)R * fr4::N);
+    frl x[R], w;
+    fr_upper_load<R>(x, base, k2);
+    fr_upper_stage<R, 0>(x, roots_l, W, k2, w);
+    if constexpr (LOGR > 1) fr_upper_stage<R, 1>(x, roots_l, W, k2, w);
+    if constexpr (LOGR > 2) fr_upper_stage<R, 2>(x, roots_l, W, k2, w);
+    if constexpr (LOGR > 3) fr_upper_stage<R, 3>(x, roots_l, W, k2, w);
+    frl sc = frl_zero();
+    if (SCALE) sc = frl_const_from_kilic(*scale);
+    fr_upper_store<R, SCALE>(x, base, k2, sc);
+}
+template <int LOGR> static void launch_fr_fft_upper(hipStream_t s, fr *data, uint64_t batch, const fr *roots_l, uint64_t W, const fr *scale) {
+    if (scale) hipLaunchKernelGGL((k_fr_fft_upper<LOGR, true>), dim3(fr4::N / 256, (uint32_t)batch), dim3(256), 0, s, data, roots_l, W, scale);
+    else hipLaunchKernelGGL((k_fr_fft_upper<LOGR, false>), dim3(fr4::N / 256, (uint32_t)batch), dim3(256), 0, s, data, roots_l, W, scale);
 }
 
 __global__ void k_fr_bitrev_copy(const fr *in, uint64_t in_stride, uint64_t n_in, fr *out, uint32_t logn, uint64_t total) {
@@ -129,7 +182,7 @@ __global__ void k_fr_fft_stage_glob(fr *data, uint32_t logn, uint64_t m, const f
 static uint32_t ilog2(uint64_t v) { uint32_t r = 0; while ((1ull << r) < v) r++; return r; }
 
 void launch_fr_fft(hipStream_t s, const fr *in, uint64_t in_stride, uint64_t n_in, fr *out, uint64_t n, uint64_t batch, const fr *roots,
-                   uint64_t W, const fr *scale, const uint32_t *tw4096) {
+                   uint64_t W, const fr *scale, const uint32_t *tw4096, const fr *roots_l) {
     if (n == 0 || batch == 0) return;
     uint32_t logn = ilog2(n);
     static const bool radix2_forced = [] { const char *e = getenv("KZG_HIP_FR_FFT"); return e && !strcmp(e, "radix2"); }();   // A/B and test hook
@@ -137,10 +190,10 @@ void launch_fr_fft(hipStream_t s, const fr *in, uint64_t in_stride, uint64_t n_i
         prof_begin(s, "fr_fft4096");
         if (scale) {
             hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fr_fft4096_r4<true>), hipFuncAttributeMaxDynamicSharedMemorySize, fr4::LDS_BYTES);
-            hipLaunchKernelGGL(k_fr_fft4096_r4<true>, dim3((uint32_t)batch), dim3(1024), fr4::LDS_BYTES, s, in, in_stride, n_in, out, tw4096, scale);
+            hipLaunchKernelGGL(k_fr_fft4096_r4<true>, dim3((uint32_t)batch), dim3(1024), fr4::LDS_BYTES, s, in, in_stride, n_in, out, tw4096, scale, 0u);
         } else {
             hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fr_fft4096_r4<false>), hipFuncAttributeMaxDynamicSharedMemorySize, fr4::LDS_BYTES);
-            hipLaunchKernelGGL(k_fr_fft4096_r4<false>, dim3((uint32_t)batch), dim3(1024), fr4::LDS_BYTES, s, in, in_stride, n_in, out, tw4096, scale);
+            hipLaunchKernelGGL(k_fr_fft4096_r4<false>, dim3((uint32_t)batch), dim3(1024), fr4::LDS_BYTES, s, in, in_stride, n_in, out, tw4096, scale, 0u);
         }
         prof_end(s, "fr_fft4096");
         return;
@@ -153,7 +206,23 @@ void launch_fr_fft(hipStream_t s, const fr *in, uint64_t in_stride, uint64_t n_i
         hipLaunchKernelGGL(k_fr_fft_tile<true>, dim3((uint32_t)batch), dim3(T), sh, s, in, in_stride, n_in, out, logn, (uint64_t)1, roots, W, scale);
         return;
     }
-    // n > 4096: bit-reversal copy, 12 stages per 4096-tile in LDS, remaining stages through global memory
+    if (n <= 16 * (uint64_t)fr4::N && tw4096 && roots_l && !radix2_forced && batch * (n / fr4::N) <= 0x7fffffffull && batch <= 65535) {
+        // 8192 .. 65 536 points: the rows (every R-th element, R = n / 4096) through the LDS-resident 4096-point kernel, then all upper
+        // stages in one pass with the row values in registers: two launches, every value read and written twice
+        const uint32_t rl = logn - 12;
+        prof_begin(s, "fr_fft4096");
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fr_fft4096_r4<false>), hipFuncAttributeMaxDynamicSharedMemorySize, fr4::LDS_BYTES);
+        hipLaunchKernelGGL(k_fr_fft4096_r4<false>, dim3((uint32_t)(batch << rl)), dim3(1024), fr4::LDS_BYTES, s, in, in_stride, n_in, out, tw4096, (const fr *)nullptr, rl);
+        prof_end(s, "fr_fft4096");
+        switch (rl) {
+        case 1: launch_fr_fft_upper<1>(s, out, batch, roots_l, W, scale); break;
+        case 2: launch_fr_fft_upper<2>(s, out, batch, roots_l, W, scale); break;
+        case 3: launch_fr_fft_upper<3>(s, out, batch, roots_l, W, scale); break;
+        default: launch_fr_fft_upper<4>(s, out, batch, roots_l, W, scale); break;
+        }
+        return;
+    }
+    // longer transforms (and KZG_HIP_FR_FFT=radix2): bit-reversal copy, 12 stages per 4096-tile in LDS, remaining stages through global memory
     uint64_t total = n * batch;
     hipLaunchKernelGGL(k_fr_bitrev_copy, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, in, in_stride, n_in, out, logn, total);
     hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fr_fft_tile<false>), hipFuncAttributeMaxDynamicSharedMemorySize, FR_TILE * 32);

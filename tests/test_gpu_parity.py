@@ -112,6 +112,27 @@ def test_fr_lazy_kernels_4096_and_das2048(kz):
         fs.close()
 
 
+def test_fr_fft_above_4096_points(kz):
+    """8192 .. 65 536 points: rows through the 4096-point LDS kernel (every R-th element), upper stages in registers (k_fr_fft_upper): each size
+    in a settings object of exactly its width and in a wider one (twiddle strides), batches with distinct rows, edge values (0, r - 1), zero
+    padding (FFT pads to the next power of two, fft_fr.go:60-68), both directions; 131 072 points still take the radix-2 stages"""
+    rng = np.random.default_rng(8192)
+    for max_scale, logn in ((13, 13), (16, 13), (14, 14), (15, 15), (16, 16), (17, 16), (17, 17)):
+        n = 1 << logn
+        fs, ofs = kz.FFTSettings(max_scale), ko.FFTSettings(max_scale)
+        rows = np.stack([rand_fr(rng, n) for _ in range(3)])
+        rows[0, :4] = ko.fr_from_ints([0, ko.R_MOD - 1, 1, ko.R_MOD - 2])
+        rows[1, n // 2:] = ko.fr_from_ints([ko.R_MOD - 1])[0]
+        for inv in (False, True):
+            got = fs.fft_batch(rows, inv=inv)
+            for b in range(3):
+                assert np.array_equal(got[b], ofs.fft(rows[b], inv)), (max_scale, logn, inv, b)
+        short = rows[2, : n // 2 + 37]                                      # padded with zeros up to n
+        assert np.array_equal(fs.fft(short), ofs.fft(short)), (max_scale, logn)
+        assert np.array_equal(fs.fft(fs.fft(rows[2]), inv=True), rows[2])
+        fs.close()
+
+
 def test_fr_radix2_kernels_in_a_fresh_process():
     """sizes other than 4096 / 2048 (and tiles of longer transforms) still run the radix-2 kernels; at the hot sizes they are re-run in a
     child process that forces them (KZG_HIP_FR_FFT=radix2), so both families stay pinned to the oracle and the reference's KATs"""
@@ -120,7 +141,7 @@ def test_fr_radix2_kernels_in_a_fresh_process():
     if os.environ.get("KZG_HIP_FR_FFT") == "radix2":
         pytest.skip("already the forced child")
     res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k",
-                          "fft_fr or das or fr_lazy or vector_C or full_das_flow"],
+                          "fft_fr or das or fr_lazy or fr_fft_above or vector_C or full_das_flow"],
                          env=dict(os.environ, KZG_HIP_FR_FFT="radix2"), capture_output=True, text=True, timeout=1200)
     assert res.returncode == 0, res.stdout[-1500:]
 
