@@ -465,6 +465,24 @@ int kzg_hip_fft_g1(kzg_hip_fft *fs, const void *vals_g1, uint64_t n, int inv, vo
     return KZG_HIP_OK;
 }
 
+// DASFFTExtension over resident rows (in place).  In a settings object of exactly twice the row length -- the only width at which the reference's
+// recursion (das_extension.go:7-84, which always walks the FULL-width tables) computes the extension -- rows of 4096 values and more go
+// through the lazy-limb transforms: coefficients (inverse transform), x -> w_2n x (one product per coefficient), values again.  The odd-index
+// evaluations are unique, so this is the reference's result bit for bit.  Other widths and sizes: the recursion itself, stage by stage.
+static int das_ext_rows(kzg_hip_fft *fs, hipStream_t s, fr *d, uint64_t n, uint64_t batch) {
+    static const bool radix2_forced = [] { const char *e = getenv("KZG_HIP_FR_FFT"); return e && !strcmp(e, "radix2"); }();
+    if (2 * n == fs->W && n >= fr4::N && n <= 16 * (uint64_t)fr4::N && fs->d_tw4096[0] && !radix2_forced) {
+        dtmp<fr> d_c(s);
+        CHK(d_c.alloc(n * batch));
+        fr_fft_rows(fs, s, d, n, n, d_c.p, n, batch, 1);
+        launch_fr_mul_table_rows(s, d_c.p, fs->d_expanded, 1, n, batch);
+        fr_fft_rows(fs, s, d_c.p, n, n, d, n, batch, 0);
+        return KZG_HIP_OK;
+    }
+    launch_das_ext(s, d, n, batch, fs->d_expanded, fs->d_reversed, fs->W, fs->d_inv_pow2 + ilog2(n), fs->d_tw_das2048);
+    return KZG_HIP_OK;
+}
+
 int kzg_hip_das_fft_extension_batch(kzg_hip_fft *fs, void *vals_fr, uint64_t n, uint64_t batch) {
     if (!fs || !vals_fr) return KZG_HIP_ERR_BAD_ARG;
     if (n * 2 > fs->W) return KZG_HIP_ERR_TOO_WIDE;      // panic das_extension.go:72-74
@@ -476,7 +494,7 @@ int kzg_hip_das_fft_extension_batch(kzg_hip_fft *fs, void *vals_fr, uint64_t n, 
     uint8_t *hp = n <= 4096 ? lease.pinned(n * batch * sizeof(fr), &dp) : nullptr;
     if (hp) {   // the LDS-resident kernel reads and writes each value once: in place in pinned host memory
         memcpy(hp, vals_fr, n * batch * sizeof(fr));
-        launch_das_ext(s, (fr *)dp, n, batch, fs->d_expanded, fs->d_reversed, fs->W, fs->d_inv_pow2 + ilog2(n), fs->d_tw_das2048);
+        CHK(das_ext_rows(fs, s, (fr *)dp, n, batch));
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(s));
         memcpy(vals_fr, hp, n * batch * sizeof(fr));
@@ -485,7 +503,7 @@ int kzg_hip_das_fft_extension_batch(kzg_hip_fft *fs, void *vals_fr, uint64_t n, 
     dtmp<fr> d(s);
     CHK(d.alloc(n * batch));
     HIPCHK(hipMemcpyAsync(d.p, vals_fr, n * batch * sizeof(fr), hipMemcpyHostToDevice, s));
-    launch_das_ext(s, d.p, n, batch, fs->d_expanded, fs->d_reversed, fs->W, fs->d_inv_pow2 + ilog2(n), fs->d_tw_das2048);
+    CHK(das_ext_rows(fs, s, d.p, n, batch));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(vals_fr, d.p, n * batch * sizeof(fr), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -525,7 +543,7 @@ int kzg_hip_das_fft_extension_batch_dev(kzg_hip_fft *fs, void *d_vals_fr, uint64
     if (n < 2 || !is_pow2(n)) return KZG_HIP_ERR_BAD_ARG;
     if (!batch) return KZG_HIP_OK;
     dev_select sel(fs);       // the caller's stream orders the work; settings tables are read-only
-    launch_das_ext((hipStream_t)stream, (fr *)d_vals_fr, n, batch, fs->d_expanded, fs->d_reversed, fs->W, fs->d_inv_pow2 + ilog2(n), fs->d_tw_das2048);
+    CHK(das_ext_rows(fs, (hipStream_t)stream, (fr *)d_vals_fr, n, batch));
     HIPCHK(hipGetLastError());
     return KZG_HIP_OK;
 }

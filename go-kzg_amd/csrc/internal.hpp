@@ -41,6 +41,7 @@ void launch_zero_leaves(hipStream_t s, const fr *expanded, uint64_t stride, cons
 void launch_zero_pair_products(hipStream_t s, const fr *f, uint64_t m, uint64_t pairs, fr *out);
 void launch_zero_join(hipStream_t s, fr *c, const fr *a, uint64_t d, uint64_t pairs);
 void launch_zero_unpad(hipStream_t s, const fr *root, uint64_t pad, uint64_t n_missing, uint64_t length, fr *poly);
+void launch_fr_mul_table_rows(hipStream_t s, fr *data, const fr *table, uint64_t stride, uint64_t n, uint64_t batch);
 void launch_poly_lincomb(hipStream_t s, const fr *vectors, uint64_t stride, const fr *scalars, uint64_t count, uint64_t n, fr *out);   // bls.PolyLinComb
 void launch_eth_quotient(hipStream_t s, const fr *poly, uint64_t poly_stride, const fr *domain, uint64_t n, uint64_t batch, const fr *z, uint64_t z_stride,
                          const fr *inv_n, fr *q, fr *y_out, uint32_t *flag, uint64_t dom_stride = 1);

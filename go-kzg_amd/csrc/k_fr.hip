@@ -639,6 +639,18 @@ void launch_zero_eval_direct(hipStream_t s, const fr *expanded, uint64_t stride,
     hipLaunchKernelGGL(k_zero_eval_direct, dim3((uint32_t)((length + 63) / 64)), dim3(64 * segs), (segs - 1) * 9 * 64 * 4, s, expanded, stride, missing,
                        n_missing, length, zero_eval, corr);
 }
+// data[b][i] *= table[i * stride] over rows of n values (the coefficient shift of the transform-based DAS extension: x -> w_2n x)
+__global__ void k_fr_mul_table_rows(fr *data, const fr *table, uint64_t stride, uint64_t n, uint64_t total) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    data[t] = mul(data[t], table[(t % n) * stride]);
+}
+void launch_fr_mul_table_rows(hipStream_t s, fr *data, const fr *table, uint64_t stride, uint64_t n, uint64_t batch) {
+    const uint64_t total = n * batch;
+    if (!total) return;
+    hipLaunchKernelGGL(k_fr_mul_table_rows, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, data, table, stride, n, total);
+}
+
 // ---- the vanishing polynomial as a product tree (large erasure sets): monic factors kept as their non-leading part ----
 // A node of degree d is x^d + a(x), deg a < d, stored as the d coefficients of a.  Leaves hold 16 roots; a leaf with fewer (the tail, and the
 // padding up to a power of two of leaves) is filled with roots at 0, i.e. multiplied by x: every node stays monic of its level's degree, and the

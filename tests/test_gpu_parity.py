@@ -186,7 +186,7 @@ def test_das_fft_extension_kat(kz):
     fs.close()
 
 
-@pytest.mark.parametrize("scale", [2, 4, 5, 9, 12, 14])
+@pytest.mark.parametrize("scale", [2, 4, 5, 9, 12, 13, 14, 15])
 def test_parametrized_das_fft_extension(kz, scale):
     fs, ofs = kz.FFTSettings(scale), ko.FFTSettings(scale)
     rng = np.random.default_rng(scale)
@@ -198,6 +198,22 @@ def test_parametrized_das_fft_extension(kz, scale):
     coeffs = fs.fft(data, inv=True)       # das_extension_test.go:59-77: upper half of the coefficients is zero
     assert not coeffs[fs.max_width // 2:].any()
     fs.close()
+
+
+def test_das_extension_long_rows_batches_and_widths(kz):
+    """rows of 4096 / 8192 values: in a settings object of exactly twice the row the extension runs as inverse transform, coefficient shift, forward
+    transform; in a wider one the reference's recursion (which walks the full-width tables, das_extension.go:38,59) stage by stage -- both against
+    the oracle's restatement of the recursion, batches with distinct rows and edge values"""
+    rng = np.random.default_rng(77)
+    for max_scale, n in ((13, 4096), (14, 4096), (14, 8192), (15, 8192)):
+        fs, ofs = kz.FFTSettings(max_scale), ko.FFTSettings(max_scale)
+        rows = np.stack([rand_fr(rng, n) for _ in range(3)])
+        rows[0, :3] = ko.fr_from_ints([0, ko.R_MOD - 1, 1])
+        rows[1] = ko.fr_from_ints([ko.R_MOD - 1])[0]
+        got = fs.das_fft_extension_batch(rows.copy())
+        for b in range(3):
+            assert np.array_equal(got[b], ofs.das_fft_extension(rows[b].copy())), (max_scale, n, b)
+        fs.close()
 
 
 def test_das_smaller_than_domain(kz):

@@ -54,14 +54,16 @@ for scale in range(4, 16):
     reps = 20 if scale < 13 else 5
     vals = rand_fr(n)
     t_fft = best(lambda: fs.fft(vals), reps)
+    fse = kz.FFTSettings(scale)                  # the reference benches FFTExtension in a settings object of exactly this scale (its recursion walks the full-width tables)
     half = rand_fr(n // 2)
-    t_ext = best(lambda: fs.das_fft_extension(half.copy()), reps)
+    t_ext = best(lambda: fse.das_fft_extension(half.copy()), reps)
     B = max(1, (1 << 22) // n)
     d_in = torch.from_numpy(rand_fr(B * n).view(np.int64).reshape(B, n, 4)).cuda()
     d_out = torch.empty_like(d_in)
     t_fft_b = dev_rate(lambda: lib.kzg_hip_fft_fr_batch_dev(fs.h, d_in.data_ptr(), n, B, 0, d_out.data_ptr(), stream), n) / B
     d_h = d_in[:, : n // 2, :].contiguous()
-    t_ext_b = dev_rate(lambda: lib.kzg_hip_das_fft_extension_batch_dev(fs.h, d_h.data_ptr(), n // 2, B, stream), n) / B
+    t_ext_b = dev_rate(lambda: lib.kzg_hip_das_fft_extension_batch_dev(fse.h, d_h.data_ptr(), n // 2, B, stream), n) / B
+    fse.close()
     del d_in, d_out, d_h
     # FFTG1 on [s^i] G
     if setup is None or setup.shape[0] < n:
