@@ -74,7 +74,8 @@ int kzg_hip_das_fft_extension(kzg_hip_fft *fs, void *vals_fr, uint64_t n);
 int kzg_hip_das_fft_extension_batch(kzg_hip_fft *fs, void *vals_fr, uint64_t n, uint64_t batch);
 
 /* device-resident batch forms of the three transforms the reference publishes benchmarks for (BENCH.md:31,43,55):
- * `batch` rows of n values each, inputs and outputs in HBM, Kilic images for G1 (converted and normalised inside) */
+ * `batch` rows of n values each, inputs and outputs in HBM, Kilic images for G1 (converted and normalised inside).  d_out must not
+ * overlap d_vals (InplaceFFT's rule, fft_fr.go:76: the name notwithstanding it takes a separate output slice). */
 int kzg_hip_fft_fr_batch_dev(kzg_hip_fft *fs, const void *d_vals_fr, uint64_t n, uint64_t batch, int inv, void *d_out_fr, void *stream);
 int kzg_hip_fft_g1_batch_dev(kzg_hip_fft *fs, const void *d_vals_g1, uint64_t n, uint64_t batch, int inv, void *d_out_g1, void *stream);
 int kzg_hip_das_fft_extension_batch_dev(kzg_hip_fft *fs, void *d_vals_fr, uint64_t n, uint64_t batch, void *stream);
