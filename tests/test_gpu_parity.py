@@ -751,8 +751,8 @@ def test_fk20_multi_batched_file_accumulation(kz):
 def test_fk20_multi_scale16_config5(kz):
     """FK20MultiDAOptimized / DAUsingFK20Multi, n2 = 65536, chunk length 16 (fk20_multi_test.go:13) -> 4096 coset proofs.
     The oracle needs minutes for the settings alone at this size, so parity is established through the coset-proof
-    identity at sampled positions (pairing-free form of CheckProofMulti, fk20_multi_test.go:86) and through linearity
-    over ALL 4096 positions (a size-independent property)."""
+    identity at ALL 4096 positions (pairing-free form of CheckProofMulti, fk20_multi_test.go:86), the byte pin of the oracle's
+    full-size run, and linearity over all positions (a size-independent property)."""
     l, n = 16, 32768
     fs = kz.FFTSettings(16)
     setup = fs.generate_testing_setup_g1(ko.fr_from_ints([S_TEST]), 65536)      # GenerateTestingSetup on the device
@@ -777,10 +777,26 @@ def test_fk20_multi_scale16_config5(kz):
         assert L.ko_g1_equal(tmp.ctypes.data, ps[j].ctypes.data), j
     w2n = pyref.root_of_unity(16)
     gen = ko.g1_generator()
-    for pos in (0, 1, 2, 777, 2048, 4095):                                      # coset-proof identity
-        x = pow(w2n, pyref.rev_bits(pos, 12), ko.R_MOD)                         # domainStride = MaxWidth / n2 = 1
-        d = pyref.coset_proof_dlog(ai, S_TEST, x, l)
-        assert ko.g1_equal(pa[pos], ko.g1_mul(gen, ko.fr_from_ints([d])[0])), pos
+    # coset-proof identity at EVERY position: proof = [(p(s) - I(s)) / (s^l - x^l)] G with I = p mod (X^l - x^l).  The l coefficients of I at all
+    # 4096 cosets at once: I_i = sum_t p[i + t l] (x^l)^t, and x^l runs over the 4096-th roots of unity, so coefficient i of every coset is one
+    # 4096-point transform (the oracle's) of the stride-l subsequence p[i::l]
+    R = ko.R_MOD
+    ofs12 = ko.FFTSettings(12)
+    sub = [ko.fr_to_ints(ofs12.fft(ko.fr_from_ints(ai[i::l] + [0] * 2048))) for i in range(l)]
+    spow = [pow(S_TEST, i, R) for i in range(l + 1)]
+    ps_ = pyref.eval_poly(ai, S_TEST)
+    w4096 = pyref.root_of_unity(12)
+    dl = []
+    for pos in range(4096):
+        k = pyref.rev_bits(pos, 12)                                             # domainStride = MaxWidth / n2 = 1: x = w_2n^bitrev(pos)
+        i_s = sum(spow[i] * sub[i][k] for i in range(l)) % R
+        dl.append((ps_ - i_s) * pow(spow[l] - pow(w4096, k, R), -1, R) % R)
+    for pos in (0, 1, 2, 777, 2048, 4095):                                      # the vectorised form against the plain restatement
+        assert dl[pos] == pyref.coset_proof_dlog(ai, S_TEST, pow(w2n, pyref.rev_bits(pos, 12), R), l), pos
+    want = ko.g1_empty(1)
+    dfr = ko.fr_from_ints(dl)
+    for pos in range(4096):
+        assert ko.g1_equal(pa[pos], ko.g1_mul(gen, dfr[pos])), pos
     fk.close(); ks.close(); fs.close()
 
 
