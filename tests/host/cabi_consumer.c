@@ -6,7 +6,7 @@
  *
  * Flow (the reference's test data: kzg_single_proofs_test.go:33-64, fk20_single_test.go:11-41):
  *   NewFFTSettings -> GenerateTestingSetup -> NewKZGSettings -> CommitToPoly (vector A) -> ComputeProofSingle(x = 17) (vector B)
- *   -> NewFK20SingleSettings -> DAUsingFK20 (vector C, positions 0 / 18 / 31) -> status codes 1..6 -> frees.
+ *   -> NewFK20SingleSettings -> DAUsingFK20 (vector C, positions 0 / 18 / 31) -> status codes 1..6 -> package eth (aggregate proof, status 11) -> frees.
  * Expected values are SURVEY.md 8(c) vectors A-C (tests/golden/derived_vectors.json), compared as 48-byte compressed hex.
  * Test infrastructure: built and run by tests/test_cabi.py (-m gpu); prints one line per check and exits non-zero on a mismatch.
  */
@@ -140,6 +140,24 @@ int main(void) {
     expect_status(kzg_hip_fft_fr(NULL, poly, 16, 0, scratch, NULL), KZG_HIP_ERR_BAD_ARG, "FFT on a NULL handle");
     memset(c48, 0xff, 48);
     expect_status(kzg_hip_g1_from_compressed(fs4, c48, 1, point), KZG_HIP_ERR_BAD_POINT, "FromCompressedG1 of 48 x 0xff");
+
+    /* ---- package eth on a 16-element "blob" (eth/eth.go:175-182): no blobs -> the proof of the zero polynomial; an element >= r -> status 11 ---- */
+    {
+        kzg_hip_eth *es = NULL;
+        unsigned char *lagrange = (unsigned char *)malloc(16 * G1), blob[16 * 32], proof[48], comm[48];
+        expect_status(kzg_hip_fft_g1(fs4, setup, 16, 1, lagrange), KZG_HIP_OK, "FFTG1(setup[:16], inv) = the Lagrange setup");
+        expect_status(kzg_hip_eth_settings_new(fs4, lagrange, 16, &es), KZG_HIP_OK, "eth settings (16 elements per blob)");
+        expect_status(kzg_hip_eth_compute_aggregate_kzg_proof(es, NULL, 0, proof, NULL), KZG_HIP_OK, "ComputeAggregateKZGProof of no blobs");
+        hex48(proof, hx);
+        check(strncmp(hx, "c00000", 6) == 0 && hx[95] == '0', "the proof of the zero polynomial is the point at infinity");
+        memset(blob, 0, sizeof blob);
+        blob[0] = 5;
+        expect_status(kzg_hip_eth_compute_aggregate_kzg_proof(es, blob, 1, proof, comm), KZG_HIP_OK, "ComputeAggregateKZGProof of one blob");
+        memset(blob + 32 * 7, 0xff, 32);
+        expect_status(kzg_hip_eth_compute_aggregate_kzg_proof(es, blob, 1, proof, comm), KZG_HIP_ERR_BAD_BLOB, "a field element >= r in a blob");
+        kzg_hip_eth_settings_free(es);
+        free(lagrange);
+    }
 
     /* ---- frees, dependents first ---- */
     kzg_hip_fk20_single_settings_free(fk);
