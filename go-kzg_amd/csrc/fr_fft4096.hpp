@@ -112,6 +112,70 @@ template <bool SCALE> KZG_HD void pass_last(uint32_t t, const uint32_t *s, const
     }
 }
 
+// ---- transforms of m = 4 .. 2048 points, 4096 / m of them per workgroup ----
+// The first stages of the 4096-point network ARE independent m-point transforms on the consecutive blocks of m positions (a stage of half-size
+// h uses w_{2h}^j whatever the total length), so a workgroup runs log4(m) of the passes above on 4096 / m transforms at once; m = 2 * 4^a adds
+// one radix-2 pass of half-size 4^a, whose twiddle w_{2h}^j is the first entry (w1) of the radix-4 table of stride h.
+// first pass: unit U = lane, positions 4 U + o of block U / (m / 4); they hold the natural indices v + (m / 4) bitrev2(o), v = bitrev(U mod (m / 4))
+template <int LOGM> KZG_HD void pass_first_small(uint32_t t, const fr *in, uint64_t in_stride, uint64_t n_in, uint64_t first, uint64_t batch, uint32_t *s,
+                                                const uint32_t *tw) {
+    constexpr uint32_t m = 1u << LOGM, q4 = m / 4;
+    const uint32_t blk = t / q4, u = t % q4;
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < LOGM - 2; k++) v |= ((u >> k) & 1u) << (LOGM - 3 - k);
+    const bool live = first + blk < batch;
+    const fr *src = in + (first + blk) * in_stride;
+    frl x[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t i = v + q4 * q;
+        x[q] = (live && i < n_in) ? frl_unpack(src[i]) : frl_zero();
+    }
+    const frl &X0 = x[0], &X1 = x[2], &X2 = x[1], &X3 = x[3];                                 // as in pass_first
+    const frl n2 = frl_sub<2>(frl_zero(), X2), n3 = frl_sub<2>(frl_zero(), X3);
+    const frl s01 = frl_add(X0, X1);
+    const frl b0 = frl_add(s01, frl_add(X2, X3));
+    const frl b2 = frl_add(s01, frl_add(n2, n3));
+    const frl a1 = frl_add(X0, frl_sub<2>(frl_zero(), X1));
+    const frl a3 = frl_add(X2, n3);
+    const frl tq = frl_mul(a3, tw_u(tw, 0, 2));
+    const frl b1 = frl_add(a1, tq), b3 = frl_sub<3>(a1, tq);
+    put(s, 4 * t + 0, b0); put(s, 4 * t + 1, b1); put(s, 4 * t + 2, b2); put(s, 4 * t + 3, b3);
+}
+// radix-2 pass of half-size H (4, 16: lanes along hi, wave-uniform twiddle; 64, 256, 1024: lanes along lo): two butterflies per lane
+template <uint32_t H> KZG_HD void pass_r2(uint32_t t, uint32_t a, uint32_t b, uint32_t *s, const uint32_t *tw) {
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        uint32_t p; frl w;
+        if (H < 64) {
+            const uint32_t c = a + 16u * r, j = c & (H - 1), g = c / H;
+            p = 64 * b + 2 * H * g + j;
+            w = tw_u(tw, (H == 4 ? 1u : 5u) + j, 0);
+        } else {
+            const uint32_t e = t + 1024u * r, j = e & (H - 1), g = e / H;
+            p = 2 * H * g + j;
+            w = tw_v(tw, H == 64 ? TW_V64 : (H == 256 ? TW_V256 : TW_V1024), H, 0, j);
+        }
+        frl x0 = get(s, p);
+        const frl y = get(s, p + H);
+        frl_sweep(x0);
+        const frl tq = frl_mul(y, w);
+        put(s, p, frl_add(x0, tq)); put(s, p + H, frl_sub<3>(x0, tq));
+    }
+}
+// positions t + 1024 q -> canonical values (SCALE: times the constant sc first); position p of the workgroup is element p of its 4096 / m transforms
+template <bool SCALE> KZG_HD void pass_store(uint32_t t, const uint32_t *s, const frl &sc, fr *dst, uint64_t limit) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t p = t + 1024u * q;
+        if (p >= limit) continue;
+        frl v = get(s, p);
+        if (SCALE) { frl_sweep(v); dst[p] = frl_canon_lt2r(frl_mul(v, sc)); }
+        else dst[p] = frl_canon(v);
+    }
+}
+
 // host side: the twiddle file from a root table of width W >= 4096 (roots[i] = w_W^i, Kilic images; ExpandedRootsOfUnity for the
 // forward transform, ReverseRootsOfUnity for the inverse)
 inline void build_twiddles(const fr *roots, uint64_t W, uint32_t *out) {

@@ -108,6 +108,39 @@ __global__ __launch_bounds__(1024) void k_fr_fft4096_r4(const fr *in, uint64_t i
     if (SCALE) sc = frl_const_from_kilic(*scale);
     fr4::pass_last<SCALE>(t, smem, tw, sc, dst);
 }
+// 4 .. 2048 points: 4096 / m transforms per workgroup through the first passes of the 4096-point network (fr_fft4096.hpp)
+template <int LOGM, bool SCALE>
+__global__ __launch_bounds__(1024) void k_fr_fft_small(const fr *in, uint64_t in_stride, uint64_t n_in, fr *out, uint64_t batch, const uint32_t *__restrict__ tw,
+                                                       const fr *scale) {
+    extern __shared__ uint32_t smem[];
+    constexpr uint32_t m = 1u << LOGM, per = fr4::N / m;
+    constexpr int A = LOGM / 2;                                            // radix-4 passes (strides 1, 4, ..., 4^(A-1))
+    const uint32_t t = threadIdx.x, a = __builtin_amdgcn_readfirstlane(t >> 6), b = t & 63u;
+    const uint64_t first = (uint64_t)blockIdx.x * per;
+    fr4::pass_first_small<LOGM>(t, in, in_stride, n_in, first, batch, smem, tw);
+    __syncthreads();
+    if constexpr (A >= 2) { fr4::pass_lo<4>(a, b, smem, tw); __syncthreads(); }
+    if constexpr (A >= 3) { fr4::pass_lo<16>(a, b, smem, tw); __syncthreads(); }
+    if constexpr (A >= 4) { fr4::pass_hi<64>(t, smem, tw); __syncthreads(); }
+    if constexpr (A >= 5) { fr4::pass_hi<256>(t, smem, tw); __syncthreads(); }
+    if constexpr (LOGM & 1) { fr4::pass_r2<(1u << (2 * A))>(t, a, b, smem, tw); __syncthreads(); }
+    frl sc = frl_zero();
+    if (SCALE) sc = frl_const_from_kilic(*scale);
+    const uint64_t left = batch - first;                                   // transforms of this workgroup that exist
+    fr4::pass_store<SCALE>(t, smem, sc, out + first * m, left >= per ? fr4::N : (uint64_t)left * m);
+}
+template <int LOGM> static void launch_fr_fft_small(hipStream_t s, const fr *in, uint64_t in_stride, uint64_t n_in, fr *out, uint64_t batch, const uint32_t *tw,
+                                                    const fr *scale) {
+    const uint32_t per = fr4::N >> LOGM, blocks = (uint32_t)((batch + per - 1) / per);
+    if (scale) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fr_fft_small<LOGM, true>), hipFuncAttributeMaxDynamicSharedMemorySize, fr4::LDS_BYTES);
+        hipLaunchKernelGGL((k_fr_fft_small<LOGM, true>), dim3(blocks), dim3(1024), fr4::LDS_BYTES, s, in, in_stride, n_in, out, batch, tw, scale);
+    } else {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fr_fft_small<LOGM, false>), hipFuncAttributeMaxDynamicSharedMemorySize, fr4::LDS_BYTES);
+        hipLaunchKernelGGL((k_fr_fft_small<LOGM, false>), dim3(blocks), dim3(1024), fr4::LDS_BYTES, s, in, in_stride, n_in, out, batch, tw, scale);
+    }
+}
+
 #define LOGR_OF(R) ((R) == 2 ? 1 : (R) == 4 ? 2 : (R) == 8 ? 3 : 4)
 // The stages above 4096 of a transform of R * 4096 points (R = 2, 4, 8, 16), all in one pass over the data: lane k2 holds the R values
 // k2 + 4096 a in registers and runs the log2 R radix-2 stages of half-size m = 4096 2^s on them (fft_fr.go:40-52 with the lazy limbs of
@@ -196,6 +229,24 @@ void launch_fr_fft(hipStream_t s, const fr *in, uint64_t in_stride, uint64_t n_i
             hipLaunchKernelGGL(k_fr_fft4096_r4<false>, dim3((uint32_t)batch), dim3(1024), fr4::LDS_BYTES, s, in, in_stride, n_in, out, tw4096, scale, 0u);
         }
         prof_end(s, "fr_fft4096");
+        return;
+    }
+    // (from one workgroup per CU on: fewer values are quicker on the one-workgroup-per-transform kernel below, whose small workgroups spread over
+    // the whole chip -- 2048 transforms of 32 points: 16 workgroups here, 2048 there)
+    static const bool shared_forced = [] { const char *e = getenv("KZG_HIP_FR_FFT"); return e && !strcmp(e, "shared"); }();   // test hook: at every batch size
+    if (n >= 4 && n < fr4::N && (shared_forced || batch * n >= 256ull * fr4::N) && tw4096 && !radix2_forced && (batch + (fr4::N / n) - 1) / (fr4::N / n) <= 0x7fffffffull) {
+        switch (logn) {
+        case 2: launch_fr_fft_small<2>(s, in, in_stride, n_in, out, batch, tw4096, scale); break;
+        case 3: launch_fr_fft_small<3>(s, in, in_stride, n_in, out, batch, tw4096, scale); break;
+        case 4: launch_fr_fft_small<4>(s, in, in_stride, n_in, out, batch, tw4096, scale); break;
+        case 5: launch_fr_fft_small<5>(s, in, in_stride, n_in, out, batch, tw4096, scale); break;
+        case 6: launch_fr_fft_small<6>(s, in, in_stride, n_in, out, batch, tw4096, scale); break;
+        case 7: launch_fr_fft_small<7>(s, in, in_stride, n_in, out, batch, tw4096, scale); break;
+        case 8: launch_fr_fft_small<8>(s, in, in_stride, n_in, out, batch, tw4096, scale); break;
+        case 9: launch_fr_fft_small<9>(s, in, in_stride, n_in, out, batch, tw4096, scale); break;
+        case 10: launch_fr_fft_small<10>(s, in, in_stride, n_in, out, batch, tw4096, scale); break;
+        default: launch_fr_fft_small<11>(s, in, in_stride, n_in, out, batch, tw4096, scale); break;
+        }
         return;
     }
     if (n <= FR_TILE) {

@@ -112,6 +112,29 @@ def test_fr_lazy_kernels_4096_and_das2048(kz):
         fs.close()
 
 
+def test_fr_fft_below_4096_points_share_a_workgroup(kz):
+    """4 .. 2048 points: 4096 / m transforms per workgroup through the first passes of the 4096-point network (k_fr_fft_small; odd log2 m adds a
+    radix-2 pass): every size, batches that do not fill the last workgroup, distinct rows with edge values, zero padding, both directions, in a
+    settings object of width 4096 and a wider one"""
+    rng = np.random.default_rng(2048)
+    for max_scale in (12, 14):
+        fs, ofs = kz.FFTSettings(max_scale), ko.FFTSettings(max_scale)
+        for logm in range(2, 12):
+            m = 1 << logm
+            per = 4096 // m
+            for batch in sorted({1, max(per - 1, 1), per, per + 1, 2 * per + 3}):
+                rows = rand_fr(rng, batch * m).reshape(batch, m, 4)
+                rows[0, :2] = ko.fr_from_ints([ko.R_MOD - 1, 0])
+                rows[-1, m // 2:] = ko.fr_from_ints([ko.R_MOD - 1])[0]
+                for inv in (False, True):
+                    got = fs.fft_batch(rows, inv=inv)
+                    for b_ in sorted({0, batch // 2, batch - 1}):
+                        assert np.array_equal(got[b_], ofs.fft(rows[b_], inv)), (max_scale, m, batch, inv, b_)
+            short = rand_fr(rng, m // 2 + 1)                                  # zero-padded up to m (fft_fr.go:60-68)
+            assert np.array_equal(fs.fft(short), ofs.fft(short)), (max_scale, m)
+        fs.close()
+
+
 def test_fr_fft_above_4096_points(kz):
     """8192 .. 65 536 points: rows through the 4096-point LDS kernel (every R-th element), upper stages in registers (k_fr_fft_upper): each size
     in a settings object of exactly its width and in a wider one (twiddle strides), batches with distinct rows, edge values (0, r - 1), zero
@@ -133,6 +156,31 @@ def test_fr_fft_above_4096_points(kz):
         fs.close()
 
 
+def test_fr_shared_workgroup_kernel_in_a_fresh_process():
+    """below 2^20 values per launch short transforms keep one workgroup each (their small workgroups spread over the chip); the shared-workgroup
+    kernel is forced at every batch size in a child process (KZG_HIP_FR_FFT=shared) for the tests that walk all sizes and ragged batches, and run
+    here on full-size launches"""
+    import subprocess
+    import sys
+    if os.environ.get("KZG_HIP_FR_FFT"):
+        pytest.skip("already a forced child")
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k",
+                          "fft_fr or fr_fft_below or inv_fft or roundtrip or zero_poly or recover or full_das_flow or evaluation_form"],
+                         env=dict(os.environ, KZG_HIP_FR_FFT="shared"), capture_output=True, text=True, timeout=1200)
+    assert res.returncode == 0, res.stdout[-1500:]
+    import gokzg_amd as kz_
+    fs, ofs = kz_.FFTSettings(12), ko.FFTSettings(12)
+    rng = np.random.default_rng(31)
+    for m in (16, 512, 2048):
+        batch = (1 << 20) // m + 3                                           # above the threshold, last workgroup partly filled
+        rows = rand_fr(rng, batch * m).reshape(batch, m, 4)
+        for inv in (False, True):
+            got = fs.fft_batch(rows, inv=inv)
+            for b_ in (0, 1, batch // 2, batch - 2, batch - 1):
+                assert np.array_equal(got[b_], ofs.fft(rows[b_], inv)), (m, inv, b_)
+    fs.close()
+
+
 def test_fr_radix2_kernels_in_a_fresh_process():
     """sizes other than 4096 / 2048 (and tiles of longer transforms) still run the radix-2 kernels; at the hot sizes they are re-run in a
     child process that forces them (KZG_HIP_FR_FFT=radix2), so both families stay pinned to the oracle and the reference's KATs"""
@@ -141,7 +189,7 @@ def test_fr_radix2_kernels_in_a_fresh_process():
     if os.environ.get("KZG_HIP_FR_FFT") == "radix2":
         pytest.skip("already the forced child")
     res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k",
-                          "fft_fr or das or fr_lazy or fr_fft_above or vector_C or full_das_flow"],
+                          "fft_fr or das or fr_lazy or fr_fft_above or fr_fft_below or vector_C or full_das_flow"],
                          env=dict(os.environ, KZG_HIP_FR_FFT="radix2"), capture_output=True, text=True, timeout=1200)
     assert res.returncode == 0, res.stdout[-1500:]
 
