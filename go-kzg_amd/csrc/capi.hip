@@ -88,7 +88,7 @@ struct kzg_hip_fft {
     fr *d_expanded_l = nullptr, *d_reversed_l = nullptr;   // the same roots as images 2^261 (the constant operand of fr_lazy.hpp's product): k_fr_fft_upper; W > 4096 only
     fr *d_inv_pow2 = nullptr;   // (2^k)^-1, k = 0..63 (Montgomery)
     uint32_t *d_tw_das2048 = nullptr;              // twiddle file of the lazy-limb DASFFTExtension(2048) (fr_das2048.hpp); null below scale 12
-    uint32_t *d_tw4096[2] = {nullptr, nullptr};   // twiddle files of the radix-4 4096-point transform, forward / inverse (fr_fft4096.hpp); null below scale 12
+    uint32_t *d_tw4096[2] = {nullptr, nullptr};   // twiddle files of the radix-4 passes, forward / inverse (fr_fft4096.hpp; narrow settings objects: the part their transforms use); null below scale 2
     fr *d_glv_expanded = nullptr, *d_glv_reversed = nullptr;   // twiddles as GLV pairs for the G1 FFT (g1_mul_glv)
     int8_t *d_wnaf_expanded = nullptr, *d_wnaf_reversed = nullptr;   // ... and their width-5 NAF digit strings (KZG_WNAF_ROW bytes per twiddle)
     uint8_t *h_stage = nullptr; size_t h_stage_cap = 0;   // pinned staging for large results of calls that hold `mu` (d2h_staged)
@@ -312,13 +312,15 @@ int kzg_hip_fft_settings_new(int device, unsigned max_scale, kzg_hip_fft **out) 
     for (int i = 1; i < 64; i++) invs[i] = mul(invs[i - 1], half);
     HIPCHK(hipMalloc((void **)&fs->d_inv_pow2, sizeof invs));
     HIPCHK(hipMemcpy(fs->d_inv_pow2, invs, sizeof invs, hipMemcpyHostToDevice));
-    if (fs->W >= fr4::N) {
+    if (fs->W >= 4) {   // the twiddle file of the radix-4 passes (narrow settings objects get the part their transforms use)
         std::vector<uint32_t> tw(fr4::TW_WORDS);
         for (int dir = 0; dir < 2; dir++) {
             fr4::build_twiddles(dir ? fs->h_reversed.data() : fs->h_expanded.data(), fs->W, tw.data());
             HIPCHK(hipMalloc((void **)&fs->d_tw4096[dir], tw.size() * 4));
             HIPCHK(hipMemcpy(fs->d_tw4096[dir], tw.data(), tw.size() * 4, hipMemcpyHostToDevice));
         }
+    }
+    if (fs->W >= fr4::N) {
         if (fs->W > fr4::N) {   // transforms above 4096 points: the roots once more, pre-scaled for the lazy-limb product
             std::vector<fr> le(fs->W + 1), lr(fs->W + 1);
             const fr k32 = fr_from_u64(32);

@@ -176,7 +176,7 @@ template <bool SCALE> KZG_HD void pass_store(uint32_t t, const uint32_t *s, cons
     }
 }
 
-// host side: the twiddle file from a root table of width W >= 4096 (roots[i] = w_W^i, Kilic images; ExpandedRootsOfUnity for the
+// host side: the twiddle file from a root table of width W (roots[i] = w_W^i, Kilic images; ExpandedRootsOfUnity for the
 // forward transform, ReverseRootsOfUnity for the inverse)
 inline void build_twiddles(const fr *roots, uint64_t W, uint32_t *out) {
     for (uint32_t i = 0; i < TW_WORDS; i++) out[i] = 0;
@@ -184,7 +184,11 @@ inline void build_twiddles(const fr *roots, uint64_t W, uint32_t *out) {
     for (int pi = 0; pi < 6; pi++) {
         const uint32_t m = ms[pi];
         for (uint32_t j = 0; j < m; j++) {
-            const fr w[3] = {roots[(uint64_t)j * (W / (2 * m))], roots[(uint64_t)j * (W / (4 * m))], roots[(uint64_t)(j + m) * (W / (4 * m))]};
+            // (a settings object narrower than 4096 only runs the passes whose roots it has: 2 m <= W for w1, 4 m <= W for w2 and w3)
+            if (2ull * m > W) continue;
+            const bool wide = 4ull * m <= W;
+            const fr w[3] = {roots[(uint64_t)j * (W / (2 * m))], wide ? roots[(uint64_t)j * (W / (4 * m))] : roots[0],
+                             wide ? roots[(uint64_t)(j + m) * (W / (4 * m))] : roots[0]};
             for (int which = 0; which < 3; which++) {
                 const frl c = frl_const_from_kilic(w[which]);
                 for (int k = 0; k < 9; k++) {

@@ -53,14 +53,14 @@ for scale in range(4, 16):
     i = scale - 4
     reps = 20 if scale < 13 else 5
     vals = rand_fr(n)
-    t_fft = best(lambda: fs.fft(vals), reps)
-    fse = kz.FFTSettings(scale)                  # the reference benches FFTExtension in a settings object of exactly this scale (its recursion walks the full-width tables)
+    fse = kz.FFTSettings(scale)                  # like the reference's benchmarks: a settings object of exactly this scale (FFTExtension's recursion walks the full-width tables)
+    t_fft = best(lambda: fse.fft(vals), reps)
     half = rand_fr(n // 2)
     t_ext = best(lambda: fse.das_fft_extension(half.copy()), reps)
     B = max(1, (1 << 22) // n)
     d_in = torch.from_numpy(rand_fr(B * n).view(np.int64).reshape(B, n, 4)).cuda()
     d_out = torch.empty_like(d_in)
-    t_fft_b = dev_rate(lambda: lib.kzg_hip_fft_fr_batch_dev(fs.h, d_in.data_ptr(), n, B, 0, d_out.data_ptr(), stream), n) / B
+    t_fft_b = dev_rate(lambda: lib.kzg_hip_fft_fr_batch_dev(fse.h, d_in.data_ptr(), n, B, 0, d_out.data_ptr(), stream), n) / B
     d_h = d_in[:, : n // 2, :].contiguous()
     t_ext_b = dev_rate(lambda: lib.kzg_hip_das_fft_extension_batch_dev(fse.h, d_h.data_ptr(), n // 2, B, stream), n) / B
     fse.close()
