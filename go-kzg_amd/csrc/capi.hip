@@ -473,7 +473,9 @@ int kzg_hip_fft_g1(kzg_hip_fft *fs, const void *vals_g1, uint64_t n, int inv, vo
 // evaluations are unique, so this is the reference's result bit for bit.  Other widths and sizes: the recursion itself, stage by stage.
 static int das_ext_rows(kzg_hip_fft *fs, hipStream_t s, fr *d, uint64_t n, uint64_t batch) {
     static const bool radix2_forced = [] { const char *e = getenv("KZG_HIP_FR_FFT"); return e && !strcmp(e, "radix2"); }();
-    if (2 * n == fs->W && n >= fr4::N && n <= 16 * (uint64_t)fr4::N && fs->d_tw4096[0] && !radix2_forced) {
+    // (... and launches of 2^20 values in rows of at most 64: the short transforms share workgroups, k_fr_fft_small)
+    const bool long_rows = n >= fr4::N && n <= 16 * (uint64_t)fr4::N, short_rows = n >= 4 && n <= 64 && n * batch >= (256ull * fr4::N);   // (measured: 8 values 3.8 -> 0.5 ns, 64 values 8.7 -> 5.7 ns per row; no gain from 128 on)
+    if (2 * n == fs->W && (long_rows || short_rows) && fs->d_tw4096[0] && !radix2_forced) {
         dtmp<fr> d_c(s);
         CHK(d_c.alloc(n * batch));
         fr_fft_rows(fs, s, d, n, n, d_c.p, n, batch, 1);

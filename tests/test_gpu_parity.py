@@ -264,6 +264,22 @@ def test_das_extension_long_rows_batches_and_widths(kz):
         fs.close()
 
 
+def test_das_extension_short_rows_in_full_launches(kz):
+    """launches of 2^20 values in rows of at most 64 (longer rows stay on the recursion kernels), exact-width settings: the extension as inverse transform, shift, forward transform on the
+    shared-workgroup kernel; sampled rows against the oracle's recursion"""
+    rng = np.random.default_rng(78)
+    for scale in (3, 6, 7, 10):
+        n = 1 << (scale - 1)
+        fs, ofs = kz.FFTSettings(scale), ko.FFTSettings(scale)
+        batch = (1 << 20) // n + 5
+        rows = rand_fr(rng, batch * n).reshape(batch, n, 4)
+        rows[0, :2] = ko.fr_from_ints([ko.R_MOD - 1, 0])
+        got = fs.das_fft_extension_batch(rows.copy())
+        for b_ in (0, 1, batch // 3, batch - 1):
+            assert np.array_equal(got[b_], ofs.das_fft_extension(rows[b_].copy())), (scale, b_)
+        fs.close()
+
+
 def test_das_smaller_than_domain(kz):
     # the reference walks the full-width tables whatever the input length (das_extension.go:38,59)
     fs, ofs = kz.FFTSettings(8), ko.FFTSettings(8)
