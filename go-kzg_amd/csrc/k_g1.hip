@@ -161,10 +161,12 @@ template <int MODE, bool PRE = false> __global__ __launch_bounds__(G1_BLOCK, 2) 
 // (x + y, x - y) formulas and the packing are computed redundantly by the four lanes, lane 0 of the quad stores.  Regular odd-digit schedule
 // (lanes of a wavefront may hold different twiddles).  DIF = false: (x, y) -> (x + w y, x - w y); DIF = true: (x, y) -> (x + y, (x - y) w).
 // WNAF: the width-5 NAF digit rows of the twiddles (wave-uniform launches) instead of the regular odd-digit schedule.
-template <bool DIF, bool WNAF> __global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_fft_stage_quad(g1j *data, uint32_t logn, uint64_t m, const fr *roots, const int8_t *wnaf, uint64_t W, uint64_t total, uint64_t batch) {
+// L = 2: the same with PAIRS of lanes (two rounds for the levels of three or four products): for launches that no longer fit four lanes per butterfly
+// into one wavefront per SIMD but still leave half of the SIMDs empty (9-16 polynomials of 4096 points).
+template <bool DIF, bool WNAF, int L> __global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_fft_stage_quad(g1j *data, uint32_t logn, uint64_t m, const fr *roots, const int8_t *wnaf, uint64_t W, uint64_t total, uint64_t batch) {
     const uint64_t t4 = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    const uint32_t role = (uint32_t)(t4 & 3u);
-    const uint64_t t = t4 >> 2;
+    const uint32_t role = (uint32_t)(t4 & (uint64_t)(L - 1));
+    const uint64_t t = t4 / L;
     if (t >= total) return;
     const uint64_t half = 1ull << (logn - 1), groups = half / m;
     const uint64_t j = t / (groups * batch), rem = t % (groups * batch), b = rem / groups, g = rem % groups;   // twiddle-major, as in k_g1_fft_stage
@@ -179,7 +181,7 @@ template <bool DIF, bool WNAF> __global__ __launch_bounds__(G1_BLOCK, 2) void k_
     for (int i = 0; i < 4; i++) { h.k1[i] = kk.l[i]; h.k2[i] = kk.l[4 + i]; }
     h.neg1 = h.neg2 = 0;
     g1aq tbl[8]; fq dz[7]; g1j packed;
-#define QMUL(pq, res) (WNAF ? g1_mul_glv_wnaf_quad((pq), kk, tbl, dz, wnaf + ti * KZG_WNAF_ROW, (res), packed, role) : g1_mul_glv_regular_quad((pq), h, tbl, dz, (res), packed, role))
+#define QMUL(pq, res) (WNAF ? g1_mul_glv_wnaf_quad<L>((pq), kk, tbl, dz, wnaf + ti * KZG_WNAF_ROW, (res), packed, role) : g1_mul_glv_regular_quad<L>((pq), h, tbl, dz, (res), packed, role))
     if (!DIF) {
         g1jq yq; int st = is_inf(y) ? 0 : 1;
         if (st == 1) {
@@ -228,33 +230,45 @@ template <bool DIF, bool WNAF> __global__ __launch_bounds__(G1_BLOCK, 2) void k_
     }
 }
 #undef QMUL
-// 4 lanes per butterfly while the quadrupled launch still fits one wavefront per SIMD (65 536 lanes on 256 CUs); KZG_HIP_G1_QUAD = 0 / 1: never / always
+// 4 lanes per butterfly while the quadrupled launch still fits one wavefront per SIMD (65 536 lanes on 256 CUs), 2 while the doubled one does;
+// KZG_HIP_G1_QUAD = 0 / 1 / 2: never / always four / always two
 static int g1_quad_forced() {
-    static const int forced = [] { const char *e = getenv("KZG_HIP_G1_QUAD"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
+    static const int forced = [] { const char *e = getenv("KZG_HIP_G1_QUAD"); return !e ? -1 : (e[0] == '0' ? 0 : e[0] == '2' ? 2 : 1); }();
     return forced;
 }
 bool g1_quad_enabled() { return g1_quad_forced() != 0; }
-// `uniform`: every wavefront of the one-lane-per-butterfly launch would hold ONE twiddle (the width-5 NAF schedule needs that; otherwise the regular
-// schedule runs, which the quad form beats up to two wavefronts per SIMD: 9-16 polynomials)
-static bool g1_stage_quad(uint64_t butterflies, bool uniform = true) {
-    if (g1_quad_forced() >= 0) return g1_quad_forced() == 1;
-    return butterflies * 4 <= (uniform ? 65536u : 131072u);
+// lanes per butterfly of a stage launch: 4, 2 or 1
+static int g1_stage_lanes(uint64_t butterflies) {
+    if (g1_quad_forced() >= 0) return g1_quad_forced() == 0 ? 1 : g1_quad_forced() == 2 ? 2 : 4;
+    return butterflies * 4 <= 65536u ? 4 : butterflies * 2 <= 65536u ? 2 : 1;
+}
+// the irregular width-5 NAF schedule where every wavefront holds one twiddle (L lanes x (n / 2 / m) batch butterflies per twiddle), else the regular one
+static bool g1_quad_wnaf(uint64_t n, uint64_t batch, uint64_t m, int lanes) {
+    static const bool off = [] { const char *e = getenv("KZG_HIP_G1_MUL"); return e && e[0] == 'r'; }();
+    return !off && ((n / 2 / m) * batch * lanes) % 64 == 0;
 }
 // these launches are at most one 256-lane workgroup per CU: 96 KiB of unused dynamic LDS keeps the dispatcher from putting two on one CU (two
 // wavefronts on a SIMD take 1.76x as long as one) while another CU stays empty
-static bool g1_quad_wnaf(uint64_t n, uint64_t batch, uint64_t m) {
-    static const bool off = [] { const char *e = getenv("KZG_HIP_G1_MUL"); return e && e[0] == 'r'; }();
-    return !off && ((n / 2 / m) * batch * 4) % 64 == 0;
-}
-static size_t g1_quad_lds(uint64_t butterflies) {
+template <bool DIF> static void launch_stage_coop(hipStream_t s, int lanes, g1j *data, uint64_t n, uint64_t batch, uint64_t m, const fr *roots, const int8_t *wnaf, uint64_t W,
+                                                  uint64_t total) {
     static const bool once = [] {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_g1_fft_stage_quad<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_g1_fft_stage_quad<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_g1_fft_stage_quad<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_g1_fft_stage_quad<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_g1_fft_stage_quad<DIF, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_g1_fft_stage_quad<DIF, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_g1_fft_stage_quad<DIF, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_g1_fft_stage_quad<DIF, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         return true; }();
     (void)once;
-    return butterflies * 4 <= 65536 ? 96 * 1024 : 0;
+    const size_t lds = total * lanes <= 65536 ? 96 * 1024 : 0;
+    const dim3 qg((uint32_t)((lanes * total + G1_BLOCK - 1) / G1_BLOCK));
+    const uint32_t logn = ilog2g(n);
+    const bool wn = g1_quad_wnaf(n, batch, m, lanes);
+    if (lanes == 4) {
+        if (wn) hipLaunchKernelGGL((k_g1_fft_stage_quad<DIF, true, 4>), qg, dim3(G1_BLOCK), lds, s, data, logn, m, roots, wnaf, W, total, batch);
+        else hipLaunchKernelGGL((k_g1_fft_stage_quad<DIF, false, 4>), qg, dim3(G1_BLOCK), lds, s, data, logn, m, roots, wnaf, W, total, batch);
+    } else {
+        if (wn) hipLaunchKernelGGL((k_g1_fft_stage_quad<DIF, true, 2>), qg, dim3(G1_BLOCK), lds, s, data, logn, m, roots, wnaf, W, total, batch);
+        else hipLaunchKernelGGL((k_g1_fft_stage_quad<DIF, false, 2>), qg, dim3(G1_BLOCK), lds, s, data, logn, m, roots, wnaf, W, total, batch);
+    }
 }
 // The twiddles' precomputed width-5 NAF digit strings (264 bytes per twiddle in HBM) replace the per-butterfly recoding only where a
 // row is shared by many lanes (>= 512: measured +2.3 % on the 512-polynomial FK20 step); with one wavefront per twiddle every row is a
@@ -308,12 +322,8 @@ void launch_g1_fft_stage_dif(hipStream_t s, g1j *data, uint64_t n, uint64_t batc
     uint64_t total = n / 2 * batch;
     if (!total) return;
     prof_begin(s, "g1_fft_stage");
-    const uint64_t per_tw = (n / 2 / m) * batch;
-    if (g1_stage_quad(total, per_tw % 64 == 0 || per_tw >= 256)) {
-        // the irregular width-5 NAF schedule where every wavefront holds one twiddle (4 lanes x (n / 2 / m) batch butterflies per twiddle), else the regular one
-        const dim3 qg((uint32_t)((4 * total + G1_BLOCK - 1) / G1_BLOCK));
-        if (g1_quad_wnaf(n, batch, m)) hipLaunchKernelGGL((k_g1_fft_stage_quad<true, true>), qg, dim3(G1_BLOCK), g1_quad_lds(total), s, data, ilog2g(n), m, roots, wnaf, W, total, batch);
-        else hipLaunchKernelGGL((k_g1_fft_stage_quad<true, false>), qg, dim3(G1_BLOCK), g1_quad_lds(total), s, data, ilog2g(n), m, roots, wnaf, W, total, batch);
+    if (const int lanes = g1_stage_lanes(total); lanes > 1) {
+        launch_stage_coop<true>(s, lanes, data, n, batch, m, roots, wnaf, W, total);
         prof_end(s, "g1_fft_stage");
         return;
     }
@@ -343,10 +353,8 @@ void launch_g1_fft_stage(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, u
     static const int forced = [] { const char *e = getenv("KZG_HIP_G1_MUL"); return !e ? -1 : e[0] == 'r' ? 0 : e[0] == 'w' ? 4 : -1; }();
     const uint64_t per_twiddle = (n / 2 / m) * batch;
     const int mode = forced >= 0 ? forced : ((per_twiddle % 64 == 0 || per_twiddle >= 256) ? 4 : 0);
-    if (g1_stage_quad(total, mode == 4)) {
-        const dim3 qg((uint32_t)((4 * total + G1_BLOCK - 1) / G1_BLOCK));
-        if (g1_quad_wnaf(n, batch, m)) hipLaunchKernelGGL((k_g1_fft_stage_quad<false, true>), qg, dim3(G1_BLOCK), g1_quad_lds(total), s, data, ilog2g(n), m, roots, wnaf, W, total, batch);
-        else hipLaunchKernelGGL((k_g1_fft_stage_quad<false, false>), qg, dim3(G1_BLOCK), g1_quad_lds(total), s, data, ilog2g(n), m, roots, wnaf, W, total, batch);
+    if (const int lanes = g1_stage_lanes(total); lanes > 1) {
+        launch_stage_coop<false>(s, lanes, data, n, batch, m, roots, wnaf, W, total);
         prof_end(s, "g1_fft_stage");
         return;
     }

@@ -1121,9 +1121,10 @@ def test_fk20_paths_agree_in_a_fresh_process():
     radix-2 / fused pipeline (KZG_HIP_G1_FFT=radix2) and the unfused one (KZG_HIP_FK20_FUSE=0) at every size."""
     import subprocess
     import sys
-    # ... and with four lanes per butterfly everywhere (KZG_HIP_G1_QUAD=1: both digit schedules of g1_quad.hpp) and nowhere (=0: the radix-8 direct passes return)
+    # ... and with four lanes per butterfly everywhere (KZG_HIP_G1_QUAD=1: both digit schedules of g1_quad.hpp), two everywhere (=2) and one (=0: the radix-8 direct passes return)
     for extra in ({"KZG_HIP_G1_FFT": "radix2"}, {"KZG_HIP_G1_FFT": "radix2", "KZG_HIP_FK20_FUSE": "0"}, {"KZG_HIP_G1_FFT": "direct"},
                   {"KZG_HIP_G1_FFT": "radix2", "KZG_HIP_G1_QUAD": "1"}, {"KZG_HIP_G1_FFT": "radix2", "KZG_HIP_G1_QUAD": "1", "KZG_HIP_G1_MUL": "regular"},
+                  {"KZG_HIP_G1_FFT": "radix2", "KZG_HIP_G1_QUAD": "2"}, {"KZG_HIP_G1_FFT": "radix2", "KZG_HIP_G1_QUAD": "2", "KZG_HIP_G1_MUL": "regular"},
                   {"KZG_HIP_G1_QUAD": "0"}):
         env = dict(os.environ, **extra)
         res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k",
