@@ -1306,7 +1306,37 @@ static int fk20_run_fused(fk20_core *c, hipStream_t s, const fr *d_poly, uint64_
     HIPCHK(hipGetLastError());
     return KZG_HIP_OK;
 }
+// Ragged batches run padded with copies of their last polynomial: the stage kernels take the irregular width-5 NAF schedule only where a wavefront
+// holds one twiddle ((n / 2 / m) * batch a multiple of 64, or >= 256), so 17 or 31 polynomials took 45.5 / 45.9 ms against 36.5 for 32, and 63 took
+// 79.9 against 64.7 for 64.  Up to 32 polynomials a stage is one wavefront per SIMD whatever the count; beyond, rows are only added where they cost under 3 %.
+static uint64_t fk20_padded_batch(uint64_t batch) {
+    static const bool off = [] { const char *e = getenv("KZG_HIP_FK20_PAD"); return e && e[0] == '0'; }();
+    if (off) return batch;
+    if (batch > 16 && batch < 32) return 32;
+    if (batch > 32 && (batch & 7)) {                          // beyond one wavefront per SIMD padding is work: only where it is < 3 % (63 -> 64: 79.9 -> 66.5 ms,
+        const uint64_t p = (batch + 7) & ~7ull;                 // 127 -> 128: 140 -> 121 ms; 65 -> 72 and 100 -> 104 measured slower)
+        if ((p - batch) * 32 <= batch) return p;
+    }
+    return batch;
+}
 static int fk20_run_dev(fk20_core *c, hipStream_t s, const fr *d_poly, uint64_t poly_stride, uint64_t n, uint64_t batch, int da, int bit_reverse, g1j *d_out) {
+    if (const uint64_t padded = fk20_padded_batch(batch); padded != batch) {
+        const uint64_t on = da ? 2 * c->k : c->k;
+        dtmp<fr> d_p2(s); dtmp<g1j> d_o2(s);
+        CHK(d_p2.alloc(padded * n)); CHK(d_o2.alloc(padded * on));
+        HIPCHK(hipMemcpy2DAsync(d_p2.p, n * sizeof(fr), d_poly, poly_stride * sizeof(fr), n * sizeof(fr), batch, hipMemcpyDeviceToDevice, s));
+        for (uint64_t b = batch; b < padded; b++)
+            HIPCHK(hipMemcpyAsync(d_p2.p + b * n, d_poly + (batch - 1) * poly_stride, n * sizeof(fr), hipMemcpyDeviceToDevice, s));
+        if (fk20_fused_ok(c, padded, da)) CHK(fk20_run_fused(c, s, d_p2.p, n, n, padded, bit_reverse, d_o2.p));
+        else {
+            dtmp<g1j> d_hext(s);
+            CHK(d_hext.alloc(padded * 2 * c->k));
+            CHK(fk20_hext(c, s, d_p2.p, n, n, padded, 0, 2 * c->k, d_hext.p));
+            CHK(fk20_finish(c, s, d_hext.p, padded, da, bit_reverse, d_o2.p));
+        }
+        HIPCHK(hipMemcpyAsync(d_out, d_o2.p, batch * on * sizeof(g1j), hipMemcpyDeviceToDevice, s));
+        return KZG_HIP_OK;
+    }
     if (fk20_fused_ok(c, batch, da)) return fk20_run_fused(c, s, d_poly, poly_stride, n, batch, bit_reverse, d_out);
     uint64_t k2 = 2 * c->k;
     dtmp<g1j> d_hext(s);

@@ -1111,6 +1111,13 @@ def test_da_using_fk20_batch_host_buffers(kz, ks4096):
         gotb = fk.da_using_fk20_batch(polys[:nb])
         for b in range(nb):
             assert np.array_equal(gotb[b], singles[b]), (nb, b)
+    # 9: two lanes per butterfly; 17 and 63: ragged batches run padded with copies of their last polynomial (to 32 / 64), the copies' proofs dropped
+    many = np.stack([ko.synthetic_blob(140 + b)[:2048] for b in range(63)])
+    for nb, rows in ((9, range(9)), (17, (0, 8, 16)), (63, (0, 31, 62))):
+        gotb = fk.da_using_fk20_batch(many[:nb])
+        assert gotb.shape[0] == nb
+        for b in rows:
+            assert np.array_equal(gotb[b], fk.da_using_fk20(many[b])), (nb, b)
     fk.close()
 
 
