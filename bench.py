@@ -637,7 +637,7 @@ def main():
                 fk20["DAUsingFK20_single_call_ms"] = float(np.median(ts))      # median of 5 calls, like the `latency` block
                 # a few polynomials per host-buffer call (four lanes per butterfly up to 8 polynomials: go-kzg_amd/csrc/g1_quad.hpp)
                 small = {}
-                for nb in (2, 8, 32):
+                for nb in (2, 8, 16, 32):
                     if nb > polys_h.shape[0]:
                         continue
                     fk.da_using_fk20_batch(polys_h[:nb])
