@@ -425,18 +425,27 @@ static uint32_t g1_fft_direct_logr(uint64_t n, uint64_t batch) {
     if (n < 2) return 0;
     // with four lanes per butterfly (g1_quad.hpp) the radix-2 network beats the direct passes from two transforms on (DAUsingFK20 on 2 / 4 polynomials:
     // 20.8 / 21.0 ms against 23.3 / 30.5 ms); a lone transform stays direct (15.1 ms against 20.7 ms)
+    // (the passes themselves run on quads or pairs where that leaves no SIMD with two wavefronts, i.e. up to 2048 points: g1_fft_direct_lanes; 4096 points on
+    // pairs would be four radix-8 passes of 1.8 ms, the same 7.1 ms as three radix-16 passes of 2.4 ms on single lanes: measured, not used)
     if (g1_quad_enabled()) return n * batch <= 4096 ? 4 : 0;
     if (n * batch <= 8192) return 4;
     if (n * batch <= 16384) return 3;
     return 0;
 }
 static bool g1_fft_direct_mode(uint64_t n, uint64_t batch) { return g1_fft_direct_logr(n, batch) != 0; }
+// lanes per (output, term) of a direct pass: as many as keep the pass at one wavefront per SIMD (65 536 lanes)
+static int g1_fft_direct_lanes(uint64_t n, uint64_t batch) {
+    static const bool off = [] { const char *e = getenv("KZG_HIP_G1_DIRECT_COOP"); return e && e[0] == '0'; }();
+    if (!g1_quad_enabled() || off) return 1;
+    const uint64_t items = (n * batch) << g1_fft_direct_logr(n, batch);
+    return items * 4 <= 65536 ? 4 : items * 2 <= 65536 ? 2 : 1;
+}
 static int g1_fft_rows(kzg_hip_fft *fs, hipStream_t s, const g1j *d_in, uint64_t in_stride, uint64_t n_valid, g1j *d_data, uint64_t n, uint64_t batch, int inv,
                        const fr *scale = nullptr) {
     if (g1_fft_direct_mode(n, batch)) {
         dtmp<g1j> d_tmp(s);
         CHK(d_tmp.alloc(n * batch));
-        launch_g1_fft_direct(s, d_in, in_stride, n_valid, d_data, d_tmp.p, n, batch, inv ? fs->d_reversed : fs->d_expanded, fs->W, scale, g1_fft_direct_logr(n, batch));
+        launch_g1_fft_direct(s, d_in, in_stride, n_valid, d_data, d_tmp.p, n, batch, inv ? fs->d_reversed : fs->d_expanded, fs->W, scale, g1_fft_direct_logr(n, batch), g1_fft_direct_lanes(n, batch));
         return KZG_HIP_OK;
     }
     launch_g1_bitrev_copy(s, d_in, in_stride, n_valid, d_data, n, batch);

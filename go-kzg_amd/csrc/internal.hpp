@@ -71,7 +71,7 @@ void launch_g1_clear_odd(hipStream_t s, g1j *data, uint64_t n_total);
 bool g1_quad_enabled();   // the stage launchers put four lanes on a butterfly for launches of at most 16 384 butterflies (g1_quad.hpp) unless KZG_HIP_G1_QUAD=0
 // latency mode: Stockham passes of radix 16 evaluated directly (k_g1.hip); result in data, tmp = batch x n scratch, scale optional
 void launch_g1_fft_direct(hipStream_t s, const g1j *in, uint64_t in_stride, uint64_t n_valid, g1j *data, g1j *tmp, uint64_t n, uint64_t batch, const fr *roots,
-                          uint64_t W, const fr *scale, uint32_t max_logr = 4);
+                          uint64_t W, const fr *scale, uint32_t max_logr = 4, int lanes = 1);
 // to_kilic: also leave the device-internal Montgomery domain (R' = 2^390) for Kilic's (2^384): every API output path ends here
 void launch_g1_normalize(hipStream_t s, const g1j *in, g1j *out, uint64_t n, bool to_kilic = false);
 void launch_g1_from_kilic(hipStream_t s, g1j *data, uint64_t n);   // in place: caller-supplied points enter the internal domain

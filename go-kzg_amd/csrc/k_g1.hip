@@ -430,10 +430,59 @@ __global__ __launch_bounds__(G1_DIRECT_BLOCK, 2) void k_g1_fft_direct(const g1j 
     }
     if (live && tt == 0) out[oidx] = acc.inf ? g1_inf() : g1jq_pack(acc.v);
 }
+// The same pass with L = 2 or 4 lanes per (output, term): the multiplication runs on the cooperative group operations of g1_quad.hpp (regular odd-digit
+// schedule: the lanes of a wavefront hold different twiddles), the group's lane 0 joins the sum.  For passes that leave SIMDs empty at one lane per
+// term: a lone transform of up to 1024 points runs radix 16 on quads (1.3 ms per pass instead of 2.0-2.4), 2048 points on pairs (1.8 ms).
+template <int L> __global__ __launch_bounds__(G1_DIRECT_BLOCK, 2) void k_g1_fft_direct_coop(const g1j *in, uint64_t in_stride, uint64_t n_valid, g1j *out, uint32_t logn,
+                                                                                          uint32_t logR, uint64_t Ns, const fr *roots, uint64_t W, const fr *scale, uint64_t total) {
+    __shared__ g1jq_slot buf[G1_DIRECT_BLOCK / L];
+    const uint32_t tid = threadIdx.x, role = tid & (uint32_t)(L - 1), item = tid / L;
+    const uint64_t t = (blockIdx.x * (uint64_t)blockDim.x + tid) / L;
+    const uint64_t n = 1ull << logn, R = 1ull << logR, cols = n >> logR;
+    const uint32_t tt = (uint32_t)(t & (R - 1));
+    const uint64_t u = (t >> logR) & (R - 1), jb = t >> (2 * logR), j = jb % cols, b = jb / cols;
+    const bool live = t < total;
+    g1jq_acc acc; acc.inf = true;
+    uint64_t oidx = 0;
+    if (live) {
+        const uint64_t k = j & (Ns - 1), idx = j + (uint64_t)tt * cols;
+        oidx = b * n + (j - k) * R + k + u * Ns;
+        g1j x = idx < n_valid ? in[b * in_stride + idx] : g1_inf();
+        if (!is_inf(x)) {
+            const uint64_t e = ((uint64_t)tt * (cols / Ns) * (Ns * u + k)) & (n - 1);
+            if (e == 0 && !scale) { acc.v = g1jq_unpack(x); acc.inf = false; }
+            else {
+                fr sc = roots[e * (W >> logn)];
+                if (scale) sc = mul(sc, *scale);
+                g1aq tbl[8]; fq dz[7]; g1j packed;
+                const int st = g1_mul_glv_regular_quad<L>(g1jq_unpack(x), glv_split_signed(from_mont<FrP>(sc)), tbl, dz, acc.v, packed, role);
+                if (st == 2) { acc.inf = is_inf(packed); if (!acc.inf) acc.v = g1jq_unpack(packed); } else acc.inf = st == 0;
+            }
+        }
+    }
+    // sum of the R terms of an output: items tt = 0 .. R - 1 are adjacent; one lane per item takes part
+#define COOP_STORE(i) do { _Pragma("unroll") for (int q = 0; q < 13; q++) { buf[i].w[q] = acc.v.x.l[q]; buf[i].w[13 + q] = acc.v.y.l[q]; buf[i].w[26 + q] = acc.v.z.l[q]; } \
+                           buf[i].inf = acc.inf ? 1u : 0u; } while (0)
+    if (role == 0) COOP_STORE(item);
+    __syncthreads();
+#pragma nounroll
+    for (uint32_t off = (uint32_t)R / 2; off >= 1; off >>= 1) {
+        if (role == 0 && tt < off && !buf[item + off].inf) {
+            g1jq q;
+#pragma unroll
+            for (int i = 0; i < 13; i++) { q.x.l[i] = buf[item + off].w[i]; q.y.l[i] = buf[item + off].w[13 + i]; q.z.l[i] = buf[item + off].w[26 + i]; }
+            acc.add(q);
+            COOP_STORE(item);
+        }
+        __syncthreads();
+    }
+#undef COOP_STORE
+    if (live && role == 0 && tt == 0) out[oidx] = acc.inf ? g1_inf() : g1jq_pack(acc.v);
+}
 // runs the passes; the result lands in `data` (batch x n).  tmp: batch x n scratch points.  scale: nullptr or a device Fr that
 // multiplies every output (folded into the last pass).
 void launch_g1_fft_direct(hipStream_t s, const g1j *in, uint64_t in_stride, uint64_t n_valid, g1j *data, g1j *tmp, uint64_t n, uint64_t batch, const fr *roots,
-                          uint64_t W, const fr *scale, uint32_t max_logr) {
+                          uint64_t W, const fr *scale, uint32_t max_logr, int lanes) {
     const uint32_t logn = ilog2g(n);
     if (max_logr < 1 || max_logr > 4) max_logr = 4;
     uint32_t npass = (logn + max_logr - 1) / max_logr;
@@ -449,9 +498,12 @@ void launch_g1_fft_direct(hipStream_t s, const g1j *in, uint64_t in_stride, uint
         // 24 KiB of unused dynamic LDS on top of the 10 KiB the kernel needs: at most 4 of these one-wave workgroups fit a CU, so the
         // 1024 of a 4096-point pass land one per SIMD instead of 8 per CU on half of the chip (measured: 2.7 vs 5.4 ms per pass)
         // (only while the pass has at most one wavefront per SIMD: two transforms are 2048 workgroups and want both wave slots)
-        const uint64_t wgs = (total + G1_DIRECT_BLOCK - 1) / G1_DIRECT_BLOCK;
-        hipLaunchKernelGGL(k_g1_fft_direct, dim3((uint32_t)wgs), dim3(G1_DIRECT_BLOCK), wgs <= 1024 ? 24 * 1024 : 0, s, src, src_stride, src_valid, dst, logn, logR, Ns,
-                           roots, W, (p + 1 == npass) ? scale : nullptr, total);
+        const uint64_t wgs = (total * lanes + G1_DIRECT_BLOCK - 1) / G1_DIRECT_BLOCK;
+        const size_t pad_lds = wgs <= 1024 ? 24 * 1024 : 0;
+        const fr *sc = (p + 1 == npass) ? scale : nullptr;
+        if (lanes == 4) hipLaunchKernelGGL(k_g1_fft_direct_coop<4>, dim3((uint32_t)wgs), dim3(G1_DIRECT_BLOCK), pad_lds, s, src, src_stride, src_valid, dst, logn, logR, Ns, roots, W, sc, total);
+        else if (lanes == 2) hipLaunchKernelGGL(k_g1_fft_direct_coop<2>, dim3((uint32_t)wgs), dim3(G1_DIRECT_BLOCK), pad_lds, s, src, src_stride, src_valid, dst, logn, logR, Ns, roots, W, sc, total);
+        else hipLaunchKernelGGL(k_g1_fft_direct, dim3((uint32_t)wgs), dim3(G1_DIRECT_BLOCK), pad_lds, s, src, src_stride, src_valid, dst, logn, logR, Ns, roots, W, sc, total);
         src = dst; src_stride = n; src_valid = n; Ns <<= logR; bits_left -= logR;
     }
     prof_end(s, "g1_fft_direct");

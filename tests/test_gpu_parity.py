@@ -684,6 +684,20 @@ def test_fft_g1_small_matches_oracle(kz, n):
     fs.close()
 
 
+@pytest.mark.parametrize("n", [16, 256, 1024, 2048])
+def test_fft_g1_lone_transforms_on_quads_and_pairs(kz, setup_1337, n):
+    """a lone transform of up to 1024 points runs its direct radix-16 passes with four lanes per (output, term), 2048 points with two
+    (k_g1_fft_direct_coop); setup points mixed with infinity, duplicates and opposite points, both directions, against the oracle"""
+    fs, ofs = kz.FFTSettings(11), ko.FFTSettings(11)
+    vals = setup_1337[:n].copy()
+    edge = edge_points()
+    for i in range(len(edge)):
+        vals[(i * 7) % n] = edge[i]
+    for inv in (False, True):
+        assert_points_equal(fs.fft_g1(vals, inv), ofs.fft_g1(vals, inv))
+    fs.close()
+
+
 def test_fft_g1_4096_trusted_setup_lagrange(kz, setup_1337):
     # BASELINE config 3: FFTG1(setup_G1, inv) == setup_G1_lagrange, 4096 x 48 B from eth/trusted_setup.json
     fs = kz.FFTSettings(12)
@@ -1135,7 +1149,7 @@ def test_fk20_paths_agree_in_a_fresh_process():
                   {"KZG_HIP_G1_QUAD": "0"}):
         env = dict(os.environ, **extra)
         res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k",
-                              "vector_C or vectors_D or config4a or batch_host_buffers or fft_g1_small or full_das_flow"],
+                              "vector_C or vectors_D or config4a or batch_host_buffers or fft_g1_small or fft_g1_lone or full_das_flow"],
                              env=env, capture_output=True, text=True, timeout=1200)
         assert res.returncode == 0, (extra, res.stdout[-1500:])
 
