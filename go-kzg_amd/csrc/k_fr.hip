@@ -141,50 +141,11 @@ template <int LOGM> static void launch_fr_fft_small(hipStream_t s, const fr *in,
     }
 }
 
-#define LOGR_OF(R) ((R) == 2 ? 1 : (R) == 4 ? 2 : (R) == 8 ? 3 : 4)
-// The stages above 4096 of a transform of R * 4096 points (R = 2, 4, 8, 16), all in one pass over the data: lane k2 holds the R values
-// k2 + 4096 a in registers and runs the log2 R radix-2 stages of half-size m = 4096 2^s on them (fft_fr.go:40-52 with the lazy limbs of
-// fr_lazy.hpp; twiddle w_{2m}^j, j = (a mod 2^s) 4096 + k2, from the settings' roots pre-scaled to the 2^261 image), then canonicalises
-// (SCALE: after the product with 1/n).  Bounds: a stage adds 2 (sum) / 3 (difference) to a bound and 2^29 / 2 * 2^29 to the limbs; from the
-// fourth stage on both operands are swept first, so every product sees limbs < 6 * 2^29 and no limb passes 2^32; final bounds <= 13.
-// (compile-time recursion instead of loops: every index into x[] must be a constant for the array to live in registers, and the
-// unroller gives up on loops whose bodies hold a 153-multiply-add product each)
-template <int R, int S, int B = 0> __device__ __forceinline__ void fr_upper_stage(frl (&x)[R], const fr *__restrict__ roots_l, uint64_t W, uint32_t k2, frl &w) {
-    if constexpr (B < R / 2) {
-        constexpr int jh = B >> (LOGR_OF(R) - 1 - S), hi = B & ((R >> (S + 1)) - 1), a = (hi << (S + 1)) + jh;   // butterflies ordered by twiddle
-        if constexpr (hi == 0) w = frl_unpack(roots_l[((uint64_t)jh * fr4::N + k2) * (W / ((uint64_t)fr4::N << (S + 1)))]);
-        frl x0 = x[a], y = x[a + (1 << S)];
-        if (S >= 3) { frl_sweep(x0); frl_sweep(y); }
-        const frl tq = frl_mul(y, w);
-        x[a] = frl_add(x0, tq);
-        x[a + (1 << S)] = frl_sub<3>(x0, tq);
-        fr_upper_stage<R, S, B + 1>(x, roots_l, W, k2, w);
-    }
-}
-template <int R, int A = 0> __device__ __forceinline__ void fr_upper_load(frl (&x)[R], const fr *base, uint32_t k2) {
-    if constexpr (A < R) { x[A] = frl_unpack(base[(uint64_t)A * fr4::N + k2]); fr_upper_load<R, A + 1>(x, base, k2); }
-}
-template <int R, bool SCALE, int A = 0> __device__ __forceinline__ void fr_upper_store(frl (&x)[R], fr *base, uint32_t k2, const frl &sc) {
-    if constexpr (A < R) {
-        if (SCALE) { frl v = x[A]; frl_sweep(v); base[(uint64_t)A * fr4::N + k2] = frl_canon_lt2r(frl_mul(v, sc)); }
-        else base[(uint64_t)A * fr4::N + k2] = frl_canon(x[A]);
-        fr_upper_store<R, SCALE, A + 1>(x, base, k2, sc);
-    }
-}
+// The stages above 4096 of a transform of R * 4096 points (fr4::upper_lane in fr_fft4096.hpp), a lane per k2
 template <int LOGR, bool SCALE>
 __global__ __launch_bounds__(256) void k_fr_fft_upper(fr *data, const fr *__restrict__ roots_l, uint64_t W, const fr *scale) {
-    constexpr int R = 1 << LOGR;
     const uint32_t k2 = blockIdx.x * 256u + threadIdx.x;
-    fr *base = data + (uint64_t)blockIdx.y * ((uint64_t)R * fr4::N);
-    frl x[R], w;
-    fr_upper_load<R>(x, base, k2);
-    fr_upper_stage<R, 0>(x, roots_l, W, k2, w);
-    if constexpr (LOGR > 1) fr_upper_stage<R, 1>(x, roots_l, W, k2, w);
-    if constexpr (LOGR > 2) fr_upper_stage<R, 2>(x, roots_l, W, k2, w);
-    if constexpr (LOGR > 3) fr_upper_stage<R, 3>(x, roots_l, W, k2, w);
-    frl sc = frl_zero();
-    if (SCALE) sc = frl_const_from_kilic(*scale);
-    fr_upper_store<R, SCALE>(x, base, k2, sc);
+    fr4::upper_lane<LOGR, SCALE>(data + (uint64_t)blockIdx.y * ((uint64_t)fr4::N << LOGR), k2, roots_l, W, scale);
 }
 template <int LOGR> static void launch_fr_fft_upper(hipStream_t s, fr *data, uint64_t batch, const fr *roots_l, uint64_t W, const fr *scale) {
     if (scale) hipLaunchKernelGGL((k_fr_fft_upper<LOGR, true>), dim3(fr4::N / 256, (uint32_t)batch), dim3(256), 0, s, data, roots_l, W, scale);

@@ -29,6 +29,51 @@ template <class F> static uint64_t inv_stress(uint64_t n, uint64_t seed) {
     return bad;
 }
 
+// k_fr_fft_small<LOGM>: one workgroup's 4096 / m transforms of m = 2^logm points through the first passes of the 4096-point network (+ one radix-2
+// pass for odd logm), lane by lane.  `batch` transforms exist (rows beyond it are zeros and are not stored).  Returns the largest raw limb seen in LDS.
+template <int LOGM> static uint32_t fr_fft_small_emul(const fr *in, uint64_t in_stride, uint64_t n_in, uint64_t batch, fr *out, const uint32_t *tw, const fr *scale) {
+    std::vector<uint32_t> lds(9 * fr4::NPAD, 0);
+    uint32_t worst = 0;
+    auto scan = [&]() { for (uint32_t v : lds) if (v > worst) worst = v; };
+    constexpr int A = LOGM / 2;
+    constexpr uint32_t m = 1u << LOGM, per = fr4::N / m;
+    uint32_t *s = lds.data();
+    for (uint32_t t = 0; t < 1024; t++) fr4::pass_first_small<LOGM>(t, in, in_stride, n_in, 0, batch, s, tw);
+    scan();
+    if (A >= 2) { for (uint32_t t = 0; t < 1024; t++) fr4::pass_lo<4>(t >> 6, t & 63, s, tw); scan(); }
+    if (A >= 3) { for (uint32_t t = 0; t < 1024; t++) fr4::pass_lo<16>(t >> 6, t & 63, s, tw); scan(); }
+    if (A >= 4) { for (uint32_t t = 0; t < 1024; t++) fr4::pass_hi<64>(t, s, tw); scan(); }
+    if (A >= 5) { for (uint32_t t = 0; t < 1024; t++) fr4::pass_hi<256>(t, s, tw); scan(); }
+    if (LOGM & 1) { for (uint32_t t = 0; t < 1024; t++) fr4::pass_r2<(1u << (2 * A))>(t, t >> 6, t & 63, s, tw); scan(); }
+    frl sc = frl_zero();
+    if (scale) sc = frl_const_from_kilic(*scale);
+    const uint64_t limit = batch >= per ? fr4::N : batch * m;
+    for (uint32_t t = 0; t < 1024; t++) { if (scale) fr4::pass_store<true>(t, s, sc, out, limit); else fr4::pass_store<false>(t, s, sc, out, limit); }
+    return worst;
+}
+// A transform of R * 4096 points as the device runs it: the R rows (every R-th element from offset bitrev(a)) through the 4096-point passes with the
+// element stride of k_fr_fft4096_r4's rows_log form, then fr4::upper_lane for every k2.  roots: W + 1 Kilic images; scale: null or the image of 1 / n.
+template <int LOGR> static void fr_fft_long_emul(const fr *in, uint64_t n_in, fr *out, const fr *roots, uint64_t W, const fr *scale) {
+    constexpr uint32_t R = 1u << LOGR;
+    std::vector<uint32_t> tw(fr4::TW_WORDS), lds(9 * fr4::NPAD);
+    fr4::build_twiddles(roots, W, tw.data());
+    std::vector<fr> roots_l(W + 1);
+    const fr k32 = fr_from_u64(32);
+    for (uint64_t i = 0; i <= W; i++) roots_l[i] = mul(roots[i], k32);
+    frl sc0 = frl_zero();
+    for (uint32_t a = 0; a < R; a++) {
+        uint32_t off = 0;
+        for (int k = 0; k < LOGR; k++) off |= ((a >> k) & 1u) << (LOGR - 1 - k);
+        uint32_t *s = lds.data();
+        for (uint32_t t = 0; t < 1024; t++) fr4::pass_first(t, in, n_in, s, tw.data(), R, off);
+        for (uint32_t t = 0; t < 1024; t++) fr4::pass_lo<4>(t >> 6, t & 63, s, tw.data());
+        for (uint32_t t = 0; t < 1024; t++) fr4::pass_lo<16>(t >> 6, t & 63, s, tw.data());
+        for (uint32_t t = 0; t < 1024; t++) fr4::pass_hi<64>(t, s, tw.data());
+        for (uint32_t t = 0; t < 1024; t++) fr4::pass_hi<256>(t, s, tw.data());
+        for (uint32_t t = 0; t < 1024; t++) fr4::pass_last<false>(t, s, tw.data(), sc0, out + (uint64_t)a * fr4::N);
+    }
+    for (uint32_t k2 = 0; k2 < fr4::N; k2++) { if (scale) fr4::upper_lane<LOGR, true>(out, k2, roots_l.data(), W, scale); else fr4::upper_lane<LOGR, false>(out, k2, roots_l.data(), W, scale); }
+}
 extern "C" {
 // the radix-4 4096-point transform of k_fr_fft4096_r4, lane by lane and pass by pass (a barrier between passes == finishing the loop over
 // the lanes): roots = W + 1 Kilic images (expanded or reversed), scale = null or the Kilic image of 1/n.  Also reports the largest raw limb
@@ -52,6 +97,30 @@ uint32_t he_fr_fft4096(const fr *in, uint64_t n_in, fr *out, const fr *roots, ui
     if (scale) sc = frl_const_from_kilic(*scale);
     for (uint32_t t = 0; t < 1024; t++) { if (scale) fr4::pass_last<true>(t, lds.data(), tw.data(), sc, out); else fr4::pass_last<false>(t, lds.data(), tw.data(), sc, out); }
     return worst;
+}
+uint32_t he_fr_fft_small(uint32_t logm, const fr *in, uint64_t in_stride, uint64_t n_in, uint64_t batch, fr *out, const fr *roots, uint64_t W, const fr *scale) {
+    std::vector<uint32_t> tw(fr4::TW_WORDS);
+    fr4::build_twiddles(roots, W, tw.data());
+    switch (logm) {
+    case 2: return fr_fft_small_emul<2>(in, in_stride, n_in, batch, out, tw.data(), scale);
+    case 3: return fr_fft_small_emul<3>(in, in_stride, n_in, batch, out, tw.data(), scale);
+    case 4: return fr_fft_small_emul<4>(in, in_stride, n_in, batch, out, tw.data(), scale);
+    case 5: return fr_fft_small_emul<5>(in, in_stride, n_in, batch, out, tw.data(), scale);
+    case 6: return fr_fft_small_emul<6>(in, in_stride, n_in, batch, out, tw.data(), scale);
+    case 7: return fr_fft_small_emul<7>(in, in_stride, n_in, batch, out, tw.data(), scale);
+    case 8: return fr_fft_small_emul<8>(in, in_stride, n_in, batch, out, tw.data(), scale);
+    case 9: return fr_fft_small_emul<9>(in, in_stride, n_in, batch, out, tw.data(), scale);
+    case 10: return fr_fft_small_emul<10>(in, in_stride, n_in, batch, out, tw.data(), scale);
+    default: return fr_fft_small_emul<11>(in, in_stride, n_in, batch, out, tw.data(), scale);
+    }
+}
+void he_fr_fft_long(uint32_t logr, const fr *in, uint64_t n_in, fr *out, const fr *roots, uint64_t W, const fr *scale) {
+    switch (logr) {
+    case 1: fr_fft_long_emul<1>(in, n_in, out, roots, W, scale); break;
+    case 2: fr_fft_long_emul<2>(in, n_in, out, roots, W, scale); break;
+    case 3: fr_fft_long_emul<3>(in, n_in, out, roots, W, scale); break;
+    default: fr_fft_long_emul<4>(in, n_in, out, roots, W, scale); break;
+    }
 }
 // the eleven passes of k_das_ext2048_r4 lane by lane (in place on vals[2048]); returns the largest raw limb seen in LDS
 uint32_t he_das_ext2048(fr *vals, const fr *expanded, const fr *reversed, uint64_t W, const fr *inv_n) {
