@@ -3,7 +3,6 @@
 // fk20_single.go:72-74 (ToeplitzPart2), fk20_multi.go:86-89 and bls.To/FromCompressedG1 (bls/bls_kilic.go:114-121).
 #define KZG_MULQ_NOINLINE 1   // many mulq call sites in this translation unit: keep the product out of line (I-cache)
 #include "internal.hpp"
-#include "g1_quad.hpp"
 #include <stdlib.h>
 
 namespace kzg {
@@ -155,81 +154,6 @@ template <int MODE, bool PRE = false> __global__ __launch_bounds__(G1_BLOCK, 2) 
     row[i0] = g1_add(x, y);
     row[i1] = g1_add(x, g1_neg(y));
 }
-// The same stages with FOUR lanes per butterfly (g1_quad.hpp): for launches that would leave most SIMDs empty (at most 16 384 butterflies: up to 8
-// polynomials of 4096 points), where the stage time is the latency of one scalar multiplication on one lane.  The quad shares the digit loop of
-// the multiplication (648 dependency levels of one product each instead of ~1 370 sequential products); loads, the table, the shared
-// (x + y, x - y) formulas and the packing are computed redundantly by the four lanes, lane 0 of the quad stores.  Regular odd-digit schedule
-// (lanes of a wavefront may hold different twiddles).  DIF = false: (x, y) -> (x + w y, x - w y); DIF = true: (x, y) -> (x + y, (x - y) w).
-// WNAF: the width-5 NAF digit rows of the twiddles (wave-uniform launches) instead of the regular odd-digit schedule.
-// L = 2: the same with PAIRS of lanes (two rounds for the levels of three or four products): for launches that no longer fit four lanes per butterfly
-// into one wavefront per SIMD but still leave half of the SIMDs empty (9-16 polynomials of 4096 points).
-template <bool DIF, bool WNAF, int L> __global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_fft_stage_quad(g1j *data, uint32_t logn, uint64_t m, const fr *roots, const int8_t *wnaf, uint64_t W, uint64_t total, uint64_t batch) {
-    const uint64_t t4 = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    const uint32_t role = (uint32_t)(t4 & (uint64_t)(L - 1));
-    const uint64_t t = t4 / L;
-    if (t >= total) return;
-    const uint64_t half = 1ull << (logn - 1), groups = half / m;
-    const uint64_t j = t / (groups * batch), rem = t % (groups * batch), b = rem / groups, g = rem % groups;   // twiddle-major, as in k_g1_fft_stage
-    g1j *row = data + (b << logn);
-    const uint64_t i0 = g * 2 * m + j, i1 = i0 + m;
-    g1j y = row[i1];
-    g1j x = row[i0];
-    const uint64_t ti = j * (W / (2 * m));
-    const fr kk = roots[ti];                                // (k1, k2) GLV pair, both halves non-negative
-    glv_halves h;
-#pragma unroll
-    for (int i = 0; i < 4; i++) { h.k1[i] = kk.l[i]; h.k2[i] = kk.l[4 + i]; }
-    h.neg1 = h.neg2 = 0;
-    g1aq tbl[8]; fq dz[7]; g1j packed;
-#define QMUL(pq, res) (WNAF ? g1_mul_glv_wnaf_quad<L>((pq), kk, tbl, dz, wnaf + ti * KZG_WNAF_ROW, (res), packed, role) : g1_mul_glv_regular_quad<L>((pq), h, tbl, dz, (res), packed, role))
-    if (!DIF) {
-        g1jq yq; int st = is_inf(y) ? 0 : 1;
-        if (st == 1) {
-            if (j) {
-                st = QMUL(g1jq_unpack(y), yq);
-                if (st == 2) y = packed; else if (st == 0) y = g1_inf();
-            } else yq = g1jq_unpack(y);
-        }
-        if (st == 1 && !is_inf(x)) {
-            g1jq sum, dif;
-            if (KZG_LIKELY(g1jq_addsub(g1jq_unpack(x), yq, sum, dif))) {
-                if (role == 0) {
-                    fp z3 = packq(sum.z);
-                    g1j o0, o1;
-                    o0.x = packq(sum.x); o0.y = packq(sum.y); o0.z = z3;
-                    o1.x = packq(dif.x); o1.y = packq(dif.y); o1.z = z3;
-                    row[i0] = o0; row[i1] = o1;
-                }
-                return;
-            }
-        }
-        if (st == 1) y = g1jq_pack(yq);
-        if (role == 0) { row[i0] = g1_add(x, y); row[i1] = g1_add(x, g1_neg(y)); }
-    } else {
-        if (!is_inf(x) && !is_inf(y)) {
-            g1jq sum, dif;
-            if (KZG_LIKELY(g1jq_addsub(g1jq_unpack(x), g1jq_unpack(y), sum, dif))) {
-                g1j o0; o0.x = packq(sum.x); o0.y = packq(sum.y); o0.z = packq(sum.z);
-                g1j o1;
-                if (j) {
-                    g1jq dq;
-                    const int st = QMUL(dif, dq);
-                    o1 = st == 1 ? g1jq_pack(dq) : st == 2 ? packed : g1_inf();
-                } else { o1.x = packq(dif.x); o1.y = packq(dif.y); o1.z = o0.z; }
-                if (role == 0) { row[i0] = o0; row[i1] = o1; }
-                return;
-            }
-        }
-        g1j s_ = g1_add(x, y), d_ = g1_add(x, g1_neg(y));   // an infinite operand or x == +-y: generic complete formulas
-        if (j && !is_inf(d_)) {
-            g1jq dq;
-            const int st = QMUL(g1jq_unpack(d_), dq);
-            d_ = st == 1 ? g1jq_pack(dq) : st == 2 ? packed : g1_inf();
-        }
-        if (role == 0) { row[i0] = s_; row[i1] = d_; }
-    }
-}
-#undef QMUL
 // 4 lanes per butterfly while the quadrupled launch still fits one wavefront per SIMD (65 536 lanes on 256 CUs), 2 while the doubled one does;
 // KZG_HIP_G1_QUAD = 0 / 1 / 2: never / always four / always two
 static int g1_quad_forced() {
@@ -241,34 +165,6 @@ bool g1_quad_enabled() { return g1_quad_forced() != 0; }
 static int g1_stage_lanes(uint64_t butterflies) {
     if (g1_quad_forced() >= 0) return g1_quad_forced() == 0 ? 1 : g1_quad_forced() == 2 ? 2 : 4;
     return butterflies * 4 <= 65536u ? 4 : butterflies * 2 <= 65536u ? 2 : 1;
-}
-// the irregular width-5 NAF schedule where every wavefront holds one twiddle (L lanes x (n / 2 / m) batch butterflies per twiddle), else the regular one
-static bool g1_quad_wnaf(uint64_t n, uint64_t batch, uint64_t m, int lanes) {
-    static const bool off = [] { const char *e = getenv("KZG_HIP_G1_MUL"); return e && e[0] == 'r'; }();
-    return !off && ((n / 2 / m) * batch * lanes) % 64 == 0;
-}
-// these launches are at most one 256-lane workgroup per CU: 96 KiB of unused dynamic LDS keeps the dispatcher from putting two on one CU (two
-// wavefronts on a SIMD take 1.76x as long as one) while another CU stays empty
-template <bool DIF> static void launch_stage_coop(hipStream_t s, int lanes, g1j *data, uint64_t n, uint64_t batch, uint64_t m, const fr *roots, const int8_t *wnaf, uint64_t W,
-                                                  uint64_t total) {
-    static const bool once = [] {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_g1_fft_stage_quad<DIF, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_g1_fft_stage_quad<DIF, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_g1_fft_stage_quad<DIF, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_g1_fft_stage_quad<DIF, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        return true; }();
-    (void)once;
-    const size_t lds = total * lanes <= 65536 ? 96 * 1024 : 0;
-    const dim3 qg((uint32_t)((lanes * total + G1_BLOCK - 1) / G1_BLOCK));
-    const uint32_t logn = ilog2g(n);
-    const bool wn = g1_quad_wnaf(n, batch, m, lanes);
-    if (lanes == 4) {
-        if (wn) hipLaunchKernelGGL((k_g1_fft_stage_quad<DIF, true, 4>), qg, dim3(G1_BLOCK), lds, s, data, logn, m, roots, wnaf, W, total, batch);
-        else hipLaunchKernelGGL((k_g1_fft_stage_quad<DIF, false, 4>), qg, dim3(G1_BLOCK), lds, s, data, logn, m, roots, wnaf, W, total, batch);
-    } else {
-        if (wn) hipLaunchKernelGGL((k_g1_fft_stage_quad<DIF, true, 2>), qg, dim3(G1_BLOCK), lds, s, data, logn, m, roots, wnaf, W, total, batch);
-        else hipLaunchKernelGGL((k_g1_fft_stage_quad<DIF, false, 2>), qg, dim3(G1_BLOCK), lds, s, data, logn, m, roots, wnaf, W, total, batch);
-    }
 }
 // The twiddles' precomputed width-5 NAF digit strings (264 bytes per twiddle in HBM) replace the per-butterfly recoding only where a
 // row is shared by many lanes (>= 512: measured +2.3 % on the 512-polynomial FK20 step); with one wavefront per twiddle every row is a
@@ -323,7 +219,7 @@ void launch_g1_fft_stage_dif(hipStream_t s, g1j *data, uint64_t n, uint64_t batc
     if (!total) return;
     prof_begin(s, "g1_fft_stage");
     if (const int lanes = g1_stage_lanes(total); lanes > 1) {
-        launch_stage_coop<true>(s, lanes, data, n, batch, m, roots, wnaf, W, total);
+        launch_g1_stage_coop_dif(s, lanes, data, n, batch, m, roots, wnaf, W, total);
         prof_end(s, "g1_fft_stage");
         return;
     }
@@ -354,7 +250,7 @@ void launch_g1_fft_stage(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, u
     const uint64_t per_twiddle = (n / 2 / m) * batch;
     const int mode = forced >= 0 ? forced : ((per_twiddle % 64 == 0 || per_twiddle >= 256) ? 4 : 0);
     if (const int lanes = g1_stage_lanes(total); lanes > 1) {
-        launch_stage_coop<false>(s, lanes, data, n, batch, m, roots, wnaf, W, total);
+        launch_g1_stage_coop_dit(s, lanes, data, n, batch, m, roots, wnaf, W, total);
         prof_end(s, "g1_fft_stage");
         return;
     }
@@ -430,55 +326,6 @@ __global__ __launch_bounds__(G1_DIRECT_BLOCK, 2) void k_g1_fft_direct(const g1j 
     }
     if (live && tt == 0) out[oidx] = acc.inf ? g1_inf() : g1jq_pack(acc.v);
 }
-// The same pass with L = 2 or 4 lanes per (output, term): the multiplication runs on the cooperative group operations of g1_quad.hpp (regular odd-digit
-// schedule: the lanes of a wavefront hold different twiddles), the group's lane 0 joins the sum.  For passes that leave SIMDs empty at one lane per
-// term: a lone transform of up to 1024 points runs radix 16 on quads (1.3 ms per pass instead of 2.0-2.4), 2048 points on pairs (1.8 ms).
-template <int L> __global__ __launch_bounds__(G1_DIRECT_BLOCK, 2) void k_g1_fft_direct_coop(const g1j *in, uint64_t in_stride, uint64_t n_valid, g1j *out, uint32_t logn,
-                                                                                          uint32_t logR, uint64_t Ns, const fr *roots, uint64_t W, const fr *scale, uint64_t total) {
-    __shared__ g1jq_slot buf[G1_DIRECT_BLOCK / L];
-    const uint32_t tid = threadIdx.x, role = tid & (uint32_t)(L - 1), item = tid / L;
-    const uint64_t t = (blockIdx.x * (uint64_t)blockDim.x + tid) / L;
-    const uint64_t n = 1ull << logn, R = 1ull << logR, cols = n >> logR;
-    const uint32_t tt = (uint32_t)(t & (R - 1));
-    const uint64_t u = (t >> logR) & (R - 1), jb = t >> (2 * logR), j = jb % cols, b = jb / cols;
-    const bool live = t < total;
-    g1jq_acc acc; acc.inf = true;
-    uint64_t oidx = 0;
-    if (live) {
-        const uint64_t k = j & (Ns - 1), idx = j + (uint64_t)tt * cols;
-        oidx = b * n + (j - k) * R + k + u * Ns;
-        g1j x = idx < n_valid ? in[b * in_stride + idx] : g1_inf();
-        if (!is_inf(x)) {
-            const uint64_t e = ((uint64_t)tt * (cols / Ns) * (Ns * u + k)) & (n - 1);
-            if (e == 0 && !scale) { acc.v = g1jq_unpack(x); acc.inf = false; }
-            else {
-                fr sc = roots[e * (W >> logn)];
-                if (scale) sc = mul(sc, *scale);
-                g1aq tbl[8]; fq dz[7]; g1j packed;
-                const int st = g1_mul_glv_regular_quad<L>(g1jq_unpack(x), glv_split_signed(from_mont<FrP>(sc)), tbl, dz, acc.v, packed, role);
-                if (st == 2) { acc.inf = is_inf(packed); if (!acc.inf) acc.v = g1jq_unpack(packed); } else acc.inf = st == 0;
-            }
-        }
-    }
-    // sum of the R terms of an output: items tt = 0 .. R - 1 are adjacent; one lane per item takes part
-#define COOP_STORE(i) do { _Pragma("unroll") for (int q = 0; q < 13; q++) { buf[i].w[q] = acc.v.x.l[q]; buf[i].w[13 + q] = acc.v.y.l[q]; buf[i].w[26 + q] = acc.v.z.l[q]; } \
-                           buf[i].inf = acc.inf ? 1u : 0u; } while (0)
-    if (role == 0) COOP_STORE(item);
-    __syncthreads();
-#pragma nounroll
-    for (uint32_t off = (uint32_t)R / 2; off >= 1; off >>= 1) {
-        if (role == 0 && tt < off && !buf[item + off].inf) {
-            g1jq q;
-#pragma unroll
-            for (int i = 0; i < 13; i++) { q.x.l[i] = buf[item + off].w[i]; q.y.l[i] = buf[item + off].w[13 + i]; q.z.l[i] = buf[item + off].w[26 + i]; }
-            acc.add(q);
-            COOP_STORE(item);
-        }
-        __syncthreads();
-    }
-#undef COOP_STORE
-    if (live && role == 0 && tt == 0) out[oidx] = acc.inf ? g1_inf() : g1jq_pack(acc.v);
-}
 // runs the passes; the result lands in `data` (batch x n).  tmp: batch x n scratch points.  scale: nullptr or a device Fr that
 // multiplies every output (folded into the last pass).
 void launch_g1_fft_direct(hipStream_t s, const g1j *in, uint64_t in_stride, uint64_t n_valid, g1j *data, g1j *tmp, uint64_t n, uint64_t batch, const fr *roots,
@@ -501,8 +348,7 @@ void launch_g1_fft_direct(hipStream_t s, const g1j *in, uint64_t in_stride, uint
         const uint64_t wgs = (total * lanes + G1_DIRECT_BLOCK - 1) / G1_DIRECT_BLOCK;
         const size_t pad_lds = wgs <= 1024 ? 24 * 1024 : 0;
         const fr *sc = (p + 1 == npass) ? scale : nullptr;
-        if (lanes == 4) hipLaunchKernelGGL(k_g1_fft_direct_coop<4>, dim3((uint32_t)wgs), dim3(G1_DIRECT_BLOCK), pad_lds, s, src, src_stride, src_valid, dst, logn, logR, Ns, roots, W, sc, total);
-        else if (lanes == 2) hipLaunchKernelGGL(k_g1_fft_direct_coop<2>, dim3((uint32_t)wgs), dim3(G1_DIRECT_BLOCK), pad_lds, s, src, src_stride, src_valid, dst, logn, logR, Ns, roots, W, sc, total);
+        if (lanes > 1) launch_g1_direct_coop(s, lanes, (uint32_t)wgs, pad_lds, src, src_stride, src_valid, dst, logn, logR, Ns, roots, W, sc, total);
         else hipLaunchKernelGGL(k_g1_fft_direct, dim3((uint32_t)wgs), dim3(G1_DIRECT_BLOCK), pad_lds, s, src, src_stride, src_valid, dst, logn, logR, Ns, roots, W, sc, total);
         src = dst; src_stride = n; src_valid = n; Ns <<= logR; bits_left -= logR;
     }
