@@ -1278,17 +1278,45 @@ static int fk20_hext(fk20_core *c, hipStream_t s, const fr *d_poly, uint64_t pol
 }
 // steps 4-7: h = IFFT_G1(hExtFFT)[:k] (scale already folded), out = FFT_G1(h || inf^k) (da) or FFT_G1(h) (plain),
 // optional reverse-bit-order, normalise
-static int fk20_finish(fk20_core *c, hipStream_t s, const g1j *d_hext, uint64_t batch, int da, int bit_reverse, g1j *d_out) {
+// (second half: d_h = the inverse transform of hExtFFT, batch x 2k points of which the first k are h; d_h is overwritten)
+static int fk20_finish_from_h(fk20_core *c, hipStream_t s, g1j *d_h, uint64_t batch, int da, int bit_reverse, g1j *d_out) {
     kzg_hip_fft *fs = c->ks->fs;
     uint64_t k = c->k, k2 = 2 * k, on = da ? k2 : k;
-    dtmp<g1j> d_a(s), d_b(s);
-    CHK(d_a.alloc(batch * k2)); CHK(d_b.alloc(batch * k2));
-    CHK(g1_fft_rows(fs, s, d_hext, k2, k2, d_a.p, k2, batch, 1));          // ToeplitzPart3, fk20_single.go:80-87
-    CHK(g1_fft_rows(fs, s, d_a.p, k2, k, d_b.p, on, batch, 0));            // fk20_single.go:163-167 / :129
-    if (bit_reverse) { launch_g1_bitrev_copy(s, d_b.p, on, on, d_a.p, on, batch); launch_g1_normalize(s, d_a.p, d_out, batch * on, true); }
+    dtmp<g1j> d_b(s);
+    CHK(d_b.alloc(batch * k2));
+    CHK(g1_fft_rows(fs, s, d_h, k2, k, d_b.p, on, batch, 0));              // fk20_single.go:163-167 / :129
+    if (bit_reverse) { launch_g1_bitrev_copy(s, d_b.p, on, on, d_h, on, batch); launch_g1_normalize(s, d_h, d_out, batch * on, true); }
     else launch_g1_normalize(s, d_b.p, d_out, batch * on, true);
     HIPCHK(hipGetLastError());
     return KZG_HIP_OK;
+}
+static int fk20_finish(fk20_core *c, hipStream_t s, const g1j *d_hext, uint64_t batch, int da, int bit_reverse, g1j *d_out) {
+    kzg_hip_fft *fs = c->ks->fs;
+    const uint64_t k2 = 2 * c->k;
+    dtmp<g1j> d_a(s);
+    CHK(d_a.alloc(batch * k2));
+    CHK(g1_fft_rows(fs, s, d_hext, k2, k2, d_a.p, k2, batch, 1));          // ToeplitzPart3, fk20_single.go:80-87
+    return fk20_finish_from_h(c, s, d_a.p, batch, da, bit_reverse, d_out);
+}
+// A lone polynomial of a single-file settings object with its table resident, on the direct passes: the Toeplitz stage and the FIRST radix-16 pass of
+// the inverse transform in one kernel (k_fb_direct_pass1: every term of that pass is a fixed-base product, nwin additions instead of a variable-base
+// multiplication), the remaining passes continue from there.  KZG_HIP_FK20_PASS1=0 turns it off (tests compare both).
+static bool fk20_pass1_fused_ok(const fk20_core *c, uint64_t batch) {
+    static const bool off = [] { const char *e = getenv("KZG_HIP_FK20_PASS1"); return e && e[0] == '0'; }();
+    const uint64_t k2 = 2 * c->k;
+    return !off && c->l == 1 && c->d_files_fb && k2 >= 32 && g1_fft_direct_mode(k2, batch) && g1_fft_direct_logr(k2, batch) == 4;
+}
+static int fk20_run_pass1_fused(fk20_core *c, hipStream_t s, const fr *d_poly, uint64_t poly_stride, uint64_t n, uint64_t batch, int da, int bit_reverse, g1j *d_out) {
+    kzg_hip_fft *fs = c->ks->fs;
+    const uint64_t k2 = 2 * c->k;
+    dtmp<fr> d_tc(s), d_cf(s); dtmp<g1j> d_p1(s), d_a(s), d_tmp(s);
+    CHK(d_tc.alloc(batch * k2)); CHK(d_cf.alloc(batch * k2)); CHK(d_p1.alloc(batch * k2)); CHK(d_a.alloc(batch * k2)); CHK(d_tmp.alloc(batch * k2));
+    launch_toeplitz_coeffs(s, d_poly, poly_stride, n, 1, batch, d_tc.p, fs->d_inv_pow2 + ilog2(k2));   // 1 / 2k folded into the scalars
+    fr_fft_rows(fs, s, d_tc.p, k2, k2, d_cf.p, k2, batch, 0);
+    launch_fb_direct_pass1(s, c->d_files_fb, k2, c->fb_c, c->fb_nwin, d_cf.p, fs->d_reversed, fs->W, batch, 4, d_p1.p);
+    launch_g1_fft_direct(s, d_p1.p, k2, k2, d_a.p, d_tmp.p, k2, batch, fs->d_reversed, fs->W, nullptr, 4, g1_fft_direct_lanes(k2, batch), 4);
+    HIPCHK(hipGetLastError());
+    return fk20_finish_from_h(c, s, d_a.p, batch, da, bit_reverse, d_out);
 }
 // DA form of a single-file settings object with its table resident: the Toeplitz stage absorbs the first two stages of the inverse
 // transform (k_fb_mul_vec_dif2), the remaining ones run decimation-in-frequency and leave h bit-reversed, which is the layout the
@@ -1347,6 +1375,7 @@ static int fk20_run_dev(fk20_core *c, hipStream_t s, const fr *d_poly, uint64_t 
         return KZG_HIP_OK;
     }
     if (fk20_fused_ok(c, batch, da)) return fk20_run_fused(c, s, d_poly, poly_stride, n, batch, bit_reverse, d_out);
+    if (fk20_pass1_fused_ok(c, batch)) return fk20_run_pass1_fused(c, s, d_poly, poly_stride, n, batch, da, bit_reverse, d_out);
     uint64_t k2 = 2 * c->k;
     dtmp<g1j> d_hext(s);
     CHK(d_hext.alloc(batch * k2));

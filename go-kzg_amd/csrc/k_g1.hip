@@ -329,14 +329,15 @@ __global__ __launch_bounds__(G1_DIRECT_BLOCK, 2) void k_g1_fft_direct(const g1j 
 // runs the passes; the result lands in `data` (batch x n).  tmp: batch x n scratch points.  scale: nullptr or a device Fr that
 // multiplies every output (folded into the last pass).
 void launch_g1_fft_direct(hipStream_t s, const g1j *in, uint64_t in_stride, uint64_t n_valid, g1j *data, g1j *tmp, uint64_t n, uint64_t batch, const fr *roots,
-                          uint64_t W, const fr *scale, uint32_t max_logr, int lanes) {
+                          uint64_t W, const fr *scale, uint32_t max_logr, int lanes, uint32_t bits_done) {
     const uint32_t logn = ilog2g(n);
     if (max_logr < 1 || max_logr > 4) max_logr = 4;
-    uint32_t npass = (logn + max_logr - 1) / max_logr;
+    // bits_done > 0: `in` already holds the result of the passes over the first bits_done bits (launch_fb_direct_pass1); continue from there
+    uint32_t bits_left = logn - bits_done;
+    uint32_t npass = (bits_left + max_logr - 1) / max_logr;
     if (!npass) { launch_g1_bitrev_copy(s, in, in_stride, n_valid, data, n, batch); return; }   // n == 1: copy (a 0-bit reversal)
     // pass p writes data when the number of passes after it is even
-    const g1j *src = in; uint64_t src_stride = in_stride, src_valid = n_valid, Ns = 1;
-    uint32_t bits_left = logn;
+    const g1j *src = in; uint64_t src_stride = in_stride, src_valid = n_valid, Ns = 1ull << bits_done;
     prof_begin(s, "g1_fft_direct");
     for (uint32_t p = 0; p < npass; p++) {
         const uint32_t logR = bits_left >= max_logr ? max_logr : bits_left;

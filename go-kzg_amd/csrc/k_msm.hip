@@ -725,6 +725,76 @@ __global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_mul_vec(const g1a *table, ui
     }
     out[t] = acc.to_jac();
 }
+// The FK20 Toeplitz stage fused with the FIRST direct pass of the inverse G1 transform of a LONE polynomial (fk20_single.go:72-74 + the first
+// radix-R pass of k_g1_fft_direct over v_i = C[i] X[i]):  out[j R + u] = sum_{t < R} w^(t cols u) C[i] X[i],  i = j + t cols, cols = N / R.
+// Every term is a fixed-base product: the scalar C[i] w^e (one F_r product) walks X[i]'s resident table -- nwin mixed additions instead of the
+// 128 doublings + 66 additions of a variable-base multiplication -- then the R terms of an output are summed as in the direct pass.  One lane per
+// (output, term); one-wavefront workgroups.  roots = ReverseRootsOfUnity (Montgomery), W = its width.
+struct fbp_slot { uint32_t w[39]; uint32_t inf; uint32_t pad; };
+__global__ __launch_bounds__(64, 2) void k_fb_direct_pass1(const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, uint32_t D, const fr *scalars, const fr *roots,
+                                                           uint64_t W, uint32_t logn, uint32_t logR, uint64_t total, g1j *out) {
+    __shared__ fbp_slot buf[64];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + tid;
+    const uint64_t n = 1ull << logn, R = 1ull << logR, cols = n >> logR;
+    const uint32_t tt = (uint32_t)(t & (R - 1));
+    const uint64_t u = (t >> logR) & (R - 1), jb = t >> (2 * logR), j = jb % cols, b = jb / cols;
+    const bool live = t < total;
+    g1jq_acc acc; acc.inf = true;
+    if (live) {
+        const uint64_t i = j + (uint64_t)tt * cols, e = ((uint64_t)tt * cols * u) & (n - 1);
+        fr kmont = scalars[b * n + i];
+        if (e) kmont = mul(kmont, roots[e * (W >> logn)]);
+        const fr k = from_mont<FrP>(kmont);
+        g1x_acc xa; xa.init();
+        uint32_t raw = scalar_bits(k, 0, c), carry, mag, ng;
+        if (raw > D) { carry = 1; mag = (1u << c) - raw; ng = 1; } else { carry = 0; mag = raw; ng = 0; }
+        g1a qn = table[((uint64_t)0 * table_n + i) * D + (mag ? mag - 1 : 0)];
+#pragma nounroll
+        for (uint32_t w = 0; w < nwin; w++) {
+            g1a q = qn;
+            const uint32_t cmag = mag, cng = ng;
+            if (w + 1 < nwin) {
+                raw = scalar_bits(k, (w + 1) * c, c) + carry;
+                if (raw > D) { carry = 1; mag = (1u << c) - raw; ng = 1; } else { carry = 0; mag = raw; ng = 0; }
+                qn = table[((uint64_t)(w + 1) * table_n + i) * D + (mag ? mag - 1 : 0)];
+            }
+            if (cmag) {
+                if (cng) q.y = neg<FpP>(q.y);
+                xa.add(q);
+            }
+        }
+        if (!xa.inf) { acc.v = g1jq_unpack(xa.to_jac()); acc.inf = false; }
+    }
+#define FBP_STORE(i_) do { _Pragma("unroll") for (int q_ = 0; q_ < 13; q_++) { buf[i_].w[q_] = acc.v.x.l[q_]; buf[i_].w[13 + q_] = acc.v.y.l[q_]; buf[i_].w[26 + q_] = acc.v.z.l[q_]; } \
+                           buf[i_].inf = acc.inf ? 1u : 0u; } while (0)
+    FBP_STORE(tid);
+    __syncthreads();
+#pragma nounroll
+    for (uint32_t off = (uint32_t)R / 2; off >= 1; off >>= 1) {
+        if (tt < off && !buf[tid + off].inf) {
+            g1jq q;
+#pragma unroll
+            for (int i = 0; i < 13; i++) { q.x.l[i] = buf[tid + off].w[i]; q.y.l[i] = buf[tid + off].w[13 + i]; q.z.l[i] = buf[tid + off].w[26 + i]; }
+            acc.add(q);
+            FBP_STORE(tid);
+        }
+        __syncthreads();
+    }
+#undef FBP_STORE
+    if (live && tt == 0) out[b * n + j * R + u] = acc.inf ? g1_inf() : g1jq_pack(acc.v);
+}
+void launch_fb_direct_pass1(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, const fr *roots, uint64_t W, uint64_t batch,
+                            uint32_t logR, g1j *out) {
+    uint32_t logn = 0;
+    while ((1ull << logn) < table_n) logn++;
+    const uint64_t total = (batch * table_n) << logR, wgs = (total + 63) / 64;
+    prof_begin(s, "fb_mul_vec");
+    hipLaunchKernelGGL(k_fb_direct_pass1, dim3((uint32_t)wgs), dim3(64), wgs <= 1024 ? 24 * 1024 : 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars, roots, W, logn, logR,
+                       total, out);
+    prof_end(s, "fb_mul_vec");
+}
+
 // The FK20 Toeplitz stage fused with the FIRST TWO decimation-in-frequency stages of the inverse G1 transform that follows it
 // (fk20_single.go:72-74 + the first two levels of ToeplitzPart3's FFTG1, :80-87).  With v_j = C[j] X[j], q = N / 4, w = the inverse
 // root of order N and i < q, two DIF stages give

@@ -1142,11 +1142,12 @@ def test_fk20_paths_agree_in_a_fresh_process():
     radix-2 / fused pipeline (KZG_HIP_G1_FFT=radix2) and the unfused one (KZG_HIP_FK20_FUSE=0) at every size."""
     import subprocess
     import sys
+    # ... without the Toeplitz stage fused into the first direct pass of a lone polynomial (KZG_HIP_FK20_PASS1=0) ...
     # ... and with four lanes per butterfly everywhere (KZG_HIP_G1_QUAD=1: both digit schedules of g1_quad.hpp), two everywhere (=2) and one (=0: the radix-8 direct passes return)
     for extra in ({"KZG_HIP_G1_FFT": "radix2"}, {"KZG_HIP_G1_FFT": "radix2", "KZG_HIP_FK20_FUSE": "0"}, {"KZG_HIP_G1_FFT": "direct"},
                   {"KZG_HIP_G1_FFT": "radix2", "KZG_HIP_G1_QUAD": "1"}, {"KZG_HIP_G1_FFT": "radix2", "KZG_HIP_G1_QUAD": "1", "KZG_HIP_G1_MUL": "regular"},
                   {"KZG_HIP_G1_FFT": "radix2", "KZG_HIP_G1_QUAD": "2"}, {"KZG_HIP_G1_FFT": "radix2", "KZG_HIP_G1_QUAD": "2", "KZG_HIP_G1_MUL": "regular"},
-                  {"KZG_HIP_G1_QUAD": "0"}):
+                  {"KZG_HIP_G1_QUAD": "0"}, {"KZG_HIP_FK20_PASS1": "0"}):
         env = dict(os.environ, **extra)
         # (the lone-transform test spends seconds in the oracle: only where the forced setting changes what it runs)
         lone = " or fft_g1_lone" if extra.get("KZG_HIP_G1_QUAD") in ("0", "2") and "KZG_HIP_G1_MUL" not in extra else ""
