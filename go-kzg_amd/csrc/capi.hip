@@ -440,12 +440,14 @@ static int g1_fft_direct_lanes(uint64_t n, uint64_t batch) {
     const uint64_t items = (n * batch) << g1_fft_direct_logr(n, batch);
     return items * 4 <= 65536 ? 4 : items * 2 <= 65536 ? 2 : 1;
 }
+// (n_out: the caller only reads the first n_out outputs -- the direct passes then skip the rest of their last pass; 0 = all)
 static int g1_fft_rows(kzg_hip_fft *fs, hipStream_t s, const g1j *d_in, uint64_t in_stride, uint64_t n_valid, g1j *d_data, uint64_t n, uint64_t batch, int inv,
-                       const fr *scale = nullptr) {
+                       const fr *scale = nullptr, uint64_t n_out = 0) {
     if (g1_fft_direct_mode(n, batch)) {
         dtmp<g1j> d_tmp(s);
         CHK(d_tmp.alloc(n * batch));
-        launch_g1_fft_direct(s, d_in, in_stride, n_valid, d_data, d_tmp.p, n, batch, inv ? fs->d_reversed : fs->d_expanded, fs->W, scale, g1_fft_direct_logr(n, batch), g1_fft_direct_lanes(n, batch));
+        launch_g1_fft_direct(s, d_in, in_stride, n_valid, d_data, d_tmp.p, n, batch, inv ? fs->d_reversed : fs->d_expanded, fs->W, scale, g1_fft_direct_logr(n, batch),
+                             g1_fft_direct_lanes(n, batch), 0, n_out);
         return KZG_HIP_OK;
     }
     launch_g1_bitrev_copy(s, d_in, in_stride, n_valid, d_data, n, batch);
@@ -1295,7 +1297,7 @@ static int fk20_finish(fk20_core *c, hipStream_t s, const g1j *d_hext, uint64_t 
     const uint64_t k2 = 2 * c->k;
     dtmp<g1j> d_a(s);
     CHK(d_a.alloc(batch * k2));
-    CHK(g1_fft_rows(fs, s, d_hext, k2, k2, d_a.p, k2, batch, 1));          // ToeplitzPart3, fk20_single.go:80-87
+    CHK(g1_fft_rows(fs, s, d_hext, k2, k2, d_a.p, k2, batch, 1, nullptr, c->k));   // ToeplitzPart3, fk20_single.go:80-87 (only h[:k] is read below)
     return fk20_finish_from_h(c, s, d_a.p, batch, da, bit_reverse, d_out);
 }
 // A lone polynomial of a single-file settings object with its table resident, on the direct passes: the Toeplitz stage and the FIRST radix-16 pass of
@@ -1314,7 +1316,7 @@ static int fk20_run_pass1_fused(fk20_core *c, hipStream_t s, const fr *d_poly, u
     launch_toeplitz_coeffs(s, d_poly, poly_stride, n, 1, batch, d_tc.p, fs->d_inv_pow2 + ilog2(k2));   // 1 / 2k folded into the scalars
     fr_fft_rows(fs, s, d_tc.p, k2, k2, d_cf.p, k2, batch, 0);
     launch_fb_direct_pass1(s, c->d_files_fb, k2, c->fb_c, c->fb_nwin, d_cf.p, fs->d_reversed, fs->W, batch, 4, d_p1.p);
-    launch_g1_fft_direct(s, d_p1.p, k2, k2, d_a.p, d_tmp.p, k2, batch, fs->d_reversed, fs->W, nullptr, 4, g1_fft_direct_lanes(k2, batch), 4);
+    launch_g1_fft_direct(s, d_p1.p, k2, k2, d_a.p, d_tmp.p, k2, batch, fs->d_reversed, fs->W, nullptr, 4, g1_fft_direct_lanes(k2, batch), 4, c->k);   // only h[:k] is read below
     HIPCHK(hipGetLastError());
     return fk20_finish_from_h(c, s, d_a.p, batch, da, bit_reverse, d_out);
 }

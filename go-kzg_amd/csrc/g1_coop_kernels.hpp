@@ -123,13 +123,14 @@ template <bool DIF> static inline void launch_stage_coop(hipStream_t s, int lane
 // schedule: the lanes of a wavefront hold different twiddles), the group's lane 0 joins the sum.  For passes that leave SIMDs empty at one lane per
 // term: a lone transform of up to 1024 points runs radix 16 on quads (1.3 ms per pass instead of 2.0-2.4), 2048 points on pairs (1.8 ms).
 template <int L> __global__ __launch_bounds__(G1_DIRECT_BLOCK, 2) void k_g1_fft_direct_coop(const g1j *in, uint64_t in_stride, uint64_t n_valid, g1j *out, uint32_t logn,
-                                                                                          uint32_t logR, uint64_t Ns, const fr *roots, uint64_t W, const fr *scale, uint64_t total) {
+                                                                                          uint32_t logR, uint64_t Ns, const fr *roots, uint64_t W, const fr *scale, uint64_t total,
+                                                                                          uint32_t logT, uint32_t logU) {
     __shared__ g1jq_slot buf[G1_DIRECT_BLOCK / L];
     const uint32_t tid = threadIdx.x, role = tid & (uint32_t)(L - 1), item = tid / L;
     const uint64_t t = (blockIdx.x * (uint64_t)blockDim.x + tid) / L;
-    const uint64_t n = 1ull << logn, R = 1ull << logR, cols = n >> logR;
-    const uint32_t tt = (uint32_t)(t & (R - 1));
-    const uint64_t u = (t >> logR) & (R - 1), jb = t >> (2 * logR), j = jb % cols, b = jb / cols;
+    const uint64_t n = 1ull << logn, R = 1ull << logR, cols = n >> logR, T = 1ull << logT;
+    const uint32_t tt = (uint32_t)(t & (T - 1));
+    const uint64_t u = (t >> logT) & ((1ull << logU) - 1), jb = t >> (logT + logU), j = jb % cols, b = jb / cols;
     const bool live = t < total;
     g1jq_acc acc; acc.inf = true;
     uint64_t oidx = 0;
@@ -155,7 +156,7 @@ template <int L> __global__ __launch_bounds__(G1_DIRECT_BLOCK, 2) void k_g1_fft_
     if (role == 0) COOP_STORE(item);
     __syncthreads();
 #pragma nounroll
-    for (uint32_t off = (uint32_t)R / 2; off >= 1; off >>= 1) {
+    for (uint32_t off = (uint32_t)T / 2; off >= 1; off >>= 1) {
         if (role == 0 && tt < off && !buf[item + off].inf) {
             g1jq q;
 #pragma unroll

@@ -76,9 +76,9 @@ void launch_fb_direct_pass1(hipStream_t s, const g1a *table, uint64_t table_n, u
 void launch_g1_stage_coop_dif(hipStream_t s, int lanes, g1j *data, uint64_t n, uint64_t batch, uint64_t m, const fr *roots, const int8_t *wnaf, uint64_t W, uint64_t total);
 void launch_g1_stage_coop_dit(hipStream_t s, int lanes, g1j *data, uint64_t n, uint64_t batch, uint64_t m, const fr *roots, const int8_t *wnaf, uint64_t W, uint64_t total);
 void launch_g1_direct_coop(hipStream_t s, int lanes, uint32_t wgs, size_t pad_lds, const g1j *src, uint64_t src_stride, uint64_t src_valid, g1j *dst, uint32_t logn, uint32_t logR,
-                           uint64_t Ns, const fr *roots, uint64_t W, const fr *sc, uint64_t total);
+                           uint64_t Ns, const fr *roots, uint64_t W, const fr *sc, uint64_t total, uint32_t logT, uint32_t logU);
 void launch_g1_fft_direct(hipStream_t s, const g1j *in, uint64_t in_stride, uint64_t n_valid, g1j *data, g1j *tmp, uint64_t n, uint64_t batch, const fr *roots,
-                          uint64_t W, const fr *scale, uint32_t max_logr = 4, int lanes = 1, uint32_t bits_done = 0);
+                          uint64_t W, const fr *scale, uint32_t max_logr = 4, int lanes = 1, uint32_t bits_done = 0, uint64_t n_out = 0);   // n_out: only the first n_out outputs are wanted (0 = all)
 // to_kilic: also leave the device-internal Montgomery domain (R' = 2^390) for Kilic's (2^384): every API output path ends here
 void launch_g1_normalize(hipStream_t s, const g1j *in, g1j *out, uint64_t n, bool to_kilic = false);
 void launch_g1_from_kilic(hipStream_t s, g1j *data, uint64_t n);   // in place: caller-supplied points enter the internal domain

@@ -278,14 +278,16 @@ void launch_g1_fft_stage(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, u
 // ---------------------------------------------------------------------------------------------------------
 struct g1jq_slot { uint32_t w[39]; uint32_t inf; uint32_t pad; };            // 41 words: odd stride, no LDS bank conflicts
 #define G1_DIRECT_BLOCK 64              // one wavefront per workgroup: the dispatcher spreads 1024 of them over the 1024 SIMDs
+// (logT, logU: only the first 2^logT terms of an output are finite -- a zero-padded input, first pass -- and only the outputs u < 2^logU of a column are
+// wanted -- a caller that keeps the lower part of the result, last pass: lanes exist for those only)
 __global__ __launch_bounds__(G1_DIRECT_BLOCK, 2) void k_g1_fft_direct(const g1j *in, uint64_t in_stride, uint64_t n_valid, g1j *out, uint32_t logn, uint32_t logR,
-                                                            uint64_t Ns, const fr *roots, uint64_t W, const fr *scale, uint64_t total) {
+                                                            uint64_t Ns, const fr *roots, uint64_t W, const fr *scale, uint64_t total, uint32_t logT, uint32_t logU) {
     __shared__ g1jq_slot buf[G1_DIRECT_BLOCK];
     const uint32_t tid = threadIdx.x;
     const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + tid;
-    const uint64_t n = 1ull << logn, R = 1ull << logR, cols = n >> logR;
-    const uint32_t tt = (uint32_t)(t & (R - 1));
-    const uint64_t u = (t >> logR) & (R - 1), jb = t >> (2 * logR), j = jb % cols, b = jb / cols;
+    const uint64_t n = 1ull << logn, R = 1ull << logR, cols = n >> logR, T = 1ull << logT;
+    const uint32_t tt = (uint32_t)(t & (T - 1));
+    const uint64_t u = (t >> logT) & ((1ull << logU) - 1), jb = t >> (logT + logU), j = jb % cols, b = jb / cols;
     const bool live = t < total;
     g1jq_acc acc; acc.inf = true;
     uint64_t oidx = 0;
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(G1_DIRECT_BLOCK, 2) void k_g1_fft_direct(const g1j 
     store(tid);
     __syncthreads();
 #pragma nounroll
-    for (uint32_t off = (uint32_t)R / 2; off >= 1; off >>= 1) {
+    for (uint32_t off = (uint32_t)T / 2; off >= 1; off >>= 1) {
         if (tt < off && !buf[tid + off].inf) {
             g1jq q;
 #pragma unroll
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(G1_DIRECT_BLOCK, 2) void k_g1_fft_direct(const g1j 
 // runs the passes; the result lands in `data` (batch x n).  tmp: batch x n scratch points.  scale: nullptr or a device Fr that
 // multiplies every output (folded into the last pass).
 void launch_g1_fft_direct(hipStream_t s, const g1j *in, uint64_t in_stride, uint64_t n_valid, g1j *data, g1j *tmp, uint64_t n, uint64_t batch, const fr *roots,
-                          uint64_t W, const fr *scale, uint32_t max_logr, int lanes, uint32_t bits_done) {
+                          uint64_t W, const fr *scale, uint32_t max_logr, int lanes, uint32_t bits_done, uint64_t n_out) {
     const uint32_t logn = ilog2g(n);
     if (max_logr < 1 || max_logr > 4) max_logr = 4;
     // bits_done > 0: `in` already holds the result of the passes over the first bits_done bits (launch_fb_direct_pass1); continue from there
@@ -342,16 +344,25 @@ void launch_g1_fft_direct(hipStream_t s, const g1j *in, uint64_t in_stride, uint
     for (uint32_t p = 0; p < npass; p++) {
         const uint32_t logR = bits_left >= max_logr ? max_logr : bits_left;
         g1j *dst = ((npass - 1 - p) & 1u) ? tmp : data;
-        const uint64_t total = batch * n << logR;
+        // terms beyond the valid input are infinity (term t reads index j + t n / R): only the first ceil(valid / (n / R)) take part; of the last pass
+        // only the outputs below n_out are wanted (output u of a column lands at k + u Ns): lanes for those only
+        uint32_t logT = logR, logU = logR;
+        const uint64_t cols = n >> logR;
+        while (logT > 0 && (cols << (logT - 1)) >= src_valid) logT--;
+        if (p + 1 == npass && n_out && n_out < n) while (logU > 0 && (Ns << (logU - 1)) >= n_out) logU--;
+        const uint64_t total = (batch * cols) << (logT + logU);
+        // as many lanes per term as keep the pass at one wavefront per SIMD (the caller's choice for full passes; pruned ones may take more)
+        int L = lanes;
+        if (g1_quad_enabled() && (logT < logR || logU < logR)) L = total * 4 <= 65536 ? 4 : total * 2 <= 65536 ? 2 : lanes;
         // 24 KiB of unused dynamic LDS on top of the 10 KiB the kernel needs: at most 4 of these one-wave workgroups fit a CU, so the
         // 1024 of a 4096-point pass land one per SIMD instead of 8 per CU on half of the chip (measured: 2.7 vs 5.4 ms per pass)
         // (only while the pass has at most one wavefront per SIMD: two transforms are 2048 workgroups and want both wave slots)
-        const uint64_t wgs = (total * lanes + G1_DIRECT_BLOCK - 1) / G1_DIRECT_BLOCK;
+        const uint64_t wgs = (total * L + G1_DIRECT_BLOCK - 1) / G1_DIRECT_BLOCK;
         const size_t pad_lds = wgs <= 1024 ? 24 * 1024 : 0;
         const fr *sc = (p + 1 == npass) ? scale : nullptr;
-        if (lanes > 1) launch_g1_direct_coop(s, lanes, (uint32_t)wgs, pad_lds, src, src_stride, src_valid, dst, logn, logR, Ns, roots, W, sc, total);
-        else hipLaunchKernelGGL(k_g1_fft_direct, dim3((uint32_t)wgs), dim3(G1_DIRECT_BLOCK), pad_lds, s, src, src_stride, src_valid, dst, logn, logR, Ns, roots, W, sc, total);
-        src = dst; src_stride = n; src_valid = n; Ns <<= logR; bits_left -= logR;
+        if (L > 1) launch_g1_direct_coop(s, L, (uint32_t)wgs, pad_lds, src, src_stride, src_valid, dst, logn, logR, Ns, roots, W, sc, total, logT, logU);
+        else hipLaunchKernelGGL(k_g1_fft_direct, dim3((uint32_t)wgs), dim3(G1_DIRECT_BLOCK), pad_lds, s, src, src_stride, src_valid, dst, logn, logR, Ns, roots, W, sc, total, logT, logU);
+        src = dst; src_stride = n; src_valid = (p + 1 == npass && n_out && n_out < n) ? n_out : n; Ns <<= logR; bits_left -= logR;
     }
     prof_end(s, "g1_fft_direct");
 }
