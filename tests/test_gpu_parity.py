@@ -1435,7 +1435,8 @@ def test_c_abi_misuse_returns_status_codes(kz):
 # ------------------------------------------------------------------ BASELINE config 4b: FK20Single, full 4096-coefficient blob
 def test_fk20_single_scale13_config4b(kz):
     """FK20Single (fk20_single.go:122-134) on a full 4096-coefficient blob needs scale 13 and an 8192-point setup
-    (GenerateTestingSetup with the reference's test secret, generated on the device).  out[i] is the proof at w_4096^i."""
+    (GenerateTestingSetup with the reference's test secret, generated on the device).  out[i] is the proof at w_4096^i.  Byte pins of the
+    oracle's full-size runs plus the proof identity at every position of both forms."""
     n = 4096
     fs = kz.FFTSettings(13)
     setup = fs.generate_testing_setup_g1(ko.fr_from_ints([S_TEST]), 8192)
@@ -1451,6 +1452,14 @@ def test_fk20_single_scale13_config4b(kz):
     for i in (0, 1, 2, 1234, 4095):
         d = pyref.single_proof_dlog(poly_i, S_TEST, pow(w, i, ko.R_MOD))
         assert ko.g1_equal(proofs[i], ko.g1_mul(gen, ko.fr_from_ints([d])[0])), i
+    # ... and at EVERY position: (p(s) - p(w^i)) / (s - w^i) with all p(w^i) from one oracle transform
+    R = ko.R_MOD
+    ofs13 = ko.FFTSettings(13)
+    ps_ = pyref.eval_poly(poly_i, S_TEST)
+    ev = ko.fr_to_ints(ofs13.fft(blob))                                        # p on the 4096-point domain
+    dl = ko.fr_from_ints([(ps_ - ev[i]) * pow(S_TEST - pow(w, i, R), -1, R) % R for i in range(n)])
+    for i in range(n):
+        assert ko.g1_equal(proofs[i], ko.g1_mul(gen, dl[i])), i
     # ... and equals ComputeProofSingle at an integer point as a cross-check of the same settings
     assert ko.g1_equal(ks.compute_proof_single(blob, 17), ko.g1_mul(gen, ko.fr_from_ints([pyref.single_proof_dlog(poly_i, S_TEST, 17)])[0]))
     # DA form on the same settings: 4096 coefficients -> 8192 proofs, sample + linearity
@@ -1461,6 +1470,14 @@ def test_fk20_single_scale13_config4b(kz):
     for pos in (0, 3, 8191):
         d = pyref.single_proof_dlog(poly_i, S_TEST, pow(w2, pyref.rev_bits(pos, 13), ko.R_MOD))
         assert ko.g1_equal(pa[pos], ko.g1_mul(gen, ko.fr_from_ints([d])[0])), pos
+    ev2 = ko.fr_to_ints(ofs13.fft(np.concatenate([blob, ko.fr_empty(n)])))  # p on the 8192-point domain
+    dl2 = []
+    for pos in range(2 * n):
+        k = pyref.rev_bits(pos, 13)
+        dl2.append((ps_ - ev2[k]) * pow(S_TEST - pow(w2, k, R), -1, R) % R)
+    dl2 = ko.fr_from_ints(dl2)
+    for pos in range(2 * n):
+        assert ko.g1_equal(pa[pos], ko.g1_mul(gen, dl2[pos])), pos
     fk.close(); ks.close(); fs.close()
 
 
