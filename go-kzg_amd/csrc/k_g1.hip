@@ -352,8 +352,9 @@ void launch_g1_fft_direct(hipStream_t s, const g1j *in, uint64_t in_stride, uint
         if (p + 1 == npass && n_out && n_out < n) while (logU > 0 && (Ns << (logU - 1)) >= n_out) logU--;
         const uint64_t total = (batch * cols) << (logT + logU);
         // as many lanes per term as keep the pass at one wavefront per SIMD (the caller's choice for full passes; pruned ones may take more)
+        static const bool coop_off = [] { const char *e = getenv("KZG_HIP_G1_DIRECT_COOP"); return e && e[0] == '0'; }();
         int L = lanes;
-        if (g1_quad_enabled() && (logT < logR || logU < logR)) L = total * 4 <= 65536 ? 4 : total * 2 <= 65536 ? 2 : lanes;
+        if (g1_quad_enabled() && !coop_off && (logT < logR || logU < logR)) L = total * 4 <= 65536 ? 4 : total * 2 <= 65536 ? 2 : lanes;
         // 24 KiB of unused dynamic LDS on top of the 10 KiB the kernel needs: at most 4 of these one-wave workgroups fit a CU, so the
         // 1024 of a 4096-point pass land one per SIMD instead of 8 per CU on half of the chip (measured: 2.7 vs 5.4 ms per pass)
         // (only while the pass has at most one wavefront per SIMD: two transforms are 2048 workgroups and want both wave slots)
