@@ -13,11 +13,14 @@ import gokzg_amd as kz  # noqa: E402
 
 
 def timeit(fn, reps):
-    fn()
-    t0 = time.time()
-    for _ in range(reps):
+    for _ in range(4):                       # the first calls after an idle period run at a lower clock (a lone DAUsingFK20: 17 ms, then 11.3)
         fn()
-    return (time.time() - t0) / reps * 1e3
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return float(np.median(ts))
 
 
 fs = kz.FFTSettings(12)
