@@ -720,7 +720,7 @@ KZG_HD void g1_wnaf_table_affine_q(const g1jq &p0, g1aq *tbl, g1jq *jt) {   // p
 // squares fit (d : 2 + 9 = 11, e : 2 + 17 = 19; 361 <= 600); from then on T = (2, 2), O = (8, 5): d : 11, e : 8, W1 - W2 : 5,
 // X3 : 2 + 3 + 3 = 8, W1 - X3 : 11, Y3 : 2 - A1 (M = 3) : 5, Z d : 22 resp. 44.  Returns false if a d vanishes (P of order < 16:
 // never in G1); the caller then builds the table the slow way.
-template <bool INL = false> KZG_HD bool g1_wnaf_table_affine_coz(const g1jq &p0, g1aq *tbl, fq *dz) {
+template <bool INL = false> KZG_HD bool g1_wnaf_table_affine_coz(const g1jq &p0, g1aq *tbl, fq *dz, fq &zc) {
     auto mulq = [](const fq &a_, const fq &b_) { return INL ? mulq_inl(a_, b_) : kzg::mulq(a_, b_); };   // INL: products inlined (the stage kernels: +x % measured)
     auto sqrq = [](const fq &a_) { return INL ? sqrq_inl(a_) : kzg::sqrq(a_); };
     fq one_q = unpackq(one<FpP>());
@@ -757,8 +757,9 @@ template <bool INL = false> KZG_HD bool g1_wnaf_table_affine_coz(const g1jq &p0,
         tbl[i + 1].x = x3; tbl[i + 1].y = y3;
     }
     if (KZG_UNLIKELY(!ok)) return false;
-    fq zi = unpackq(inv<FpP>(packq(z)));                       // 1 / Z_8
     const fq beta_q = unpackq(glv_beta());
+#ifdef KZG_WNAF_TABLE_AFFINE                                // A/B builds: the table normalised to affine points of E with one inversion (round 2)
+    fq zi = unpackq(inv<FpP>(packq(z)));                       // 1 / Z_8
 #pragma nounroll
     for (int i = 7; i >= 0; i--) {
         fq zi2 = sqrq(zi);
@@ -767,6 +768,25 @@ template <bool INL = false> KZG_HD bool g1_wnaf_table_affine_coz(const g1jq &p0,
         tbl[i].bx = mulq(tbl[i].x, beta_q);
         if (i) zi = mulq(zi, dz[i - 1]);                       // 1 / Z_i = (1 / Z_{i+1}) d_i
     }
+    zc = one_q;
+#else
+    // No inversion: entry i sits at Z_{i+1} = Z_1 d_0 .. d_{i-1}; all are brought to the COMMON Z_8 (times (Z_8 / Z_{i+1})^2, ^3) and read as AFFINE
+    // points of the isomorphic curve E': y^2 = x^3 + b Z_8^6 -- the doubling and mixed-addition formulas of an a = 0 curve do not contain b, and
+    // (x, y) -> (beta x, y) is the same endomorphism there -- so the multiplication runs on E' unchanged and its result (X, Y, Z) is the point
+    // (X, Y, Z Z_8) of E: one product at the end (`zc`) instead of a ~38 000-instruction inversion per multiplication.
+    fq r = one_q;
+    tbl[7].x = mulq(tbl[7].x, one_q); tbl[7].y = mulq(tbl[7].y, one_q);    // bounds (8, 5) -> 2 like the scaled entries
+    tbl[7].bx = mulq(tbl[7].x, beta_q);
+#pragma nounroll
+    for (int i = 6; i >= 0; i--) {
+        r = (i == 6) ? dz[6] : mulq(r, dz[i]);                 // Z_8 / Z_{i+1} = d_i .. d_6
+        const fq r2 = sqrq(r);
+        tbl[i].x = mulq(tbl[i].x, r2);
+        tbl[i].y = mulq(tbl[i].y, mulq(r2, r));
+        tbl[i].bx = mulq(tbl[i].x, beta_q);
+    }
+    zc = z;
+#endif
     return true;
 }
 KZG_HD void g1_wnaf_table_affine(const g1j &p, g1aq *tbl, g1jq *jt) { g1_wnaf_table_affine_q(g1jq_unpack(p), tbl, jt); }
@@ -845,7 +865,7 @@ KZG_HD bool g1jq_add_slow_copy_a(g1jq &acc, const g1aq *t, bool ng, bool phi) {
 // width-5 NAF GLV multiplication with the AFFINE table (what the G1 FFT stages run since round 2).  Same contract as
 // g1_mul_glv_wnaf_q; `dz` is scratch for the 7 Z ratios of the co-Z chain (only alive while the table is built).
 // (the multiplicand arrives unpacked: the product of a butterfly's difference in the decimation-in-frequency stages needs no pack / unpack)
-template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_wnaf_loop_aq(const g1jq &pq, const fr &kk, const g1aq *tbl, const int8_t *d1, const int8_t *d2, int stride, int n1, int n2, g1jq &out, g1j &packed) {
+template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_wnaf_loop_aq(const g1jq &pq, const fr &kk, const g1aq *tbl, const fq &zc, const int8_t *d1, const int8_t *d2, int stride, int n1, int n2, g1jq &out, g1j &packed) {
     int j = (n1 > n2 ? n1 : n2) - 1;
     if (j < 0) return 0;                                   // k == 0
     g1jq acc;
@@ -882,28 +902,32 @@ template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_wnaf_loop_aq
 #pragma nounroll
     for (; pend > 0; pend--) acc = g1jq_dbl(acc);
     out = acc;
+    out.z = mulq(out.z, zc);                               // back from the table's isomorphic curve
     return 1;
 }
 // table for the multiplications below (co-Z chain); `dz`: 7 field elements of scratch.  false: a difference of the chain vanished (P of
 // order < 16, never in G1) -- the callers then take the generic path for the whole product.
-KZG_HD bool g1_wnaf_table(const g1jq &pq, g1aq *tbl, fq *dz) {
+// zc: the factor the multiplication's result Z has to be multiplied with (the table lives on an isomorphic curve: g1_wnaf_table_affine_coz)
+KZG_HD bool g1_wnaf_table(const g1jq &pq, g1aq *tbl, fq *dz, fq &zc) {
 #ifdef KZG_WNAF_TABLE_NOINLINE                              // A/B builds: the chain's products as calls (-0.2 .. -0.6 % FK20 measured)
-    return g1_wnaf_table_affine_coz<false>(pq, tbl, dz);
+    return g1_wnaf_table_affine_coz<false>(pq, tbl, dz, zc);
 #else
-    return g1_wnaf_table_affine_coz<true>(pq, tbl, dz);
+    return g1_wnaf_table_affine_coz<true>(pq, tbl, dz, zc);
 #endif
 }
 template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_mul_glv_wnaf_aq_q(const g1jq &pq, const fr &kk, g1aq *tbl, fq *dz, int8_t *d1, int8_t *d2, int stride, g1jq &out, g1j &packed) {
-    if (!g1_wnaf_table(pq, tbl, dz)) { g1j pc = g1jq_pack(pq); fr kc = kk; g1_mul_glv_cold(&packed, &pc, &kc); return 2; }
+    fq zc;
+    if (!g1_wnaf_table(pq, tbl, dz, zc)) { g1j pc = g1jq_pack(pq); fr kc = kk; g1_mul_glv_cold(&packed, &pc, &kc); return 2; }
     const int n1 = glv_wnaf5(kk, 0, d1, stride), n2 = glv_wnaf5(kk, 4, d2, stride);
-    return g1_wnaf_loop_aq<INL_DBL, INL_ADD>(pq, kk, tbl, d1, d2, stride, n1, n2, out, packed);
+    return g1_wnaf_loop_aq<INL_DBL, INL_ADD>(pq, kk, tbl, zc, d1, d2, stride, n1, n2, out, packed);
 }
 // the digit strings come PRECOMPUTED (the twiddles of an FFTSettings are fixed: their width-5 NAF recodings are built once on the
 // host with the same glv_wnaf5 and live in HBM): `dg` = 132 bytes for k1 (digit i at [i], the length at [131]) followed by 132 for k2
 #define KZG_WNAF_ROW 264
 template <bool INL_DBL = false, bool INL_ADD = false> KZG_HD int g1_mul_glv_wnaf_aq_pre_q(const g1jq &pq, const fr &kk, g1aq *tbl, fq *dz, const int8_t *dg, g1jq &out, g1j &packed) {
-    if (!g1_wnaf_table(pq, tbl, dz)) { g1j pc = g1jq_pack(pq); fr kc = kk; g1_mul_glv_cold(&packed, &pc, &kc); return 2; }
-    return g1_wnaf_loop_aq<INL_DBL, INL_ADD>(pq, kk, tbl, dg, dg + 132, 1, (int)(uint8_t)dg[131], (int)(uint8_t)dg[132 + 131], out, packed);
+    fq zc;
+    if (!g1_wnaf_table(pq, tbl, dz, zc)) { g1j pc = g1jq_pack(pq); fr kc = kk; g1_mul_glv_cold(&packed, &pc, &kc); return 2; }
+    return g1_wnaf_loop_aq<INL_DBL, INL_ADD>(pq, kk, tbl, zc, dg, dg + 132, 1, (int)(uint8_t)dg[131], (int)(uint8_t)dg[132 + 131], out, packed);
 }
 // ---- regular variant on the same affine table: what lanes with DIFFERENT scalars run (the direct G1 FFT passes, the late stages of
 // small batches) ---------------------------------------------------------------------------------------------------------------------
@@ -917,7 +941,8 @@ KZG_HD void g1_mul_glv_signed_cold(g1j *o, const g1j *p, const glv_halves *h) { 
 template <bool INL = true> KZG_HD int g1_mul_glv_regular_aq(const g1jq &pq, const glv_halves &h, g1aq *tbl, fq *dz, g1jq &out, g1j &packed) {
     const bool on1 = (h.k1[0] | h.k1[1] | h.k1[2] | h.k1[3]) != 0, on2 = (h.k2[0] | h.k2[1] | h.k2[2] | h.k2[3]) != 0;
     if (!on1 && !on2) return 0;
-    if (!g1_wnaf_table(pq, tbl, dz)) { g1j pc = g1jq_pack(pq); glv_halves hc = h; g1_mul_glv_signed_cold(&packed, &pc, &hc); return 2; }
+    fq zc;
+    if (!g1_wnaf_table(pq, tbl, dz, zc)) { g1j pc = g1jq_pack(pq); glv_halves hc = h; g1_mul_glv_signed_cold(&packed, &pc, &hc); return 2; }
     const bool n1 = h.neg1 != 0, n2 = h.neg2 != 0;
     // the digit window of step i is bits 4 i .. 4 i + 4: kept at the top of a 129-bit shift register (bit 128 in the fifth word)
     uint32_t a0 = h.k1[0] | 1u, a1 = h.k1[1], a2 = h.k1[2], a3 = h.k1[3], a4 = 0;
@@ -949,6 +974,7 @@ template <bool INL = true> KZG_HD int g1_mul_glv_regular_aq(const g1jq &pq, cons
     if (on2 && !(h.k2[0] & 1u) && !degenerate && !g1jq_madd_entry<INL>(acc, &tbl[0], !n2, true)) degenerate = g1jq_add_slow_copy_a(acc, &tbl[0], !n2, true);
     if (degenerate) { g1j pc = g1jq_pack(pq); glv_halves hc = h; g1_mul_glv_signed_cold(&packed, &pc, &hc); return 2; }
     out = acc;
+    out.z = mulq(out.z, zc);                               // back from the table's isomorphic curve
     return 1;
 }
 KZG_HD void glv_wnaf5_row(const fr &kk, int8_t *row) {      // host side of the above

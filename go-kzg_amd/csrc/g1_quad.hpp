@@ -131,7 +131,8 @@ __device__ __forceinline__ void quad_entry(const g1aq *t, bool ng, bool phi, fq 
 template <int L = 4> __device__ __forceinline__ int g1_mul_glv_regular_quad(const g1jq &pq, const glv_halves &h, g1aq *tbl, fq *dz, g1jq &out, g1j &packed, uint32_t role) {
     const bool on1 = (h.k1[0] | h.k1[1] | h.k1[2] | h.k1[3]) != 0, on2 = (h.k2[0] | h.k2[1] | h.k2[2] | h.k2[3]) != 0;
     if (!on1 && !on2) return 0;
-    if (!g1_wnaf_table(pq, tbl, dz)) { g1j pc = g1jq_pack(pq); glv_halves hc = h; g1_mul_glv_signed_cold(&packed, &pc, &hc); return 2; }
+    fq zc;
+    if (!g1_wnaf_table(pq, tbl, dz, zc)) { g1j pc = g1jq_pack(pq); glv_halves hc = h; g1_mul_glv_signed_cold(&packed, &pc, &hc); return 2; }
     const bool n1 = h.neg1 != 0, n2 = h.neg2 != 0;
     uint32_t a0 = h.k1[0] | 1u, a1 = h.k1[1], a2 = h.k1[2], a3 = h.k1[3], a4 = 0;
     uint32_t b0 = h.k2[0] | 1u, b1 = h.k2[1], b2 = h.k2[2], b3 = h.k2[3], b4 = 0;
@@ -163,14 +164,15 @@ template <int L = 4> __device__ __forceinline__ int g1_mul_glv_regular_quad(cons
     if (degenerate) { g1j pc = g1jq_pack(pq); glv_halves hc = h; g1_mul_glv_signed_cold(&packed, &pc, &hc); return 2; }   // (a degenerate addition never ends at infinity silently)
     // XYZZ -> the Jacobian image (X ZZ, Y ZZZ, ZZ): two more products, one level
     coop_mul2<L>(role, acc.x, acc.y, acc.zz, acc.zzz, out.x, out.y);
-    out.z = acc.zz;
+    out.z = mulq_inl(acc.zz, zc);                          // ... and back from the table's isomorphic curve
     return 1;
 }
 // The width-5 NAF schedule of g1_wnaf_loop_aq on a quad, digits from the twiddle's precomputed row (KZG_WNAF_ROW bytes: 132 for k1 -- digit i at
 // [i], the length at [131] -- then 132 for k2): 128 doublings + ~43 additions = ~556 levels.  For launches whose wavefronts hold ONE twiddle (the
 // zero-digit runs are data-dependent branches).  Same return contract.
 template <int L = 4> __device__ __forceinline__ int g1_mul_glv_wnaf_quad(const g1jq &pq, const fr &kk, g1aq *tbl, fq *dz, const int8_t *dg, g1jq &out, g1j &packed, uint32_t role) {
-    if (!g1_wnaf_table(pq, tbl, dz)) { g1j pc = g1jq_pack(pq); fr kc = kk; g1_mul_glv_cold(&packed, &pc, &kc); return 2; }
+    fq zc;
+    if (!g1_wnaf_table(pq, tbl, dz, zc)) { g1j pc = g1jq_pack(pq); fr kc = kk; g1_mul_glv_cold(&packed, &pc, &kc); return 2; }
     const int8_t *d1 = dg, *d2 = dg + 132;
     const int n1 = (int)(uint8_t)dg[131], n2 = (int)(uint8_t)dg[132 + 131];
     int j = (n1 > n2 ? n1 : n2) - 1;
@@ -205,7 +207,7 @@ template <int L = 4> __device__ __forceinline__ int g1_mul_glv_wnaf_quad(const g
 #pragma nounroll
     for (; pend > 0; pend--) quad_xyzz_dbl<L>(acc, role);
     coop_mul2<L>(role, acc.x, acc.y, acc.zz, acc.zzz, out.x, out.y);
-    out.z = acc.zz;
+    out.z = mulq_inl(acc.zz, zc);                          // ... and back from the table's isomorphic curve
     return 1;
 }
 #endif

@@ -260,8 +260,9 @@ int he_wnaf_table(g1j *out8, const g1j *a, int coz) {
     g1jq pq = g1jq_unpack(IN(a));
     g1aq tbl[8]; g1jq jt[8]; fq dz[7];
     int ok = 1;
-    if (coz) ok = (coz == 2 ? g1_wnaf_table_affine_coz<true>(pq, tbl, dz) : g1_wnaf_table_affine_coz<false>(pq, tbl, dz)) ? 1 : 0; else g1_wnaf_table_affine_q(pq, tbl, jt);
-    for (int i = 0; i < 8; i++) { g1j o; o.x = packq(tbl[i].x); o.y = packq(tbl[i].y); o.z = one<FpP>(); out8[i] = OUT(o); }
+    fq zc = unpackq(one<FpP>());                           // the co-Z table lives at a common Z (an affine table of an isomorphic curve): (x, y, zc) is the multiple
+    if (coz) ok = (coz == 2 ? g1_wnaf_table_affine_coz<true>(pq, tbl, dz, zc) : g1_wnaf_table_affine_coz<false>(pq, tbl, dz, zc)) ? 1 : 0; else g1_wnaf_table_affine_q(pq, tbl, jt);
+    for (int i = 0; i < 8; i++) { g1j o; o.x = packq(tbl[i].x); o.y = packq(tbl[i].y); o.z = packq(zc); out8[i] = OUT(g1_normalize(o)); }
     return ok;
 }
 // acc (= a, any Jacobian image) += sign * phi? * b (normalised to affine here) through g1jq_madd_entry; 1: fast formulas, 0: slow path
