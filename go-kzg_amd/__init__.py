@@ -233,10 +233,7 @@ class FFTSettings:
     def evaluate_poly_in_evaluation_form(self, poly, x, scale=0):
         """bls.EvaluatePolyInEvaluationForm(y, poly, x, fs.ExpandedRootsOfUnity[:fs.MaxWidth], scale) (bls/globals.go:106-153)"""
         poly, x, y = _fr(poly), _fr(x), fr_empty(1)
-        st = lib().kzg_hip_evaluate_poly_in_evaluation_form(self.h, _p(poly), poly.shape[0], _p(x), scale, _p(y))
-        if st == ERR_BAD_ARG:
-            raise KzgError(st, "x is in the domain")
-        _chk(st)
+        _chk(lib().kzg_hip_evaluate_poly_in_evaluation_form(self.h, _p(poly), poly.shape[0], _p(x), scale, _p(y)))
         return y[0]
 
     def das_fft_extension(self, vals):
@@ -614,10 +611,7 @@ class EthSettings:
     def evaluate_polynomial_in_evaluation_form(self, polynomial, x):
         """eth.EvaluatePolynomialInEvaluationForm (eth/helpers.go:207-211)"""
         poly, x, y = _fr(polynomial), _fr(x), fr_empty(1)
-        st = lib().kzg_hip_eth_evaluate_polynomial_in_evaluation_form(self.h, _p(poly), poly.shape[0], _p(x), _p(y))
-        if st == ERR_BAD_ARG:
-            raise KzgError(st, "x is in the domain")
-        _chk(st)
+        _chk(lib().kzg_hip_eth_evaluate_polynomial_in_evaluation_form(self.h, _p(poly), poly.shape[0], _p(x), _p(y)))
         return y[0]
 
     def compute_aggregate_kzg_proof(self, blobs):

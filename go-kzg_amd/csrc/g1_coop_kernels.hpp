@@ -107,7 +107,7 @@ template <bool DIF> static inline void launch_stage_coop(hipStream_t s, int lane
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_g1_fft_stage_quad<DIF, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         return true; }();
     (void)once;
-    const size_t lds = total * lanes <= 65536 ? 96 * 1024 : 0;
+    const size_t lds = total * lanes <= device_simd_lanes() ? 96 * 1024 : 0;
     const dim3 qg((uint32_t)((lanes * total + G1_BLOCK - 1) / G1_BLOCK));
     const uint32_t logn = ilog2_coop(n);
     const bool wn = g1_quad_wnaf(n, batch, m, lanes);

@@ -88,6 +88,11 @@ void launch_g1_decompress(hipStream_t s, const uint8_t *in48, g1j *out, uint64_t
 void launch_g1_fixed_base_powers(hipStream_t s, const fr *powers, uint64_t n, g1j *out);   // out[i] = powers[i] * G
 
 // ---------------- k_msm.hip ----------------
+// Lanes of ONE wavefront on every SIMD of the calling thread's current device: CUs x 4 SIMDs x 64 lanes (65 536 on the 256 CUs of an MI355X
+// in SPX mode; fewer on a partitioned part).  Every "does this launch still fit one wavefront per SIMD" heuristic of the launchers is written
+// against this value, never against a literal.  Cached per device, thread-safe.
+uint64_t device_simd_lanes();
+inline uint64_t device_simds() { return device_simd_lanes() / 64; }
 struct msm_plan {
     uint32_t c;        // window bits (fixed-base walk: signed digits in [-2^(c-1), 2^(c-1)]; bucket MSM: always 8)
     uint32_t nwin;     // windows of the fixed-base walk

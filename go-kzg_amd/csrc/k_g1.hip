@@ -164,7 +164,8 @@ bool g1_quad_enabled() { return g1_quad_forced() != 0; }
 // lanes per butterfly of a stage launch: 4, 2 or 1
 static int g1_stage_lanes(uint64_t butterflies) {
     if (g1_quad_forced() >= 0) return g1_quad_forced() == 0 ? 1 : g1_quad_forced() == 2 ? 2 : 4;
-    return butterflies * 4 <= 65536u ? 4 : butterflies * 2 <= 65536u ? 2 : 1;
+    const uint64_t one_round = device_simd_lanes();
+    return butterflies * 4 <= one_round ? 4 : butterflies * 2 <= one_round ? 2 : 1;
 }
 // The twiddles' precomputed width-5 NAF digit strings (264 bytes per twiddle in HBM) replace the per-butterfly recoding only where a
 // row is shared by many lanes (>= 512: measured +2.3 % on the 512-polynomial FK20 step); with one wavefront per twiddle every row is a
@@ -354,12 +355,12 @@ void launch_g1_fft_direct(hipStream_t s, const g1j *in, uint64_t in_stride, uint
         // as many lanes per term as keep the pass at one wavefront per SIMD (the caller's choice for full passes; pruned ones may take more)
         static const bool coop_off = [] { const char *e = getenv("KZG_HIP_G1_DIRECT_COOP"); return e && e[0] == '0'; }();
         int L = lanes;
-        if (g1_quad_enabled() && !coop_off && (logT < logR || logU < logR)) L = total * 4 <= 65536 ? 4 : total * 2 <= 65536 ? 2 : lanes;
+        if (g1_quad_enabled() && !coop_off && (logT < logR || logU < logR)) L = total * 4 <= device_simd_lanes() ? 4 : total * 2 <= device_simd_lanes() ? 2 : lanes;
         // 24 KiB of unused dynamic LDS on top of the 10 KiB the kernel needs: at most 4 of these one-wave workgroups fit a CU, so the
         // 1024 of a 4096-point pass land one per SIMD instead of 8 per CU on half of the chip (measured: 2.7 vs 5.4 ms per pass)
         // (only while the pass has at most one wavefront per SIMD: two transforms are 2048 workgroups and want both wave slots)
         const uint64_t wgs = (total * L + G1_DIRECT_BLOCK - 1) / G1_DIRECT_BLOCK;
-        const size_t pad_lds = wgs <= 1024 ? 24 * 1024 : 0;
+        const size_t pad_lds = wgs <= device_simds() ? 24 * 1024 : 0;
         const fr *sc = (p + 1 == npass) ? scale : nullptr;
         if (L > 1) launch_g1_direct_coop(s, L, (uint32_t)wgs, pad_lds, src, src_stride, src_valid, dst, logn, logR, Ns, roots, W, sc, total, logT, logU);
         else hipLaunchKernelGGL(k_g1_fft_direct, dim3((uint32_t)wgs), dim3(G1_DIRECT_BLOCK), pad_lds, s, src, src_stride, src_valid, dst, logn, logR, Ns, roots, W, sc, total, logT, logU);

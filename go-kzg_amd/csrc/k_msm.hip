@@ -424,7 +424,7 @@ void launch_msm(hipStream_t s, const msm_plan &p, const g1a *table, const fr *sc
                        L.offsets_off, K);
     // lanes per bucket: fill one round of resident wavefronts (131 072 lanes) when the batch alone does not, at most 16
     uint32_t S = 1;
-    while (S < 16 && batch * L.K * S * 2 <= 131072) S *= 2;
+    while (S < 16 && batch * L.K * S * 2 <= 2 * device_simd_lanes()) S *= 2;
     uint64_t total = batch * L.K * S;
     prof_begin(s, "msm_accumulate");
     hipLaunchKernelGGL(k_msm_accumulate, dim3((uint32_t)((total + MSM_ACC_BLOCK - 1) / MSM_ACC_BLOCK)), dim3(MSM_ACC_BLOCK), 0, s, table, ws, L.per_blob,
@@ -790,7 +790,7 @@ void launch_fb_direct_pass1(hipStream_t s, const g1a *table, uint64_t table_n, u
     while ((1ull << logn) < table_n) logn++;
     const uint64_t total = (batch * table_n) << logR, wgs = (total + 63) / 64;
     prof_begin(s, "fb_mul_vec");
-    hipLaunchKernelGGL(k_fb_direct_pass1, dim3((uint32_t)wgs), dim3(64), wgs <= 1024 ? 24 * 1024 : 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars, roots, W, logn, logR,
+    hipLaunchKernelGGL(k_fb_direct_pass1, dim3((uint32_t)wgs), dim3(64), wgs <= device_simds() ? 24 * 1024 : 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars, roots, W, logn, logR,
                        total, out);
     prof_end(s, "fb_mul_vec");
 }
@@ -908,22 +908,26 @@ void launch_fb_mul_vec(hipStream_t s, const g1a *table, uint64_t table_n, uint32
     prof_end(s, "fb_mul_vec");
 }
 
+uint64_t device_simd_lanes() {
+    static std::atomic<uint64_t> lanes_of_device[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::atomic<uint64_t> &slot = lanes_of_device[dev >= 0 && dev < 64 ? dev : 0];
+    uint64_t lanes = slot.load(std::memory_order_relaxed);
+    if (!lanes) {
+        int cus = 256;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); cus = 256; }
+        lanes = (uint64_t)(cus > 0 ? cus : 256) * 4 * 64;
+        slot.store(lanes, std::memory_order_relaxed);        // (a racing thread computes the same value)
+    }
+    return lanes;
+}
 static uint32_t fb_blocks_per_blob(uint64_t n, uint64_t batch, uint32_t *wsplit = nullptr) {
     // 131072 lanes = 2048 wavefronts = exactly the resident capacity at 2 waves per SIMD: ONE round.  Measured (512 blobs):
     // 131072 lanes 5.7 ms, 262144 lanes (two rounds) 6.4 ms, 98304 / 65536 lanes 10.4 ms.  KZG_HIP_FB_LANES overrides.
     // (thread-safe: coalescer leaders on several host threads get here at once; one value per device)
     static const uint64_t forced_lanes = [] { const char *e = getenv("KZG_HIP_FB_LANES"); return e ? strtoull(e, nullptr, 10) : 0ull; }();
-    static std::atomic<uint64_t> lanes_of_device[16];
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::atomic<uint64_t> &slot = lanes_of_device[dev >= 0 && dev < 16 ? dev : 0];
-    uint64_t lanes = forced_lanes ? forced_lanes : slot.load(std::memory_order_relaxed);
-    if (!lanes) {                                            // CUs x 4 SIMDs x 2 resident waves x 64 lanes (256 CUs: 131072)
-        int cus = 256;
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        lanes = (uint64_t)(cus > 0 ? cus : 256) * 4 * 2 * 64;
-        slot.store(lanes, std::memory_order_relaxed);        // (a racing thread computes the same value)
-    }
+    uint64_t lanes = forced_lanes ? forced_lanes : 2 * device_simd_lanes();   // CUs x 4 SIMDs x 2 resident waves x 64 lanes (256 CUs: 131072)
     if (lanes < FB_ACC_BLOCK) lanes = FB_ACC_BLOCK;
     uint64_t target = lanes / FB_ACC_BLOCK;
     uint64_t bpb = target / (batch ? batch : 1);

@@ -212,18 +212,16 @@ int kzg_hip_eth_compute_aggregate_kzg_proof(kzg_hip_eth *eth, const void *blobs_
  * blobs and the EXPECTED commitments (batch x 48), then y = EvaluatePolynomialInEvaluationForm(aggregatedPoly, z).  Writes the aggregated
  * commitment (one G1 Kilic image), z, y (optional) and the aggregated polynomial (n Fr, optional); the pairing check of
  * VerifyKZGProofFromPoints (eth/helpers.go:55-68) stays with the caller.  KZG_HIP_ERR_BAD_BLOB as above; KZG_HIP_ERR_BAD_POINT: a commitment does
- * not decode (:153-156); KZG_HIP_ERR_BAD_ARG: z inside the domain (the reference's barycentric formula divides by zero there). */
+ * not decode (:153-156).  z inside the domain (probability 2^-243): y = 0, what the reference's formula returns there (see below). */
 int kzg_hip_eth_compute_aggregated_poly_and_commitment(kzg_hip_eth *eth, const void *blobs_le32, const void *commitments48, uint64_t batch, void *out_poly_fr,
                                                        void *out_commitment_g1, void *out_z_fr, void *out_y_fr);
 /* bls.EvaluatePolyInEvaluationForm(y, poly, x, fs.ExpandedRootsOfUnity[:fs.MaxWidth], scale) (bls/globals.go:106-153, as called in
  * fft_fr_test.go:73-99): poly[i] = f(w^(i << scale)), n = MaxWidth >> scale (else KZG_HIP_ERR_LEN_MISMATCH: the reference's panic), barycentric
- * evaluation at x.  KZG_HIP_ERR_BAD_ARG: x is one of the roots (the formula divides by zero). */
+ * evaluation at x.  x one of the roots: y = 0 like the reference, whose last factor (x^n - 1) / n vanishes there whatever its batch inversion made of
+ * the zero denominator (bls/globals.go:141-152) -- NOT f(x). */
 int kzg_hip_evaluate_poly_in_evaluation_form(kzg_hip_fft *fs, const void *poly_fr, uint64_t n, const void *x_fr, uint32_t scale, void *out_y_fr);
 /* eth.EvaluatePolynomialInEvaluationForm (eth/helpers.go:207-211): the same on DomainFr (bit-reversed order) */
 int kzg_hip_eth_evaluate_polynomial_in_evaluation_form(kzg_hip_eth *eth, const void *poly_fr, uint64_t n, const void *x_fr, void *out_y_fr);
-/* test hook: SHA-256 of a host buffer through the transcript's implementation (x86 SHA extensions or the portable loop; no device needed) */
-void kzg_hip_test_sha256(const void *data, uint64_t len, void *out32);
-
 /* ---- erasure recovery ----
  * FFTSettings.ZeroPolyViaMultiplication (zero_poly.go:116-217): vanishing polynomial of the missing indices of a size-`length`
  * domain; writes `length` evaluations and `length` coefficients (zero-padded).  No missing index -> all zeros (:117-119). */
@@ -234,23 +232,6 @@ int kzg_hip_zero_poly_via_multiplication(kzg_hip_fft *fs, const uint64_t *missin
  * sample is not reproduced (the reference's error). */
 int kzg_hip_recover_poly_from_samples(kzg_hip_fft *fs, const void *samples_fr, const uint8_t *present, uint64_t n, void *out_fr);
 
-/* ---- instrumentation for bench.py: HIP-event time of the dominant kernel since the last reset (ms) and launch count ---- */
-void kzg_hip_prof_reset(kzg_hip_fft *fs, int enable);
-int kzg_hip_prof_read(kzg_hip_fft *fs, const char *kernel, double *total_ms, uint64_t *launches);
-/* live calibration for the roofline: lane-operations per second of v_mad_u64_u32 and v_add_u32 and lazy 13-limb F_p products per
- * second (8 resident waves per SIMD, independent chains) on the handle's device */
-int kzg_hip_calibrate(kzg_hip_fft *fs, double *mad_per_s, double *add_per_s, double *fp_mul_per_s);
-/* drop-in measurement: `threads` host threads each make `calls` blocking one-polynomial calls (op 0: kzg_hip_commit_to_poly,
- * op 1: kzg_hip_compute_proof_single) on host buffers taken round-robin from blobs_fr (nblobs x n Fr); out_g1 holds `threads`
- * points (each thread's last result); *seconds = wall time from the common start to the last return */
-int kzg_hip_bench_drop_in(kzg_hip_kzg *ks, int op, const void *blobs_fr, uint64_t n, uint64_t nblobs, unsigned threads, unsigned calls, void *out_g1,
-                          double *seconds);
-/* the same for kzg_hip_eth_compute_kzg_proof: thread t evaluates at z = 5 + t; out48 holds `threads` proofs (each thread's last) */
-int kzg_hip_bench_drop_in_eth_proof(kzg_hip_eth *eth, const void *polys_fr, uint64_t n, uint64_t npolys, unsigned threads, unsigned calls, void *out48,
-                                    double *seconds);
-/* and for kzg_hip_fft_fr on host buffers (thread t transforms row t % nrows of vals_fr, nrows x n Fr; out_fr: threads x n Fr): the
- * per-handle stream pool at work */
-int kzg_hip_bench_threads_fft_fr(kzg_hip_fft *fs, const void *vals_fr, uint64_t n, uint64_t nrows, unsigned threads, unsigned calls, void *out_fr, double *seconds);
 /* shape of the fixed-base table CommitToPoly walks (built lazily by the first commitment): signed window bits c, window count and
  * bytes of HBM; all zero before the first commitment or when the setup is too small for a table (classic bucket path) */
 int kzg_hip_kzg_table_info(kzg_hip_kzg *ks, uint32_t *window_bits, uint32_t *windows, uint64_t *table_bytes);

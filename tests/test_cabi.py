@@ -9,10 +9,13 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    src = open(os.path.join(ROOT, "include", "kzg_hip.h")).read()
+def declared_symbols(path=os.path.join(ROOT, "include", "kzg_hip.h")):
+    src = open(path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(kzg_hip_[a-z0-9_]+)\s*\(", src)))
+
+
+INTERNAL_H = os.path.join(ROOT, "go-kzg_amd", "csrc", "kzg_hip_internal.h")
 
 
 def test_header_declares_the_boundary():
@@ -26,8 +29,15 @@ def test_header_declares_the_boundary():
 def test_library_exports_every_declared_symbol():
     import gokzg_amd
     lib = ctypes.CDLL(gokzg_amd.LIB_PATH)
-    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    missing = [s for s in declared_symbols() + declared_symbols(INTERNAL_H) if not hasattr(lib, s)]
     assert not missing, missing
+    # the boundary header carries no bench / test / calibration hook: those live in go-kzg_amd/csrc/kzg_hip_internal.h
+    assert not [s for s in declared_symbols() if re.search(r"_(bench|test|prof|calibrate)(_|$)", s)]
+    # ... and nothing is exported that neither header declares
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", gokzg_amd.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(l.split()[-1] for l in out.splitlines() if " T " in l and not l.split()[-1].startswith(("_init", "_fini")))
+    assert set(exported) == set(declared_symbols() + declared_symbols(INTERNAL_H)), sorted(set(exported) ^ set(declared_symbols() + declared_symbols(INTERNAL_H)))
     gokzg_amd.lib()   # the binding's own signature table must resolve too
 
 
