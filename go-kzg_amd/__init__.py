@@ -119,6 +119,18 @@ def lib():
         "kzg_hip_calibrate": (i32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "kzg_hip_bench_drop_in": (i32, [vp, i32, vp, u64, u64, u32, u32, vp, C.POINTER(C.c_double)]),
         "kzg_hip_kzg_table_info": (i32, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(u64)]),
+        "kzg_hip_da_using_fk20_multi_batch": (i32, [vp, vp, u64, u64, vp]),
+        "kzg_hip_multi_settings_new": (i32, [C.POINTER(i32), u32, u32, vp, u64, pp]), "kzg_hip_multi_settings_free": (None, [vp]),
+        "kzg_hip_multi_device_count": (u32, [vp]), "kzg_hip_multi_device": (i32, [vp, u32]),
+        "kzg_hip_multi_fft": (vp, [vp, u32]), "kzg_hip_multi_kzg": (vp, [vp, u32]),
+        "kzg_hip_multi_transport": (C.c_char_p, [vp]), "kzg_hip_multi_transport_note": (C.c_char_p, [vp]), "kzg_hip_multi_exchanges": (u64, [vp]),
+        "kzg_hip_multi_set_fft_sharding": (i32, [vp, i32]), "kzg_hip_multi_set_table_budget_gb": (i32, [vp, C.c_double]),
+        "kzg_hip_multi_commit_to_poly_batch": (i32, [vp, vp, u64, u64, vp]),
+        "kzg_hip_multi_compute_proof_single_batch": (i32, [vp, vp, u64, u64, vp, vp]),
+        "kzg_hip_multi_fk20_single_settings_new": (i32, [vp, u64, pp]), "kzg_hip_multi_fk20_single_settings_free": (None, [vp]),
+        "kzg_hip_multi_da_using_fk20_batch": (i32, [vp, vp, u64, u64, vp]), "kzg_hip_multi_da_using_fk20": (i32, [vp, vp, u64, vp]),
+        "kzg_hip_multi_fk20_multi_settings_new": (i32, [vp, u64, u64, pp]), "kzg_hip_multi_fk20_multi_settings_free": (None, [vp]),
+        "kzg_hip_multi_da_using_fk20_multi_batch": (i32, [vp, vp, u64, u64, vp]), "kzg_hip_multi_da_using_fk20_multi": (i32, [vp, vp, u64, vp]),
         "kzg_hip_prof_reset": (None, [vp, i32]), "kzg_hip_prof_read": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64)]),
     }
     for name, (res, args) in sig.items():
@@ -555,6 +567,148 @@ class FK20MultiSettings:
         poly = _fr(poly)
         out = g1_empty(2 * poly.shape[0] // self.chunk_len)
         _chk(lib().kzg_hip_da_using_fk20_multi(self.h, _p(poly), poly.shape[0], _p(out)))
+        return out
+
+    def da_using_fk20_multi_batch(self, polys):
+        """DAUsingFK20Multi on each row of polys (batch, n, 4) -> (batch, 2n / chunk_len, 3, 6)"""
+        polys = np.ascontiguousarray(polys, dtype=np.uint64)
+        b, n = polys.shape[0], polys.shape[1]
+        out = np.zeros((b, 2 * n // self.chunk_len, 3, 6), dtype=np.uint64)
+        _chk(lib().kzg_hip_da_using_fk20_multi_batch(self.h, _p(polys), n, b, _p(out)))
+        return out
+
+
+class _Borrowed:
+    """a settings object owned by a MultiKZGSettings: same methods, close() is a no-op"""
+
+    def close(self):
+        self.h = None
+
+
+class _BorrowedFFT(_Borrowed, FFTSettings):
+    def __init__(self, h, max_scale, device):
+        self.h, self.max_scale, self.max_width, self.device = C.c_void_p(h), max_scale, 1 << max_scale, device
+
+
+class _BorrowedKZG(_Borrowed, KZGSettings):
+    def __init__(self, h, fs, n_setup):
+        self.h, self.fs, self.n_setup = C.c_void_p(h), fs, n_setup
+
+
+class MultiKZGSettings:
+    """NewFFTSettings(max_scale) + NewKZGSettings(fs, secret_g1) on EVERY device of `devices`, behind one handle
+    (kzg_hip_multi_*, include/kzg_hip.h): what the Go shim exposes as kzg.NewMultiKZGSettings.  A list may repeat a device."""
+
+    def __init__(self, devices, max_scale, secret_g1):
+        secret_g1 = _g1(secret_g1)
+        devs = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        _chk(lib().kzg_hip_multi_settings_new(devs, len(devices), max_scale, _p(secret_g1), secret_g1.shape[0], C.byref(h)))
+        self.h, self.devices, self.max_scale, self.n_setup = h, list(devices), max_scale, secret_g1.shape[0]
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().kzg_hip_multi_settings_free(self.h)
+            self.h = None
+
+    @property
+    def transport(self):
+        """"rccl" (ncclAllGather between distinct devices) or "peer-copy" (hipMemcpyPeerAsync: a repeated device, or no librccl)"""
+        return lib().kzg_hip_multi_transport(self.h).decode()
+
+    @property
+    def transport_note(self):
+        return lib().kzg_hip_multi_transport_note(self.h).decode()
+
+    @property
+    def exchanges(self):
+        return lib().kzg_hip_multi_exchanges(self.h)
+
+    def fft_settings(self, i):
+        return _BorrowedFFT(lib().kzg_hip_multi_fft(self.h, i), self.max_scale, lib().kzg_hip_multi_device(self.h, i))
+
+    def kzg_settings(self, i):
+        """entry i's KZGSettings (borrowed): every single-device method on a chosen device"""
+        return _BorrowedKZG(lib().kzg_hip_multi_kzg(self.h, i), self.fft_settings(i), self.n_setup)
+
+    def set_fft_sharding(self, mode):
+        """one-polynomial FK20 calls: "gather" (all-gather of hExtFFT, transforms on the first device), "sharded" (both G1 transforms
+        sharded too: five all-gathers) or None (default: sharded from 4 devices on)"""
+        _chk(lib().kzg_hip_multi_set_fft_sharding(self.h, {None: -1, "gather": 0, "sharded": 1}[mode]))
+
+    def set_table_budget_gb(self, gb):
+        _chk(lib().kzg_hip_multi_set_table_budget_gb(self.h, float(gb)))
+
+    def commit_to_poly_batch(self, coeffs):
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64)
+        b, n = coeffs.shape[0], coeffs.shape[1]
+        out = g1_empty(b)
+        _chk(lib().kzg_hip_multi_commit_to_poly_batch(self.h, _p(coeffs), n, b, _p(out)))
+        return out
+
+    def compute_proof_single_batch(self, polys, xs):
+        polys = np.ascontiguousarray(polys, dtype=np.uint64)
+        xs = np.ascontiguousarray(xs, dtype=np.uint64)
+        b, n = polys.shape[0], polys.shape[1]
+        out = g1_empty(b)
+        _chk(lib().kzg_hip_multi_compute_proof_single_batch(self.h, _p(polys), n, b, _p(xs), _p(out)))
+        return out
+
+
+class MultiFK20SingleSettings:
+    """NewFK20SingleSettings (kzg.go:43-64) on every device of a MultiKZGSettings"""
+
+    def __init__(self, mks, n2):
+        h = C.c_void_p()
+        _chk(lib().kzg_hip_multi_fk20_single_settings_new(mks.h, n2, C.byref(h)))
+        self.h, self.mks, self.n2 = h, mks, n2
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().kzg_hip_multi_fk20_single_settings_free(self.h)
+            self.h = None
+
+    def da_using_fk20(self, poly):
+        """ONE polynomial over all devices (Toeplitz stage by output position + all-gather(s))"""
+        poly = _fr(poly)
+        out = g1_empty(2 * poly.shape[0])
+        _chk(lib().kzg_hip_multi_da_using_fk20(self.h, _p(poly), poly.shape[0], _p(out)), error_ok=True)
+        return out
+
+    def da_using_fk20_batch(self, polys):
+        """polynomials divided among the devices"""
+        polys = np.ascontiguousarray(polys, dtype=np.uint64)
+        b, n = polys.shape[0], polys.shape[1]
+        out = np.zeros((b, 2 * n, 3, 6), dtype=np.uint64)
+        _chk(lib().kzg_hip_multi_da_using_fk20_batch(self.h, _p(polys), n, b, _p(out)))
+        return out
+
+
+class MultiFK20MultiSettings:
+    """NewFK20MultiSettings (kzg.go:73-116) on every device of a MultiKZGSettings"""
+
+    def __init__(self, mks, n2, chunk_len):
+        h = C.c_void_p()
+        _chk(lib().kzg_hip_multi_fk20_multi_settings_new(mks.h, n2, chunk_len, C.byref(h)))
+        self.h, self.mks, self.n2, self.chunk_len = h, mks, n2, chunk_len
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().kzg_hip_multi_fk20_multi_settings_free(self.h)
+            self.h = None
+
+    def da_using_fk20_multi(self, poly):
+        """ONE polynomial over all devices (fk20_multi.go:113-133)"""
+        poly = _fr(poly)
+        out = g1_empty(2 * poly.shape[0] // self.chunk_len)
+        _chk(lib().kzg_hip_multi_da_using_fk20_multi(self.h, _p(poly), poly.shape[0], _p(out)), error_ok=True)
+        return out
+
+    def da_using_fk20_multi_batch(self, polys):
+        polys = np.ascontiguousarray(polys, dtype=np.uint64)
+        b, n = polys.shape[0], polys.shape[1]
+        out = np.zeros((b, 2 * n // self.chunk_len, 3, 6), dtype=np.uint64)
+        _chk(lib().kzg_hip_multi_da_using_fk20_multi_batch(self.h, _p(polys), n, b, _p(out)))
         return out
 
 

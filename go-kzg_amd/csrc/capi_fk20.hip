@@ -330,6 +330,14 @@ int kzg_hip_da_using_fk20_multi(kzg_hip_fk20m *fk, const void *poly_fr, uint64_t
     if (!coalescing_enabled()) return fk20_run_host(&fk->c, poly_fr, n, n, 1, 0, 1, 1, out_g1);
     return fk20_da_coalesced(&fk->c, poly_fr, n, out_g1);
 }
+int kzg_hip_da_using_fk20_multi_batch(kzg_hip_fk20m *fk, const void *poly_fr, uint64_t n, uint64_t batch, void *out_g1) {
+    if (!fk || !poly_fr || !out_g1) return KZG_HIP_ERR_BAD_ARG;
+    if (n > fk->c.ks->fs->W / 2) return KZG_HIP_ERR_TOO_WIDE;     // fk20_multi.go:115-117
+    if (!is_pow2(n)) return KZG_HIP_ERR_NOT_POW2;                 // fk20_multi.go:118-120
+    if (2 * n != fk->c.n2) return KZG_HIP_ERR_LEN_MISMATCH;
+    if (!batch) return KZG_HIP_OK;
+    return fk20_run_host(&fk->c, poly_fr, n, n, batch, 0, 1, 1, out_g1);
+}
 int kzg_hip_da_using_fk20_multi_batch_dev(kzg_hip_fk20m *fk, const void *d_poly_fr, uint64_t n, uint64_t batch, void *d_out_g1, void *stream) {
     if (!fk || !d_poly_fr || !d_out_g1) return KZG_HIP_ERR_BAD_ARG;
     if (n > fk->c.ks->fs->W / 2) return KZG_HIP_ERR_TOO_WIDE;

@@ -1,0 +1,475 @@
+// capi_multi.hip -- several GPUs behind ONE handle of the C ABI (threading row: "multi-GPU handle owns one context per device"; 8e).
+//
+// The reference is a single-process library (kzg.go:11-19, fk20_multi.go:58-109): a drop-in that uses the 8 GPUs of a node has to do so
+// inside the library.  A kzg_hip_multi owns one FFTSettings + KZGSettings (+ tables) per listed device and offers
+//   * batch calls, sharded by polynomial (contiguous shares, a host thread per device on the single-device entry points, results written
+//     straight into the caller's buffer): no data-path collective;
+//   * ONE DAUsingFK20 / DAUsingFK20Multi split over the devices: the Toeplitz stage by output position, an ALL-GATHER of the
+//     hExtFFT slices, and then either the two G1 transforms on the first device ("gather") or both transforms sharded by decimation with
+//     two more all-gathers each (5 in total, the scheme of SURVEY.md 8e; "sharded").
+// The all-gather is ncclAllGather on ncclUint8 over single-process communicators (ncclCommInitAll; RCCL over xGMI) when every listed device
+// is distinct; a list that repeats a device (a 1-GPU box testing [0, 0]) or a process without RCCL exchanges the same slices with
+// hipMemcpyPeerAsync.  RCCL is bound at the first multi-device handle, not at load time: librccl.so is 573 MB, single-GPU callers never
+// need it, and a process that already holds a copy (PyTorch bundles one with the same SONAME) must not get a second one.
+#include "capi_common.hpp"
+#include <rccl/rccl.h>   // types and prototypes; the functions are resolved at run time (rccl_api)
+#include <dlfcn.h>
+#include <atomic>
+
+namespace {
+
+struct rccl_api {
+    void *h = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+// one binding per process; nullptr (with the reason in *why) when no RCCL can be found
+rccl_api *rccl_bind(std::string *why) {
+    static std::mutex mu;
+    static rccl_api api;
+    static bool tried = false;
+    static std::string err;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!tried) {
+        tried = true;
+        const char *names[] = {getenv("KZG_HIP_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *nm : names) {
+            if (!nm || !*nm) continue;
+            api.h = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+            if (api.h) break;
+            err = dlerror();
+        }
+        if (api.h) {
+            api.CommInitAll = (decltype(api.CommInitAll))dlsym(api.h, "ncclCommInitAll");
+            api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.h, "ncclCommDestroy");
+            api.AllGather = (decltype(api.AllGather))dlsym(api.h, "ncclAllGather");
+            api.GroupStart = (decltype(api.GroupStart))dlsym(api.h, "ncclGroupStart");
+            api.GroupEnd = (decltype(api.GroupEnd))dlsym(api.h, "ncclGroupEnd");
+            api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.h, "ncclGetErrorString");
+            if (!api.CommInitAll || !api.CommDestroy || !api.AllGather || !api.GroupStart || !api.GroupEnd || !api.GetErrorString) {
+                err = "librccl lacks one of ncclCommInitAll / ncclCommDestroy / ncclAllGather / ncclGroupStart / ncclGroupEnd / ncclGetErrorString";
+                dlclose(api.h); api.h = nullptr;
+            }
+        }
+    }
+    if (!api.h) { if (why) *why = err; return nullptr; }
+    return &api;
+}
+
+}  // namespace
+
+struct multi_dev {
+    int device = 0;
+    kzg_hip_fft *fs = nullptr;
+    kzg_hip_kzg *ks = nullptr;
+    hipStream_t s = nullptr;       // this device's stream for sharded calls
+    hipEvent_t ev = nullptr;       // ... and its event for the peer-copy exchange and the cross-stream barrier
+};
+struct kzg_hip_multi {
+    std::vector<multi_dev> d;
+    rccl_api *nccl = nullptr;              // non-null: the exchange is ncclAllGather
+    std::vector<ncclComm_t> comms;
+    std::string transport = "peer-copy", transport_note;
+    int fft_mode = -1;                     // -1 default policy, 0 gather, 1 sharded transforms
+    std::mutex mu;                         // sharded calls (collectives) on a handle run one at a time
+    std::atomic<uint64_t> n_allgather{0};  // exchanges performed (tests and bench read it)
+};
+struct kzg_hip_multi_fk20s { kzg_hip_multi *m = nullptr; std::vector<kzg_hip_fk20s *> fk; uint64_t n2 = 0; };
+struct kzg_hip_multi_fk20m { kzg_hip_multi *m = nullptr; std::vector<kzg_hip_fk20m *> fk; uint64_t n2 = 0, l = 1; };
+
+namespace {
+
+// contiguous share of `total` units for part i of `parts` (the split multi_gpu.py's shard_units makes between ranks)
+inline void share(uint64_t total, uint64_t parts, uint64_t i, uint64_t *lo, uint64_t *hi) {
+    uint64_t base = total / parts, rem = total % parts;
+    *lo = i * base + std::min<uint64_t>(i, rem);
+    *hi = *lo + base + (i < rem ? 1 : 0);
+}
+
+// runs f(i) on one host thread per device (the calling thread takes device 0) and returns the first non-zero status
+template <class F> int per_device(kzg_hip_multi *m, F f) {
+    const size_t D = m->d.size();
+    std::vector<int> st(D, KZG_HIP_OK);
+    std::vector<std::string> errs(D);
+    std::vector<std::thread> th;
+    auto body = [&](size_t i) {
+        try { st[i] = f(i); } catch (const std::exception &e) { g_last_error = e.what(); st[i] = KZG_HIP_ERR_HIP; }
+        if (st[i] == KZG_HIP_ERR_HIP) errs[i] = g_last_error;   // g_last_error is thread-local: carry the text to the caller's thread
+    };
+    for (size_t i = 1; i < D; i++) th.emplace_back(body, i);
+    body(0);
+    for (auto &t : th) t.join();
+    for (size_t i = 0; i < D; i++)
+        if (st[i] != KZG_HIP_OK) { if (st[i] == KZG_HIP_ERR_HIP) g_last_error = errs[i]; return st[i]; }
+    return KZG_HIP_OK;
+}
+
+// stream-ordered temporaries of one device of a sharded call; frees on that device whatever the calling thread's current device is
+struct mtmp {
+    int device; hipStream_t s; std::vector<void *> ptrs;
+    mtmp(int dev, hipStream_t st) : device(dev), s(st) {}
+    mtmp(mtmp &&) = default;
+    mtmp(const mtmp &) = delete;
+    template <class T> int alloc(T **p, size_t count) {
+        *p = nullptr;
+        if (!count) count = 1;
+        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipMallocAsync((void **)p, count * sizeof(T), s));
+        ptrs.push_back(*p);
+        return KZG_HIP_OK;
+    }
+    ~mtmp() { if (ptrs.empty()) return; (void)hipSetDevice(device); for (void *p : ptrs) (void)hipFreeAsync(p, s); }
+};
+// whatever way a sharded call returns, every device's stream has drained before its temporaries are released and the handle is unlocked
+struct drain_all {
+    kzg_hip_multi *m;
+    explicit drain_all(kzg_hip_multi *mm) : m(mm) {}
+    ~drain_all() { for (auto &d : m->d) { (void)hipSetDevice(d.device); (void)hipStreamSynchronize(d.s); } }
+};
+
+// every stream waits for everything enqueued so far on every other stream
+int cross_barrier(kzg_hip_multi *m) {
+    for (auto &d : m->d) { HIPCHK(hipSetDevice(d.device)); HIPCHK(hipEventRecord(d.ev, d.s)); }
+    for (auto &d : m->d) {
+        HIPCHK(hipSetDevice(d.device));
+        for (auto &o : m->d) if (&o != &d) HIPCHK(hipStreamWaitEvent(d.s, o.ev, 0));
+    }
+    return KZG_HIP_OK;
+}
+
+// In-place all-gather of bytes: device i holds its slice at buf[i] + i * bytes_each and ends with all D slices in buf[i].
+int all_gather_bytes(kzg_hip_multi *m, const std::vector<uint8_t *> &buf, size_t bytes_each) {
+    const size_t D = m->d.size();
+    m->n_allgather++;
+    if (m->nccl) {
+        rccl_api *n = m->nccl;
+        ncclResult_t r = n->GroupStart();
+        hipError_t he = hipSuccess;
+        for (size_t i = 0; i < D && r == ncclSuccess && he == hipSuccess; i++) {   // one thread drives every communicator: the calls form one group
+            he = hipSetDevice(m->d[i].device);
+            if (he == hipSuccess) r = n->AllGather(buf[i] + i * bytes_each, buf[i], bytes_each, ncclUint8, m->comms[i], m->d[i].s);
+        }
+        ncclResult_t r2 = n->GroupEnd();   // always closed, also after a failure inside the group
+        if (r == ncclSuccess) r = r2;
+        HIPCHK(he);
+        if (r != ncclSuccess) { g_last_error = std::string("ncclAllGather failed: ") + n->GetErrorString(r); return KZG_HIP_ERR_HIP; }
+        return KZG_HIP_OK;
+    }
+    // peer copies: device j pulls slice i from device i once i's stream has produced it
+    for (auto &d : m->d) { HIPCHK(hipSetDevice(d.device)); HIPCHK(hipEventRecord(d.ev, d.s)); }
+    for (size_t j = 0; j < D; j++) {
+        HIPCHK(hipSetDevice(m->d[j].device));
+        for (size_t i = 0; i < D; i++) {
+            if (i == j) continue;
+            HIPCHK(hipStreamWaitEvent(m->d[j].s, m->d[i].ev, 0));
+            if (m->d[i].device == m->d[j].device) HIPCHK(hipMemcpyAsync(buf[j] + i * bytes_each, buf[i] + i * bytes_each, bytes_each, hipMemcpyDeviceToDevice, m->d[j].s));
+            else HIPCHK(hipMemcpyPeerAsync(buf[j] + i * bytes_each, m->d[j].device, buf[i] + i * bytes_each, m->d[i].device, bytes_each, m->d[j].s));
+        }
+    }
+    return cross_barrier(m);   // a source buffer may be released (stream-ordered, on its own stream) only after every reader is done
+}
+
+// x[a] = src[D a + r], a < count: the residue class r of a sequence (decimation in time by D)
+__global__ void k_multi_gather_stride(const g1j *src, uint64_t D, uint64_t r, uint64_t count, g1j *x) {
+    uint64_t a = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (a < count) x[a] = src[D * a + r];
+}
+// operands of the radix-D combine of a transform of size N = D M from its D sub-transforms Y_r (M points each):
+//   out[t] = sum_r w_N^(r t) Y_r[t mod M]   for t in [t0, t0 + cnt)
+// row r of pts / sc (cnt entries each) holds Y_r[t mod M] and w^(r t); roots = Expanded / ReverseRootsOfUnity with stride W / N
+__global__ void k_multi_combine_operands(const g1j *Y, const fr *roots, uint64_t root_stride, uint64_t N, uint64_t M, uint64_t D, uint64_t t0, uint64_t cnt, g1j *pts, fr *sc) {
+    uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (e >= D * cnt) return;
+    uint64_t r = e / cnt, t = t0 + e % cnt;
+    pts[e] = Y[r * M + (t & (M - 1))];
+    sc[e] = roots[((r * t) & (N - 1)) * root_stride];
+}
+
+// One G1 transform of size N (inv: with ReverseRootsOfUnity, unscaled) of the sequence x (replicated on every device; only x[:n_valid] is
+// non-trivial) sharded by decimation in time over the D devices: device r transforms the residue class r (size M = N / D), the sub-results
+// are all-gathered, device r combines the output slice [r cnt, (r + 1) cnt) of the first n_out = D cnt outputs.  out[r] receives that slice
+// at out[r] + r * cnt (the caller all-gathers or reads it).  Two launches of scalar multiplications per device: M-point transform, D - 1
+// products per output.
+int sharded_g1_fft(kzg_hip_multi *m, std::vector<mtmp> &tmp, const std::vector<const g1j *> &x, uint64_t n_valid, uint64_t N, int inv, uint64_t n_out,
+                   const std::vector<g1j *> &out) {
+    const uint64_t D = m->d.size(), M = N / D, cnt = n_out / D;
+    std::vector<uint8_t *> ybuf(D);
+    for (uint64_t r = 0; r < D; r++) {
+        multi_dev &d = m->d[r];
+        g1j *xr = nullptr, *Y = nullptr;
+        const uint64_t valid_r = n_valid > r ? (n_valid - r + D - 1) / D : 0;   // elements D a + r below n_valid
+        CHK(tmp[r].alloc(&xr, std::max<uint64_t>(valid_r, 1))); CHK(tmp[r].alloc(&Y, N));
+        HIPCHK(hipSetDevice(d.device));
+        if (valid_r) hipLaunchKernelGGL(k_multi_gather_stride, dim3((uint32_t)((valid_r + 255) / 256)), dim3(256), 0, d.s, x[r], D, r, valid_r, xr);
+        CHK(g1_fft_rows(d.fs, d.s, xr, valid_r, valid_r, Y + r * M, M, 1, inv));
+        HIPCHK(hipGetLastError());
+        ybuf[r] = (uint8_t *)Y;
+    }
+    CHK(all_gather_bytes(m, ybuf, M * sizeof(g1j)));
+    for (uint64_t r = 0; r < D; r++) {
+        multi_dev &d = m->d[r];
+        g1j *pts = nullptr, *prod = nullptr; fr *sc = nullptr;
+        CHK(tmp[r].alloc(&pts, D * cnt)); CHK(tmp[r].alloc(&prod, D * cnt)); CHK(tmp[r].alloc(&sc, D * cnt));
+        HIPCHK(hipSetDevice(d.device));
+        const fr *roots = inv ? d.fs->d_reversed : d.fs->d_expanded;
+        hipLaunchKernelGGL(k_multi_combine_operands, dim3((uint32_t)((D * cnt + 255) / 256)), dim3(256), 0, d.s, (const g1j *)ybuf[r], roots, d.fs->W / N, N, M, D, r * cnt, cnt, pts, sc);
+        HIPCHK(hipMemcpyAsync(prod, pts, cnt * sizeof(g1j), hipMemcpyDeviceToDevice, d.s));           // the term of class 0 has twiddle one
+        launch_g1_mul_vec(d.s, pts + cnt, (D - 1) * cnt, sc + cnt, 1, (D - 1) * cnt, prod + cnt);
+        launch_g1_sum_files(d.s, prod, D, cnt, 1, out[r] + r * cnt);
+        HIPCHK(hipGetLastError());
+    }
+    return KZG_HIP_OK;
+}
+
+bool sharded_fft_default(const kzg_hip_multi *m) {
+    if (const char *e = getenv("KZG_HIP_MULTI_FFT")) return !strcmp(e, "sharded");
+    if (m->fft_mode >= 0) return m->fft_mode == 1;
+    return m->d.size() >= 4;   // two devices halve one of three launches of a lone transform and pay two exchanges for it
+}
+
+// DAUsingFK20 / DAUsingFK20Multi of ONE polynomial over all devices of the handle (fk20_single.go:176-196, fk20_multi.go:113-133)
+int fk20_da_sharded(kzg_hip_multi *m, const std::vector<fk20_core *> &core, const void *poly_fr, uint64_t n, void *out_g1) {
+    KZG_TRY
+    std::lock_guard<std::mutex> lk(m->mu);
+    const uint64_t D = m->d.size(), k = core[0]->k, k2 = 2 * k;
+    const uint64_t cnt = (k2 + D - 1) / D;                       // output positions per device (the last share may be short)
+    std::vector<mtmp> tmp; tmp.reserve(D);
+    for (auto &d : m->d) tmp.emplace_back(d.device, d.s);
+    drain_all drain(m);                                          // declared after tmp: streams drain before the temporaries go
+    std::vector<uint8_t *> hext(D);
+    // (1) Toeplitz stage, sharded by output position; every device needs the coefficients (n x 32 B)
+    for (uint64_t i = 0; i < D; i++) {
+        multi_dev &d = m->d[i];
+        fr *d_poly = nullptr; g1j *d_hext = nullptr;
+        CHK(tmp[i].alloc(&d_poly, n)); CHK(tmp[i].alloc(&d_hext, D * cnt));
+        HIPCHK(hipSetDevice(d.device));
+        HIPCHK(hipMemcpyAsync(d_poly, poly_fr, n * sizeof(fr), hipMemcpyHostToDevice, d.s));
+        const uint64_t j0 = std::min(i * cnt, k2), j1 = std::min(j0 + cnt, k2);
+        if (j1 > j0) CHK(fk20_hext(core[i], d.s, d_poly, n, n, 1, j0, j1 - j0, d_hext + j0));
+        hext[i] = (uint8_t *)d_hext;
+    }
+    CHK(all_gather_bytes(m, hext, cnt * sizeof(g1j)));           // all-gather #1: hExtFFT
+    const bool pow2_devs = (D & (D - 1)) == 0;
+    g1j *d_res = nullptr;                                        // the 2k proofs, reverse-bit order, Kilic images, on device 0
+    if (D > 1 && pow2_devs && k2 >= 8 * D && sharded_fft_default(m)) {
+        // (2) h = IFFT_G1(hExtFFT)[:k] (1 / 2k is folded into the Toeplitz coefficients): sub-transforms, all-gather #2, combine, all-gather #3
+        std::vector<const g1j *> x(D); std::vector<g1j *> hbuf(D); std::vector<uint8_t *> hb(D);
+        for (uint64_t i = 0; i < D; i++) { x[i] = (const g1j *)hext[i]; CHK(tmp[i].alloc(&hbuf[i], k)); hb[i] = (uint8_t *)hbuf[i]; }
+        CHK(sharded_g1_fft(m, tmp, x, k2, k2, 1, k, hbuf));
+        CHK(all_gather_bytes(m, hb, (k / D) * sizeof(g1j)));
+        // (3) proofs = FFT_G1(h || inf^k): sub-transforms on the k / D valid entries of each class, all-gather #4, combine,
+        //     normalise the own slice, all-gather #5 of the proof points
+        std::vector<g1j *> pbuf(D), nbuf(D); std::vector<uint8_t *> nb(D);
+        for (uint64_t i = 0; i < D; i++) { x[i] = hbuf[i]; CHK(tmp[i].alloc(&pbuf[i], k2)); CHK(tmp[i].alloc(&nbuf[i], k2)); nb[i] = (uint8_t *)nbuf[i]; }
+        CHK(sharded_g1_fft(m, tmp, x, k, k2, 0, k2, pbuf));
+        const uint64_t M = k2 / D;
+        for (uint64_t i = 0; i < D; i++) {
+            HIPCHK(hipSetDevice(m->d[i].device));
+            launch_g1_normalize(m->d[i].s, pbuf[i] + i * M, nbuf[i] + i * M, M, true);
+            HIPCHK(hipGetLastError());
+        }
+        CHK(all_gather_bytes(m, nb, M * sizeof(g1j)));
+        CHK(tmp[0].alloc(&d_res, k2));
+        HIPCHK(hipSetDevice(m->d[0].device));
+        launch_g1_bitrev_copy(m->d[0].s, nbuf[0], k2, k2, d_res, k2, 1);   // reverseBitOrderG1 (fk20_single.go:192-194)
+        HIPCHK(hipGetLastError());
+    } else {
+        CHK(tmp[0].alloc(&d_res, k2));
+        HIPCHK(hipSetDevice(m->d[0].device));
+        CHK(fk20_finish(core[0], m->d[0].s, (const g1j *)hext[0], 1, 1, 1, d_res));
+    }
+    HIPCHK(hipSetDevice(m->d[0].device));
+    HIPCHK(hipMemcpyAsync(out_g1, d_res, k2 * sizeof(g1j), hipMemcpyDeviceToHost, m->d[0].s));
+    HIPCHK(hipStreamSynchronize(m->d[0].s));
+    return KZG_HIP_OK;
+    KZG_CATCH
+}
+
+}  // namespace
+
+extern "C" {
+
+int kzg_hip_multi_settings_new(const int *devices, uint32_t n_devices, unsigned max_scale, const void *secret_g1, uint64_t n_setup, kzg_hip_multi **out) {
+    if (!out) return KZG_HIP_ERR_BAD_ARG;
+    *out = nullptr;
+    if (!devices || !n_devices || n_devices > 64 || !secret_g1) return KZG_HIP_ERR_BAD_ARG;
+    const int visible = kzg_hip_device_count();
+    if (visible < 1) return KZG_HIP_ERR_NO_DEVICE;
+    for (uint32_t i = 0; i < n_devices; i++) if (devices[i] < 0 || devices[i] >= visible) return KZG_HIP_ERR_NO_DEVICE;
+    KZG_TRY
+    kzg_hip_multi *m = new kzg_hip_multi;
+    m->d.resize(n_devices);
+    for (uint32_t i = 0; i < n_devices; i++) m->d[i].device = devices[i];
+    int st = per_device(m, [&](size_t i) -> int {
+        multi_dev &d = m->d[i];
+        CHK(kzg_hip_fft_settings_new(d.device, max_scale, &d.fs));
+        CHK(kzg_hip_kzg_settings_new(d.fs, secret_g1, n_setup, &d.ks));
+        HIPCHK(hipSetDevice(d.device));
+        HIPCHK(hipStreamCreateWithFlags(&d.s, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&d.ev, hipEventDisableTiming));
+        return KZG_HIP_OK;
+    });
+    if (st) { kzg_hip_multi_settings_free(m); return st; }
+    // exchange transport: RCCL when every device is listed once (KZG_HIP_MULTI_TRANSPORT=rccl also for a single device: the binding's own test;
+    // =peer never binds RCCL)
+    bool distinct = true;
+    for (uint32_t i = 0; i < n_devices; i++) for (uint32_t j = 0; j < i; j++) if (devices[i] == devices[j]) distinct = false;
+    const char *force = getenv("KZG_HIP_MULTI_TRANSPORT");
+    const bool want_rccl = force ? !strcmp(force, "rccl") && distinct : (distinct && n_devices >= 2);
+    if (want_rccl) {
+        std::string why;
+        rccl_api *api = rccl_bind(&why);
+        if (!api) m->transport_note = "RCCL not bound (" + why + ")";
+        else {
+            m->comms.assign(n_devices, nullptr);
+            ncclResult_t r = api->CommInitAll(m->comms.data(), (int)n_devices, devices);
+            if (r != ncclSuccess) { m->transport_note = std::string("ncclCommInitAll: ") + api->GetErrorString(r); m->comms.clear(); }
+            else { m->nccl = api; m->transport = "rccl"; }
+        }
+    } else if (!distinct) m->transport_note = "the device list repeats a device";
+    *out = m;
+    return KZG_HIP_OK;
+    KZG_CATCH
+}
+void kzg_hip_multi_settings_free(kzg_hip_multi *m) {
+    if (!m) return;
+    if (m->nccl) for (ncclComm_t c : m->comms) if (c) (void)m->nccl->CommDestroy(c);
+    for (auto &d : m->d) {
+        (void)hipSetDevice(d.device);
+        if (d.s) { (void)hipStreamSynchronize(d.s); (void)hipStreamDestroy(d.s); }
+        if (d.ev) (void)hipEventDestroy(d.ev);
+        if (d.ks) kzg_hip_kzg_settings_free(d.ks);
+        if (d.fs) kzg_hip_fft_settings_free(d.fs);
+    }
+    (void)hipGetLastError();
+    delete m;
+}
+uint32_t kzg_hip_multi_device_count(const kzg_hip_multi *m) { return m ? (uint32_t)m->d.size() : 0; }
+int kzg_hip_multi_device(const kzg_hip_multi *m, uint32_t i) { return (m && i < m->d.size()) ? m->d[i].device : -1; }
+kzg_hip_fft *kzg_hip_multi_fft(kzg_hip_multi *m, uint32_t i) { return (m && i < m->d.size()) ? m->d[i].fs : nullptr; }
+kzg_hip_kzg *kzg_hip_multi_kzg(kzg_hip_multi *m, uint32_t i) { return (m && i < m->d.size()) ? m->d[i].ks : nullptr; }
+const char *kzg_hip_multi_transport(const kzg_hip_multi *m) { return m ? m->transport.c_str() : ""; }
+const char *kzg_hip_multi_transport_note(const kzg_hip_multi *m) { return m ? m->transport_note.c_str() : ""; }
+uint64_t kzg_hip_multi_exchanges(const kzg_hip_multi *m) { return m ? m->n_allgather.load() : 0; }
+int kzg_hip_multi_set_fft_sharding(kzg_hip_multi *m, int mode) {
+    if (!m || mode < -1 || mode > 1) return KZG_HIP_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(m->mu);
+    m->fft_mode = mode;
+    return KZG_HIP_OK;
+}
+int kzg_hip_multi_set_table_budget_gb(kzg_hip_multi *m, double gb) {
+    if (!m) return KZG_HIP_ERR_BAD_ARG;
+    for (auto &d : m->d) CHK(kzg_hip_kzg_set_table_budget_gb(d.ks, gb));
+    return KZG_HIP_OK;
+}
+
+// ---- batches sharded by polynomial: device i takes rows [lo_i, hi_i) and writes its results in place ----
+int kzg_hip_multi_commit_to_poly_batch(kzg_hip_multi *m, const void *coeffs_fr, uint64_t n, uint64_t batch, void *out_g1) {
+    if (!m || !coeffs_fr || !out_g1) return KZG_HIP_ERR_BAD_ARG;
+    if (!batch) return KZG_HIP_OK;
+    KZG_TRY
+    return per_device(m, [&](size_t i) -> int {
+        uint64_t lo, hi; share(batch, m->d.size(), i, &lo, &hi);
+        if (hi == lo) return KZG_HIP_OK;
+        return kzg_hip_commit_to_poly_batch(m->d[i].ks, (const uint8_t *)coeffs_fr + lo * n * sizeof(fr), n, hi - lo, (uint8_t *)out_g1 + lo * sizeof(g1j));
+    });
+    KZG_CATCH
+}
+int kzg_hip_multi_compute_proof_single_batch(kzg_hip_multi *m, const void *poly_fr, uint64_t n, uint64_t batch, const uint64_t *xs, void *out_g1) {
+    if (!m || !poly_fr || !xs || !out_g1) return KZG_HIP_ERR_BAD_ARG;
+    if (!batch) return KZG_HIP_OK;
+    KZG_TRY
+    return per_device(m, [&](size_t i) -> int {
+        uint64_t lo, hi; share(batch, m->d.size(), i, &lo, &hi);
+        if (hi == lo) return KZG_HIP_OK;
+        return kzg_hip_compute_proof_single_batch(m->d[i].ks, (const uint8_t *)poly_fr + lo * n * sizeof(fr), n, hi - lo, xs + lo, (uint8_t *)out_g1 + lo * sizeof(g1j));
+    });
+    KZG_CATCH
+}
+
+// ---- FK20 single ----
+int kzg_hip_multi_fk20_single_settings_new(kzg_hip_multi *m, uint64_t n2, kzg_hip_multi_fk20s **out) {
+    if (!m || !out) return KZG_HIP_ERR_BAD_ARG;
+    *out = nullptr;
+    KZG_TRY
+    kzg_hip_multi_fk20s *f = new kzg_hip_multi_fk20s;
+    f->m = m; f->n2 = n2; f->fk.assign(m->d.size(), nullptr);
+    int st = per_device(m, [&](size_t i) -> int { return kzg_hip_fk20_single_settings_new(m->d[i].ks, n2, &f->fk[i]); });
+    if (st) { kzg_hip_multi_fk20_single_settings_free(f); return st; }
+    *out = f;
+    return KZG_HIP_OK;
+    KZG_CATCH
+}
+void kzg_hip_multi_fk20_single_settings_free(kzg_hip_multi_fk20s *f) {
+    if (!f) return;
+    for (auto *p : f->fk) kzg_hip_fk20_single_settings_free(p);
+    delete f;
+}
+int kzg_hip_multi_da_using_fk20_batch(kzg_hip_multi_fk20s *f, const void *poly_fr, uint64_t n, uint64_t batch, void *out_g1) {
+    if (!f || !poly_fr || !out_g1) return KZG_HIP_ERR_BAD_ARG;
+    if (!batch) return KZG_HIP_OK;
+    KZG_TRY
+    kzg_hip_multi *m = f->m;
+    return per_device(m, [&](size_t i) -> int {
+        uint64_t lo, hi; share(batch, m->d.size(), i, &lo, &hi);
+        if (hi == lo) return KZG_HIP_OK;
+        return kzg_hip_da_using_fk20_batch(f->fk[i], (const uint8_t *)poly_fr + lo * n * sizeof(fr), n, hi - lo, (uint8_t *)out_g1 + lo * 2 * n * sizeof(g1j));
+    });
+    KZG_CATCH
+}
+int kzg_hip_multi_da_using_fk20(kzg_hip_multi_fk20s *f, const void *poly_fr, uint64_t n, void *out_g1) {
+    if (!f || !poly_fr || !out_g1) return KZG_HIP_ERR_BAD_ARG;
+    if (n > f->m->d[0].fs->W / 2) return KZG_HIP_ERR_TOO_WIDE;   // fk20_single.go:178-180
+    if (!is_pow2(n)) return KZG_HIP_ERR_NOT_POW2;               // fk20_single.go:181-183
+    if (2 * n != f->n2) return KZG_HIP_ERR_LEN_MISMATCH;
+    std::vector<fk20_core *> cores;
+    for (auto *p : f->fk) cores.push_back(&p->c);
+    return fk20_da_sharded(f->m, cores, poly_fr, n, out_g1);
+}
+
+// ---- FK20 multi ----
+int kzg_hip_multi_fk20_multi_settings_new(kzg_hip_multi *m, uint64_t n2, uint64_t chunk_len, kzg_hip_multi_fk20m **out) {
+    if (!m || !out) return KZG_HIP_ERR_BAD_ARG;
+    *out = nullptr;
+    KZG_TRY
+    kzg_hip_multi_fk20m *f = new kzg_hip_multi_fk20m;
+    f->m = m; f->n2 = n2; f->l = chunk_len; f->fk.assign(m->d.size(), nullptr);
+    int st = per_device(m, [&](size_t i) -> int { return kzg_hip_fk20_multi_settings_new(m->d[i].ks, n2, chunk_len, &f->fk[i]); });
+    if (st) { kzg_hip_multi_fk20_multi_settings_free(f); return st; }
+    *out = f;
+    return KZG_HIP_OK;
+    KZG_CATCH
+}
+void kzg_hip_multi_fk20_multi_settings_free(kzg_hip_multi_fk20m *f) {
+    if (!f) return;
+    for (auto *p : f->fk) kzg_hip_fk20_multi_settings_free(p);
+    delete f;
+}
+int kzg_hip_multi_da_using_fk20_multi_batch(kzg_hip_multi_fk20m *f, const void *poly_fr, uint64_t n, uint64_t batch, void *out_g1) {
+    if (!f || !poly_fr || !out_g1) return KZG_HIP_ERR_BAD_ARG;
+    if (!batch) return KZG_HIP_OK;
+    KZG_TRY
+    kzg_hip_multi *m = f->m;
+    const uint64_t per = 2 * n / f->l;
+    return per_device(m, [&](size_t i) -> int {
+        uint64_t lo, hi; share(batch, m->d.size(), i, &lo, &hi);
+        if (hi == lo) return KZG_HIP_OK;
+        return kzg_hip_da_using_fk20_multi_batch(f->fk[i], (const uint8_t *)poly_fr + lo * n * sizeof(fr), n, hi - lo, (uint8_t *)out_g1 + lo * per * sizeof(g1j));
+    });
+    KZG_CATCH
+}
+int kzg_hip_multi_da_using_fk20_multi(kzg_hip_multi_fk20m *f, const void *poly_fr, uint64_t n, void *out_g1) {
+    if (!f || !poly_fr || !out_g1) return KZG_HIP_ERR_BAD_ARG;
+    if (n > f->m->d[0].fs->W / 2) return KZG_HIP_ERR_TOO_WIDE;     // fk20_multi.go:115-117
+    if (!is_pow2(n)) return KZG_HIP_ERR_NOT_POW2;                 // fk20_multi.go:118-120
+    if (2 * n != f->n2) return KZG_HIP_ERR_LEN_MISMATCH;
+    std::vector<fk20_core *> cores;
+    for (auto *p : f->fk) cores.push_back(&p->c);
+    return fk20_da_sharded(f->m, cores, poly_fr, n, out_g1);
+}
+
+}  // extern "C"

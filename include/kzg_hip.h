@@ -169,6 +169,8 @@ void kzg_hip_fk20_multi_settings_free(kzg_hip_fk20m *fk);
 int kzg_hip_fk20_multi(kzg_hip_fk20m *fk, const void *poly_fr, uint64_t n, void *out_g1 /* n / chunk_len */);
 int kzg_hip_fk20_multi_da_optimized(kzg_hip_fk20m *fk, const void *poly_fr, uint64_t n2, void *out_g1 /* n2 / chunk_len */);
 int kzg_hip_da_using_fk20_multi(kzg_hip_fk20m *fk, const void *poly_fr, uint64_t n, void *out_g1 /* 2n / chunk_len */);
+/* `batch` polynomials of n coefficients -> batch x 2n / chunk_len proofs (DAUsingFK20Multi on each), host buffers */
+int kzg_hip_da_using_fk20_multi_batch(kzg_hip_fk20m *fk, const void *poly_fr, uint64_t n, uint64_t batch, void *out_g1);
 int kzg_hip_da_using_fk20_multi_batch_dev(kzg_hip_fk20m *fk, const void *d_poly_fr, uint64_t n, uint64_t batch, void *d_out_g1, void *stream);
 /* Sharded form for one process per GPU: this rank computes hExtFFT for output positions
  * [j0, j0 + cnt) only and writes cnt points as OPAQUE 144-byte device-internal Jacobian images (not Kilic images: the
@@ -231,6 +233,49 @@ int kzg_hip_zero_poly_via_multiplication(kzg_hip_fft *fs, const uint64_t *missin
  * n samples, present[i] == 0 <=> samples[i] == nil; writes the n reconstructed values.  KZG_HIP_ERR_RECOVERY when a known
  * sample is not reproduced (the reference's error). */
 int kzg_hip_recover_poly_from_samples(kzg_hip_fft *fs, const void *samples_fr, const uint8_t *present, uint64_t n, void *out_fr);
+
+/* ---- several GPUs behind ONE handle (SURVEY.md 8b threading row: "multi-GPU handle owns one context per device"; 8e) ----
+ * The reference is a single-process library (kzg.go:11-19): a drop-in that uses every GPU of a node does so inside this library.
+ * kzg_hip_multi_settings_new builds an FFTSettings (NewFFTSettings(max_scale), fft.go:44) and a KZGSettings (NewKZGSettings, kzg.go:21-36)
+ * with their tables on EVERY listed device.  A list may repeat a device (each entry gets its own settings and tables: how a 1-GPU box
+ * exercises the multi-device code paths).
+ *   _batch calls: the polynomials are divided into contiguous shares, one per device, results land in the caller's buffer in input order;
+ *     no data-path collective (blobs are independent).
+ *   kzg_hip_multi_da_using_fk20 / _da_using_fk20_multi: ONE polynomial over all devices (fk20_multi.go:58-109, kzg.go:73-116): the Toeplitz
+ *     stage is sharded by output position, the hExtFFT slices are ALL-GATHERED, then either the first device runs the two G1 transforms
+ *     ("gather") or both transforms are sharded by decimation with two more all-gathers each, the last one of the proof points ("sharded":
+ *     the five all-gathers of SURVEY.md 8e; default from 4 devices on, kzg_hip_multi_set_fft_sharding / KZG_HIP_MULTI_FFT=gather|sharded).
+ * Exchange transport (kzg_hip_multi_transport): "rccl" = ncclAllGather on ncclUint8 over single-process communicators (ncclCommInitAll;
+ * RCCL over xGMI), used when every listed device is distinct; "peer-copy" = hipMemcpyPeerAsync between the devices' streams, used when the
+ * list repeats a device or librccl cannot be bound (kzg_hip_multi_transport_note says why).  Results are identical either way and
+ * identical to the single-device calls (tests/test_multi_device.py). */
+typedef struct kzg_hip_multi kzg_hip_multi;
+typedef struct kzg_hip_multi_fk20s kzg_hip_multi_fk20s;
+typedef struct kzg_hip_multi_fk20m kzg_hip_multi_fk20m;
+int kzg_hip_multi_settings_new(const int *devices, uint32_t n_devices, unsigned max_scale, const void *secret_g1, uint64_t n_setup, kzg_hip_multi **out);
+void kzg_hip_multi_settings_free(kzg_hip_multi *m);
+uint32_t kzg_hip_multi_device_count(const kzg_hip_multi *m);
+int kzg_hip_multi_device(const kzg_hip_multi *m, uint32_t i);          /* device ordinal of entry i (-1 out of range) */
+kzg_hip_fft *kzg_hip_multi_fft(kzg_hip_multi *m, uint32_t i);          /* entry i's settings, BORROWED (owned by the multi handle): */
+kzg_hip_kzg *kzg_hip_multi_kzg(kzg_hip_multi *m, uint32_t i);          /* any single-device call can be made on a chosen device     */
+const char *kzg_hip_multi_transport(const kzg_hip_multi *m);           /* "rccl" or "peer-copy" */
+const char *kzg_hip_multi_transport_note(const kzg_hip_multi *m);      /* why the transport is not "rccl" ("" otherwise) */
+uint64_t kzg_hip_multi_exchanges(const kzg_hip_multi *m);              /* all-gathers performed on this handle so far */
+int kzg_hip_multi_set_fft_sharding(kzg_hip_multi *m, int mode);        /* 0 gather, 1 sharded transforms, -1 default policy */
+int kzg_hip_multi_set_table_budget_gb(kzg_hip_multi *m, double gb);    /* kzg_hip_kzg_set_table_budget_gb on every entry */
+/* CommitToPoly / ComputeProofSingle on `batch` polynomials (kzg_single_proofs.go:17-19,36-54), sharded by polynomial */
+int kzg_hip_multi_commit_to_poly_batch(kzg_hip_multi *m, const void *coeffs_fr, uint64_t n, uint64_t batch, void *out_g1);
+int kzg_hip_multi_compute_proof_single_batch(kzg_hip_multi *m, const void *poly_fr, uint64_t n, uint64_t batch, const uint64_t *xs, void *out_g1);
+/* NewFK20SingleSettings on every entry (kzg.go:43-64); DAUsingFK20 on a batch (sharded by polynomial) and on ONE polynomial (sharded inside) */
+int kzg_hip_multi_fk20_single_settings_new(kzg_hip_multi *m, uint64_t n2, kzg_hip_multi_fk20s **out);
+void kzg_hip_multi_fk20_single_settings_free(kzg_hip_multi_fk20s *fk);
+int kzg_hip_multi_da_using_fk20_batch(kzg_hip_multi_fk20s *fk, const void *poly_fr, uint64_t n, uint64_t batch, void *out_g1);
+int kzg_hip_multi_da_using_fk20(kzg_hip_multi_fk20s *fk, const void *poly_fr, uint64_t n, void *out_g1 /* 2n */);
+/* NewFK20MultiSettings on every entry (kzg.go:73-116); DAUsingFK20Multi likewise */
+int kzg_hip_multi_fk20_multi_settings_new(kzg_hip_multi *m, uint64_t n2, uint64_t chunk_len, kzg_hip_multi_fk20m **out);
+void kzg_hip_multi_fk20_multi_settings_free(kzg_hip_multi_fk20m *fk);
+int kzg_hip_multi_da_using_fk20_multi_batch(kzg_hip_multi_fk20m *fk, const void *poly_fr, uint64_t n, uint64_t batch, void *out_g1);
+int kzg_hip_multi_da_using_fk20_multi(kzg_hip_multi_fk20m *fk, const void *poly_fr, uint64_t n, void *out_g1 /* 2n / chunk_len */);
 
 /* shape of the fixed-base table CommitToPoly walks (built lazily by the first commitment): signed window bits c, window count and
  * bytes of HBM; all zero before the first commitment or when the setup is too small for a table (classic bucket path) */

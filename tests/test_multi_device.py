@@ -1,0 +1,183 @@
+"""Several devices behind ONE handle of the C ABI (kzg_hip_multi_*, go-kzg_amd/csrc/capi_multi.hip; SURVEY.md 8b threading row, 8e).
+
+The test box has one GPU, so the device lists repeat device 0: every entry still owns its settings, tables and stream, the batches
+are divided among the entries and the one-polynomial FK20 calls exchange their slices between the entries' buffers (peer copies; the
+RCCL leg is exercised with a single-device communicator).  Results must equal the single-device calls bit for bit, and the oracle's
+vectors / byte pins (tests/golden/)."""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import koracle as ko  # noqa: E402  (the checker)
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+KATS = json.load(open(os.path.join(GOLDEN, "reference_kats.json")))
+DERIVED = json.load(open(os.path.join(GOLDEN, "derived_vectors.json")))
+FK20_PINS = json.load(open(os.path.join(GOLDEN, "fk20_pins.json")))
+S_TEST = int(KATS["test_secret"]["value"])
+TEST_POLY = KATS["test_poly"]["values"]
+
+
+@pytest.fixture(scope="module")
+def kz():
+    import gokzg_amd
+    assert gokzg_amd.device_count() >= 1, "no gfx950 device: the HIP path is the only path"
+    return gokzg_amd
+
+
+@pytest.fixture(scope="module")
+def setup_1337():
+    raw = np.frombuffer(open(os.path.join(GOLDEN, "trusted_setup_g1.bin"), "rb").read(), dtype=np.uint8)
+    return ko.g1_affine(ko.g1_decompress(raw))
+
+
+def rand_fr(rng, n):
+    return ko.fr_from_ints([int.from_bytes(rng.bytes(32), "little") % ko.R_MOD for _ in range(n)])
+
+
+def fk20_multi_test_poly(chunk_count=32):
+    """the polynomial of fk20_multi_test.go:21-32"""
+    poly = []
+    for i in range(chunk_count):
+        vals = [1, 2, 3, 4 + i, 7, 8 + i * i, 9, 10, 13, 14, 1, 15, 0, 1000, 0, 33]
+        vals[12] = ko.R_MOD - 1
+        vals[14] = ko.R_MOD - 134
+        poly += vals
+    return poly
+
+
+def sha(fs, proofs):
+    return hashlib.sha256(fs.to_compressed_g1(proofs).tobytes()).hexdigest()
+
+
+def test_handle_shape_transport_and_misuse(kz, setup_1337):
+    m = kz.MultiKZGSettings([0, 0], 12, setup_1337)
+    L = kz.lib()
+    assert L.kzg_hip_multi_device_count(m.h) == 2 and L.kzg_hip_multi_device(m.h, 1) == 0 and L.kzg_hip_multi_device(m.h, 2) == -1
+    assert m.transport == "peer-copy" and "repeats" in m.transport_note          # RCCL refuses two ranks on one device
+    assert L.kzg_hip_multi_kzg(m.h, 0) != L.kzg_hip_multi_kzg(m.h, 1)             # every entry owns its settings
+    assert not L.kzg_hip_multi_kzg(m.h, 2)
+    m.close()
+    with pytest.raises(kz.NoDeviceError):
+        kz.MultiKZGSettings([0, kz.device_count()], 12, setup_1337)              # a device that is not there
+    with pytest.raises(kz.KzgPanic) as e:
+        kz.MultiKZGSettings([], 12, setup_1337)
+    assert e.value.status == kz.ERR_BAD_ARG
+    with pytest.raises(kz.KzgPanic) as e:
+        kz.MultiKZGSettings([0, 0], 13, setup_1337)                               # kzg.go:25-27: setup shorter than the domain
+    assert e.value.status == kz.ERR_LEN_MISMATCH
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+def test_batches_are_divided_among_the_entries(kz, setup_1337, devices):
+    """CommitToPoly / ComputeProofSingle on ragged batches: entry i takes a contiguous share, results in input order, equal to one device's"""
+    m = kz.MultiKZGSettings(devices, 12, setup_1337)
+    m.set_table_budget_gb(10)                                                    # c = 11 tables: three of them stay small
+    ks = m.kzg_settings(0)                                                        # the same call on one entry is the single-device reference
+    rng = np.random.default_rng(len(devices))
+    for batch in (1, 2, 37):
+        blobs = np.stack([rand_fr(rng, 4096) for _ in range(min(batch, 5))])
+        blobs = np.concatenate([blobs] * (batch // blobs.shape[0] + 1))[:batch].copy()
+        blobs[-1, :7] = 0
+        got = m.commit_to_poly_batch(blobs)
+        assert np.array_equal(got, ks.commit_to_poly_batch(blobs)), batch
+        xs = np.arange(5, 5 + batch, dtype=np.uint64)
+        assert np.array_equal(m.compute_proof_single_batch(blobs, xs), ks.compute_proof_single_batch(blobs, xs)), batch
+    # vector F: the first synthetic blob on the s = 1337 setup
+    f = m.commit_to_poly_batch(np.stack([ko.synthetic_blob(1), ko.synthetic_blob(2)]))
+    assert ko.g1_compress(f[:1])[0].tobytes().hex() == DERIVED["F_blob_seed1"]["commit_monomial_s1337"]
+    m.close()
+
+
+@pytest.mark.parametrize("devices,mode,exchanges", [([0, 0], "gather", 1), ([0, 0], "sharded", 5), ([0, 0, 0, 0], None, 5), ([0, 0, 0], "sharded", 1)])
+def test_one_polynomial_fk20_vectors_C_and_E(kz, devices, mode, exchanges, monkeypatch):
+    """DAUsingFK20 (fk20_single_test.go:12-22, scale 5) and DAUsingFK20Multi (fk20_multi_test.go, scale 10, chunk 16) of ONE polynomial over the
+    entries: vectors C and E of SURVEY.md 8c, both exchange schemes; three entries are not a power of two and fall back to one all-gather"""
+    monkeypatch.setenv("KZG_HIP_FK20_FB_BUDGET_GB", "4")
+    # vector C: scale 5, 32 proofs (sharded transforms need 2k >= 8 D: just long enough at 4 entries)
+    m = kz.MultiKZGSettings(devices, 5, ko.generate_testing_setup_g1(S_TEST, 33))
+    m.set_fft_sharding(mode)
+    fk = kz.MultiFK20SingleSettings(m, 32)
+    poly = ko.fr_from_ints(TEST_POLY)
+    e0 = m.exchanges
+    proofs = fk.da_using_fk20(poly)
+    c = DERIVED["C_da_using_fk20_scale5"]
+    assert hashlib.sha256(ko.g1_compress(proofs).tobytes()).hexdigest() == c["sha256"]
+    assert m.exchanges - e0 == exchanges
+    batch = fk.da_using_fk20_batch(np.stack([poly] * 5))                         # and the batch form: rows divided among the entries
+    assert all(np.array_equal(batch[i], proofs) for i in range(5))
+    fk.close(); m.close()
+    # vector E: scale 10, chunk length 16 -> 64 coset proofs from 2k = 64 positions: sharded transforms at 2 and 4 entries
+    n2, l = 1024, 16
+    m = kz.MultiKZGSettings(devices, 10, ko.generate_testing_setup_g1(S_TEST, n2))
+    m.set_fft_sharding(mode)
+    fkm = kz.MultiFK20MultiSettings(m, n2, l)
+    poly = ko.fr_from_ints(fk20_multi_test_poly())
+    e0 = m.exchanges
+    proofs = fkm.da_using_fk20_multi(poly)
+    assert m.exchanges - e0 == exchanges
+    e = DERIVED["E_da_using_fk20_multi_scale10_l16"]
+    assert hashlib.sha256(ko.g1_compress(proofs).tobytes()).hexdigest() == e["sha256"]
+    rng = np.random.default_rng(7)
+    polys = np.stack([rand_fr(rng, n2 // 2) for _ in range(3)])
+    single = kz.FK20MultiSettings(m.kzg_settings(0), n2, l)
+    want = np.stack([single.da_using_fk20_multi(p) for p in polys])
+    assert np.array_equal(fkm.da_using_fk20_multi_batch(polys), want)
+    assert np.array_equal(single.da_using_fk20_multi_batch(polys), want)          # the single-device host batch form added with it
+    for p, w in zip(polys, want):
+        assert np.array_equal(fkm.da_using_fk20_multi(p), w)
+    with pytest.raises(kz.KzgPanic) as ex:
+        fkm.da_using_fk20_multi(polys[0][:256])
+    assert ex.value.status == kz.ERR_LEN_MISMATCH
+    single.close(); fkm.close(); m.close()
+
+
+@pytest.mark.parametrize("mode", ["gather", "sharded"])
+def test_config4a_one_polynomial_over_two_entries_byte_pin(kz, setup_1337, mode):
+    """BASELINE config 4a (DAUsingFK20, scale 12, blob(seed 4)[:2048] -> 4096 proofs) through the multi-device handle on [0, 0]: the oracle's byte pin"""
+    m = kz.MultiKZGSettings([0, 0], 12, setup_1337)
+    m.set_fft_sharding(mode)
+    fk = kz.MultiFK20SingleSettings(m, 4096)
+    proofs = fk.da_using_fk20(ko.synthetic_blob(4)[:2048])
+    assert sha(m.fft_settings(0), proofs) == FK20_PINS["config4a_da_using_fk20_seed4"]["sha256"]
+    fk.close(); m.close()
+
+
+@pytest.mark.parametrize("devices,mode", [([0, 0], "gather"), ([0, 0], "sharded"), ([0] * 8, "sharded")])
+def test_config5_one_polynomial_byte_pin(kz, devices, mode, monkeypatch):
+    """BASELINE config 5 (DAUsingFK20Multi, scale 16, chunk 16 -> 4096 coset proofs) of ONE polynomial over 2 and 8 entries, Toeplitz stage by
+    output position and, in "sharded", both G1 transforms by decimation (five all-gathers): all proofs hash to the oracle's pin"""
+    monkeypatch.setenv("KZG_HIP_FK20_FB_BUDGET_GB", "24" if len(devices) == 2 else "6")
+    l, n = 16, 32768
+    fs = kz.FFTSettings(16)
+    setup = fs.generate_testing_setup_g1(ko.fr_from_ints([S_TEST]), 65536)
+    m = kz.MultiKZGSettings(devices, 16, setup)
+    m.set_fft_sharding(mode)
+    fk = kz.MultiFK20MultiSettings(m, 2 * n, l)
+    e0 = m.exchanges
+    proofs = fk.da_using_fk20_multi(ko.synthetic_blob(5, n))
+    assert m.exchanges - e0 == (5 if mode == "sharded" else 1)
+    pin = FK20_PINS["config5_da_using_fk20_multi_seed5"]
+    assert sha(fs, proofs) == pin["sha256"]
+    fk.close(); m.close(); fs.close()
+
+
+def test_rccl_leg_on_a_single_device_communicator(kz, monkeypatch):
+    """the RCCL binding itself (librccl bound at run time, ncclCommInitAll, grouped ncclAllGather on ncclUint8, ncclCommDestroy) with the one
+    device a test box has: a one-rank all-gather in place, results unchanged"""
+    monkeypatch.setenv("KZG_HIP_MULTI_TRANSPORT", "rccl")
+    monkeypatch.setenv("KZG_HIP_FK20_FB_BUDGET_GB", "4")
+    m = kz.MultiKZGSettings([0], 5, ko.generate_testing_setup_g1(S_TEST, 33))
+    assert m.transport == "rccl", m.transport_note
+    fk = kz.MultiFK20SingleSettings(m, 32)
+    proofs = fk.da_using_fk20(ko.fr_from_ints(TEST_POLY))
+    assert m.exchanges == 1
+    assert hashlib.sha256(ko.g1_compress(proofs).tobytes()).hexdigest() == DERIVED["C_da_using_fk20_scale5"]["sha256"]
+    fk.close(); m.close()
