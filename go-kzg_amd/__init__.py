@@ -94,6 +94,7 @@ def lib():
         "kzg_hip_toeplitz_part2": (i32, [vp, vp, vp, u64, vp]), "kzg_hip_toeplitz_part3": (i32, [vp, vp, u64, vp]),
         "kzg_hip_fk20_single_settings_new": (i32, [vp, u64, pp]), "kzg_hip_fk20_single_settings_free": (None, [vp]),
         "kzg_hip_fk20_single_x_ext_fft": (i32, [vp, vp]), "kzg_hip_fk20_single": (i32, [vp, vp, u64, vp]),
+        "kzg_hip_fk20_single_batch": (i32, [vp, vp, u64, u64, vp]), "kzg_hip_fk20_single_batch_dev": (i32, [vp, vp, u64, u64, vp, vp]),
         "kzg_hip_fk20_single_da_optimized": (i32, [vp, vp, u64, vp]), "kzg_hip_da_using_fk20": (i32, [vp, vp, u64, vp]),
         "kzg_hip_da_using_fk20_batch": (i32, [vp, vp, u64, u64, vp]), "kzg_hip_da_using_fk20_batch_dev": (i32, [vp, vp, u64, u64, vp, vp]),
         "kzg_hip_fk20_multi_settings_new": (i32, [vp, u64, u64, pp]), "kzg_hip_fk20_multi_settings_free": (None, [vp]),
@@ -516,6 +517,14 @@ class FK20SingleSettings:
         poly = _fr(poly)
         out = g1_empty(poly.shape[0])
         _chk(lib().kzg_hip_fk20_single(self.h, _p(poly), poly.shape[0], _p(out)))
+        return out
+
+    def fk20_single_batch(self, polys):
+        """FK20Single on each row of polys (batch, n, 4) -> (batch, n, 3, 6)"""
+        polys = np.ascontiguousarray(polys, dtype=np.uint64)
+        b, n = polys.shape[0], polys.shape[1]
+        out = np.zeros((b, n, 3, 6), dtype=np.uint64)
+        _chk(lib().kzg_hip_fk20_single_batch(self.h, _p(polys), n, b, _p(out)))
         return out
 
     def fk20_single_da_optimized(self, poly):

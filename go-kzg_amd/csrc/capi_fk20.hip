@@ -113,16 +113,18 @@ static int fk20_run_pass1_fused(fk20_core *c, hipStream_t s, const fr *d_poly, u
     HIPCHK(hipGetLastError());
     return fk20_finish_from_h(c, s, d_a.p, batch, da, bit_reverse, d_out);
 }
-// DA form of a single-file settings object with its table resident: the Toeplitz stage absorbs the first two stages of the inverse
+// A single-file settings object with its table resident: the Toeplitz stage absorbs the first two stages of the inverse
 // transform (k_fb_mul_vec_dif2), the remaining ones run decimation-in-frequency and leave h bit-reversed, which is the layout the
 // forward (decimation-in-time) transform reads: 10 instead of 12 multiplying stages for the inverse transform and no reordering
 // passes.  Same group elements as the plain pipeline; outputs are normalised, so the bytes are identical (tests compare both).
+// The plain form (FK20Single, fk20_single.go:122-137: proofs = FFT_G1(h) on k points) continues from the EVEN positions of that layout, which
+// are h[:k] in k-point bit-reversed order.
 static bool fk20_fused_ok(const fk20_core *c, uint64_t batch, int da) {
     static const bool off = [] { const char *e = getenv("KZG_HIP_FK20_FUSE"); return e && e[0] == '0'; }();
     const uint64_t k2 = 2 * c->k;
-    return !off && da && c->l == 1 && c->d_files_fb && k2 >= 8 && !g1_fft_direct_mode(k2, batch);
+    return !off && c->l == 1 && c->d_files_fb && k2 >= 8 && !g1_fft_direct_mode(k2, batch) && (da || !g1_fft_direct_mode(c->k, batch));
 }
-static int fk20_run_fused(fk20_core *c, hipStream_t s, const fr *d_poly, uint64_t poly_stride, uint64_t n, uint64_t batch, int bit_reverse, g1j *d_out) {
+static int fk20_run_fused(fk20_core *c, hipStream_t s, const fr *d_poly, uint64_t poly_stride, uint64_t n, uint64_t batch, int da, int bit_reverse, g1j *d_out) {
     kzg_hip_fft *fs = c->ks->fs;
     const uint64_t k2 = 2 * c->k;
     dtmp<fr> d_tc(s), d_cf(s); dtmp<g1j> d_a(s), d_b(s);
@@ -131,6 +133,15 @@ static int fk20_run_fused(fk20_core *c, hipStream_t s, const fr *d_poly, uint64_
     fr_fft_rows(fs, s, d_tc.p, k2, k2, d_cf.p, k2, batch, 0);
     launch_fb_mul_vec_dif2(s, c->d_files_fb, k2, c->fb_c, c->fb_nwin, d_cf.p, fs->d_reversed, fs->W, batch, d_a.p);
     for (uint64_t m = k2 / 8; m >= 1; m >>= 1) launch_g1_fft_stage_dif(s, d_a.p, k2, batch, m, fs->d_glv_reversed, fs->d_wnaf_reversed, fs->W);
+    if (!da) {                                                  // FK20Single: transform of k points on h[:k]
+        const uint64_t k = c->k;
+        launch_g1_take_even(s, d_a.p, d_b.p, batch * k);
+        for (uint64_t m = 1; m < k; m <<= 1) launch_g1_fft_stage(s, d_b.p, k, batch, m, fs->d_glv_expanded, fs->d_wnaf_expanded, fs->W);
+        if (bit_reverse) { launch_g1_bitrev_copy(s, d_b.p, k, k, d_a.p, k, batch); launch_g1_normalize(s, d_a.p, d_out, batch * k, true); }
+        else launch_g1_normalize(s, d_b.p, d_out, batch * k, true);
+        HIPCHK(hipGetLastError());
+        return KZG_HIP_OK;
+    }
     launch_g1_clear_odd(s, d_a.p, batch * k2);                  // h[:k] || inf^k, in bit-reversed order
     for (uint64_t m = 1; m < k2; m <<= 1) launch_g1_fft_stage(s, d_a.p, k2, batch, m, fs->d_glv_expanded, fs->d_wnaf_expanded, fs->W);
     if (bit_reverse) { launch_g1_bitrev_copy(s, d_a.p, k2, k2, d_b.p, k2, batch); launch_g1_normalize(s, d_b.p, d_out, batch * k2, true); }
@@ -159,7 +170,7 @@ int fk20_run_dev(fk20_core *c, hipStream_t s, const fr *d_poly, uint64_t poly_st
         HIPCHK(hipMemcpy2DAsync(d_p2.p, n * sizeof(fr), d_poly, poly_stride * sizeof(fr), n * sizeof(fr), batch, hipMemcpyDeviceToDevice, s));
         for (uint64_t b = batch; b < padded; b++)
             HIPCHK(hipMemcpyAsync(d_p2.p + b * n, d_poly + (batch - 1) * poly_stride, n * sizeof(fr), hipMemcpyDeviceToDevice, s));
-        if (fk20_fused_ok(c, padded, da)) CHK(fk20_run_fused(c, s, d_p2.p, n, n, padded, bit_reverse, d_o2.p));
+        if (fk20_fused_ok(c, padded, da)) CHK(fk20_run_fused(c, s, d_p2.p, n, n, padded, da, bit_reverse, d_o2.p));
         else {
             dtmp<g1j> d_hext(s);
             CHK(d_hext.alloc(padded * 2 * c->k));
@@ -169,7 +180,7 @@ int fk20_run_dev(fk20_core *c, hipStream_t s, const fr *d_poly, uint64_t poly_st
         HIPCHK(hipMemcpyAsync(d_out, d_o2.p, batch * on * sizeof(g1j), hipMemcpyDeviceToDevice, s));
         return KZG_HIP_OK;
     }
-    if (fk20_fused_ok(c, batch, da)) return fk20_run_fused(c, s, d_poly, poly_stride, n, batch, bit_reverse, d_out);
+    if (fk20_fused_ok(c, batch, da)) return fk20_run_fused(c, s, d_poly, poly_stride, n, batch, da, bit_reverse, d_out);
     if (fk20_pass1_fused_ok(c, batch)) return fk20_run_pass1_fused(c, s, d_poly, poly_stride, n, batch, da, bit_reverse, d_out);
     uint64_t k2 = 2 * c->k;
     dtmp<g1j> d_hext(s);
@@ -234,6 +245,20 @@ int kzg_hip_fk20_single(kzg_hip_fk20s *fk, const void *poly_fr, uint64_t n, void
     if (!fk || !poly_fr || !out_g1) return KZG_HIP_ERR_BAD_ARG;
     if (2 * n != fk->c.n2) return KZG_HIP_ERR_LEN_MISMATCH;   // ToeplitzPart2 length panic, fk20_single.go:60-62
     return fk20_run_host(&fk->c, poly_fr, n, n, 1, 0, 0, 0, out_g1);
+}
+// `batch` polynomials of n coefficients -> batch x n proofs (FK20Single on each): host buffers / device pointers + stream
+int kzg_hip_fk20_single_batch(kzg_hip_fk20s *fk, const void *poly_fr, uint64_t n, uint64_t batch, void *out_g1) {
+    if (!fk || !poly_fr || !out_g1) return KZG_HIP_ERR_BAD_ARG;
+    if (2 * n != fk->c.n2) return KZG_HIP_ERR_LEN_MISMATCH;   // ToeplitzPart2 length panic, fk20_single.go:60-62
+    if (!batch) return KZG_HIP_OK;
+    return fk20_run_host(&fk->c, poly_fr, n, n, batch, 0, 0, 0, out_g1);
+}
+int kzg_hip_fk20_single_batch_dev(kzg_hip_fk20s *fk, const void *d_poly_fr, uint64_t n, uint64_t batch, void *d_out_g1, void *stream) {
+    if (!fk || !d_poly_fr || !d_out_g1) return KZG_HIP_ERR_BAD_ARG;
+    if (2 * n != fk->c.n2) return KZG_HIP_ERR_LEN_MISMATCH;
+    if (!batch) return KZG_HIP_OK;
+    dev_guard g(fk->c.ks->fs);
+    return fk20_run_dev(&fk->c, (hipStream_t)stream, (const fr *)d_poly_fr, n, n, batch, 0, 0, (g1j *)d_out_g1);
 }
 int kzg_hip_fk20_single_da_optimized(kzg_hip_fk20s *fk, const void *poly_fr, uint64_t n2, void *out_g1) {
     if (!fk || !poly_fr || !out_g1) return KZG_HIP_ERR_BAD_ARG;

@@ -68,6 +68,7 @@ void launch_g1_fft_stage(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, u
 // FK20 transforms (h[:n] || inf in bit-reversed order)
 void launch_g1_fft_stage_dif(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, uint64_t m, const fr *roots, const int8_t *wnaf, uint64_t W);
 void launch_g1_clear_odd(hipStream_t s, g1j *data, uint64_t n_total);
+void launch_g1_take_even(hipStream_t s, const g1j *in, g1j *out, uint64_t total);   // out[t] = in[2 t]
 bool g1_quad_enabled();   // the stage launchers put four lanes on a butterfly for launches of at most 16 384 butterflies (g1_quad.hpp) unless KZG_HIP_G1_QUAD=0
 // latency mode: Stockham passes of radix 16 evaluated directly (k_g1.hip); result in data, tmp = batch x n scratch, scale optional
 void launch_fb_direct_pass1(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, const fr *roots, uint64_t W, uint64_t batch,

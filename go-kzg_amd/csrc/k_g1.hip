@@ -239,6 +239,16 @@ void launch_g1_clear_odd(hipStream_t s, g1j *data, uint64_t n_total) {
     if (n_total < 2) return;
     hipLaunchKernelGGL(k_g1_clear_odd, dim3((uint32_t)((n_total / 2 + 255) / 256)), dim3(256), 0, s, data, n_total / 2);
 }
+// out[t] = in[2 t]: the even positions of a bit-reversed 2k-point sequence are its first k entries in k-point bit-reversed order (FK20Single
+// between its two transforms: h[:k] of the inverse transform feeds a transform of HALF the size, fk20_single.go:128-129)
+__global__ void k_g1_take_even(const g1j *in, g1j *out, uint64_t total) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t < total) out[t] = in[2 * t];
+}
+void launch_g1_take_even(hipStream_t s, const g1j *in, g1j *out, uint64_t total) {
+    if (!total) return;
+    hipLaunchKernelGGL(k_g1_take_even, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, in, out, total);
+}
 void launch_g1_fft_stage(hipStream_t s, g1j *data, uint64_t n, uint64_t batch, uint64_t m, const fr *roots, const int8_t *wnaf, uint64_t W) {
     uint64_t total = n / 2 * batch;
     if (!total) return;

@@ -158,6 +158,9 @@ void kzg_hip_fk20_single_settings_free(kzg_hip_fk20s *fk);
 int kzg_hip_fk20_single_x_ext_fft(const kzg_hip_fk20s *fk, void *out_g1 /* n2 points */);
 int kzg_hip_fk20_single(kzg_hip_fk20s *fk, const void *poly_fr, uint64_t n, void *out_g1 /* n */);
 int kzg_hip_fk20_single_da_optimized(kzg_hip_fk20s *fk, const void *poly_fr, uint64_t n2, void *out_g1 /* n2 */);
+/* `batch` polynomials of n coefficients -> batch x n proofs (FK20Single on each; BASELINE config 4b: n = 4096 at scale 13) */
+int kzg_hip_fk20_single_batch(kzg_hip_fk20s *fk, const void *poly_fr, uint64_t n, uint64_t batch, void *out_g1);
+int kzg_hip_fk20_single_batch_dev(kzg_hip_fk20s *fk, const void *d_poly_fr, uint64_t n, uint64_t batch, void *d_out_g1, void *stream);
 int kzg_hip_da_using_fk20(kzg_hip_fk20s *fk, const void *poly_fr, uint64_t n, void *out_g1 /* 2n */);
 /* `batch` polynomials of n coefficients -> batch x 2n proofs (DAUsingFK20 on each) */
 int kzg_hip_da_using_fk20_batch(kzg_hip_fk20s *fk, const void *poly_fr, uint64_t n, uint64_t batch, void *out_g1);

@@ -1136,6 +1136,38 @@ def test_da_using_fk20_batch_host_buffers(kz, ks4096):
     fk.close()
 
 
+def test_fk20_single_batch_host_buffers(kz):
+    """FK20Single (fk20_single.go:122-137) on batches: from 5 polynomials on the Toeplitz stage is fused with two DIF stages and the second
+    transform (k points) continues from the even positions of the bit-reversed layout; 1-4 polynomials take the direct passes.  Against the
+    oracle at scale 8 and against one-polynomial calls; the same rows through the DA form of the same settings"""
+    n2 = 256
+    fs = kz.FFTSettings(8)
+    setup = ko.generate_testing_setup_g1(S_TEST, n2)
+    ks = kz.KZGSettings(fs, setup)
+    fk = kz.FK20SingleSettings(ks, n2)
+    ofk = ko.FK20SingleSettings(ko.KZGSettings(ko.FFTSettings(8), setup), n2)
+    rng = np.random.default_rng(256)
+    polys = np.stack([rand_fr(rng, n2 // 2) for _ in range(40)])
+    polys[3, 100:] = 0
+    polys[7] = 0                                              # the zero polynomial: every proof is the point at infinity
+    singles = [fk.fk20_single(p) for p in polys[:9]]
+    for b in (0, 3, 7):
+        assert_points_equal(singles[b], ofk.fk20_single(polys[b]))
+    for nb in (1, 3, 5, 9, 17, 40):
+        got = fk.fk20_single_batch(polys[:nb])
+        assert got.shape == (nb, n2 // 2, 3, 6)
+        for b in range(min(nb, 9)):
+            assert np.array_equal(got[b], singles[b]), (nb, b)
+    assert np.array_equal(fk.fk20_single_batch(polys)[39], fk.fk20_single(polys[39]))
+    da = fk.da_using_fk20_batch(polys[:9])
+    for b in (0, 7, 8):
+        assert np.array_equal(da[b], fk.da_using_fk20(polys[b])), b
+    with pytest.raises(kz.KzgPanic) as e:
+        fk.fk20_single_batch(polys[:, :64])
+    assert e.value.status == kz.ERR_LEN_MISMATCH
+    fk.close(); ks.close(); fs.close()
+
+
 def test_fk20_paths_agree_in_a_fresh_process():
     """FK20 runs through three pipelines depending on size: direct radix-16 passes (a lone transform), the radix-2 network, and -- for
     DA forms of single-file settings with a resident table -- the Toeplitz stage fused with two decimation-in-frequency stages.  The
@@ -1461,6 +1493,12 @@ def test_fk20_single_scale13_config4b(kz):
     dl = ko.fr_from_ints([(ps_ - ev[i]) * pow(S_TEST - pow(w, i, R), -1, R) % R for i in range(n)])
     for i in range(n):
         assert ko.g1_equal(proofs[i], ko.g1_mul(gen, dl[i])), i
+    # the batch form (what bench.py times as fk20_4096): 6 blobs in one call, row 0 is the pinned blob, rows equal one-polynomial calls
+    six = np.stack([ko.synthetic_blob(1 + b) for b in range(6)])
+    got6 = fk.fk20_single_batch(six)
+    assert np.array_equal(got6[0], proofs) and np.array_equal(got6[5], fk.fk20_single(six[5]))
+    da6 = fk.da_using_fk20_batch(six)
+    assert proofs_sha256(fs, da6[0]) == FK20_PINS["config4b_da_using_fk20_seed1"]["sha256"] and np.array_equal(da6[5], fk.da_using_fk20(six[5]))
     # ... and equals ComputeProofSingle at an integer point as a cross-check of the same settings
     assert ko.g1_equal(ks.compute_proof_single(blob, 17), ko.g1_mul(gen, ko.fr_from_ints([pyref.single_proof_dlog(poly_i, S_TEST, 17)])[0]))
     # DA form on the same settings: 4096 coefficients -> 8192 proofs, sample + linearity
