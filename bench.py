@@ -17,7 +17,7 @@ Extra objects on the JSON line:
   roofline      -- dominant kernel of the commitment step (k_fb_accumulate, the fixed-base table walk): algorithmic bytes per launch /
                    HIP-event launch time vs 8 TB/s, the PMC traffic of the committed rocprofv3 passes (profiles/), and `mac`: the
                    kernel's v_mad_u64_u32 rate against the rate MEASURED on this GPU in this run (kzg_hip_calibrate).
-  roofline_fk20 -- the same for the FK20 half of the metric (dominant kernel k_g1_fft_stage).
+  roofline.secondary.fk20 -- the same for the FK20 half of the metric (dominant kernel k_g1_fft_stage).
   cpu_baseline  -- the oracle's restatement of bls.LinCombG1 (Kilic-style Pippenger) on the host: one core and all cores (one blob
                    per core), CPU model and core count stated; the Go toolchain probe (rank 0, N = 1).
   table_sweep   -- commitments/s against the HBM budget of the fixed-base table (10 / 32 / 64 / 210 GB).
@@ -25,6 +25,15 @@ Extra objects on the JSON line:
   lincomb       -- variable-base bls.LinCombG1 on a cached point set (GLV bucket MSM), batch 1 / 64 / 512.
   latency       -- single-call latencies of the reference-shaped entry points.
   fk20          -- DAUsingFK20 (2048 coefficients -> 4096 proofs) all-proofs/s, own timed loop, self-checked against the byte pin.
+  fk20_4096     -- the metric's literal input, a 4096-ELEMENT blob (BASELINE config 4b): FK20Single 4096 coefficients -> 4096 proofs and
+                   DAUsingFK20 4096 -> 8192 at scale 13 on the 8192-point setup of the reference's test secret: batch rates, lone latencies,
+                   roofline on SURVEY.md 8(d)'s 1 310 720 B per unit, self-checked against the config-4b byte pins.
+  self_check    -- EVERY output of the timed steps, not one: sum_b rho_b C_b == CommitToPoly(sum_b rho_b blob_b) for random rho (one B-term
+                   LinCombG1 over the step's outputs as caller-supplied points + one commitment), and for the FK20 blocks
+                   sum_b rho_b sum_j sigma_j proof_b[j] == sum_j sigma_j FK20(sum_b rho_b p_b)[j] (the right side through the one-polynomial path).
+  in_process    -- the multi-device handle of the C ABI (kzg_hip_multi_*, what a Go caller sees) in a child process after this one has released
+                   its tables: host-buffer batches divided among the devices, ONE polynomial sharded inside the library (all-gather schemes).
+  roofline.secondary -- the rooflines of the FK20 / F_r kernels; roofline.profile_avg_ms -- the same launch shape in the committed kernel trace.
   fk20_multi    -- BASELINE config 5: DAUsingFK20Multi at scale 16, chunk 16 (32768 coefficients -> 4096 coset proofs).
   reference_benchmarks -- FFT_Fr / DAS extension / FFT_G1 at scale 12 beside the reference's published BENCH.md numbers.
 """
@@ -51,6 +60,8 @@ N_COEFF = 4096
 BYTES_PER_COMMIT = 131072 + 96
 BYTES_SETUP = 393216
 FK20_BYTES = 851968
+FK20_4096_BYTES = 1310720                  # 131 072 poly + 786 432 xExtFFT + 393 216 proofs
+S_TEST = 1927409816240961209460912649124   # the reference's test secret (kzg_single_proofs_test.go:15): setups longer than eth/trusted_setup.json
 
 
 def splitmix_blobs(base_seed, batch, n=N_COEFF):
@@ -264,6 +275,129 @@ def self_launch(n_ranks):
     return 0
 
 
+def run_in_process_child(devices, timeout=420):
+    """the multi-device leg in a child process (a crash or a hang there must not cost the bench line): returns its `in_process` object"""
+    cmd = [sys.executable, os.path.abspath(__file__), "--in-process-child", "--devices", ",".join(str(d) for d in devices)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK")}
+    try:
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+        for line in reversed(res.stdout.splitlines()):
+            if line.startswith('{"in_process"'):
+                return json.loads(line)["in_process"]
+        return {"error": "child exit code %d, no result line" % res.returncode, "stderr_tail": res.stderr[-600:]}
+    except subprocess.TimeoutExpired:
+        return {"error": "child timed out after %d s" % timeout}
+    except Exception as e:                                    # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
+def in_process_child(devices):
+    """Times the multi-device handle of the C ABI (kzg_hip_multi_*: what a Go caller gets from NewMultiKZGSettings) on `devices`: host-buffer
+    batches divided among the devices (PCIe-inclusive, the only form a Go slice can take) and ONE polynomial sharded inside the library.
+    On a single device the one-polynomial legs also run on the list [d, d] (two entries, one GPU): that measures the orchestration and the
+    exchange, not a speed-up.  Prints one line {"in_process": {...}}."""
+    import gokzg_amd as kz
+    golden = os.path.join(ROOT, "tests", "golden")
+    pins = json.load(open(os.path.join(golden, "fk20_pins.json")))
+    out = {"devices": devices, "entry": "kzg_hip_multi_* (include/kzg_hip.h), host buffers, blocking calls"}
+
+    def med(fn, reps=5, warm=2):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return float(np.median(ts))
+
+    try:
+        D = len(devices)
+        fs0 = kz.FFTSettings(12, device=devices[0])
+        raw = np.frombuffer(open(os.path.join(golden, "trusted_setup_g1.bin"), "rb").read(), dtype=np.uint8)
+        setup = fs0.from_compressed_g1(raw)
+
+        def mont(seed, batch, n=N_COEFF):
+            o, ok = fs0.fr_from_32(splitmix_blobs_le32(seed, batch, n).reshape(-1, 32))
+            assert ok
+            return o.reshape(batch, n, 4)
+
+        def sha(fsx, pts):
+            return hashlib.sha256(fsx.to_compressed_g1(pts).tobytes()).hexdigest()
+        m = kz.MultiKZGSettings(devices, 12, setup)
+        out["transport"], out["transport_note"] = m.transport, m.transport_note
+        per = 1024
+        blobs = mont(1, per * D)
+        exp_f = json.load(open(os.path.join(golden, "derived_vectors.json")))["F_blob_seed1"]["commit_monomial_s1337"]
+        got = m.commit_to_poly_batch(blobs)
+        ks0 = m.kzg_settings(0)
+        one_dev = ks0.commit_to_poly_batch(blobs[:per])
+        ms_all = med(lambda: m.commit_to_poly_batch(blobs), 3, 1)
+        ms_one = med(lambda: ks0.commit_to_poly_batch(blobs[:per]), 3, 1)
+        out["commit_to_poly_batch"] = {"blobs_per_device": per, "table": "library default (64 GB, 14-bit windows) on every device",
+                                       "commitments_per_s": per * D / ms_all * 1e3, "one_device_same_call_per_s": per / ms_one * 1e3,
+                                       "scaling_vs_one_device": (per * D / ms_all) / (per / ms_one),
+                                       "vector_F": fs0.to_compressed_g1(got[:1])[0].tobytes().hex() == exp_f, "first_share_equals_one_device": bool(np.array_equal(got[:per], one_dev))}
+        # FK20 (config 4a): batches divided among the devices, and ONE polynomial sharded inside the library
+        mfk = kz.MultiFK20SingleSettings(m, 4096)
+        fper = 32
+        polys = mont(4, fper * D)[:, :2048, :].copy()
+        pr = mfk.da_using_fk20_batch(polys)
+        ms_fk = med(lambda: mfk.da_using_fk20_batch(polys), 2, 1)
+        fk0 = kz.FK20SingleSettings(ks0, 4096)
+        ms_fk1 = med(lambda: fk0.da_using_fk20_batch(polys[:fper]), 2, 1)
+        out["da_using_fk20_batch"] = {"polynomials_per_device": fper, "all_proofs_per_s": fper * D / ms_fk * 1e3, "one_device_same_call_per_s": fper / ms_fk1 * 1e3,
+                                      "byte_pin_row0": sha(fs0, pr[0]) == pins["config4a_da_using_fk20_seed4"]["sha256"]}
+        one = {"unsharded_one_device_ms": med(lambda: fk0.da_using_fk20(polys[0]))}
+        for mode in ("gather", "sharded"):
+            if D == 1 and mode == "sharded":
+                continue
+            m.set_fft_sharding(mode)
+            e0 = m.exchanges
+            okp = sha(fs0, mfk.da_using_fk20(polys[0])) == pins["config4a_da_using_fk20_seed4"]["sha256"]
+            one[mode] = {"ms": med(lambda: mfk.da_using_fk20(polys[0])), "all_gathers_per_call": None, "byte_pin": okp}
+            e1 = m.exchanges
+            mfk.da_using_fk20(polys[0])
+            one[mode]["all_gathers_per_call"] = m.exchanges - e1
+        out["da_using_fk20_one_polynomial"] = one
+        fk0.close(); mfk.close(); m.close()
+
+        # config 5: ONE DAUsingFK20Multi (scale 16, chunk 16) over the devices; on a single device also over two entries of it
+        fs16 = kz.FFTSettings(16, device=devices[0])
+        sec = np.frombuffer((S_TEST * ((1 << 256) % R_MOD) % R_MOD).to_bytes(32, "little"), dtype=np.uint64).reshape(1, 4)
+        setup16 = fs16.generate_testing_setup_g1(sec, 65536)
+        poly5 = mont(5, 1, 32768)[0]
+        pin5 = pins["config5_da_using_fk20_multi_seed5"]["sha256"]
+        cfg5 = {}
+        for devs in ([devices] if D > 1 else [devices, devices * 2]):
+            m16 = kz.MultiKZGSettings(devs, 16, setup16)
+            mfkm = kz.MultiFK20MultiSettings(m16, 65536, 16)
+            row = {"devices": devs, "transport": m16.transport}
+            if "unsharded_one_device_ms" not in cfg5:
+                fkm0 = kz.FK20MultiSettings(m16.kzg_settings(0), 65536, 16)
+                cfg5["unsharded_one_device_ms"] = med(lambda: fkm0.da_using_fk20_multi(poly5), 3, 2)
+                fkm0.close()
+            for mode in ("gather", "sharded"):
+                if len(devs) == 1 and mode == "sharded":
+                    continue
+                m16.set_fft_sharding(mode)
+                okp = sha(fs16, mfkm.da_using_fk20_multi(poly5)) == pin5
+                e1 = m16.exchanges
+                row[mode] = {"ms": med(lambda: mfkm.da_using_fk20_multi(poly5), 3, 1), "byte_pin": okp}
+                row[mode]["all_gathers_per_call"] = (m16.exchanges - e1) // 4
+            cfg5["%d_entries" % len(devs)] = row
+            mfkm.close(); m16.close()
+        cfg5["note"] = ("entries of ONE device share its SIMDs: the figures there are orchestration + exchange cost, not a speed-up" if D == 1 else
+                        "Toeplitz stage by output position on every device; gather = transforms on the first device, sharded = five all-gathers")
+        out["da_using_fk20_multi_one_polynomial_scale16"] = cfg5
+        fs16.close(); fs0.close()
+    except Exception as e:                                    # noqa: BLE001
+        import traceback
+        out["error"] = "%s: %s | %s" % (type(e).__name__, e, traceback.format_exc().strip().splitlines()[-3:])
+    print(json.dumps({"in_process": out}))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -277,7 +411,14 @@ def main():
     ap.add_argument("--no-fk20", action="store_true")
     ap.add_argument("--table-gb", type=float, default=210.0, help="HBM budget of the commitment table for the headline (library default: 64)")
     ap.add_argument("--no-extras", action="store_true", help="skip table_sweep / drop_in / lincomb / latency (profiling runs)")
+    ap.add_argument("--fk20-4096-batch", type=int, default=512, help="polynomials per step of the fk20_4096 block (0: skip)")
+    ap.add_argument("--no-in-process", action="store_true", help="skip the multi-device-handle leg (a child process at the end)")
+    ap.add_argument("--in-process-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--devices", type=str, default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.in_process_child:
+        sys.exit(in_process_child([int(x) for x in args.devices.split(",") if x != ""]))
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
@@ -323,6 +464,24 @@ def main():
             break
         except (OSError, ValueError):
             continue
+
+    shapes, shapes_file = [], None
+    for name in ("r04_kernel_shapes.json",):                 # (kernel, grid, workgroup) rows of the committed rocprofv3 kernel trace (tools/rocprof_summary.py)
+        try:
+            shapes = json.load(open(os.path.join(ROOT, "profiles", name)))["rows"]
+            shapes_file = "profiles/" + name
+            break
+        except (OSError, ValueError, KeyError):
+            continue
+
+    def profile_avg_ms(prefix, grid, wg):
+        """average duration of the launches of that shape in the committed kernel trace (all kernels whose name starts with `prefix`)"""
+        rows_ = [r for r in shapes if r["kernel"].startswith(prefix) and r["grid"] == grid and r["workgroup"] == wg]
+        calls = sum(r["calls"] for r in rows_)
+        if not calls:
+            return None, None
+        return sum(r["avg_us"] * r["calls"] for r in rows_) / calls * 1e-3, "%s: %s, grid %d, workgroup %d (%d launches)" % (
+            shapes_file.replace(".json", ".md"), " + ".join(sorted(set(r["kernel"] for r in rows_))), grid, wg, calls)
 
     def mont_blobs(seed, batch, n=N_COEFF):
         """synthetic scalars as Montgomery images: vectorised splitmix + mod r on the host, FrFrom32 on the device"""
@@ -382,6 +541,46 @@ def main():
     secs = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, barrier, max_over_ranks)
     value = B * world * args.steps / secs
 
+    def poly_lincomb(d_rows, stride, rho_h, count, n):
+        """sum_c rho_c row_c over device-resident rows (bls.PolyLinComb's kernel), returned as host images"""
+        d_rho = torch.from_numpy(np.ascontiguousarray(rho_h).view(np.int64)).cuda()
+        d_comb = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+        st = lib.kzg_hip_bench_poly_lincomb_dev(fs.h, d_rows.data_ptr(), stride, d_rho.data_ptr(), count, n, d_comb.data_ptr(), stream)
+        if st:
+            raise RuntimeError("bench_poly_lincomb_dev status %d" % st)
+        torch.cuda.synchronize()
+        return d_comb.cpu().numpy().view(np.uint64).reshape(n, 4)
+
+    def all_ranks_ok(ok):
+        if not use_dist:
+            return bool(ok)
+        t = torch.tensor([1 if ok else 0], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    def check_proof_rows(fsx, d_proofs_, rows, per_row, d_polys_, n_coeff, one_polynomial, seed):
+        """every proof of a timed FK20 step: FK20 is linear in the polynomial, so for random rho, sigma
+        sum_b rho_b (sum_j sigma_j proof_b[j]) == sum_j sigma_j FK20(sum_b rho_b p_b)[j]; the left side is `rows` LinCombG1 calls over the step's
+        outputs as caller-supplied points (bucket pipeline) and one more over their results, the right side the ONE-polynomial path of the
+        library (direct passes: other kernels than the batch) on the combined polynomial"""
+        sigma, rho = mont_blobs(seed, 1, n=per_row)[0], mont_blobs(seed + 1, 1, n=rows)[0]
+        P = d_proofs_.cpu().numpy().view(np.uint64).reshape(rows, per_row, 3, 6)
+        R = np.stack([fsx.lin_comb_g1(P[b], sigma) for b in range(rows)])
+        lhs = fsx.lin_comb_g1(R, rho)
+        q = one_polynomial(poly_lincomb(d_polys_, n_coeff, rho, rows, n_coeff))
+        return bool(np.array_equal(lhs, fsx.lin_comb_g1(q, sigma)))
+
+    # ALL outputs of the last timed step (the KAT above pins blob 0 only): sum_b rho_b C_b == CommitToPoly(sum_b rho_b blob_b) for random rho --
+    # one B-term LinCombG1 over the step's outputs as caller-supplied points and one lone commitment (other launch shapes than the timed one)
+    rho_c = mont_blobs(0xC0FFEE + rank, 1, n=B)[0]
+    lhs_c = fs.lin_comb_g1(d_out.cpu().numpy().view(np.uint64).reshape(B, 3, 6), rho_c)
+    rhs_c = ks.commit_to_poly(poly_lincomb(d_blobs, N_COEFF, rho_c, B, N_COEFF))
+    if not all_ranks_ok(np.array_equal(lhs_c, rhs_c)):
+        raise SystemExit("bench self-check failed: sum_b rho_b C_b != CommitToPoly(sum_b rho_b blob_b) over the %d outputs of the timed step" % B)
+    self_check = {"rows_checked": B, "per_rank": True, "ranks": world,
+                  "method": "sum_b rho_b C_b == CommitToPoly(sum_b rho_b blob_b), rho random in F_r: one %d-term LinCombG1 over the step's outputs + one commitment; "
+                            "blob 0 also against SURVEY.md vector F" % B}
+
     # SURVEY.md 8(d) config 2 also names the batch sizes 1, 64 and 1024: the same step at those sizes and at round 1's 512 (secondary
     # figures; the headline's step is `--batch` blobs: the end of a launch -- block trees, one inversion per blob -- is amortised over more
     # work the larger the step)
@@ -432,9 +631,15 @@ def main():
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_s * 1e3,
                     "algorithmic_bytes_per_launch": alg_bytes,
                     "table": {"window_bits": tab_c, "windows": tab_w, "GB": tab_bytes / 1e9},
+                    "secondary": {},
                     "traffic_source": (pmc.get("_file") if pm_sc == 1.0 else "%s (counters of the %d-blob launch x %g)" % (pmc.get("_file"), pm["batch"], pm_sc)) if pm_ok else None,
                     "note": "integer-issue-bound kernel (see mac / issue); traffic (PMC passes committed under profiles/) exceeds the algorithmic bytes by design: fixed-base table gathers trade HBM bandwidth for integer work (DESIGN.md 4)"}
 
+        if dominant == b"fb_accumulate" and B >= 512:           # one 256-lane workgroup per blob from 512 blobs on: the row of this launch shape
+            pa_, ps_ = profile_avg_ms("k_fb_accumulate", B * 256, 256)
+            roofline["profile_avg_ms"], roofline["profile_source"] = pa_, ps_
+            if pa_:
+                roofline["profile_frac"] = alg_bytes / (pa_ * 1e-3) * 1e-9 / HBM_PEAK_GBS
         if tab_w:
             # What bounds the walk is integer issue, not HBM.  One XYZZ mixed addition = 6 products (338 v_mad_u64_u32 each) + 2 squarings
             # (260) + one two-product reduction (507) = 3055 multiply-adds; B * n * windows of them per launch (zero digits: < 2^-15).
@@ -458,7 +663,7 @@ def main():
     # Everything below is secondary to the headline measured above.  On one GPU a failure in a secondary leg is recorded in
     # `secondary_error` and the line is still printed; with several ranks it is raised (a rank that skipped ahead would leave the others
     # in a barrier).
-    table_sweep = drop_in = lincomb = latency = fk20 = roofline_fk20 = fk20m = ref_benches = None
+    table_sweep = drop_in = lincomb = latency = fk20 = roofline_fk20 = fk20m = ref_benches = fk20_4096 = roofline_fk20_4096 = roofline_fft_fr = roofline_das = None
     secondary_error = None
     try:
         if os.environ.get("KZG_BENCH_FAIL_SECONDARY"):           # test hook (tests/test_bench_dist.py)
@@ -623,9 +828,14 @@ def main():
                     raise SystemExit("bench self-check failed: FK20 proofs of blob(seed 4) do not match the byte pin")
             fsteps = max(1, args.steps // 2)
             fsecs = timed_steps(fk_step, fsteps, 1, torch.cuda.synchronize, barrier, max_over_ranks)
+            rows_ok = all_ranks_ok(check_proof_rows(fs, d_proofs, FB, 4096, d_polys, 2048, fk.da_using_fk20, 0xFA20 + 2 * rank))
+            if not rows_ok:
+                raise SystemExit("bench self-check failed: the random linear combination over all %d x 4096 FK20 proofs of the timed step does not match" % FB)
             fk20 = {"metric": "FK20 all-proofs/s (DAUsingFK20, 2048 coeffs -> 4096 proofs, scale 12)",
                     "value": FB * world * fsteps / fsecs, "batch_per_gpu": FB,
-                    "ms_per_all_proofs": fsecs / fsteps / FB * 1e3, "self_check_byte_pin": fk_ok}
+                    "ms_per_all_proofs": fsecs / fsteps / FB * 1e3, "self_check_byte_pin": fk_ok,
+                    "self_check": {"rows_checked": FB, "proofs_checked": FB * 4096,
+                                   "method": "sum_b rho_b sum_j sigma_j proof_b[j] == sum_j sigma_j DAUsingFK20(sum_b rho_b p_b)[j] (right side on the one-polynomial path)"}}
             if not args.no_extras and world == 1:
                 for _ in range(3):
                     fk.da_using_fk20(polys_h[0])
@@ -693,6 +903,7 @@ def main():
                                  "kernel_ms_per_all_proofs": tot2.value / FB, "algorithmic_bytes_per_step": alg,
                                  "traffic": (pf.get("fetch_bytes_per_step", 0) + pf.get("write_bytes_per_step", 0)) * psc if psc else None,
                                  "traffic_source": ((pmc.get("_file") + " (same launch shape)") if psc == 1 else "%s (counters of the %d-polynomial step x %g)" % (pmc.get("_file"), pf["batch"], psc)) if psc else None,
+                                 "profile_avg_ms": profile_avg_ms("k_g1_fft_stage", FB * 2048, 256)[0], "profile_source": profile_avg_ms("k_g1_fft_stage", FB * 2048, 256)[1],
                                  "share_of_step": kern_s / (fsecs / fsteps), "table_walk_ms_per_step": tot3.value if cnt3.value else None,
                                  "mac": {"mads_per_all_proofs": mads_unit, "achieved_Tmad_s": FB * mads_unit / kern_s * 1e-12, "measured_peak_Tmad_s": cal_mad * 1e-12,
                                          "frac": FB * mads_unit / kern_s / cal_mad},
@@ -719,6 +930,96 @@ def main():
                 except Exception as e:                           # noqa: BLE001
                     fk20["all_gather_proofs"] = {"error": "%s: %s" % (type(e).__name__, e)}
             fk.close()
+
+        if not args.no_fk20 and args.fk20_4096_batch > 0:
+            # The metric's literal input: a 4096-ELEMENT blob (BASELINE config 4b).  FK20Single (fk20_single.go:122-137) needs a domain of twice
+            # the polynomial's length: scale 13, 8192-point setup [s^i]G1 of the reference's test secret (GenerateTestingSetup on the device).
+            # Two forms on the same settings: FK20Single 4096 coefficients -> 4096 proofs (131 072 MulG1 in the reference, against 81 920 for
+            # config 4a) and DAUsingFK20 4096 -> 8192 proofs.
+            fs13 = kz.FFTSettings(13, device=local)
+            sec13 = np.frombuffer((S_TEST * ((1 << 256) % R_MOD) % R_MOD).to_bytes(32, "little"), dtype=np.uint64).reshape(1, 4)
+            ks13 = kz.KZGSettings(fs13, fs13.generate_testing_setup_g1(sec13, 8192))
+            fk13 = kz.FK20SingleSettings(ks13, 8192)
+            QB = args.fk20_4096_batch
+            q_h = mont_blobs(1 + rank * QB, QB)                     # row 0 of rank 0 is blob(seed 1): config 4b's pinned polynomial
+            d_q = torch.from_numpy(q_h.view(np.int64)).cuda()
+            d_qp = torch.zeros((QB, 4096, 18), dtype=torch.int64, device="cuda")
+            d_qda = torch.zeros((QB, 8192, 18), dtype=torch.int64, device="cuda")
+
+            def q_step():
+                st = lib.kzg_hip_fk20_single_batch_dev(fk13.h, d_q.data_ptr(), 4096, QB, d_qp.data_ptr(), stream)
+                if st:
+                    raise RuntimeError("fk20_single_batch_dev status %d %s" % (st, lib.kzg_hip_last_error().decode()))
+
+            def qda_step():
+                st = lib.kzg_hip_da_using_fk20_batch_dev(fk13.h, d_q.data_ptr(), 4096, QB, d_qda.data_ptr(), stream)
+                if st:
+                    raise RuntimeError("da_using_fk20_batch_dev (4096) status %d %s" % (st, lib.kzg_hip_last_error().decode()))
+
+            q_step(); qda_step()
+            torch.cuda.synchronize()
+            q_ok = None
+            if rank == 0:
+                h1 = hashlib.sha256(fs13.to_compressed_g1(d_qp[0].cpu().numpy().view(np.uint64).reshape(4096, 3, 6)).tobytes()).hexdigest()
+                h2 = hashlib.sha256(fs13.to_compressed_g1(d_qda[0].cpu().numpy().view(np.uint64).reshape(8192, 3, 6)).tobytes()).hexdigest()
+                q_ok = h1 == pins["config4b_fk20_single_seed1"]["sha256"] and h2 == pins["config4b_da_using_fk20_seed1"]["sha256"]
+                if not q_ok:
+                    raise SystemExit("bench self-check failed: FK20 proofs of the 4096-element blob(seed 1) do not match the config-4b byte pins")
+            qsteps = max(1, args.steps // 2)
+            qsecs = timed_steps(q_step, qsteps, 1, torch.cuda.synchronize, barrier, max_over_ranks)
+            qdsecs = timed_steps(qda_step, qsteps, 1, torch.cuda.synchronize, barrier, max_over_ranks)
+            rows_ok = all_ranks_ok(check_proof_rows(fs13, d_qp, QB, 4096, d_q, 4096, fk13.fk20_single, 0xFB20 + 2 * rank)
+                                   and check_proof_rows(fs13, d_qda, QB, 8192, d_q, 4096, fk13.da_using_fk20, 0xFC20 + 2 * rank))
+            if not rows_ok:
+                raise SystemExit("bench self-check failed: the random linear combination over all FK20 proofs of the 4096-element blobs does not match")
+            fk20_4096 = {"metric": "FK20 all-proofs/s on 4096-element blobs (FK20Single, 4096 coeffs -> 4096 proofs, scale 13; BASELINE config 4b)",
+                         "value": QB * world * qsteps / qsecs, "batch_per_gpu": QB, "ms_per_all_proofs": qsecs / qsteps / QB * 1e3,
+                         "da_using_fk20_4096_to_8192": {"value": QB * world * qsteps / qdsecs, "ms_per_all_proofs": qdsecs / qsteps / QB * 1e3},
+                         "rate_over_config_4a": (QB * world * qsteps / qsecs) / fk20["value"] if fk20 else None,
+                         "reference_work_ratio_4b_over_4a": 131072 / 81920,
+                         "self_check_byte_pins": q_ok,
+                         "self_check": {"rows_checked": QB, "proofs_checked": QB * (4096 + 8192),
+                                        "method": "random linear combination over every proof of both forms against the one-polynomial path; row 0 against the config-4b pins"}}
+            if not args.no_extras and world == 1:
+                def med(fn, reps=5):
+                    for _ in range(3):
+                        fn()
+                    ts_ = []
+                    for _ in range(reps):
+                        t0_ = time.perf_counter()
+                        fn()
+                        ts_.append((time.perf_counter() - t0_) * 1e3)
+                    return float(np.median(ts_))
+                fk20_4096["FK20Single_4096_single_call_ms"] = med(lambda: fk13.fk20_single(q_h[0]))
+                fk20_4096["DAUsingFK20_4096_single_call_ms"] = med(lambda: fk13.da_using_fk20(q_h[0]))
+            # roofline of the stage kernel at this shape: HIP events around every stage launch of one FK20Single step (separate un-timed pass)
+            lib.kzg_hip_prof_reset(fs13.h, 1)
+            q_step()
+            torch.cuda.synchronize()
+            tq, cq = C.c_double(0), C.c_uint64(0)
+            lib.kzg_hip_prof_read(fs13.h, b"g1_fft_stage", C.byref(tq), C.byref(cq))
+            lib.kzg_hip_prof_reset(fs13.h, 0)
+            if cq.value:
+                kq = tq.value * 1e-3
+                per_mul = 126 * 1963 + 42.7 * 3315 + 33100          # multiply-adds of one twiddle multiplication (see the 4a block)
+                # a transform of N points multiplies in N/2 log2 N - (N - 1) butterflies (twiddle 1 does not multiply); inverse transform of 8192
+                # points with its two widest stages inside the Toeplitz stage (4095 + 4094 multiplications, 8192 butterflies fewer), forward of 4096
+                fusedq = int(cq.value) == 23
+                muls = (45057 - 8189 + 20481) if fusedq else (45057 + 20481)
+                bfly = (13 * 4096 - 8192 + 12 * 2048) if fusedq else (13 * 4096 + 12 * 2048)
+                mads_q = muls * per_mul + bfly * 7384
+                algq = QB * FK20_4096_BYTES
+                roofline_fk20_4096 = {"bound": "hbm", "kernel": "k_g1_fft_stage", "achieved": algq / kq * 1e-9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": algq / kq * 1e-9 / HBM_PEAK_GBS, "traffic": None, "launches_per_step": int(cq.value), "avg_launch_ms": tq.value / cq.value,
+                                      "algorithmic_bytes_per_step": algq, "algorithmic_bytes_per_unit": FK20_4096_BYTES,
+                                      "kernel_ms_per_all_proofs": tq.value / QB, "share_of_step": kq / (qsecs / qsteps),
+                                      "mac": {"mads_per_all_proofs": mads_q, "achieved_Tmad_s": QB * mads_q / kq * 1e-12, "measured_peak_Tmad_s": cal_mad * 1e-12,
+                                              "frac": QB * mads_q / kq / cal_mad},
+                                      "pipeline": ("Toeplitz stage fused with two DIF stages (k_fb_mul_vec_dif2), 11 DIF launches on 8192 points + 12 DIT launches on the 4096 even positions"
+                                                   if fusedq else "%d stage launches (unfused)" % int(cq.value)),
+                                      "note": "one step = %d polynomials of 4096 coefficients (FK20Single at scale 13)" % QB}
+            del d_q, d_qp, d_qda
+            fk13.close(); ks13.close(); fs13.close()
 
         fk20m = None
         if not args.no_fk20 and args.fk20_multi_batch > 0:
@@ -749,8 +1050,11 @@ def main():
                     raise SystemExit("bench self-check failed: FK20Multi proofs of blob(seed 5) do not match the byte pin")
             msteps = max(1, args.steps // 2)
             msecs = timed_steps(fkm_step, msteps, 1, torch.cuda.synchronize, barrier, max_over_ranks)
+            if not all_ranks_ok(check_proof_rows(fs16, d_mproofs, MB, 4096, d_mp, 32768, fkm.da_using_fk20_multi, 0xFD20 + 2 * rank)):
+                raise SystemExit("bench self-check failed: the random linear combination over all %d x 4096 FK20Multi proofs of the timed step does not match" % MB)
             fk20m = {"metric": "FK20Multi all-coset-proofs/s (DAUsingFK20Multi, scale 16, chunk 16: 32768 coeffs -> 4096 proofs)",
-                     "value": MB * world * msteps / msecs, "batch_per_gpu": MB, "ms_per_all_proofs": msecs / msteps / MB * 1e3, "self_check_byte_pin": fkm_ok}
+                     "value": MB * world * msteps / msecs, "batch_per_gpu": MB, "ms_per_all_proofs": msecs / msteps / MB * 1e3, "self_check_byte_pin": fkm_ok,
+                     "self_check": {"rows_checked": MB, "proofs_checked": MB * 4096, "method": "random linear combination over every coset proof against the one-polynomial path"}}
             if use_dist or args.sharded_fk20_multi:
                 # ONE FK20Multi with its Toeplitz stage sharded over the ranks and an RCCL all-gather of the 144-byte point slices
                 # (BASELINE config 5, go-kzg_amd/multi_gpu.py).  A latency figure, reported beside the throughput numbers; a failure
@@ -813,7 +1117,7 @@ def main():
             r_fr, r_das, r_g1 = rate(fr_step, FB, 5), rate(das_step, FB, 5), rate(g1_step, GB, 2)
             torch.cuda.synchronize()
 
-            def fr_roofline(prof_name, pmc_key, kernel, alg_bytes_unit, mads_unit, what):
+            def fr_roofline(prof_name, pmc_key, kernel, alg_bytes_unit, mads_unit, what, lanes_per_unit):
                 """HBM roofline of an LDS-resident F_r transform kernel (bytes in + bytes out per transform), its multiply-add rate
                 against the v_mad_u64_u32 rate measured in this run, and the committed counter pass of the same launch shape"""
                 t_, c_ = C.c_double(0), C.c_uint64(0)
@@ -830,6 +1134,7 @@ def main():
                        "traffic_source": (pmc.get("_file") + " (same launch shape; FETCH_SIZE x 2 per the guide's correction for wide coalesced reads)") if same else None,
                        "mac": {"mads_per_launch": FB * mads_unit, "achieved_Tmad_s": FB * mads_unit / avg * 1e-12, "measured_peak_Tmad_s": cal_mad * 1e-12,
                                "frac": FB * mads_unit / avg / cal_mad}}
+                out["profile_avg_ms"], out["profile_source"] = profile_avg_ms(kernel, FB * lanes_per_unit, lanes_per_unit)
                 if same:
                     valu = pk["valu_insts_per_launch"]
                     model = FB * mads_unit / cal_mad + max(valu * 64.0 - FB * mads_unit, 0.0) / cal_add
@@ -839,13 +1144,12 @@ def main():
                                                           "parked_waitcnt_or_barrier": pk["sq_wait_any"] / pk["sq_wave_cycles"]}}
                 return out
             # multiply-adds per transform: 1024 lanes x (21 products of 153 + 4 canonicalisations of 8); per extension: 512 lanes x (46 products of 153)
-            roofline_fft_fr = fr_roofline(b"fr_fft4096", "k_fr_fft4096_r4", "k_fr_fft4096_r4", 2 * 4096 * 32, 1024 * (21 * 153 + 4 * 8), "%d forward transforms of 4096 points" % FB)
-            roofline_das = fr_roofline(b"das_ext2048", "k_das_ext2048_r4", "k_das_ext2048_r4", 2 * 2048 * 32, 512 * (46 * 153 + 5 * 9), "%d extensions of 2048 values" % FB)
+            roofline_fft_fr = fr_roofline(b"fr_fft4096", "k_fr_fft4096_r4", "k_fr_fft4096_r4", 2 * 4096 * 32, 1024 * (21 * 153 + 4 * 8), "%d forward transforms of 4096 points" % FB, 1024)
+            roofline_das = fr_roofline(b"das_ext2048", "k_das_ext2048_r4", "k_das_ext2048_r4", 2 * 2048 * 32, 512 * (46 * 153 + 5 * 9), "%d extensions of 2048 values" % FB, 512)
             lib.kzg_hip_prof_reset(fs.h, 0)
             ref_benches = {
                 "fft_fr_scale12_per_s": {"value": r_fr, "reference_published": 1e9 / 1911871, "source": "BENCH.md:43 (Kilic, 5950X, 1 thread)", "batch": FB},
                 "das_fft_extension_scale12_per_s": {"value": r_das, "reference_published": 1e9 / 1169011, "source": "BENCH.md:31", "batch": FB},
-                "roofline_fft_fr": roofline_fft_fr, "roofline_das_ext": roofline_das,
                 "fft_g1_scale12_per_s": {"value": r_g1, "reference_published": 1e9 / 3745748396, "source": "BENCH.md:55", "batch": GB},
             }
 
@@ -854,6 +1158,19 @@ def main():
             raise
         import traceback
         secondary_error = "%s: %s | %s" % (type(e).__name__, e, traceback.format_exc().strip().splitlines()[-3:])
+    if roofline is not None:                                  # the other kernels' rooflines live under the headline kernel's
+        roofline["secondary"] = {"fk20": roofline_fk20, "fk20_4096": roofline_fk20_4096, "fft_fr": roofline_fft_fr, "das_ext": roofline_das}
+    # the multi-device handle of the C ABI, in a child process once this one has released its tables (every rank releases; rank 0 runs it)
+    in_process = None
+    ks.close()
+    fs.close()
+    del d_blobs, d_out
+    torch.cuda.empty_cache()
+    if not args.no_in_process and not args.no_fk20 and not os.environ.get("KZG_BENCH_FAIL_SECONDARY"):
+        barrier()
+        if rank == 0:
+            in_process = run_in_process_child(list(range(world)) if (world > 1 and torch.cuda.device_count() >= world) else [local])
+        barrier()
     if rank == 0:
         print(json.dumps({
             "metric": "KZG commitments/sec (CommitToPoly, 4096-element blob)", "value": value, "unit": "commitments/s",
@@ -862,13 +1179,12 @@ def main():
             "data": "synthetic",
             "config": {"workload": "CommitToPoly, 4096-coeff blobs, eth/trusted_setup.json monomial setup (s=1337), %d blobs/step/GPU resident in HBM, fixed-base table budget %g GB (opt-in; library default 64 GB, see table_sweep)" % (B, args.table_gb),
                        "global_batch": B * world, "parallelism": "dp%d (independent blobs, no data-path collective)" % world},
-            "rccl": rccl, "roofline": roofline, "roofline_fk20": roofline_fk20, "cpu_baseline": base, "batch_sweep": batch_sweep, "table_sweep": table_sweep, "drop_in": drop_in,
-            "lincomb": lincomb, "latency": latency, "fk20": fk20, "fk20_multi": fk20m, "reference_benchmarks": ref_benches, "secondary_error": secondary_error,
+            "rccl": rccl, "roofline": roofline, "cpu_baseline": base, "self_check": self_check, "batch_sweep": batch_sweep, "table_sweep": table_sweep, "drop_in": drop_in,
+            "lincomb": lincomb, "latency": latency, "fk20": fk20, "fk20_4096": fk20_4096, "fk20_multi": fk20m, "reference_benchmarks": ref_benches, "in_process": in_process,
+            "secondary_error": secondary_error,
         }))
     if use_dist:
         dist.destroy_process_group()
-    ks.close()
-    fs.close()
 
 
 if __name__ == "__main__":

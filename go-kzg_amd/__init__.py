@@ -132,6 +132,7 @@ def lib():
         "kzg_hip_multi_da_using_fk20_batch": (i32, [vp, vp, u64, u64, vp]), "kzg_hip_multi_da_using_fk20": (i32, [vp, vp, u64, vp]),
         "kzg_hip_multi_fk20_multi_settings_new": (i32, [vp, u64, u64, pp]), "kzg_hip_multi_fk20_multi_settings_free": (None, [vp]),
         "kzg_hip_multi_da_using_fk20_multi_batch": (i32, [vp, vp, u64, u64, vp]), "kzg_hip_multi_da_using_fk20_multi": (i32, [vp, vp, u64, vp]),
+        "kzg_hip_bench_poly_lincomb_dev": (i32, [vp, vp, u64, vp, u64, u64, vp, vp]),
         "kzg_hip_prof_reset": (None, [vp, i32]), "kzg_hip_prof_read": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64)]),
     }
     for name, (res, args) in sig.items():

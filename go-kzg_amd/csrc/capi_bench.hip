@@ -84,6 +84,15 @@ int kzg_hip_bench_drop_in_eth_proof(kzg_hip_eth *eth, const void *polys_fr, uint
     return KZG_HIP_OK;
     KZG_CATCH
 }
+// bls.PolyLinComb over device-resident rows (bls/globals.go:155-178): out[i] = sum_c scalars[c] * vectors[c * stride + i].  bench.py's check of
+// EVERY output of a timed step needs the random linear combination of the step's input polynomials; this is the kernel the eth aggregation uses.
+int kzg_hip_bench_poly_lincomb_dev(kzg_hip_fft *fs, const void *d_vectors_fr, uint64_t stride, const void *d_scalars_fr, uint64_t count, uint64_t n, void *d_out_fr, void *stream) {
+    if (!fs || !d_vectors_fr || !d_scalars_fr || !d_out_fr || !n) return KZG_HIP_ERR_BAD_ARG;
+    dev_select sel(fs);
+    launch_poly_lincomb((hipStream_t)stream, (const fr *)d_vectors_fr, stride, (const fr *)d_scalars_fr, count, n, (fr *)d_out_fr);
+    HIPCHK(hipGetLastError());
+    return KZG_HIP_OK;
+}
 // the same for the host-buffer (I)FFT over F_r (fft_fr.go:55-74): `threads` host threads x `calls` blocking kzg_hip_fft_fr calls of n values each
 // (thread t transforms vals[t % nrows]); out: threads x n Fr (each thread's last result)
 int kzg_hip_bench_threads_fft_fr(kzg_hip_fft *fs, const void *vals_fr, uint64_t n, uint64_t nrows, unsigned threads, unsigned calls, void *out_fr, double *seconds) {

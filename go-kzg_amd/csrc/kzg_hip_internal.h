@@ -28,6 +28,10 @@ int kzg_hip_bench_drop_in_eth_proof(kzg_hip_eth *eth, const void *polys_fr, uint
 /* and for kzg_hip_fft_fr on host buffers (thread t transforms row t % nrows of vals_fr, nrows x n Fr; out_fr: threads x n Fr): the
  * per-handle stream pool at work */
 int kzg_hip_bench_threads_fft_fr(kzg_hip_fft *fs, const void *vals_fr, uint64_t n, uint64_t nrows, unsigned threads, unsigned calls, void *out_fr, double *seconds);
+/* bls.PolyLinComb over device-resident rows (bls/globals.go:155-178): out[i] = sum_c scalars[c] * vectors[c * stride + i]; bench.py forms the random
+ * linear combination of a timed step's input polynomials with it when it checks ALL outputs of the step */
+int kzg_hip_bench_poly_lincomb_dev(kzg_hip_fft *fs, const void *d_vectors_fr, uint64_t stride, const void *d_scalars_fr, uint64_t count, uint64_t n, void *d_out_fr,
+                                   void *stream);
 /* test hook: SHA-256 of a host buffer through the transcript's implementation (x86 SHA extensions or the portable loop; no device needed) */
 void kzg_hip_test_sha256(const void *data, uint64_t len, void *out32);
 

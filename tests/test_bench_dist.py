@@ -138,7 +138,7 @@ def test_bench_two_ranks_under_torch_distributed_run():
     port = _free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "64", "--fk20-batch", "8", "--fk20-multi-batch", "2",
-           "--table-gb", "4", "--no-extras"]
+           "--table-gb", "4", "--no-extras", "--fk20-4096-batch", "4", "--no-in-process"]
     # own session: on a timeout the whole process group (launcher + both ranks) is killed, nothing is left holding the device or the pipes
     import signal
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
@@ -157,7 +157,9 @@ def test_bench_two_ranks_under_torch_distributed_run():
     assert d["cpu_baseline"] is None                                # rank 0 at N = 1 only
     assert d["fk20"]["self_check_byte_pin"] is True and d["fk20"]["all_gather_proofs"]["own_slice_intact"] is True
     assert d["fk20"]["all_gather_proofs"]["ranks"] == 2
-    assert d["fk20_multi"]["self_check_byte_pin"] is True
+    assert d["fk20_multi"]["self_check_byte_pin"] is True and d["fk20_multi"]["self_check"]["rows_checked"] == 2
+    assert d["self_check"]["rows_checked"] == 64 and d["fk20"]["self_check"]["rows_checked"] == 8       # every output of the timed steps is checked
+    assert d["fk20_4096"]["self_check_byte_pins"] is True and d["fk20_4096"]["value"] > 0              # the 4096-element blob (config 4b) is timed
     assert d["fk20_multi"]["sharded_one_polynomial"]["matches_unsharded"] is True, d["fk20_multi"]["sharded_one_polynomial"]
 
 
@@ -173,7 +175,7 @@ def test_bench_self_launches_its_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(KZG_BENCH_BACKEND="gloo", KZG_HIP_FK20_FB_BUDGET_GB="3")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "64", "--fk20-batch", "8",
-           "--fk20-multi-batch", "2", "--table-gb", "4"]
+           "--fk20-multi-batch", "2", "--table-gb", "4", "--fk20-4096-batch", "4", "--no-in-process"]
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
     try:
         out, err = proc.communicate(timeout=600)
