@@ -6,7 +6,7 @@
  *
  * Flow (the reference's test data: kzg_single_proofs_test.go:33-64, fk20_single_test.go:11-41):
  *   NewFFTSettings -> GenerateTestingSetup -> NewKZGSettings -> CommitToPoly (vector A) -> ComputeProofSingle(x = 17) (vector B)
- *   -> NewFK20SingleSettings -> DAUsingFK20 (vector C, positions 0 / 18 / 31) -> status codes 1..6 -> package eth (aggregate proof, status 11) -> frees.
+ *   -> NewFK20SingleSettings -> DAUsingFK20 (vector C, positions 0 / 18 / 31) -> status codes 1..6 -> package eth (aggregate proof, status 11) -> the multi-device handle on {0, 0} -> frees.
  * Expected values are SURVEY.md 8(c) vectors A-C (tests/golden/derived_vectors.json), compared as 48-byte compressed hex.
  * Test infrastructure: built and run by tests/test_cabi.py (-m gpu); prints one line per check and exits non-zero on a mismatch.
  */
@@ -157,6 +157,47 @@ int main(void) {
         expect_status(kzg_hip_eth_compute_aggregate_kzg_proof(es, blob, 1, proof, comm), KZG_HIP_ERR_BAD_BLOB, "a field element >= r in a blob");
         kzg_hip_eth_settings_free(es);
         free(lagrange);
+    }
+
+    /* ---- several devices behind one handle (kzg_hip_multi_*): the list {0, 0} -- two entries on the one GPU a test box has -- must give the
+     * bytes of the single-device calls: vector A through the batch form (two polynomials divided among the entries), vector C through ONE
+     * DAUsingFK20 sharded inside the library (gather scheme, then the five-all-gather scheme) ---- */
+    {
+        kzg_hip_multi *m = NULL;
+        kzg_hip_multi_fk20s *mfk = NULL;
+        int devs[2] = {0, 0}, no_such[2] = {0, 4096};
+        unsigned char two_polys[2 * 16 * FR], two_out[2 * G1];
+        uint64_t before;
+        expect_status(kzg_hip_multi_settings_new(no_such, 2, 5, setup, 33, &m), KZG_HIP_ERR_NO_DEVICE, "NewMultiKZGSettings with a device that is not there");
+        expect_status(kzg_hip_multi_settings_new(devs, 2, 5, setup, 33, &m), KZG_HIP_OK, "NewMultiKZGSettings({0, 0}, scale 5)");
+        check(kzg_hip_multi_device_count(m) == 2 && kzg_hip_multi_device(m, 1) == 0, "two entries, both on device 0");
+        check(strcmp(kzg_hip_multi_transport(m), "peer-copy") == 0, "a repeated device exchanges by peer copies (RCCL needs distinct devices)");
+        memcpy(two_polys, poly, 16 * FR);
+        memcpy(two_polys + 16 * FR, poly, 16 * FR);
+        expect_status(kzg_hip_multi_commit_to_poly_batch(m, two_polys, 16, 2, two_out), KZG_HIP_OK, "multi CommitToPoly x 2");
+        kzg_hip_g1_to_compressed(fs5, two_out, 2, c48);
+        hex48(c48, hx);
+        check(strcmp(hx, VEC_A) == 0, "multi: vector A from entry 0");
+        hex48(c48 + 48, hx);
+        check(strcmp(hx, VEC_A) == 0, "multi: vector A from entry 1");
+        expect_status(kzg_hip_multi_fk20_single_settings_new(m, 32, &mfk), KZG_HIP_OK, "multi NewFK20SingleSettings(32)");
+        for (i = 0; i < 2; i++) {
+            expect_status(kzg_hip_multi_set_fft_sharding(m, i), KZG_HIP_OK, i ? "sharded transforms" : "gather");
+            before = kzg_hip_multi_exchanges(m);
+            memset(proofs, 0, 32 * G1);
+            expect_status(kzg_hip_multi_da_using_fk20(mfk, poly, 16, proofs), KZG_HIP_OK, "multi DAUsingFK20 of one polynomial");
+            check(kzg_hip_multi_exchanges(m) - before == (i ? 5u : 1u), i ? "five all-gathers" : "one all-gather");
+            kzg_hip_g1_to_compressed(fs5, proofs, 32, c48);
+            hex48(c48, hx);
+            check(strcmp(hx, VEC_C0) == 0, "multi: vector C proof 0");
+            hex48(c48 + 18 * 48, hx);
+            check(strcmp(hx, VEC_C18) == 0, "multi: vector C proof 18");
+            hex48(c48 + 31 * 48, hx);
+            check(strcmp(hx, VEC_C31) == 0, "multi: vector C proof 31");
+        }
+        expect_status(kzg_hip_multi_da_using_fk20(mfk, poly, 8, proofs), KZG_HIP_ERR_LEN_MISMATCH, "multi DAUsingFK20 with half the coefficients");
+        kzg_hip_multi_fk20_single_settings_free(mfk);
+        kzg_hip_multi_settings_free(m);
     }
 
     /* ---- frees, dependents first ---- */

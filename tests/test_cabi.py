@@ -122,7 +122,7 @@ def test_c_consumer_runs_the_vectors():
     assert res.returncode == 0, res.stdout + res.stderr
     assert "PASSED: 0 failure(s)" in res.stdout and "FAIL " not in res.stdout
     for what in ("vector A", "vector B", "vector C: proof 18", "status 1 (want 1)", "status 2 (want 2)", "status 3 (want 3)", "status 4 (want 4)",
-                 "status 5 (want 5)", "status 6 (want 6)"):
+                 "status 5 (want 5)", "status 6 (want 6)", "multi: vector A from entry 1", "multi: vector C proof 18", "five all-gathers"):
         assert what in res.stdout, what
 
 
@@ -192,3 +192,95 @@ def test_cpp_mirror_runs_the_reference_tests():
     assert "PASSED: 0 failure(s)" in res.stdout and "FAIL" not in res.stdout
     for name in ("TestInvFFT", "TestDASFFTExtension", "TestKZGSettings_DAUsingFK20", "TestErrorsAndPanics", "TestEth_ComputeAggregateKZGProof"):
         assert "ok   " + name in res.stdout, name
+
+
+# ---- the cgo shim (go-kzg_amd/goshim/): no Go toolchain in this image, so the files are checked against the header textually ----
+GOSHIM = os.path.join(ROOT, "go-kzg_amd", "goshim")
+
+
+def header_prototypes(path=os.path.join(ROOT, "include", "kzg_hip.h")):
+    """{function: number of parameters} and the set of KZG_HIP_* macros of the boundary header"""
+    src = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(kzg_hip_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        params = m.group(2).strip()
+        protos[m.group(1)] = 0 if params in ("", "void") else params.count(",") + 1
+    return protos, set(re.findall(r"#define\s+(KZG_HIP_[A-Z0-9_]+)", src))
+
+
+def go_c_calls(text):
+    """(name, argument count) of every C.kzg_hip_*(...) call in a Go source text; comments and string literals are skipped"""
+    text = re.sub(r"//[^\n]*", "", text)
+    text = re.sub(r'"(?:\\.|[^"\\])*"', '""', text)
+    calls = []
+    for m in re.finditer(r"\bC\.(kzg_hip_[a-z0-9_]+)\s*\(", text):
+        i, depth, args, cur = m.end(), 1, 0, False
+        while depth:
+            ch = text[i]
+            if ch in "([{":
+                depth += 1
+            elif ch in ")]}":
+                depth -= 1
+            elif ch == "," and depth == 1:
+                args += 1
+            if not ch.isspace() and depth >= 1 and not (ch == ")" and depth == 0):
+                cur = True
+            i += 1
+        calls.append((m.group(1), args + 1 if cur else 0))
+    return calls
+
+
+def go_sources():
+    out = []
+    for dirpath, _, files in os.walk(GOSHIM):
+        for f in sorted(files):
+            assert f.endswith(".go"), "only compilable Go sources belong in goshim/: " + f
+            out.append(os.path.join(dirpath, f))
+    return sorted(out)
+
+
+def test_go_shim_calls_match_the_header():
+    """every C.kzg_hip_* call of the shim names a function of include/kzg_hip.h with the right number of arguments, every C.KZG_HIP_* constant
+    exists, type names are the header's opaque types, braces balance, each file belongs to the package of its directory and carries the build tag"""
+    protos, macros = header_prototypes()
+    types = {"kzg_hip_fft", "kzg_hip_kzg", "kzg_hip_fk20s", "kzg_hip_fk20m", "kzg_hip_points", "kzg_hip_eth", "kzg_hip_multi", "kzg_hip_multi_fk20s", "kzg_hip_multi_fk20m"}
+    files = go_sources()
+    assert {os.path.basename(os.path.dirname(f)) for f in files} == {"kzg", "bls", "eth"}
+    bound = set()
+    for path in files:
+        text = open(path).read()
+        pkg = os.path.basename(os.path.dirname(path))
+        assert re.search(r"^package %s$" % pkg, text, flags=re.M), path
+        assert text.startswith("//go:build kzg_hip"), path
+        assert '#include "kzg_hip.h"' in text and 'import "C"' in text, path
+        code = re.sub(r'"(?:\\.|[^"\\])*"', '""', re.sub(r"//[^\n]*", "", re.sub(r"/\*.*?\*/", "", text, flags=re.S)))
+        for o, c in ("{}", "()", "[]"):
+            assert code.count(o) == code.count(c), (path, o)
+        for name, nargs in go_c_calls(text):
+            assert name in protos, "%s calls C.%s, which include/kzg_hip.h does not declare" % (path, name)
+            assert nargs == protos[name], "%s: C.%s called with %d arguments, the header declares %d" % (path, name, nargs, protos[name])
+            bound.add(name)
+        for mac in re.findall(r"\bC\.(KZG_HIP_[A-Z0-9_]+)", text):
+            assert mac in macros, (path, mac)
+        for t in re.findall(r"\*C\.(kzg_hip_[a-z0-9_]+)\b(?!\s*\()", text):
+            assert t in types, (path, t)
+    # every host-buffer entry point of the boundary is reachable from Go; the _dev forms take device pointers and a HIP stream (no Go value
+    # can be one) and a few introspection calls are for tests
+    not_for_go = {n for n in protos if n.endswith("_dev")} | {"kzg_hip_fft_max_width", "kzg_hip_fft_roots", "kzg_hip_multi_device", "kzg_hip_multi_device_count",
+                                                              "kzg_hip_multi_exchanges", "kzg_hip_multi_fft", "kzg_hip_multi_kzg", "kzg_hip_g1_marshal_text",
+                                                              "kzg_hip_g1_unmarshal_text"}
+    missing = sorted(set(protos) - bound - not_for_go)
+    assert not missing, "header functions without a Go binding: %s" % missing
+    for must in ("kzg_hip_eth_settings_free", "kzg_hip_generate_testing_setup_g1", "kzg_hip_evaluate_poly_in_evaluation_form", "kzg_hip_multi_settings_new",
+                 "kzg_hip_multi_da_using_fk20_multi"):
+        assert must in bound, must
+
+
+def test_go_shim_parser_catches_drift():
+    """the checker itself: a renamed function and a dropped argument are both reported"""
+    protos, _ = header_prototypes()
+    assert protos["kzg_hip_fft_settings_new"] == 3 and protos["kzg_hip_device_count"] == 0 and protos["kzg_hip_multi_settings_new"] == 6
+    calls = dict(go_c_calls('x := C.kzg_hip_fft_settings_new(C.int(dev), 12, &fs) // C.kzg_hip_nope(1)\ny := C.kzg_hip_device_count()\n'
+                            'z := C.kzg_hip_commit_to_poly(ks.hip(), frPtr(c), C.uint64_t(len(c)))'))
+    assert calls == {"kzg_hip_fft_settings_new": 3, "kzg_hip_device_count": 0, "kzg_hip_commit_to_poly": 3}
+    assert calls["kzg_hip_commit_to_poly"] != protos["kzg_hip_commit_to_poly"]
