@@ -165,7 +165,15 @@ struct g1x_acc {
         // branch weights: the compiler lays the (never taken) generic path out of the straight line of the walk loop: +2.7 % measured
         if (KZG_UNLIKELY(is_inf(q))) return;
         if (KZG_UNLIKELY(inf)) { v = g1xq_from_affine(q); inf = false; return; }
+#ifdef KZG_AB_FAKE_UNPACK   // TIMING-ONLY A/B (wrong results): what the walk would cost if table entries arrived as 13 limbs (profiles/r04_walk_ab.md)
+        fq fx_, fy_;
+#pragma unroll
+        for (int i_ = 0; i_ < 12; i_++) { fx_.l[i_] = q.x.l[i_]; fy_.l[i_] = q.y.l[i_]; }
+        fx_.l[12] = q.x.l[0] >> 8; fy_.l[12] = q.y.l[0] >> 8;
+        if (KZG_LIKELY(g1x_madd_fast(v, fx_, fy_))) return;
+#else
         if (KZG_LIKELY(g1x_madd_fast(v, unpackq(q.x), unpackq(q.y)))) return;
+#endif
         g1x s = g1x_madd(g1xq_pack(v), q);          // P == Q or P == -Q: generic, complete formulas
         if (is_inf(s)) inf = true; else v = g1xq_unpack(s);
     }

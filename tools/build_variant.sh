@@ -9,6 +9,6 @@ make -C $R/go-kzg_amd/csrc -j4 >/dev/null
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -DKZG_FP_MUL_NOINLINE -Wno-unused-value -fvisibility=hidden"
 /opt/rocm/bin/hipcc $FLAGS "$@" -c $R/go-kzg_amd/csrc/$FILE.hip -o $OUT/$FILE.o
 OBJS=""
-for f in k_fr k_g1 k_g1_coop_dif k_g1_coop_dit k_g1_coop_direct k_msm capi; do if [ $f = $FILE ]; then OBJS="$OBJS $OUT/$f.o"; else OBJS="$OBJS $R/go-kzg_amd/_build/$f.o"; fi; done
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $OUT/libkzg_hip.so $OBJS $R/go-kzg_amd/_build/sha256.o
+for o in $R/go-kzg_amd/_build/*.o; do f=$(basename $o .o); if [ $f = $FILE ]; then OBJS="$OBJS $OUT/$f.o"; else OBJS="$OBJS $o"; fi; done
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $OUT/libkzg_hip.so $OBJS
 echo $OUT/libkzg_hip.so
