@@ -457,7 +457,7 @@ def main():
     golden = os.path.join(ROOT, "tests", "golden")
     pins = json.load(open(os.path.join(golden, "fk20_pins.json")))
     pmc = {}
-    for name in ("r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):   # counters of the committed rocprofv3 passes (tools/profile_round.sh)
+    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):   # counters of the committed rocprofv3 passes (tools/profile_round.sh)
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             pmc["_file"] = "profiles/" + name

@@ -80,9 +80,10 @@ template <bool ROW = true> __device__ __forceinline__ void point_down_any(g1xq &
 // Sums are taken in a data-dependent order; the group law is commutative and the result is normalised, so the output bytes do
 // not depend on it.
 // ---------------------------------------------------------------------------------------------------------
+#define MSM_SEG 64                      // entries per lane of the balanced accumulate (k_msm_accumulate_seg)
 struct msm_ws_layout {
-    size_t entries_off, offsets_off, buckets_off, gsum_off, per_blob;
-    uint64_t K, nent;
+    size_t entries_off, offsets_off, buckets_off, gsum_off, segs_off, per_blob;
+    uint64_t K, nent, nseg;
 };
 static msm_ws_layout ws_layout(const msm_plan &p, uint64_t n) {
     msm_ws_layout L;
@@ -90,9 +91,11 @@ static msm_ws_layout ws_layout(const msm_plan &p, uint64_t n) {
     L.nent = n * 32;                                      // 2 halves x 16 windows
     size_t o = 0;
     L.entries_off = o; o += ((L.nent * 4 + 15) / 16) * 16;
-    L.offsets_off = o; o += (((L.K + 1) * 4 + 15) / 16) * 16;
+    L.offsets_off = o; o += (((2 * L.K + 1) * 4 + 15) / 16) * 16;   // one offset per (bucket, GLV half): key 2 b holds the phi half, key 2 b + 1 the plain one
     L.buckets_off = o; o += ((L.K * sizeof(fb_partial) + 15) / 16) * 16;
     L.gsum_off = o; o += (((size_t)p.ngroups * sizeof(fb_partial) + 15) / 16) * 16;
+    L.nseg = (L.nent + MSM_SEG - 1) / MSM_SEG;
+    L.segs_off = o; o += ((L.nseg * 2 * sizeof(fb_partial) + 15) / 16) * 16;   // two boundary partial sums per segment
     L.per_blob = o;
     return L;
 }
@@ -125,11 +128,13 @@ __global__ __launch_bounds__(MSM_SORT_T) void k_msm_sort(uint32_t ngroups, uint6
     uint32_t *entries = (uint32_t *)(ws + b * per_blob + entries_off);
     uint32_t *offsets = (uint32_t *)(ws + b * per_blob + offsets_off);
     const uint32_t wmask = ngroups - 1;                     // 15: a group per window; 7: windows 8..15 fold onto 0..7 (2^64 P_i rows)
+    // K = 2 x buckets here: within a bucket the entries of the phi half (key 2 b) come before the plain ones (key 2 b + 1), so that a walk adds
+    // the phi half un-mapped first and applies phi ONCE to the running sum (phi is an endomorphism: phi(P1) + phi(P2) = phi(P1 + P2))
     for (uint32_t i = tid; i < K; i += MSM_SORT_T) hist[i] = 0;
     __syncthreads();
     for (uint64_t i = tid; i < n; i += MSM_SORT_T)
-        for_each_glv_digit(sc[i], [&](uint32_t w, uint32_t mag, uint32_t, uint32_t) {
-            if (mag) atomicAdd(&hist[(w & wmask) * MSM_NB + mag - 1], 1u);
+        for_each_glv_digit(sc[i], [&](uint32_t w, uint32_t mag, uint32_t half, uint32_t) {
+            if (mag) atomicAdd(&hist[(((w & wmask) * MSM_NB + mag - 1) << 1) | (half ^ 1u)], 1u);
         });
     __syncthreads();
     // exclusive prefix sum over K bins: per-thread chunk sums, block scan of the 1024 partials, write back
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(MSM_SORT_T) void k_msm_sort(uint32_t ngroups, uint6
     for (uint64_t i = tid; i < n; i += MSM_SORT_T)
         for_each_glv_digit(sc[i], [&](uint32_t w, uint32_t mag, uint32_t half, uint32_t neg) {
             if (!mag) return;
-            uint32_t slot = atomicAdd(&hist[(w & wmask) * MSM_NB + mag - 1], 1u);
+            uint32_t slot = atomicAdd(&hist[(((w & wmask) * MSM_NB + mag - 1) << 1) | (half ^ 1u)], 1u);
             uint32_t pidx = (uint32_t)i + ((w & ~wmask) ? (uint32_t)table_n : 0u);      // window >= 8 of a folded plan: the 2^64 P_i row
             entries[slot] = (pidx << 2) | (half << 1) | neg;
         });
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(MSM_ACC_BLOCK, 2) void k_msm_accumulate(const g1a *
     if (live) {
         const uint32_t *entries = (const uint32_t *)(ws + b * per_blob + entries_off);
         const uint32_t *offsets = (const uint32_t *)(ws + b * per_blob + offsets_off);
-        const uint32_t s0 = offsets[key], len = offsets[key + 1] - s0;
+        const uint32_t s0 = offsets[2 * key], len = offsets[2 * key + 2] - s0;
         const uint32_t s = s0 + (uint32_t)((uint64_t)len * sidx / S), e = s0 + (uint32_t)((uint64_t)len * (sidx + 1) / S);
 #pragma nounroll
         for (uint32_t i = s; i < e; i++) {
@@ -196,6 +201,82 @@ __global__ __launch_bounds__(MSM_ACC_BLOCK, 2) void k_msm_accumulate(const g1a *
         }
     }
     if (live && sidx == 0) fb_partial_store(((fb_partial *)(ws + b * per_blob + buckets_off))[key], acc);
+}
+
+// Balanced form for batches that fill the GPU on their own (S == 1): a lane per SEGMENT of MSM_SEG consecutive sorted entries instead of a lane per
+// bucket.  Bucket lists are Poisson-distributed (mean 64 entries at n = 4096: a wavefront of 64 bucket lanes waits for a list of ~84), segments are
+// all equal.  A lane walks its entries bucket by bucket: buckets that lie wholly inside the segment are stored straight to the bucket array; the
+// bucket of the first entry and the bucket of the last entry may continue in the neighbouring segments -- their partial sums go to the segment's two
+// slots and k_msm_merge_segs adds them up per bucket (on average one addition per bucket).  Inside a bucket the phi half comes first (k_msm_sort):
+// it is accumulated un-mapped and phi -- X <- beta X on the XYZZ sum -- is applied once, when the walk crosses into the plain half or leaves the bucket.
+__device__ __forceinline__ void acc_apply_phi(g1x_acc &a) { if (!a.inf) a.v.x = mulq(a.v.x, unpackq(glv_beta())); }
+__global__ __launch_bounds__(MSM_ACC_BLOCK, 2) void k_msm_accumulate_seg(const g1a *table, uint8_t *ws, size_t per_blob, size_t entries_off, size_t offsets_off,
+                                                                      size_t buckets_off, size_t segs_off, uint32_t K2, uint64_t nseg, uint64_t total) {
+    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const uint64_t b = t / nseg; const uint32_t seg = (uint32_t)(t % nseg);
+    const uint32_t *entries = (const uint32_t *)(ws + b * per_blob + entries_off);
+    const uint32_t *offsets = (const uint32_t *)(ws + b * per_blob + offsets_off);
+    fb_partial *buckets = (fb_partial *)(ws + b * per_blob + buckets_off);
+    fb_partial *slots = (fb_partial *)(ws + b * per_blob + segs_off) + 2ull * seg;
+    const uint32_t E = offsets[K2];
+    const uint32_t s = seg * MSM_SEG, e = s + MSM_SEG < E ? s + MSM_SEG : E;
+    if (s >= e) return;                                    // beyond the blob's entries (zero digits are not entries): no bucket reaches into this segment
+    // key of the first entry: the last key whose offset is <= s (empty keys share an offset with their successor: take the last one)
+    uint32_t lo = 0, hi = K2;                              // invariant: offsets[lo] <= s < offsets[hi]
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (offsets[mid] <= s) lo = mid; else hi = mid; }
+    uint32_t key = lo, kend = offsets[key + 1];
+    const uint32_t first_bucket = key >> 1;
+    const bool first_open = offsets[key & ~1u] < s;        // the first bucket started in an earlier segment
+    g1x_acc acc; acc.init();
+    uint32_t en_next = entries[s];
+    g1a qn = table[en_next >> 2];
+#pragma nounroll
+    for (uint32_t i = s; i < e; i++) {
+        while (i >= kend) {                                // leave key (possibly across several empty keys)
+            if (!(key & 1u)) acc_apply_phi(acc);           // end of a phi half: map the sum
+            if (key & 1u) {                                // end of a bucket
+                const uint32_t bk = key >> 1;
+                if (bk == first_bucket && first_open) fb_partial_store(slots[0], acc); else fb_partial_store(buckets[bk], acc);
+                acc.init();
+            }
+            key++; kend = offsets[key + 1];
+        }
+        g1a q = qn; const uint32_t en = en_next;
+        if (i + 1 < e) { en_next = entries[i + 1]; qn = table[en_next >> 2]; }   // the next gather is in flight during this addition
+        if (en & 1u) q.y = neg<FpP>(q.y);
+        acc.add(q);
+    }
+    // the bucket of the last entry: closed here if the segment holds its end, else a boundary partial
+    if (!(key & 1u)) acc_apply_phi(acc);
+    const uint32_t bk = key >> 1;
+    const bool last_closed = offsets[2 * bk + 2] <= e;
+    // slot 0: the segment's first bucket unless it lies wholly inside; slot 1: its last bucket (if another one) when it continues beyond
+    if (bk == first_bucket) { if (!first_open && last_closed) fb_partial_store(buckets[bk], acc); else fb_partial_store(slots[0], acc); }
+    else if (last_closed) fb_partial_store(buckets[bk], acc);
+    else fb_partial_store(slots[1], acc);
+}
+// a lane per (blob, bucket): buckets that straddle segment boundaries are the sum of their segments' boundary partials; empty buckets are infinity;
+// buckets inside one segment were stored by the walk
+__global__ __launch_bounds__(MSM_ACC_BLOCK, 2) void k_msm_merge_segs(uint8_t *ws, size_t per_blob, size_t offsets_off, size_t buckets_off, size_t segs_off, uint32_t K, uint64_t total) {
+    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const uint64_t b = t / K; const uint32_t bk = (uint32_t)(t % K);
+    const uint32_t *offsets = (const uint32_t *)(ws + b * per_blob + offsets_off);
+    fb_partial *buckets = (fb_partial *)(ws + b * per_blob + buckets_off);
+    const fb_partial *slots = (const fb_partial *)(ws + b * per_blob + segs_off);
+    const uint32_t a = offsets[2 * bk], z = offsets[2 * bk + 2];
+    g1x_acc acc; acc.init();
+    if (a == z) { fb_partial_store(buckets[bk], acc); return; }
+    const uint32_t seg_lo = a / MSM_SEG, seg_hi = (z - 1) / MSM_SEG;
+    if (seg_lo == seg_hi) return;
+#pragma nounroll
+    for (uint32_t sg = seg_lo; sg <= seg_hi; sg++) {
+        const fb_partial &p = slots[2ull * sg + ((sg == seg_lo && a > seg_lo * MSM_SEG) ? 1 : 0)];
+        g1xq v; fb_partial_load(p, v);
+        g1x_acc_merge(acc, v, p.inf != 0);
+    }
+    fb_partial_store(buckets[bk], acc);
 }
 
 // sum_{d=1..128} d * B_d for one (blob, window group) = sum_m T_m with the suffix sums T_m = sum_{d >= m} B_d: a Hillis-Steele
@@ -419,16 +500,25 @@ void launch_msm(hipStream_t s, const msm_plan &p, const g1a *table, const fr *sc
     msm_ws_layout L = ws_layout(p, n);
     uint8_t *ws = (uint8_t *)workspace;
     uint32_t K = (uint32_t)L.K;
-    size_t sh = (size_t)(K + MSM_SORT_T) * 4;
+    const uint32_t K2 = 2 * K;                                // sort keys: (bucket, GLV half)
+    size_t sh = (size_t)(K2 + MSM_SORT_T) * 4;
     hipLaunchKernelGGL(k_msm_sort, dim3((uint32_t)batch), dim3(MSM_SORT_T), sh, s, p.ngroups, p.table_n, scalars, sc_stride, n, ws, L.per_blob, L.entries_off,
-                       L.offsets_off, K);
+                       L.offsets_off, K2);
     // lanes per bucket: fill one round of resident wavefronts (131 072 lanes) when the batch alone does not, at most 16
     uint32_t S = 1;
     while (S < 16 && batch * L.K * S * 2 <= 2 * device_simd_lanes()) S *= 2;
     uint64_t total = batch * L.K * S;
+    static const int seg_mode = [] { const char *e = getenv("KZG_HIP_MSM_SEG"); return e ? atoi(e) : -1; }();   // 0 / 1: never / always the balanced form (A/B runs, tests)
     prof_begin(s, "msm_accumulate");
-    hipLaunchKernelGGL(k_msm_accumulate, dim3((uint32_t)((total + MSM_ACC_BLOCK - 1) / MSM_ACC_BLOCK)), dim3(MSM_ACC_BLOCK), 0, s, table, ws, L.per_blob,
-                       L.entries_off, L.offsets_off, L.buckets_off, K, S, total);
+    if (seg_mode == 1 || (seg_mode < 0 && S == 1)) {
+        const uint64_t tseg = batch * L.nseg, tb = batch * L.K;
+        hipLaunchKernelGGL(k_msm_accumulate_seg, dim3((uint32_t)((tseg + MSM_ACC_BLOCK - 1) / MSM_ACC_BLOCK)), dim3(MSM_ACC_BLOCK), 0, s, table, ws, L.per_blob,
+                           L.entries_off, L.offsets_off, L.buckets_off, L.segs_off, K2, L.nseg, tseg);
+        hipLaunchKernelGGL(k_msm_merge_segs, dim3((uint32_t)((tb + MSM_ACC_BLOCK - 1) / MSM_ACC_BLOCK)), dim3(MSM_ACC_BLOCK), 0, s, ws, L.per_blob, L.offsets_off,
+                           L.buckets_off, L.segs_off, K, tb);
+    } else
+        hipLaunchKernelGGL(k_msm_accumulate, dim3((uint32_t)((total + MSM_ACC_BLOCK - 1) / MSM_ACC_BLOCK)), dim3(MSM_ACC_BLOCK), 0, s, table, ws, L.per_blob,
+                           L.entries_off, L.offsets_off, L.buckets_off, K, S, total);
     prof_end(s, "msm_accumulate");
     hipLaunchKernelGGL(k_msm_reduce, dim3((uint32_t)(batch * p.ngroups)), dim3(MSM_NB), 0, s, ws, L.per_blob, L.buckets_off, L.gsum_off, p.ngroups);
     hipLaunchKernelGGL(k_msm_combine, dim3((uint32_t)((batch + 63) / 64)), dim3(256), 0, s, ws, L.per_blob, L.gsum_off, p.ngroups, batch, out, to_kilic ? 1 : 0);
