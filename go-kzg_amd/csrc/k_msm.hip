@@ -74,13 +74,16 @@ template <bool ROW = true> __device__ __forceinline__ void point_down_any(g1xq &
 //   k_i P_i = s1 |k1| P_i + s2 |k2| phi(P_i), |k1|, |k2| < 2^126.5 (glv_split_signed): 16 signed 8-bit windows per half, no carry
 //   out of the top one.  ngroups = 16: one bucket group per window (120 doublings in the final Horner);  ngroups = 8: the table
 //   also holds 2^64 P_i (a cached point set, kzg_hip_points_new), window w >= 8 of a half uses it and the Horner has 56 doublings.
-// Pipeline per blob:  sort (workgroup per blob, LDS histogram + scatter)  ->  accumulate (S lanes per bucket walk a share of its
-// list with mixed additions, LDS merge)  ->  reduce (128 lanes per window group: suffix scan + tree, sum_d d B_d = sum_m
+// Pipeline per blob:  sort (workgroup per blob, LDS histogram + scatter; keys (bucket, GLV half), the phi half first)  ->  accumulate (small batches:
+// S lanes per bucket walk a share of its list with mixed additions, LDS merge; batches that fill the GPU: a lane per segment of 64 sorted entries,
+// k_msm_accumulate_seg + k_msm_merge_segs)  ->  reduce (128 lanes per window group: suffix scan + tree, sum_d d B_d = sum_m
 // sum_{d >= m} B_d)  ->  combine (Horner over the groups, then normalise).  Everything between the kernels is lazy XYZZ limbs.
 // Sums are taken in a data-dependent order; the group law is commutative and the result is normalised, so the output bytes do
 // not depend on it.
 // ---------------------------------------------------------------------------------------------------------
+#ifndef MSM_SEG
 #define MSM_SEG 64                      // entries per lane of the balanced accumulate (k_msm_accumulate_seg)
+#endif
 struct msm_ws_layout {
     size_t entries_off, offsets_off, buckets_off, gsum_off, segs_off, per_blob;
     uint64_t K, nent, nseg;
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(MSM_ACC_BLOCK, 2) void k_msm_accumulate(const g1a *
     if (live && sidx == 0) fb_partial_store(((fb_partial *)(ws + b * per_blob + buckets_off))[key], acc);
 }
 
-// Balanced form for batches that fill the GPU on their own (S == 1): a lane per SEGMENT of MSM_SEG consecutive sorted entries instead of a lane per
+// Balanced form for batches that fill the GPU on their own: a lane per SEGMENT of MSM_SEG consecutive sorted entries instead of a lane per
 // bucket.  Bucket lists are Poisson-distributed (mean 64 entries at n = 4096: a wavefront of 64 bucket lanes waits for a list of ~84), segments are
 // all equal.  A lane walks its entries bucket by bucket: buckets that lie wholly inside the segment are stored straight to the bucket array; the
 // bucket of the first entry and the bucket of the last entry may continue in the neighbouring segments -- their partial sums go to the segment's two
@@ -510,7 +513,9 @@ void launch_msm(hipStream_t s, const msm_plan &p, const g1a *table, const fr *sc
     uint64_t total = batch * L.K * S;
     static const int seg_mode = [] { const char *e = getenv("KZG_HIP_MSM_SEG"); return e ? atoi(e) : -1; }();   // 0 / 1: never / always the balanced form (A/B runs, tests)
     prof_begin(s, "msm_accumulate");
-    if (seg_mode == 1 || (seg_mode < 0 && S == 1)) {
+    // from one full round of resident lanes on (64 MSMs of 4096 points): measured 2.19 vs 2.98 ms at 64, 12.3 vs 17.3 ms at 512; below, the S-lanes-per-bucket
+    // form wins (32: 1.89 vs 2.07 ms, 8: 1.14 vs 1.47 ms: its lanes are shorter and a lone MSM is latency-bound)
+    if (seg_mode == 1 || (seg_mode < 0 && batch * L.nseg >= 2 * device_simd_lanes())) {
         const uint64_t tseg = batch * L.nseg, tb = batch * L.K;
         hipLaunchKernelGGL(k_msm_accumulate_seg, dim3((uint32_t)((tseg + MSM_ACC_BLOCK - 1) / MSM_ACC_BLOCK)), dim3(MSM_ACC_BLOCK), 0, s, table, ws, L.per_blob,
                            L.entries_off, L.offsets_off, L.buckets_off, L.segs_off, K2, L.nseg, tseg);
