@@ -175,7 +175,7 @@ def test_bench_self_launches_its_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(KZG_BENCH_BACKEND="gloo", KZG_HIP_FK20_FB_BUDGET_GB="3")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "64", "--fk20-batch", "8",
-           "--fk20-multi-batch", "2", "--table-gb", "4", "--fk20-4096-batch", "4", "--no-in-process"]
+           "--fk20-multi-batch", "2", "--table-gb", "4", "--fk20-4096-batch", "4"]   # (with the in_process leg: rank 0 runs the child, rank 1 waits on the store)
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
     try:
         out, err = proc.communicate(timeout=600)
@@ -193,6 +193,10 @@ def test_bench_self_launches_its_ranks():
     assert [t["rank"] for t in r["tables_per_rank"]] == [0, 1] and all(t["windows"] > 0 for t in r["tables_per_rank"])
     assert r["all_gather_proofs_ms"] > 0 and r["sharded_one_polynomial_ms"] > 0 and r["sharded_one_polynomial_matches_unsharded"] is True
     assert d["fk20"]["self_check_byte_pin"] is True and d["fk20_multi"]["self_check_byte_pin"] is True
+    ip = d["in_process"]                                       # the multi-device handle, timed in a child process by rank 0 (one GPU here: devices [0])
+    assert "error" not in ip, ip
+    assert ip["commit_to_poly_batch"]["vector_F"] is True and ip["da_using_fk20_batch"]["byte_pin_row0"] is True
+    assert ip["da_using_fk20_multi_one_polynomial_scale16"]["2_entries"]["sharded"]["byte_pin"] is True
 
 
 def test_self_launch_plumbing_without_a_gpu():

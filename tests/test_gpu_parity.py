@@ -482,6 +482,56 @@ def test_lincomb_edge_scalars_and_cached_points(kz, fs16, setup_1337):
     lag_set.close(); fs12.close()
 
 
+def test_bucket_pipeline_balanced_accumulate(kz, setup_1337):
+    """Batches that fill the GPU walk the sorted entries in segments of 64 (k_msm_accumulate_seg + k_msm_merge_segs; phi applied once per bucket
+    half): 80 linear combinations over 4096 caller-type points on the bucket pipeline (table budget 0) against the fixed-base walk of the same
+    points, with rows built to stress the segment logic -- one scalar for every point (a window's entries all fall into ONE bucket that spans 64
+    segments), a scalar whose halves have a single non-zero window, the zero row, a row of ones (only the plain half, only window 0), r - 1 (negated
+    halves), rows that stop short (ragged lengths through the coalesced one-row calls are covered elsewhere) -- plus oracle rows"""
+    fs = kz.FFTSettings(12)
+    pts = setup_1337.copy()
+    pts[17] = ko.g1_zero()[0]                                  # an infinity among the points
+    pts[19] = pts[18]                                          # P == Q inside a bucket whenever their digits agree
+    pts[21] = ko.g1_sub(ko.g1_zero()[0], pts[20])              # ... and P == -Q
+    cached = kz.G1Points(fs, pts)
+    rng = np.random.default_rng(64)
+    r = ko.R_MOD
+    B = 80
+    rows = np.stack([rand_fr(rng, 4096) for _ in range(6)])
+    rows = np.concatenate([rows] * (B // 6 + 1))[:B].copy()
+    same = ko.fr_from_ints([0x1234567890abcdef1234567890abcdef1234567890abcdef1234567890abcdef % r])[0]
+    rows[3, :] = same                                          # every point with the same scalar: 32 buckets of 4096 entries each
+    rows[4, :] = 0                                             # no entries at all
+    rows[5, :] = ko.fr_from_ints([1])[0]                       # one bucket in one window, plain half only
+    rows[6, :] = ko.fr_from_ints([r - 1])[0]
+    rows[7, :] = ko.fr_from_ints([LAMBDA])[0]                  # only the phi half
+    rows[8, 100:] = 0                                          # a short list: most segments are empty
+    rows[9, :] = ko.fr_from_ints([(LAMBDA << 8) % r])[0]
+    rows[10, ::2] = same
+    want = cached.lin_comb_batch(rows)                         # the set's own fixed-base table
+    cached.set_table_budget_gb(0)
+    got = cached.lin_comb_batch(rows)                          # bucket pipeline, 80 x 2048 segments: the balanced form
+    assert np.array_equal(got, want), np.nonzero((got != want).any(axis=(1, 2)))[0][:8]
+    for b in (0, 3, 5, 7, 10):
+        assert_points_equal(got[b], ko.lincomb_g1(pts, rows[b]))
+    assert np.array_equal(got[4], ko.g1_zero()[0])
+    assert np.array_equal(cached.lin_comb_batch(rows[:8]), want[:8])   # a small batch takes the lane-per-bucket form: same bytes
+    cached.close(); fs.close()
+
+
+def test_bucket_pipeline_forms_in_fresh_processes():
+    """the balanced accumulate forced at every batch size (KZG_HIP_MSM_SEG=1: lone MSMs on caller-supplied points, ragged lengths, edge scalars) and
+    never (=0), through the linear-combination tests"""
+    import subprocess
+    import sys
+    for mode in ("1", "0"):
+        env = dict(os.environ, KZG_HIP_MSM_SEG=mode)
+        res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k",
+                              "lincomb_matches_oracle or lincomb_edge or empty_lincomb or bucket_pipeline_balanced or commit_to_eval or proof_multi"],
+                             env=env, capture_output=True, text=True, timeout=1200)
+        assert res.returncode == 0, (mode, res.stdout[-1500:])
+
+
 def test_generate_testing_setup(kz, fs16):
     s = ko.fr_from_ints([S_TEST])
     got = fs16.generate_testing_setup_g1(s, 33)
