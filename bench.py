@@ -1178,6 +1178,20 @@ def main():
                 store.set("kzg_bench_in_process_done", "1")
             else:
                 store.wait(["kzg_bench_in_process_done"], datetime.timedelta(seconds=600))
+    if rccl is not None and isinstance(in_process, dict) and "error" not in in_process:
+        # the same job through ONE process: the multi-device handle of the C ABI over the ranks' devices (full object under `in_process`)
+        try:
+            c5 = in_process["da_using_fk20_multi_one_polynomial_scale16"]
+            rows5 = {k: v for k, v in c5.items() if k.endswith("_entries")}
+            rccl["in_process_multi_device_handle"] = {
+                "devices": in_process["devices"], "transport": in_process["transport"],
+                "commit_to_poly_batch_per_s_host_buffers": in_process["commit_to_poly_batch"]["commitments_per_s"],
+                "scaling_vs_one_device": in_process["commit_to_poly_batch"]["scaling_vs_one_device"],
+                "da_using_fk20_batch_per_s_host_buffers": in_process["da_using_fk20_batch"]["all_proofs_per_s"],
+                "one_fk20_multi_scale16_ms": {k: {m_: v[m_]["ms"] for m_ in ("gather", "sharded") if m_ in v} for k, v in rows5.items()},
+                "one_fk20_multi_scale16_unsharded_ms": c5.get("unsharded_one_device_ms")}
+        except (KeyError, TypeError):
+            pass
     if rank == 0:
         print(json.dumps({
             "metric": "KZG commitments/sec (CommitToPoly, 4096-element blob)", "value": value, "unit": "commitments/s",
