@@ -426,6 +426,7 @@ int kzg_hip_multi_da_using_fk20(kzg_hip_multi_fk20s *f, const void *poly_fr, uin
     if (n > f->m->d[0].fs->W / 2) return KZG_HIP_ERR_TOO_WIDE;   // fk20_single.go:178-180
     if (!is_pow2(n)) return KZG_HIP_ERR_NOT_POW2;               // fk20_single.go:181-183
     if (2 * n != f->n2) return KZG_HIP_ERR_LEN_MISMATCH;
+    if (f->fk.size() == 1 && !f->m->nccl) return kzg_hip_da_using_fk20(f->fk[0], poly_fr, n, out_g1);   // one entry: nothing to exchange, the single-device call has the shorter pipeline
     std::vector<fk20_core *> cores;
     for (auto *p : f->fk) cores.push_back(&p->c);
     return fk20_da_sharded(f->m, cores, poly_fr, n, out_g1);
@@ -467,6 +468,7 @@ int kzg_hip_multi_da_using_fk20_multi(kzg_hip_multi_fk20m *f, const void *poly_f
     if (n > f->m->d[0].fs->W / 2) return KZG_HIP_ERR_TOO_WIDE;     // fk20_multi.go:115-117
     if (!is_pow2(n)) return KZG_HIP_ERR_NOT_POW2;                 // fk20_multi.go:118-120
     if (2 * n != f->n2) return KZG_HIP_ERR_LEN_MISMATCH;
+    if (f->fk.size() == 1 && !f->m->nccl) return kzg_hip_da_using_fk20_multi(f->fk[0], poly_fr, n, out_g1);
     std::vector<fk20_core *> cores;
     for (auto *p : f->fk) cores.push_back(&p->c);
     return fk20_da_sharded(f->m, cores, poly_fr, n, out_g1);

@@ -50,3 +50,38 @@ for k in ("k_g1_fft_stage",):
     e["valu_insts_per_step"] = e["valu_insts_per_launch"] * L
 json.dump(pm, open(os.path.join(R, "profiles", "r04_pmc.json"), "w"), indent=1)
 print("ok", {k: v.get("fetch_bytes_per_launch") for k, v in pm.items() if isinstance(v, dict)})
+
+
+def kernel_stats(trace_dir):
+    """profiles/r04_kernel_stats.md + r04_kernel_shapes.json from the trace step of tools/profile_round4.sh (gpurun_out/<trace_dir>)"""
+    src_ = os.path.join(R, "gpurun_out", trace_dir)
+    d_ = json.loads(open(os.path.join(src_, "bench_line.json")).read())
+    t_ = json.loads(open(os.path.join(src_, "trace_bench.json")).read().strip().splitlines()[-1])
+    rows_ = json.load(open(os.path.join(src_, "kernel_shapes.json")))["rows"]
+    r_ = [x for x in rows_ if x["kernel"].startswith("k_fb_accumulate") and x["grid"] == 1048576 and x["workgroup"] == 256][0]
+    avg = r_["avg_us"] / 1e3
+    hdr = """# r04 -- kernel trace of `python bench.py --no-cpu-baseline --no-extras --no-in-process` at its default step sizes (rocprofv3 --kernel-trace --stats, tools/profile_round4.sh), 1x MI355X
+
+One row per LAUNCH SHAPE (kernel, grid, workgroup) -- tools/rocprof_summary.py; `r04_kernel_shapes.json` holds the same rows for bench.py, which prints the
+row of the launch it puts on its roofline line as `roofline.profile_avg_ms` beside its own HIP-event figure.
+
+* headline: `k_fb_accumulate<0>`, grid 1 048 576 = 4096 workgroups x 256 lanes (one workgroup per blob, 16-bit-window table: `--no-extras` skips the table sweep,
+  so every launch of this shape walks the headline's table): avg %.2f ms under the profiler (%d launches) -> 0.5377 GB / %.2f ms = %.1f GB/s = %.4f of 8 TB/s.
+  (HIP events in the un-profiled run of the same build on the same box: %.2f ms per launch: the two agree.)
+* FK20 (config 4a, 1024 polynomials per step): `k_g1_fft_stage<4, 1>` / `k_g1_fft_stage_dif<1>`, grid 2 097 152 (a lane per butterfly; the 512-polynomial step of
+  8192-point transforms of the fk20_4096 block has the same grid and the same work per lane).
+* the `k_msm_*` rows with thousands of calls are bench.py's self-check of EVERY output (one LinCombG1 per FK20 polynomial over its proofs as caller-supplied points).
+
+Profiled line: %d commitments/s (%.2f ms per 4096-blob step), FK20 %d all-proofs/s, FK20 on 4096-element blobs %d/s.  Un-profiled line of the same build on the same box: %d commitments/s (%.2f ms per step), FK20 %d, FK20 on 4096-element blobs %d, FFT_Fr %.2f M/s, DAS extension %.2f M/s.
+
+""" % (avg, r_["calls"], avg, 0.5377 / (avg * 1e-3), 0.5377 / (avg * 1e-3) / 8000, d_["roofline"]["avg_launch_ms"], t_["value"], t_["ms_per_step"], t_["fk20"]["value"],
+       t_["fk20_4096"]["value"], d_["value"], d_["ms_per_step"], d_["fk20"]["value"], d_["fk20_4096"]["value"],
+       d_["reference_benchmarks"]["fft_fr_scale12_per_s"]["value"] / 1e6, d_["reference_benchmarks"]["das_fft_extension_scale12_per_s"]["value"] / 1e6)
+    open(os.path.join(R, "profiles", "r04_kernel_stats.md"), "w").write(hdr + open(os.path.join(src_, "kernel_stats.md")).read())
+    json.dump({"source": "rocprofv3 --kernel-trace --stats of `python bench.py --no-cpu-baseline --no-extras --no-in-process` (tools/profile_round4.sh); one row per (kernel, grid, workgroup)",
+               "rows": rows_}, open(os.path.join(R, "profiles", "r04_kernel_shapes.json"), "w"), indent=0)
+    print("kernel stats ok: k_fb_accumulate %.2f ms" % avg)
+
+
+if len(sys.argv) > 2:
+    kernel_stats(sys.argv[2])
