@@ -480,8 +480,8 @@ def main():
         calls = sum(r["calls"] for r in rows_)
         if not calls:
             return None, None
-        return sum(r["avg_us"] * r["calls"] for r in rows_) / calls * 1e-3, "%s: %s, grid %d, workgroup %d (%d launches)" % (
-            shapes_file.replace(".json", ".md"), " + ".join(sorted(set(r["kernel"] for r in rows_))), grid, wg, calls)
+        return sum(r["avg_us"] * r["calls"] for r in rows_) / calls * 1e-3, "profiles/r04_kernel_stats.md (rows: %s): %s, grid %d, workgroup %d (%d launches)" % (
+            shapes_file, " + ".join(sorted(set(r["kernel"] for r in rows_))), grid, wg, calls)
 
     def mont_blobs(seed, batch, n=N_COEFF):
         """synthetic scalars as Montgomery images: vectorised splitmix + mod r on the host, FrFrom32 on the device"""
@@ -1012,6 +1012,7 @@ def main():
                 roofline_fk20_4096 = {"bound": "hbm", "kernel": "k_g1_fft_stage", "achieved": algq / kq * 1e-9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": algq / kq * 1e-9 / HBM_PEAK_GBS, "traffic": None, "launches_per_step": int(cq.value), "avg_launch_ms": tq.value / cq.value,
                                       "algorithmic_bytes_per_step": algq, "algorithmic_bytes_per_unit": FK20_4096_BYTES,
+                                      "profile_avg_ms": profile_avg_ms("k_g1_fft_stage", QB * 4096, 256)[0], "profile_source": profile_avg_ms("k_g1_fft_stage", QB * 4096, 256)[1],
                                       "kernel_ms_per_all_proofs": tq.value / QB, "share_of_step": kq / (qsecs / qsteps),
                                       "mac": {"mads_per_all_proofs": mads_q, "achieved_Tmad_s": QB * mads_q / kq * 1e-12, "measured_peak_Tmad_s": cal_mad * 1e-12,
                                               "frac": QB * mads_q / kq / cal_mad},
