@@ -128,6 +128,10 @@ def lib():
         "kzg_hip_multi_set_fft_sharding": (i32, [vp, i32]), "kzg_hip_multi_set_table_budget_gb": (i32, [vp, C.c_double]),
         "kzg_hip_multi_commit_to_poly_batch": (i32, [vp, vp, u64, u64, vp]),
         "kzg_hip_multi_compute_proof_single_batch": (i32, [vp, vp, u64, u64, vp, vp]),
+        "kzg_hip_multi_fft_fr_batch": (i32, [vp, vp, u64, u64, i32, vp]), "kzg_hip_multi_das_fft_extension_batch": (i32, [vp, vp, u64, u64]),
+        "kzg_hip_multi_eth_settings_new": (i32, [vp, vp, u64, pp]), "kzg_hip_multi_eth_settings_free": (None, [vp]),
+        "kzg_hip_multi_eth_blob_to_kzg_commitment_batch": (i32, [vp, vp, u64, vp, vp]),
+        "kzg_hip_multi_eth_compute_kzg_proof_batch": (i32, [vp, vp, u64, u64, vp, vp, vp, vp]),
         "kzg_hip_multi_fk20_single_settings_new": (i32, [vp, u64, pp]), "kzg_hip_multi_fk20_single_settings_free": (None, [vp]),
         "kzg_hip_multi_da_using_fk20_batch": (i32, [vp, vp, u64, u64, vp]), "kzg_hip_multi_da_using_fk20": (i32, [vp, vp, u64, vp]),
         "kzg_hip_multi_fk20_multi_settings_new": (i32, [vp, u64, u64, pp]), "kzg_hip_multi_fk20_multi_settings_free": (None, [vp]),
@@ -656,6 +660,19 @@ class MultiKZGSettings:
         _chk(lib().kzg_hip_multi_commit_to_poly_batch(self.h, _p(coeffs), n, b, _p(out)))
         return out
 
+    def fft_batch(self, vals, inv=False):
+        """FFT (fft_fr.go:55-74) on every row, rows divided among the devices"""
+        vals = np.ascontiguousarray(vals, dtype=np.uint64)
+        out = np.zeros_like(vals)
+        _chk(lib().kzg_hip_multi_fft_fr_batch(self.h, _p(vals), vals.shape[1], vals.shape[0], int(inv), _p(out)), error_ok=True)
+        return out
+
+    def das_fft_extension_batch(self, vals):
+        """DASFFTExtension (das_extension.go:71-84) on every row; returns the odd values"""
+        vals = np.ascontiguousarray(vals, dtype=np.uint64).copy()
+        _chk(lib().kzg_hip_multi_das_fft_extension_batch(self.h, _p(vals), vals.shape[1], vals.shape[0]))
+        return vals
+
     def compute_proof_single_batch(self, polys, xs):
         polys = np.ascontiguousarray(polys, dtype=np.uint64)
         xs = np.ascontiguousarray(xs, dtype=np.uint64)
@@ -663,6 +680,38 @@ class MultiKZGSettings:
         out = g1_empty(b)
         _chk(lib().kzg_hip_multi_compute_proof_single_batch(self.h, _p(polys), n, b, _p(xs), _p(out)))
         return out
+
+
+class MultiEthSettings:
+    """package eth (eth/globals.go:39-72) on every device of a MultiKZGSettings: batches divided among the devices"""
+
+    def __init__(self, mks, setup_g1_lagrange):
+        lag = _g1(setup_g1_lagrange)
+        h = C.c_void_p()
+        _chk(lib().kzg_hip_multi_eth_settings_new(mks.h, _p(lag), lag.shape[0], C.byref(h)))
+        self.h, self.mks, self.n = h, mks, lag.shape[0]
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().kzg_hip_multi_eth_settings_free(self.h)
+            self.h = None
+
+    def blob_to_kzg_commitment_batch(self, blobs):
+        blobs = np.ascontiguousarray(blobs, dtype=np.uint8).reshape(-1, self.n, 32)
+        b = blobs.shape[0]
+        out, ok = np.zeros((b, 48), dtype=np.uint8), np.zeros(b, dtype=np.uint8)
+        _chk(lib().kzg_hip_multi_eth_blob_to_kzg_commitment_batch(self.h, _p(blobs), b, _p(out), _p(ok)))
+        return out, ok.astype(bool)
+
+    def compute_kzg_proof_batch(self, polynomials, zs):
+        polys = np.ascontiguousarray(polynomials, dtype=np.uint64).reshape(-1, self.n, 4)
+        zs = np.ascontiguousarray(zs, dtype=np.uint64).reshape(-1, 4)
+        b = polys.shape[0]
+        if zs.shape[0] != b:
+            raise KzgError(ERR_LEN_MISMATCH, "one z per polynomial")
+        out, ys, ok = np.zeros((b, 48), dtype=np.uint8), fr_empty(b), np.zeros(b, dtype=np.uint8)
+        _chk(lib().kzg_hip_multi_eth_compute_kzg_proof_batch(self.h, _p(polys), self.n, b, _p(zs), _p(out), _p(ys), _p(ok)))
+        return out, ys, ok.astype(bool)
 
 
 class MultiFK20SingleSettings:

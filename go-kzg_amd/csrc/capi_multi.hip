@@ -78,6 +78,7 @@ struct kzg_hip_multi {
     std::mutex mu;                         // sharded calls (collectives) on a handle run one at a time
     std::atomic<uint64_t> n_allgather{0};  // exchanges performed (tests and bench read it)
 };
+struct kzg_hip_multi_eth { kzg_hip_multi *m = nullptr; std::vector<kzg_hip_eth *> eth; uint64_t n = 0; };
 struct kzg_hip_multi_fk20s { kzg_hip_multi *m = nullptr; std::vector<kzg_hip_fk20s *> fk; uint64_t n2 = 0; };
 struct kzg_hip_multi_fk20m { kzg_hip_multi *m = nullptr; std::vector<kzg_hip_fk20m *> fk; uint64_t n2 = 0, l = 1; };
 
@@ -387,6 +388,76 @@ int kzg_hip_multi_compute_proof_single_batch(kzg_hip_multi *m, const void *poly_
         uint64_t lo, hi; share(batch, m->d.size(), i, &lo, &hi);
         if (hi == lo) return KZG_HIP_OK;
         return kzg_hip_compute_proof_single_batch(m->d[i].ks, (const uint8_t *)poly_fr + lo * n * sizeof(fr), n, hi - lo, xs + lo, (uint8_t *)out_g1 + lo * sizeof(g1j));
+    });
+    KZG_CATCH
+}
+
+// ---- transforms over F_r on batches of rows (fft_fr.go:55-105, das_extension.go:71-84), rows divided among the devices ----
+int kzg_hip_multi_fft_fr_batch(kzg_hip_multi *m, const void *vals_fr, uint64_t n, uint64_t batch, int inv, void *out_fr) {
+    if (!m || !vals_fr || !out_fr) return KZG_HIP_ERR_BAD_ARG;
+    if (!batch) return KZG_HIP_OK;
+    KZG_TRY
+    return per_device(m, [&](size_t i) -> int {
+        uint64_t lo, hi; share(batch, m->d.size(), i, &lo, &hi);
+        if (hi == lo) return KZG_HIP_OK;
+        return kzg_hip_fft_fr_batch(m->d[i].fs, (const uint8_t *)vals_fr + lo * n * sizeof(fr), n, hi - lo, inv, (uint8_t *)out_fr + lo * n * sizeof(fr));
+    });
+    KZG_CATCH
+}
+int kzg_hip_multi_das_fft_extension_batch(kzg_hip_multi *m, void *vals_fr, uint64_t n, uint64_t batch) {
+    if (!m || !vals_fr) return KZG_HIP_ERR_BAD_ARG;
+    if (!batch) return KZG_HIP_OK;
+    KZG_TRY
+    return per_device(m, [&](size_t i) -> int {
+        uint64_t lo, hi; share(batch, m->d.size(), i, &lo, &hi);
+        if (hi == lo) return KZG_HIP_OK;
+        return kzg_hip_das_fft_extension_batch(m->d[i].fs, (uint8_t *)vals_fr + lo * n * sizeof(fr), n, hi - lo);
+    });
+    KZG_CATCH
+}
+
+// ---- package eth on every device (eth/globals.go:39-72): BlobToKZGCommitment / ComputeKZGProof on batches, rows divided among the devices ----
+int kzg_hip_multi_eth_settings_new(kzg_hip_multi *m, const void *lagrange_g1, uint64_t n, kzg_hip_multi_eth **out) {
+    if (!m || !out) return KZG_HIP_ERR_BAD_ARG;
+    *out = nullptr;
+    KZG_TRY
+    kzg_hip_multi_eth *e = new kzg_hip_multi_eth;
+    e->m = m; e->n = n; e->eth.assign(m->d.size(), nullptr);
+    int st = per_device(m, [&](size_t i) -> int { return kzg_hip_eth_settings_new(m->d[i].fs, lagrange_g1, n, &e->eth[i]); });
+    if (st) { kzg_hip_multi_eth_settings_free(e); return st; }
+    *out = e;
+    return KZG_HIP_OK;
+    KZG_CATCH
+}
+void kzg_hip_multi_eth_settings_free(kzg_hip_multi_eth *e) {
+    if (!e) return;
+    for (auto *p : e->eth) kzg_hip_eth_settings_free(p);
+    delete e;
+}
+int kzg_hip_multi_eth_blob_to_kzg_commitment_batch(kzg_hip_multi_eth *e, const void *blobs_le32, uint64_t batch, void *out48, uint8_t *ok) {
+    if (!e || !blobs_le32 || !out48 || !ok) return KZG_HIP_ERR_BAD_ARG;
+    if (!batch) return KZG_HIP_OK;
+    KZG_TRY
+    kzg_hip_multi *m = e->m;
+    return per_device(m, [&](size_t i) -> int {
+        uint64_t lo, hi; share(batch, m->d.size(), i, &lo, &hi);
+        if (hi == lo) return KZG_HIP_OK;
+        return kzg_hip_eth_blob_to_kzg_commitment_batch(e->eth[i], (const uint8_t *)blobs_le32 + lo * e->n * 32, hi - lo, (uint8_t *)out48 + lo * 48, ok + lo);
+    });
+    KZG_CATCH
+}
+int kzg_hip_multi_eth_compute_kzg_proof_batch(kzg_hip_multi_eth *e, const void *polys_fr, uint64_t n, uint64_t batch, const void *zs_fr, void *out48, void *ys_fr, uint8_t *ok) {
+    if (!e || !out48 || !ok) return KZG_HIP_ERR_BAD_ARG;
+    if (n != e->n) return KZG_HIP_ERR_LEN_MISMATCH;                               // "polynomial has invalid length", eth/helpers.go:186-188
+    if (!batch) return KZG_HIP_OK;
+    if (!polys_fr || !zs_fr) return KZG_HIP_ERR_BAD_ARG;
+    KZG_TRY
+    kzg_hip_multi *m = e->m;
+    return per_device(m, [&](size_t i) -> int {
+        uint64_t lo, hi; share(batch, m->d.size(), i, &lo, &hi);
+        if (hi == lo) return KZG_HIP_OK;
+        return kzg_hip_eth_compute_kzg_proof_batch(e->eth[i], (const uint8_t *)polys_fr + lo * n * sizeof(fr), n, hi - lo, (const uint8_t *)zs_fr + lo * sizeof(fr),
+                                                   (uint8_t *)out48 + lo * 48, ys_fr ? (uint8_t *)ys_fr + lo * sizeof(fr) : nullptr, ok + lo);
     });
     KZG_CATCH
 }

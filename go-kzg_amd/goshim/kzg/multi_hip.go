@@ -116,6 +116,96 @@ func (m *MultiKZGSettings) ComputeProofSingleBatch(polys [][]bls.Fr, xs []uint64
 	return out
 }
 
+// FFTBatch: FFT (fft_fr.go:55-74) on every row (rows of a power-of-two length), rows divided among the devices.
+func (m *MultiKZGSettings) FFTBatch(rows [][]bls.Fr, inv bool) [][]bls.Fr {
+	defer runtime.KeepAlive(m)
+	if len(rows) == 0 {
+		return nil
+	}
+	flat, n := flattenRows(rows, "FFTBatch")
+	outFlat := make([]bls.Fr, len(flat))
+	hipMust(C.kzg_hip_multi_fft_fr_batch(m.h, frPtr(flat), C.uint64_t(n), C.uint64_t(len(rows)), cBool(inv), frPtr(outFlat)))
+	out := make([][]bls.Fr, len(rows))
+	for b := range out {
+		out[b] = outFlat[n*b : n*(b+1)]
+	}
+	return out
+}
+
+// DASFFTExtensionBatch: DASFFTExtension (das_extension.go:71-84) on every row, in place like the reference.
+func (m *MultiKZGSettings) DASFFTExtensionBatch(rows [][]bls.Fr) {
+	defer runtime.KeepAlive(m)
+	if len(rows) == 0 {
+		return
+	}
+	flat, n := flattenRows(rows, "DASFFTExtensionBatch")
+	hipMust(C.kzg_hip_multi_das_fft_extension_batch(m.h, frPtr(flat), C.uint64_t(n), C.uint64_t(len(rows))))
+	for b := range rows {
+		copy(rows[b], flat[n*b:n*(b+1)])
+	}
+}
+
+// MultiEthSettings: the device side of package eth (bit-reversed Lagrange setup, DomainFr; eth/globals.go:39-72) on every device.  Blobs are
+// n x 32 little-endian bytes (eth.Blob), commitments and proofs 48 bytes; package eth wraps these with its own types.
+type MultiEthSettings struct {
+	h *C.kzg_hip_multi_eth
+	m *MultiKZGSettings
+	n int
+}
+
+// NewMultiEthSettings takes setup_G1_lagrange in NATURAL order (as eth/trusted_setup.json stores it).
+func NewMultiEthSettings(m *MultiKZGSettings, lagrangeNaturalOrder []bls.G1Point) *MultiEthSettings {
+	defer runtime.KeepAlive(m)
+	e := &MultiEthSettings{m: m, n: len(lagrangeNaturalOrder)}
+	hipMust(C.kzg_hip_multi_eth_settings_new(m.h, g1Ptr(lagrangeNaturalOrder), C.uint64_t(len(lagrangeNaturalOrder)), &e.h))
+	runtime.SetFinalizer(e, (*MultiEthSettings).Close)
+	return e
+}
+func (e *MultiEthSettings) Close() {
+	if e.h != nil {
+		C.kzg_hip_multi_eth_settings_free(e.h)
+		e.h = nil
+	}
+}
+
+// BlobsToKZGCommitments: eth.BlobToKZGCommitment (eth/eth.go:145-151) on every blob (len(blobs) = count x n x 32 bytes), blobs divided among the devices;
+// valid[b] == false marks a blob with a field element >= r (its commitment is zeroed).
+func (e *MultiEthSettings) BlobsToKZGCommitments(blobs []byte) (commitments [][48]byte, valid []bool) {
+	defer runtime.KeepAlive(e)
+	count := len(blobs) / (e.n * 32)
+	if count == 0 {
+		return nil, nil
+	}
+	commitments = make([][48]byte, count)
+	ok := make([]C.uint8_t, count)
+	hipMust(C.kzg_hip_multi_eth_blob_to_kzg_commitment_batch(e.h, unsafe.Pointer(&blobs[0]), C.uint64_t(count), unsafe.Pointer(&commitments[0]), &ok[0]))
+	valid = make([]bool, count)
+	for i := range valid {
+		valid[i] = ok[i] != 0
+	}
+	return commitments, valid
+}
+
+// ComputeKZGProofs: eth.ComputeKZGProof (eth/helpers.go:179-203) of polynomials[b] (evaluation form) at zs[b]; valid[b] == false is that row's "invalid z challenge".
+func (e *MultiEthSettings) ComputeKZGProofs(polynomials [][]bls.Fr, zs []bls.Fr) (proofs [][48]byte, valid []bool) {
+	defer runtime.KeepAlive(e)
+	if len(polynomials) != len(zs) {
+		panic("ComputeKZGProofs: len(polynomials) != len(zs)")
+	}
+	if len(polynomials) == 0 {
+		return nil, nil
+	}
+	flat, n := flattenRows(polynomials, "ComputeKZGProofs")
+	proofs = make([][48]byte, len(polynomials))
+	ok := make([]C.uint8_t, len(polynomials))
+	hipMust(C.kzg_hip_multi_eth_compute_kzg_proof_batch(e.h, frPtr(flat), C.uint64_t(n), C.uint64_t(len(polynomials)), frPtr(zs), unsafe.Pointer(&proofs[0]), nil, &ok[0]))
+	valid = make([]bool, len(polynomials))
+	for i := range valid {
+		valid[i] = ok[i] != 0
+	}
+	return proofs, valid
+}
+
 // MultiFK20SingleSettings: NewFK20SingleSettings (kzg.go:43-64) on every device of a MultiKZGSettings.
 type MultiFK20SingleSettings struct {
 	h *C.kzg_hip_multi_fk20s

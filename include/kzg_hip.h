@@ -269,6 +269,16 @@ int kzg_hip_multi_set_table_budget_gb(kzg_hip_multi *m, double gb);    /* kzg_hi
 /* CommitToPoly / ComputeProofSingle on `batch` polynomials (kzg_single_proofs.go:17-19,36-54), sharded by polynomial */
 int kzg_hip_multi_commit_to_poly_batch(kzg_hip_multi *m, const void *coeffs_fr, uint64_t n, uint64_t batch, void *out_g1);
 int kzg_hip_multi_compute_proof_single_batch(kzg_hip_multi *m, const void *poly_fr, uint64_t n, uint64_t batch, const uint64_t *xs, void *out_g1);
+/* FFT / InplaceFFT (fft_fr.go:55-105) and DASFFTExtension (das_extension.go:71-84; in place) on `batch` rows of n values, rows divided among the devices */
+int kzg_hip_multi_fft_fr_batch(kzg_hip_multi *m, const void *vals_fr, uint64_t n, uint64_t batch, int inv, void *out_fr);
+int kzg_hip_multi_das_fft_extension_batch(kzg_hip_multi *m, void *vals_fr, uint64_t n, uint64_t batch);
+/* package eth on every entry (eth/globals.go:39-72; lagrange_g1 in natural order as for kzg_hip_eth_settings_new): BlobToKZGCommitment (eth/eth.go:145-151)
+ * and ComputeKZGProof (eth/helpers.go:179-203) on batches, rows divided among the devices; flags and error codes as in the single-device calls */
+typedef struct kzg_hip_multi_eth kzg_hip_multi_eth;
+int kzg_hip_multi_eth_settings_new(kzg_hip_multi *m, const void *lagrange_g1, uint64_t n, kzg_hip_multi_eth **out);
+void kzg_hip_multi_eth_settings_free(kzg_hip_multi_eth *eth);
+int kzg_hip_multi_eth_blob_to_kzg_commitment_batch(kzg_hip_multi_eth *eth, const void *blobs_le32, uint64_t batch, void *out48, uint8_t *ok);
+int kzg_hip_multi_eth_compute_kzg_proof_batch(kzg_hip_multi_eth *eth, const void *polys_fr, uint64_t n, uint64_t batch, const void *zs_fr, void *out48, void *ys_fr, uint8_t *ok);
 /* NewFK20SingleSettings on every entry (kzg.go:43-64); DAUsingFK20 on a batch (sharded by polynomial) and on ONE polynomial (sharded inside) */
 int kzg_hip_multi_fk20_single_settings_new(kzg_hip_multi *m, uint64_t n2, kzg_hip_multi_fk20s **out);
 void kzg_hip_multi_fk20_single_settings_free(kzg_hip_multi_fk20s *fk);

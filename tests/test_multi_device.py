@@ -96,6 +96,40 @@ def test_batches_are_divided_among_the_entries(kz, setup_1337, devices):
     m.close()
 
 
+def test_eth_and_transform_batches_are_divided_among_the_entries(kz, setup_1337):
+    """package eth on every entry (BlobToKZGCommitment / ComputeKZGProof on batches incl. an invalid blob and a z inside the domain) and the F_r transform
+    batches (FFT, DASFFTExtension) through the multi-device handle: equal to the single-device calls, vector F in its eth form"""
+    raw = np.frombuffer(open(os.path.join(GOLDEN, "trusted_setup_g1_lagrange.bin"), "rb").read(), dtype=np.uint8)
+    lag = ko.g1_affine(ko.g1_decompress(raw))
+    m = kz.MultiKZGSettings([0, 0, 0], 12, setup_1337)
+    me = kz.MultiEthSettings(m, lag)
+    fs0 = m.fft_settings(0)
+    e0 = kz.EthSettings(fs0, lag)
+    rng = np.random.default_rng(12)
+    B = 7
+    polys = np.stack([ko.synthetic_blob(1 + b) for b in range(B)])
+    blobs = fs0.fr_to_32(polys.reshape(-1, 4)).reshape(B, 4096, 32).copy()
+    blobs[5, 100] = 0xff                                       # a field element >= r: that blob is refused, the others are not
+    got, ok = me.blob_to_kzg_commitment_batch(blobs)
+    want, wok = e0.blob_to_kzg_commitment_batch(blobs)
+    assert np.array_equal(got, want) and np.array_equal(ok, wok) and not ok[5] and ok[[0, 1, 2, 3, 4, 6]].all()
+    assert got[0].tobytes().hex() == DERIVED["F_blob_seed1"]["commit_eth_bitrev_lagrange"]
+    zs = rand_fr(rng, B)
+    zs[3] = fs0.expanded_roots_of_unity()[5]                   # z in the domain: "invalid z challenge" for that row only
+    pg, yg, okg = me.compute_kzg_proof_batch(polys, zs)
+    pw, yw, okw = e0.compute_kzg_proof_batch(polys, zs)
+    assert np.array_equal(pg, pw) and np.array_equal(yg, yw) and np.array_equal(okg, okw) and not okg[3] and okg[[0, 1, 2, 4, 5, 6]].all()
+    half = np.ascontiguousarray(polys[:, :2048])                # "polynomial has invalid length" (eth/helpers.go:186-188)
+    out48, okb = np.zeros((B, 48), dtype=np.uint8), np.zeros(B, dtype=np.uint8)
+    assert kz.lib().kzg_hip_multi_eth_compute_kzg_proof_batch(me.h, half.ctypes.data, 2048, B, zs.ctypes.data, out48.ctypes.data, None, okb.ctypes.data) == kz.ERR_LEN_MISMATCH
+    rows = np.stack([rand_fr(rng, 4096) for _ in range(5)])
+    for inv in (False, True):
+        assert np.array_equal(m.fft_batch(rows, inv), fs0.fft_batch(rows, inv))
+    assert np.array_equal(m.das_fft_extension_batch(rows[:, :2048]), fs0.das_fft_extension_batch(rows[:, :2048]))
+    assert np.array_equal(m.fft_batch(rows[:1, :64]), fs0.fft_batch(rows[:1, :64]))     # one row: two entries get nothing
+    e0.close(); me.close(); m.close()
+
+
 @pytest.mark.parametrize("devices,mode,exchanges", [([0, 0], "gather", 1), ([0, 0], "sharded", 5), ([0, 0, 0, 0], None, 5), ([0, 0, 0], "sharded", 1)])
 def test_one_polynomial_fk20_vectors_C_and_E(kz, devices, mode, exchanges, monkeypatch):
     """DAUsingFK20 (fk20_single_test.go:12-22, scale 5) and DAUsingFK20Multi (fk20_multi_test.go, scale 10, chunk 16) of ONE polynomial over the
