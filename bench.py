@@ -334,8 +334,12 @@ def in_process_child(devices):
         one_dev = ks0.commit_to_poly_batch(blobs[:per])
         ms_all = med(lambda: m.commit_to_poly_batch(blobs), 3, 1)
         ms_one = med(lambda: ks0.commit_to_poly_batch(blobs[:per]), 3, 1)
+        with kz.pinned(blobs):                                  # kzg_hip_host_register: every device reads its share of the range in place over PCIe
+            ms_pin = med(lambda: m.commit_to_poly_batch(blobs), 3, 1)
+            pin_same = bool(np.array_equal(m.commit_to_poly_batch(blobs), got))
         out["commit_to_poly_batch"] = {"blobs_per_device": per, "table": "library default (64 GB, 14-bit windows) on every device",
                                        "commitments_per_s": per * D / ms_all * 1e3, "one_device_same_call_per_s": per / ms_one * 1e3,
+                                       "commitments_per_s_pinned_input": per * D / ms_pin * 1e3, "pinned_same_results": pin_same,
                                        "scaling_vs_one_device": (per * D / ms_all) / (per / ms_one),
                                        "vector_F": fs0.to_compressed_g1(got[:1])[0].tobytes().hex() == exp_f, "first_share_equals_one_device": bool(np.array_equal(got[:per], one_dev))}
         # FK20 (config 4a): batches divided among the devices, and ONE polynomial sharded inside the library

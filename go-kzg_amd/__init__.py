@@ -65,6 +65,7 @@ def lib():
     pp = C.POINTER(C.c_void_p)
     sig = {
         "kzg_hip_device_count": (i32, []), "kzg_hip_last_error": (C.c_char_p, []), "kzg_hip_version": (C.c_char_p, []),
+        "kzg_hip_host_register": (i32, [vp, u64]), "kzg_hip_host_unregister": (i32, [vp]),
         "kzg_hip_fft_settings_new": (i32, [i32, u32, pp]), "kzg_hip_fft_settings_free": (None, [vp]),
         "kzg_hip_fft_max_width": (u64, [vp]), "kzg_hip_fft_roots": (i32, [vp, i32, vp]),
         "kzg_hip_fft_fr": (i32, [vp, vp, u64, i32, vp, C.POINTER(u64)]), "kzg_hip_inplace_fft_fr": (i32, [vp, vp, vp, u64, i32]),
@@ -153,6 +154,21 @@ API_SYMBOLS = None  # filled by tests from include/kzg_hip.h
 
 def device_count():
     return lib().kzg_hip_device_count()
+
+
+class pinned:
+    """`with pinned(array):` -- the array's memory is pinned (kzg_hip_host_register) for the duration: batch calls read it in place over PCIe"""
+
+    def __init__(self, array):
+        self.a = array
+
+    def __enter__(self):
+        _chk(lib().kzg_hip_host_register(self.a.ctypes.data, self.a.nbytes))
+        return self.a
+
+    def __exit__(self, *exc):
+        lib().kzg_hip_host_unregister(self.a.ctypes.data)
+        return False
 
 
 _ERR_STATUS = (ERR_TOO_WIDE, ERR_NOT_POW2)

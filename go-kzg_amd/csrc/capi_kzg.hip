@@ -128,6 +128,24 @@ int kzg_hip_commit_to_poly_batch_dev(kzg_hip_kzg *ks, const void *d_coeffs_fr, u
     dev_guard g(ks->fs);
     return commit_rows(ks, (hipStream_t)stream, (const fr *)d_coeffs_fr, n, batch, (g1j *)d_out_g1);
 }
+// device-visible address of a host pointer that lies in pinned memory (registered with kzg_hip_host_register / hipHostRegister, or from hipHostMalloc); null for
+// pageable memory.  The current device must be the handle's.
+const void *host_mapped_pointer(const void *host) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }   // pageable memory is "invalid value" for this query
+    if (a.type != hipMemoryTypeHost || !a.devicePointer) return nullptr;
+    return a.devicePointer;
+}
+int kzg_hip_host_register(void *host, uint64_t bytes) {
+    if (!host || !bytes) return KZG_HIP_ERR_BAD_ARG;
+    HIPCHK(hipHostRegister(host, bytes, hipHostRegisterPortable | hipHostRegisterMapped));
+    return KZG_HIP_OK;
+}
+int kzg_hip_host_unregister(void *host) {
+    if (!host) return KZG_HIP_ERR_BAD_ARG;
+    HIPCHK(hipHostUnregister(host));
+    return KZG_HIP_OK;
+}
 int kzg_hip_commit_to_poly_batch(kzg_hip_kzg *ks, const void *coeffs_fr, uint64_t n, uint64_t batch, void *out_g1) {
     if (!ks || !out_g1) return KZG_HIP_ERR_BAD_ARG;
     if (n > ks->n_setup) return KZG_HIP_ERR_LEN_MISMATCH;
@@ -137,7 +155,16 @@ int kzg_hip_commit_to_poly_batch(kzg_hip_kzg *ks, const void *coeffs_fr, uint64_
     dev_guard g(ks->fs);
     hipStream_t s = ks->fs->stream;
     dtmp<fr> d_sc(s); dtmp<g1j> d_out(s);
-    CHK(d_sc.alloc(n * batch)); CHK(d_out.alloc(batch));
+    CHK(d_out.alloc(batch));
+    // Pinned input (kzg_hip_host_register, hipHostMalloc): the walk reads the coefficients IN PLACE over PCIe -- each scalar is loaded exactly once, 128 KiB per
+    // blob = 13 GB/s at 100 k commitments/s -- instead of waiting for a staged copy of pageable memory (the calling thread copies at ~10 GB/s: 67-78 k/s)
+    if (const fr *mapped = (const fr *)host_mapped_pointer(coeffs_fr)) {
+        CHK(commit_rows(ks, s, mapped, n, batch, d_out.p));
+        HIPCHK(hipMemcpyAsync(out_g1, d_out.p, batch * sizeof(g1j), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return KZG_HIP_OK;
+    }
+    CHK(d_sc.alloc(n * batch));
     // Large batches are uploaded in chunks on a second stream: the copy of chunk i + 1 (from pageable host memory it occupies the
     // calling thread) runs while the GPU walks chunk i.  Chunks keep >= 256 blobs so that a walk still fills one round of waves.
     uint64_t chunk = batch >= 1024 ? 512 : (batch >= 512 ? 256 : batch);

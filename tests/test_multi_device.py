@@ -96,6 +96,28 @@ def test_batches_are_divided_among_the_entries(kz, setup_1337, devices):
     m.close()
 
 
+def test_pinned_input_is_read_in_place(kz, setup_1337):
+    """kzg_hip_host_register: a batch whose input lies in pinned memory is walked in place over PCIe (no staged copy) -- same bytes as from pageable
+    memory, on one device and through the multi-device handle (each entry reads its share of the one registered range); an offset INTO the range works,
+    unregistering restores the staged path, misuse is a status code"""
+    m = kz.MultiKZGSettings([0, 0], 12, setup_1337)
+    m.set_table_budget_gb(10)
+    ks = m.kzg_settings(0)
+    rng = np.random.default_rng(77)
+    blobs = np.stack([rand_fr(rng, 4096) for _ in range(9)])
+    want = ks.commit_to_poly_batch(blobs)
+    with kz.pinned(blobs):
+        assert np.array_equal(ks.commit_to_poly_batch(blobs), want)
+        assert np.array_equal(ks.commit_to_poly_batch(blobs[3:]), want[3:])          # a pointer inside the registered range
+        assert np.array_equal(m.commit_to_poly_batch(blobs), want)
+        assert np.array_equal(ks.commit_to_poly_batch(blobs[:, :1000].copy()), ks.commit_to_poly_batch(np.ascontiguousarray(blobs[:, :1000])))   # pageable beside it
+    assert np.array_equal(ks.commit_to_poly_batch(blobs), want)                     # unregistered again: staged copy
+    L = kz.lib()
+    assert L.kzg_hip_host_register(None, 16) == kz.ERR_BAD_ARG and L.kzg_hip_host_unregister(None) == kz.ERR_BAD_ARG
+    assert L.kzg_hip_host_unregister(blobs.ctypes.data) == kz.ERR_HIP              # not registered (any more)
+    m.close()
+
+
 def test_eth_and_transform_batches_are_divided_among_the_entries(kz, setup_1337):
     """package eth on every entry (BlobToKZGCommitment / ComputeKZGProof on batches incl. an invalid blob and a z inside the domain) and the F_r transform
     batches (FFT, DASFFTExtension) through the multi-device handle: equal to the single-device calls, vector F in its eth form"""
