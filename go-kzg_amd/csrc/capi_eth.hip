@@ -89,10 +89,15 @@ int kzg_hip_eth_blob_to_kzg_commitment_batch(kzg_hip_eth *eth, const void *blobs
     hipStream_t s = eth->fs->stream;
     uint64_t n = eth->n;
     dtmp<uint8_t> d_in(s), d_c(s); dtmp<fr> d_poly(s); dtmp<g1j> d_out(s); dtmp<uint32_t> d_bad(s);
-    CHK(d_in.alloc(batch * n * 32)); CHK(d_c.alloc(batch * 48)); CHK(d_poly.alloc(batch * n)); CHK(d_out.alloc(batch)); CHK(d_bad.alloc(batch));
+    CHK(d_c.alloc(batch * 48)); CHK(d_poly.alloc(batch * n)); CHK(d_out.alloc(batch)); CHK(d_bad.alloc(batch));
     HIPCHK(hipMemsetAsync(d_bad.p, 0, batch * 4, s));
-    HIPCHK(hipMemcpyAsync(d_in.p, blobs_le32, batch * n * 32, hipMemcpyHostToDevice, s));
-    launch_fr_from_le32(s, d_in.p, d_poly.p, n, batch, d_bad.p);                 // BlobToPolynomial, eth/helpers.go:264-273
+    const uint8_t *src = (const uint8_t *)host_mapped_pointer(blobs_le32);     // pinned blobs (kzg_hip_host_register): the conversion kernel reads them in place over PCIe
+    if (!src) {
+        CHK(d_in.alloc(batch * n * 32));
+        HIPCHK(hipMemcpyAsync(d_in.p, blobs_le32, batch * n * 32, hipMemcpyHostToDevice, s));
+        src = d_in.p;
+    }
+    launch_fr_from_le32(s, src, d_poly.p, n, batch, d_bad.p);                    // BlobToPolynomial, eth/helpers.go:264-273
     CHK(commit_rows(eth->ks, s, d_poly.p, n, batch, d_out.p));                  // PolynomialToKZGCommitment, eth/helpers.go:98-103
     launch_g1_from_kilic(s, d_out.p, batch);                                    // commit_rows leaves Kilic images; compress wants internal
     launch_g1_compress(s, d_out.p, d_c.p, batch);

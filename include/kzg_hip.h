@@ -54,8 +54,8 @@ int kzg_hip_device_count(void);                 /* number of usable gfx950 devic
 const char *kzg_hip_last_error(void);           /* thread-local text of the last KZG_HIP_ERR_HIP            */
 const char *kzg_hip_version(void);
 
-/* Pinning of caller memory (optional).  Batch entry points that take host buffers check whether the INPUT lies in pinned memory; kzg_hip_commit_to_poly_batch
- * (and the multi-device form) then reads the coefficients in place over PCIe instead of staging a copy of pageable memory: 67-78 k -> ~95 k commitments/s from host
+/* Pinning of caller memory (optional).  kzg_hip_commit_to_poly_batch and kzg_hip_eth_blob_to_kzg_commitment_batch (and their multi-device forms) check whether
+ * their INPUT lies in pinned memory and then read the coefficients in place over PCIe instead of staging a copy of pageable memory: 67-78 k -> ~95 k commitments/s from host
  * buffers on one GPU.  The range stays pinned (and visible to every device) until kzg_hip_host_unregister; a Go caller pins the slice first (runtime.Pinner). */
 int kzg_hip_host_register(void *host, uint64_t bytes);
 int kzg_hip_host_unregister(void *host);

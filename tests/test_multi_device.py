@@ -136,6 +136,9 @@ def test_eth_and_transform_batches_are_divided_among_the_entries(kz, setup_1337)
     want, wok = e0.blob_to_kzg_commitment_batch(blobs)
     assert np.array_equal(got, want) and np.array_equal(ok, wok) and not ok[5] and ok[[0, 1, 2, 3, 4, 6]].all()
     assert got[0].tobytes().hex() == DERIVED["F_blob_seed1"]["commit_eth_bitrev_lagrange"]
+    with kz.pinned(blobs):                                     # pinned blobs are converted in place over PCIe: same bytes
+        gp, okp = me.blob_to_kzg_commitment_batch(blobs)
+        assert np.array_equal(gp, want) and np.array_equal(okp, wok)
     zs = rand_fr(rng, B)
     zs[3] = fs0.expanded_roots_of_unity()[5]                   # z in the domain: "invalid z challenge" for that row only
     pg, yg, okg = me.compute_kzg_proof_batch(polys, zs)
