@@ -201,6 +201,65 @@ class FK20MultiSettings {
     kzg_hip_fk20m *h_ = nullptr; uint64_t chunk_;
 };
 
+// Several GPUs behind one settings object (kzg_hip_multi_*; the Go shim's NewMultiKZGSettings): NewFFTSettings(maxScale) + NewKZGSettings(fs, secretG1) on
+// every device of `devices` (a device may be listed more than once); batches are divided among the devices, ONE DAUsingFK20 / DAUsingFK20Multi is sharded
+// inside the library (Toeplitz stage by output position, all-gather of the slices: RCCL between distinct devices).
+class MultiKZGSettings {
+  public:
+    MultiKZGSettings(const std::vector<int> &devices, unsigned maxScale, const std::vector<G1Point> &secretG1) {
+        detail::must(kzg_hip_multi_settings_new(devices.data(), (uint32_t)devices.size(), maxScale, secretG1.data(), secretG1.size(), &h_));
+    }
+    ~MultiKZGSettings() { kzg_hip_multi_settings_free(h_); }
+    MultiKZGSettings(const MultiKZGSettings &) = delete;
+    MultiKZGSettings &operator=(const MultiKZGSettings &) = delete;
+    kzg_hip_multi *handle() const { return h_; }
+    std::string Transport() const { return kzg_hip_multi_transport(h_); }           // "rccl" or "peer-copy"
+    uint64_t Exchanges() const { return kzg_hip_multi_exchanges(h_); }
+    void SetFFTSharding(int mode) const { detail::must(kzg_hip_multi_set_fft_sharding(h_, mode)); }   // 0 gather, 1 sharded transforms, -1 default
+    void SetTableBudgetGB(double gb) const { detail::must(kzg_hip_multi_set_table_budget_gb(h_, gb)); }
+    std::vector<G1Point> CommitToPolyBatch(const std::vector<Fr> &coeffsFlat, uint64_t n) const {   // CommitToPoly on coeffsFlat.size() / n polynomials
+        std::vector<G1Point> out(coeffsFlat.size() / n);
+        detail::must(kzg_hip_multi_commit_to_poly_batch(h_, coeffsFlat.data(), n, out.size(), out.data()));
+        return out;
+    }
+
+  private:
+    kzg_hip_multi *h_ = nullptr;
+};
+class MultiFK20SingleSettings {
+  public:
+    MultiFK20SingleSettings(const MultiKZGSettings *m, uint64_t n2) { detail::must(kzg_hip_multi_fk20_single_settings_new(m->handle(), n2, &h_)); }
+    ~MultiFK20SingleSettings() { kzg_hip_multi_fk20_single_settings_free(h_); }
+    MultiFK20SingleSettings(const MultiFK20SingleSettings &) = delete;
+    MultiFK20SingleSettings &operator=(const MultiFK20SingleSettings &) = delete;
+    std::vector<G1Point> DAUsingFK20(const std::vector<Fr> &poly) const {            // ONE polynomial over all devices
+        std::vector<G1Point> out(2 * poly.size()); detail::must(kzg_hip_multi_da_using_fk20(h_, poly.data(), poly.size(), out.data())); return out;
+    }
+    std::vector<G1Point> DAUsingFK20Batch(const std::vector<Fr> &polysFlat, uint64_t n) const {   // polynomials divided among the devices
+        std::vector<G1Point> out(2 * polysFlat.size());
+        detail::must(kzg_hip_multi_da_using_fk20_batch(h_, polysFlat.data(), n, polysFlat.size() / n, out.data()));
+        return out;
+    }
+
+  private:
+    kzg_hip_multi_fk20s *h_ = nullptr;
+};
+class MultiFK20MultiSettings {
+  public:
+    MultiFK20MultiSettings(const MultiKZGSettings *m, uint64_t n2, uint64_t chunkLen) : chunk_(chunkLen) {
+        detail::must(kzg_hip_multi_fk20_multi_settings_new(m->handle(), n2, chunkLen, &h_));
+    }
+    ~MultiFK20MultiSettings() { kzg_hip_multi_fk20_multi_settings_free(h_); }
+    MultiFK20MultiSettings(const MultiFK20MultiSettings &) = delete;
+    MultiFK20MultiSettings &operator=(const MultiFK20MultiSettings &) = delete;
+    std::vector<G1Point> DAUsingFK20Multi(const std::vector<Fr> &poly) const {       // ONE polynomial over all devices (fk20_multi.go:113-133)
+        std::vector<G1Point> out(2 * poly.size() / chunk_); detail::must(kzg_hip_multi_da_using_fk20_multi(h_, poly.data(), poly.size(), out.data())); return out;
+    }
+
+  private:
+    kzg_hip_multi_fk20m *h_ = nullptr; uint64_t chunk_;
+};
+
 // package eth (eth/globals.go:39-72, eth/eth.go:145-182, eth/helpers.go:179-211): byte-level callers.  Blob = FieldElementsPerBlob x 32 little-endian
 // bytes, KZGCommitment / KZGProof = 48 bytes; `error` returns of the reference are kzg::Error with its texts.
 namespace eth {

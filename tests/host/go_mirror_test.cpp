@@ -170,6 +170,35 @@ static void TestErrorsAndPanics() {
     catch (const Panic &p) { CHECK(std::string(p.what()) == "domain too small for extending requested values", "%s", p.what()); }
 }
 
+// fk20_single_test.go:12-41 again, through a settings object that spans TWO entries of device 0 (the multi-device handle): same proofs, in both exchange schemes
+static void TestMultiKZGSettings_DAUsingFK20() {
+    FFTSettings fs(5);
+    auto s1 = fs.GenerateTestingSetupG1(SECRET, 32 + 1);
+    MultiKZGSettings m({0, 0}, 5, s1);
+    CHECK(m.Transport() == "peer-copy", "two entries on one GPU exchange by peer copies");
+    MultiFK20SingleSettings fk(&m, 32);
+    KZGSettings ks(&fs, s1);
+    FK20SingleSettings fk1(&ks, 32);
+    auto polynomial = testPoly(fs, {1, 2, 3, 4, 7, 7, 7, 7, 13, 13, 13, 13, 13, 13, 13, 13});
+    auto want = fk1.DAUsingFK20(polynomial);
+    for (int mode = 0; mode < 2; mode++) {
+        m.SetFFTSharding(mode);
+        uint64_t before = m.Exchanges();
+        auto got = fk.DAUsingFK20(polynomial);
+        CHECK(m.Exchanges() - before == (mode ? 5u : 1u), "all-gathers of scheme %d", mode);
+        CHECK(got.size() == 32, "32 proofs");
+        bool same = got.size() == want.size();
+        for (size_t i = 0; same && i < got.size(); i++) same = EqualG1(got[i], want[i]);
+        CHECK(same, "multi-device proofs equal the single-device ones (scheme %d)", mode);
+    }
+    std::vector<Fr> two(polynomial);
+    two.insert(two.end(), polynomial.begin(), polynomial.end());
+    auto cs = m.CommitToPolyBatch(two, 16);
+    CHECK(cs.size() == 2 && EqualG1(cs[0], ks.CommitToPoly(polynomial)) && EqualG1(cs[1], cs[0]), "CommitToPolyBatch over the two entries");
+    auto bytes = fs.ToCompressedG1(cs);
+    CHECK(hex(bytes, 0, 48) == KAT["A_commit"][0], "vector A through the multi-device handle");
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) { printf("usage: go_mirror_test <kat file>\n"); return 2; }
     std::ifstream f(argv[1]);
@@ -182,7 +211,7 @@ int main(int argc, char **argv) {
         {"TestKZGSettings_CommitToEvalPoly_and_CheckProofSingle", TestKZGSettings_CommitToEvalPoly_and_CheckProofSingle},
         {"TestKZGSettings_DAUsingFK20", TestKZGSettings_DAUsingFK20},
         {"TestFFTSettings_RecoverPolyFromSamples_Simple", TestFFTSettings_RecoverPolyFromSamples_Simple}, {"TestErrorsAndPanics", TestErrorsAndPanics},
-        {"TestEth_ComputeAggregateKZGProof", TestEth_ComputeAggregateKZGProof}};
+        {"TestEth_ComputeAggregateKZGProof", TestEth_ComputeAggregateKZGProof}, {"TestMultiKZGSettings_DAUsingFK20", TestMultiKZGSettings_DAUsingFK20}};
     for (auto &t : tests) {
         int before = failures;
         try { t.fn(); } catch (const std::exception &e) { failures++; printf("FAIL %s: unexpected %s\n", t.name, e.what()); }
