@@ -417,6 +417,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip table_sweep / drop_in / lincomb / latency (profiling runs)")
     ap.add_argument("--fk20-4096-batch", type=int, default=512, help="polynomials per step of the fk20_4096 block (0: skip)")
     ap.add_argument("--no-in-process", action="store_true", help="skip the multi-device-handle leg (a child process at the end)")
+    ap.add_argument("--in-process", action="store_true", help="(default) also time the multi-device handle of the C ABI over the job's devices: reported under in_process and rccl")
     ap.add_argument("--in-process-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--devices", type=str, default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
