@@ -70,6 +70,7 @@ def lib():
         "kzg_hip_fft_max_width": (u64, [vp]), "kzg_hip_fft_roots": (i32, [vp, i32, vp]),
         "kzg_hip_fft_fr": (i32, [vp, vp, u64, i32, vp, C.POINTER(u64)]), "kzg_hip_inplace_fft_fr": (i32, [vp, vp, vp, u64, i32]),
         "kzg_hip_fft_fr_batch": (i32, [vp, vp, u64, u64, i32, vp]), "kzg_hip_fft_g1": (i32, [vp, vp, u64, i32, vp]),
+        "kzg_hip_fft_g1_batch": (i32, [vp, vp, u64, u64, i32, vp]), "kzg_hip_multi_fft_g1_batch": (i32, [vp, vp, u64, u64, i32, vp]),
         "kzg_hip_das_fft_extension": (i32, [vp, vp, u64]), "kzg_hip_das_fft_extension_batch": (i32, [vp, vp, u64, u64]),
         "kzg_hip_fft_fr_batch_dev": (i32, [vp, vp, u64, u64, i32, vp, vp]), "kzg_hip_fft_g1_batch_dev": (i32, [vp, vp, u64, u64, i32, vp, vp]),
         "kzg_hip_das_fft_extension_batch_dev": (i32, [vp, vp, u64, u64, vp]),
@@ -262,6 +263,13 @@ class FFTSettings:
         vals = _g1(vals)
         out = g1_empty(vals.shape[0])
         _chk(lib().kzg_hip_fft_g1(self.h, _p(vals), vals.shape[0], int(inv), _p(out)), error_ok=True)
+        return out
+
+    def fft_g1_batch(self, vals, inv=False):
+        """FFTG1 on every row of vals (batch, n, 3, 6)"""
+        vals = np.ascontiguousarray(vals, dtype=np.uint64)
+        out = np.zeros_like(vals)
+        _chk(lib().kzg_hip_fft_g1_batch(self.h, _p(vals), vals.shape[1], vals.shape[0], int(inv), _p(out)), error_ok=True)
         return out
 
     def evaluate_poly_in_evaluation_form(self, poly, x, scale=0):
@@ -681,6 +689,13 @@ class MultiKZGSettings:
         vals = np.ascontiguousarray(vals, dtype=np.uint64)
         out = np.zeros_like(vals)
         _chk(lib().kzg_hip_multi_fft_fr_batch(self.h, _p(vals), vals.shape[1], vals.shape[0], int(inv), _p(out)), error_ok=True)
+        return out
+
+    def fft_g1_batch(self, vals, inv=False):
+        """FFTG1 (fft_g1.go:58-94) on every row, rows divided among the devices"""
+        vals = np.ascontiguousarray(vals, dtype=np.uint64)
+        out = np.zeros_like(vals)
+        _chk(lib().kzg_hip_multi_fft_g1_batch(self.h, _p(vals), vals.shape[1], vals.shape[0], int(inv), _p(out)), error_ok=True)
         return out
 
     def das_fft_extension_batch(self, vals):

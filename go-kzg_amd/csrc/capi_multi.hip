@@ -404,6 +404,17 @@ int kzg_hip_multi_fft_fr_batch(kzg_hip_multi *m, const void *vals_fr, uint64_t n
     });
     KZG_CATCH
 }
+int kzg_hip_multi_fft_g1_batch(kzg_hip_multi *m, const void *vals_g1, uint64_t n, uint64_t batch, int inv, void *out_g1) {
+    if (!m || !vals_g1 || !out_g1) return KZG_HIP_ERR_BAD_ARG;
+    if (!batch) return KZG_HIP_OK;
+    KZG_TRY
+    return per_device(m, [&](size_t i) -> int {
+        uint64_t lo, hi; share(batch, m->d.size(), i, &lo, &hi);
+        if (hi == lo) return KZG_HIP_OK;
+        return kzg_hip_fft_g1_batch(m->d[i].fs, (const uint8_t *)vals_g1 + lo * n * sizeof(g1j), n, hi - lo, inv, (uint8_t *)out_g1 + lo * n * sizeof(g1j));
+    });
+    KZG_CATCH
+}
 int kzg_hip_multi_das_fft_extension_batch(kzg_hip_multi *m, void *vals_fr, uint64_t n, uint64_t batch) {
     if (!m || !vals_fr) return KZG_HIP_ERR_BAD_ARG;
     if (!batch) return KZG_HIP_OK;

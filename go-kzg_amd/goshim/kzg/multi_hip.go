@@ -132,6 +132,19 @@ func (m *MultiKZGSettings) FFTBatch(rows [][]bls.Fr, inv bool) [][]bls.Fr {
 	return out
 }
 
+// FFTG1BatchFlat: FFTG1 (fft_g1.go:58-94) on len(points) / n rows stored back to back, rows divided among the devices.
+func (m *MultiKZGSettings) FFTG1BatchFlat(points []bls.G1Point, n int, inv bool) []bls.G1Point {
+	defer runtime.KeepAlive(m)
+	if n <= 0 || len(points)%n != 0 {
+		panic("FFTG1BatchFlat: len(points) is not a multiple of n")
+	}
+	out := make([]bls.G1Point, len(points))
+	if len(points) > 0 {
+		hipMust(C.kzg_hip_multi_fft_g1_batch(m.h, g1Ptr(points), C.uint64_t(n), C.uint64_t(len(points)/n), cBool(inv), g1Ptr(out)))
+	}
+	return out
+}
+
 // DASFFTExtensionBatch: DASFFTExtension (das_extension.go:71-84) on every row, in place like the reference.
 func (m *MultiKZGSettings) DASFFTExtensionBatch(rows [][]bls.Fr) {
 	defer runtime.KeepAlive(m)

@@ -83,6 +83,7 @@ int kzg_hip_das_fft_extension_batch(kzg_hip_fft *fs, void *vals_fr, uint64_t n, 
  * `batch` rows of n values each, inputs and outputs in HBM, Kilic images for G1 (converted and normalised inside).  d_out must not
  * overlap d_vals (InplaceFFT's rule, fft_fr.go:76: the name notwithstanding it takes a separate output slice). */
 int kzg_hip_fft_fr_batch_dev(kzg_hip_fft *fs, const void *d_vals_fr, uint64_t n, uint64_t batch, int inv, void *d_out_fr, void *stream);
+int kzg_hip_fft_g1_batch(kzg_hip_fft *fs, const void *vals_g1, uint64_t n, uint64_t batch, int inv, void *out_g1);   /* FFTG1 on `batch` rows of n points, host buffers */
 int kzg_hip_fft_g1_batch_dev(kzg_hip_fft *fs, const void *d_vals_g1, uint64_t n, uint64_t batch, int inv, void *d_out_g1, void *stream);
 int kzg_hip_das_fft_extension_batch_dev(kzg_hip_fft *fs, void *d_vals_fr, uint64_t n, uint64_t batch, void *stream);
 
@@ -278,6 +279,7 @@ int kzg_hip_multi_compute_proof_single_batch(kzg_hip_multi *m, const void *poly_
 /* FFT / InplaceFFT (fft_fr.go:55-105) and DASFFTExtension (das_extension.go:71-84; in place) on `batch` rows of n values, rows divided among the devices */
 int kzg_hip_multi_fft_fr_batch(kzg_hip_multi *m, const void *vals_fr, uint64_t n, uint64_t batch, int inv, void *out_fr);
 int kzg_hip_multi_das_fft_extension_batch(kzg_hip_multi *m, void *vals_fr, uint64_t n, uint64_t batch);
+int kzg_hip_multi_fft_g1_batch(kzg_hip_multi *m, const void *vals_g1, uint64_t n, uint64_t batch, int inv, void *out_g1);   /* FFTG1 (fft_g1.go:58-94) likewise */
 /* package eth on every entry (eth/globals.go:39-72; lagrange_g1 in natural order as for kzg_hip_eth_settings_new): BlobToKZGCommitment (eth/eth.go:145-151)
  * and ComputeKZGProof (eth/helpers.go:179-203) on batches, rows divided among the devices; flags and error codes as in the single-device calls */
 typedef struct kzg_hip_multi_eth kzg_hip_multi_eth;

@@ -152,6 +152,12 @@ def test_eth_and_transform_batches_are_divided_among_the_entries(kz, setup_1337)
         assert np.array_equal(m.fft_batch(rows, inv), fs0.fft_batch(rows, inv))
     assert np.array_equal(m.das_fft_extension_batch(rows[:, :2048]), fs0.das_fft_extension_batch(rows[:, :2048]))
     assert np.array_equal(m.fft_batch(rows[:1, :64]), fs0.fft_batch(rows[:1, :64]))     # one row: two entries get nothing
+    g1rows = np.stack([setup_1337[64 * b:64 * b + 64] for b in range(5)])               # FFTG1 on batches: host batch form and the multi-device one
+    for inv in (False, True):
+        want_g1 = np.stack([fs0.fft_g1(r, inv) for r in g1rows])
+        assert np.array_equal(fs0.fft_g1_batch(g1rows, inv), want_g1) and np.array_equal(m.fft_g1_batch(g1rows, inv), want_g1)
+    with pytest.raises(kz.KzgError):
+        fs0.fft_g1_batch(g1rows[:, :48])                                                 # fft_g1.go:63-65: not a power of two
     e0.close(); me.close(); m.close()
 
 
