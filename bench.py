@@ -325,7 +325,7 @@ def in_process_child(devices):
         def sha(fsx, pts):
             return hashlib.sha256(fsx.to_compressed_g1(pts).tobytes()).hexdigest()
         m = kz.MultiKZGSettings(devices, 12, setup)
-        out["transport"], out["transport_note"] = m.transport, m.transport_note
+        out["transport"], out["transport_note"], out["transport_self_test"] = m.transport, m.transport_note, m.transport_self_test
         per = 1024
         blobs = mont(1, per * D)
         exp_f = json.load(open(os.path.join(golden, "derived_vectors.json")))["F_blob_seed1"]["commit_monomial_s1337"]
@@ -763,9 +763,15 @@ def main():
                     lincomb[key][str(bs)] = {"msm_per_s": bs * world * reps / lsecs, "ms_per_step": lsecs / reps * 1e3}
             pts.set_table_budget_gb(0)
             lc_rates("bucket_pipeline_batch")
+            torch.cuda.synchronize()
+            nchk = min(B, 512)                                   # the last step of each form ran on the first 512 blobs
+            d_lc_bucket = d_lc_out[:nchk].clone()                # the bucket pipeline's own output, before the table walk overwrites the buffer
             pts.set_table_budget_gb(32)
             lc_rates("batch")
             lincomb["table"] = "budget 32 GB"
+            torch.cuda.synchronize()
+            lincomb["bucket_pipeline_matches_fixed_base_commitments"] = bool(torch.equal(d_lc_bucket, d_out[:nchk]))   # k_msm_* (incl. reduce_chunks at 512) vs k_fb_accumulate
+            lincomb["matches_fixed_base_commitments"] = bool(torch.equal(d_lc_out[:nchk], d_out[:nchk]))              # the set's 32 GB table vs the settings' table
             # one linear combination per call (bls.LinCombG1's shape) from 64 host threads: coalesced into batched bucket MSMs
             import threading
             lc_T, lc_per = 64, 30
@@ -782,8 +788,6 @@ def main():
             lc_t0 = time.perf_counter()
             [t.join() for t in lc_ths]
             lincomb["one_call_at_a_time_from_64_threads_per_s"] = lc_T * lc_per / (time.perf_counter() - lc_t0)
-            nchk = min(B, 512)                                   # the last lincomb step used the first 512 blobs
-            lincomb["matches_fixed_base_commitments"] = bool(torch.equal(d_lc_out[:nchk], d_out[:nchk]))
 
             # --- single-call latencies through the host-buffer entry points (ms)
             # median of the timed calls (a one-off ~50 ms host / driver hiccup somewhere in this block was seen to land in one of the ten

@@ -126,7 +126,7 @@ def lib():
         "kzg_hip_multi_settings_new": (i32, [C.POINTER(i32), u32, u32, vp, u64, pp]), "kzg_hip_multi_settings_free": (None, [vp]),
         "kzg_hip_multi_device_count": (u32, [vp]), "kzg_hip_multi_device": (i32, [vp, u32]),
         "kzg_hip_multi_fft": (vp, [vp, u32]), "kzg_hip_multi_kzg": (vp, [vp, u32]),
-        "kzg_hip_multi_transport": (C.c_char_p, [vp]), "kzg_hip_multi_transport_note": (C.c_char_p, [vp]), "kzg_hip_multi_exchanges": (u64, [vp]),
+        "kzg_hip_multi_transport": (C.c_char_p, [vp]), "kzg_hip_multi_transport_note": (C.c_char_p, [vp]), "kzg_hip_multi_transport_check": (C.c_char_p, [vp]), "kzg_hip_multi_exchanges": (u64, [vp]),
         "kzg_hip_multi_set_fft_sharding": (i32, [vp, i32]), "kzg_hip_multi_set_table_budget_gb": (i32, [vp, C.c_double]),
         "kzg_hip_multi_commit_to_poly_batch": (i32, [vp, vp, u64, u64, vp]),
         "kzg_hip_multi_compute_proof_single_batch": (i32, [vp, vp, u64, u64, vp, vp]),
@@ -651,8 +651,14 @@ class MultiKZGSettings:
 
     @property
     def transport(self):
-        """"rccl" (ncclAllGather between distinct devices) or "peer-copy" (hipMemcpyPeerAsync: a repeated device, or no librccl)"""
+        """"rccl" (ncclAllGather between distinct devices), "peer-copy" (hipMemcpyPeerAsync: a repeated device, or no librccl) or
+        "host-staged" (device -> pinned host -> device: what is left when the other two fail the creation-time self-test)"""
         return lib().kzg_hip_multi_transport(self.h).decode()
+
+    @property
+    def transport_self_test(self):
+        """outcome of the exchange test the constructor ran: "ok: <transport>, <entries> entries, ..." """
+        return lib().kzg_hip_multi_transport_check(self.h).decode()
 
     @property
     def transport_note(self):

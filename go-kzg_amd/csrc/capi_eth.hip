@@ -91,7 +91,7 @@ int kzg_hip_eth_blob_to_kzg_commitment_batch(kzg_hip_eth *eth, const void *blobs
     dtmp<uint8_t> d_in(s), d_c(s); dtmp<fr> d_poly(s); dtmp<g1j> d_out(s); dtmp<uint32_t> d_bad(s);
     CHK(d_c.alloc(batch * 48)); CHK(d_poly.alloc(batch * n)); CHK(d_out.alloc(batch)); CHK(d_bad.alloc(batch));
     HIPCHK(hipMemsetAsync(d_bad.p, 0, batch * 4, s));
-    const uint8_t *src = (const uint8_t *)host_mapped_pointer(blobs_le32);     // pinned blobs (kzg_hip_host_register): the conversion kernel reads them in place over PCIe
+    const uint8_t *src = (const uint8_t *)host_mapped_pointer(blobs_le32, (size_t)batch * n * 32);     // pinned blobs (kzg_hip_host_register): the conversion kernel reads them in place over PCIe
     if (!src) {
         CHK(d_in.alloc(batch * n * 32));
         HIPCHK(hipMemcpyAsync(d_in.p, blobs_le32, batch * n * 32, hipMemcpyHostToDevice, s));

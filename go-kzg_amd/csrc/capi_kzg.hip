@@ -128,21 +128,45 @@ int kzg_hip_commit_to_poly_batch_dev(kzg_hip_kzg *ks, const void *d_coeffs_fr, u
     dev_guard g(ks->fs);
     return commit_rows(ks, (hipStream_t)stream, (const fr *)d_coeffs_fr, n, batch, (g1j *)d_out_g1);
 }
-// device-visible address of a host pointer that lies in pinned memory (registered with kzg_hip_host_register / hipHostRegister, or from hipHostMalloc); null for
-// pageable memory.  The current device must be the handle's.
-const void *host_mapped_pointer(const void *host) {
+// Ranges pinned through kzg_hip_host_register: the in-place paths need the EXTENT of a pinned range, which hipPointerGetAttributes does not report.
+namespace {
+std::mutex g_reg_mu;
+std::map<uintptr_t, size_t> g_registered;   // base -> bytes
+}
+// device-visible address of the host range [host, host + bytes) if ALL of it lies in pinned, mapped memory (registered with kzg_hip_host_register, or
+// from hipHostMalloc / hipHostRegister where the runtime reports the allocation's extent); null for pageable memory and for a range that starts in a
+// pinned allocation but runs past its end (a kernel reading it in place would fault: such input takes the staged copy).  The current device must be the handle's.
+const void *host_mapped_pointer(const void *host, size_t bytes) {
     hipPointerAttribute_t a;
     if (hipPointerGetAttributes(&a, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }   // pageable memory is "invalid value" for this query
     if (a.type != hipMemoryTypeHost || !a.devicePointer) return nullptr;
-    return a.devicePointer;
+    const uintptr_t h = (uintptr_t)host;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        auto it = g_registered.upper_bound(h);
+        if (it != g_registered.begin()) {
+            --it;
+            if (h >= it->first && h < it->first + it->second) return (h + bytes <= it->first + it->second) ? a.devicePointer : nullptr;
+        }
+    }
+    // pinned by someone else (hipHostMalloc, a framework's pinned allocator): trust the runtime's extent if it has one, otherwise stage
+    hipDeviceptr_t base = nullptr; size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)a.devicePointer) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    const uintptr_t d = (uintptr_t)a.devicePointer, b = (uintptr_t)base;
+    return (d >= b && d + bytes <= b + size) ? a.devicePointer : nullptr;
 }
 int kzg_hip_host_register(void *host, uint64_t bytes) {
     if (!host || !bytes) return KZG_HIP_ERR_BAD_ARG;
+    KZG_TRY
     HIPCHK(hipHostRegister(host, bytes, hipHostRegisterPortable | hipHostRegisterMapped));
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    g_registered[(uintptr_t)host] = bytes;
     return KZG_HIP_OK;
+    KZG_CATCH
 }
 int kzg_hip_host_unregister(void *host) {
     if (!host) return KZG_HIP_ERR_BAD_ARG;
+    { std::lock_guard<std::mutex> lk(g_reg_mu); g_registered.erase((uintptr_t)host); }
     HIPCHK(hipHostUnregister(host));
     return KZG_HIP_OK;
 }
@@ -158,7 +182,7 @@ int kzg_hip_commit_to_poly_batch(kzg_hip_kzg *ks, const void *coeffs_fr, uint64_
     CHK(d_out.alloc(batch));
     // Pinned input (kzg_hip_host_register, hipHostMalloc): the walk reads the coefficients IN PLACE over PCIe -- each scalar is loaded exactly once, 128 KiB per
     // blob = 13 GB/s at 100 k commitments/s -- instead of waiting for a staged copy of pageable memory (the calling thread copies at ~10 GB/s: 67-78 k/s)
-    if (const fr *mapped = (const fr *)host_mapped_pointer(coeffs_fr)) {
+    if (const fr *mapped = (const fr *)host_mapped_pointer(coeffs_fr, (size_t)n * batch * sizeof(fr))) {
         CHK(commit_rows(ks, s, mapped, n, batch, d_out.p));
         HIPCHK(hipMemcpyAsync(out_g1, d_out.p, batch * sizeof(g1j), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));

@@ -11,10 +11,22 @@
 // is distinct; a list that repeats a device (a 1-GPU box testing [0, 0]) or a process without RCCL exchanges the same slices with
 // hipMemcpyPeerAsync.  RCCL is bound at the first multi-device handle, not at load time: librccl.so is 573 MB, single-GPU callers never
 // need it, and a process that already holds a copy (PyTorch bundles one with the same SONAME) must not get a second one.
+//
+// What may be handed to another device (round 5).  Every buffer that an all-gather reads or writes lives in the handle's EXCHANGE ARENA of
+// its device: one block from hipMalloc (never the stream-ordered pool, whose memory is not mapped to peers unless hipMemPoolSetAccess says
+// so), with hipDeviceEnablePeerAccess granted for every distinct pair of listed devices at creation.  all_gather_bytes only accepts `xbuf`
+// values, and only the arena makes them, so no hipMallocAsync pointer can reach ncclAllGather or a peer copy.  The handle PROVES its
+// transport when it is created (transport_self_test): every entry writes a pattern into its slice, one all_gather_bytes, every entry's
+// buffer is read back and compared; a transport that errs or delivers wrong bytes is replaced by the next one -- rccl -> peer-copy ->
+// host-staged (device -> pinned host -> device, no peer mapping involved) -- with the reason in kzg_hip_multi_transport_note.
+// KZG_HIP_MULTI_FAULT (tests only; comma list of "rccl", "rccl-corrupt", "peer", "peer-corrupt") makes the named leg fail so that the
+// fall-backs run on a one-GPU box.
 #include "capi_common.hpp"
 #include <rccl/rccl.h>   // types and prototypes; the functions are resolved at run time (rccl_api)
 #include <dlfcn.h>
 #include <atomic>
+#include <deque>
+#include <functional>
 
 namespace {
 
@@ -62,22 +74,66 @@ rccl_api *rccl_bind(std::string *why) {
 
 }  // namespace
 
+// a buffer that may cross devices: only exch_arena::take makes one (hipMalloc memory, peer access granted)
+struct xbuf { uint8_t *p = nullptr; };
+// One block of hipMalloc memory per entry of the handle, bump-allocated per sharded call (calls are serialised by kzg_hip_multi::mu and every
+// stream has drained when one returns, so a call starts from an empty arena and may grow it).
+struct exch_arena {
+    int device = 0; uint8_t *base = nullptr; size_t cap = 0, used = 0;
+    int reserve(size_t bytes) {            // nothing of this arena is in flight when this is called
+        used = 0;
+        if (bytes <= cap) return KZG_HIP_OK;
+        HIPCHK(hipSetDevice(device));
+        if (base) { HIPCHK(hipFree(base)); base = nullptr; cap = 0; }
+        size_t want = std::max<size_t>(bytes, 1u << 20);
+        HIPCHK(hipMalloc((void **)&base, want));
+        cap = want;
+        return KZG_HIP_OK;
+    }
+    int take(size_t bytes, xbuf *out) {
+        size_t at = (used + 255) & ~(size_t)255;
+        if (at + bytes > cap) { g_last_error = "exchange arena too small (internal sizing error)"; return KZG_HIP_ERR_HIP; }
+        out->p = base + at; used = at + bytes;
+        return KZG_HIP_OK;
+    }
+    void release() { if (base) { (void)hipSetDevice(device); (void)hipFree(base); base = nullptr; cap = used = 0; } }
+};
+// a host thread bound to one entry of the handle for its lifetime: batch calls hand it that entry's share (no thread creation per call)
+struct dev_worker {
+    std::thread th; std::mutex mu; std::condition_variable cv; std::deque<std::function<void()>> q; bool stop = false;
+    void loop() {
+        for (;;) {
+            std::function<void()> f;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || !q.empty(); }); if (q.empty()) return; f = std::move(q.front()); q.pop_front(); }
+            f();
+        }
+    }
+    void post(std::function<void()> f) { { std::lock_guard<std::mutex> lk(mu); q.push_back(std::move(f)); } cv.notify_one(); }
+    void shutdown() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_one(); if (th.joinable()) th.join(); }
+};
 struct multi_dev {
     int device = 0;
     kzg_hip_fft *fs = nullptr;
     kzg_hip_kzg *ks = nullptr;
     hipStream_t s = nullptr;       // this device's stream for sharded calls
     hipEvent_t ev = nullptr;       // ... and its event for the peer-copy exchange and the cross-stream barrier
+    exch_arena arena;              // the memory other devices may read or write
 };
+enum multi_transport { T_RCCL = 0, T_PEER = 1, T_HOST = 2 };
 struct kzg_hip_multi {
     std::vector<multi_dev> d;
+    std::vector<std::unique_ptr<dev_worker>> workers;   // entry i > 0 is served by workers[i - 1]; entry 0 by the calling thread
     rccl_api *nccl = nullptr;              // non-null: the exchange is ncclAllGather
     std::vector<ncclComm_t> comms;
-    std::string transport = "peer-copy", transport_note;
+    int tkind = T_PEER;
+    std::string transport = "peer-copy", transport_note, self_test;
+    uint8_t *h_stage = nullptr; size_t h_stage_cap = 0;   // pinned, portable: the host-staged exchange
+    unsigned fault = 0;                    // KZG_HIP_MULTI_FAULT bits (tests)
     int fft_mode = -1;                     // -1 default policy, 0 gather, 1 sharded transforms
     std::mutex mu;                         // sharded calls (collectives) on a handle run one at a time
     std::atomic<uint64_t> n_allgather{0};  // exchanges performed (tests and bench read it)
 };
+enum { FAULT_RCCL = 1, FAULT_RCCL_CORRUPT = 2, FAULT_PEER = 4, FAULT_PEER_CORRUPT = 8 };
 struct kzg_hip_multi_eth { kzg_hip_multi *m = nullptr; std::vector<kzg_hip_eth *> eth; uint64_t n = 0; };
 struct kzg_hip_multi_fk20s { kzg_hip_multi *m = nullptr; std::vector<kzg_hip_fk20s *> fk; uint64_t n2 = 0; };
 struct kzg_hip_multi_fk20m { kzg_hip_multi *m = nullptr; std::vector<kzg_hip_fk20m *> fk; uint64_t n2 = 0, l = 1; };
@@ -91,25 +147,38 @@ inline void share(uint64_t total, uint64_t parts, uint64_t i, uint64_t *lo, uint
     *hi = *lo + base + (i < rem ? 1 : 0);
 }
 
-// runs f(i) on one host thread per device (the calling thread takes device 0) and returns the first non-zero status
+// runs f(i) for every entry -- entry 0 on the calling thread, entry i > 0 on its worker -- and returns the first non-zero status.  Nothing
+// here creates a thread, so nothing here can throw std::system_error past the callers' KZG_CATCH with threads still joinable.
 template <class F> int per_device(kzg_hip_multi *m, F f) {
     const size_t D = m->d.size();
     std::vector<int> st(D, KZG_HIP_OK);
     std::vector<std::string> errs(D);
-    std::vector<std::thread> th;
+    std::mutex done_mu; std::condition_variable done_cv; size_t pending = 0;
     auto body = [&](size_t i) {
-        try { st[i] = f(i); } catch (const std::exception &e) { g_last_error = e.what(); st[i] = KZG_HIP_ERR_HIP; }
+        try { st[i] = f(i); }
+        catch (const std::exception &e) { g_last_error = e.what(); st[i] = KZG_HIP_ERR_HIP; }
+        catch (...) { g_last_error = "unknown exception"; st[i] = KZG_HIP_ERR_HIP; }
         if (st[i] == KZG_HIP_ERR_HIP) errs[i] = g_last_error;   // g_last_error is thread-local: carry the text to the caller's thread
     };
-    for (size_t i = 1; i < D; i++) th.emplace_back(body, i);
+    for (size_t i = 1; i < D; i++) {
+        if (i - 1 >= m->workers.size()) { body(i); continue; }   // (a handle under construction whose workers could not all be started)
+        { std::lock_guard<std::mutex> lk(done_mu); pending++; }
+        try {
+            m->workers[i - 1]->post([&, i] { body(i); std::lock_guard<std::mutex> lk(done_mu); if (--pending == 0) done_cv.notify_one(); });
+        } catch (...) {                                          // the queue could not grow: run the share here instead
+            { std::lock_guard<std::mutex> lk(done_mu); pending--; }
+            body(i);
+        }
+    }
     body(0);
-    for (auto &t : th) t.join();
+    { std::unique_lock<std::mutex> lk(done_mu); done_cv.wait(lk, [&] { return pending == 0; }); }   // every posted share has finished, whatever its status
     for (size_t i = 0; i < D; i++)
         if (st[i] != KZG_HIP_OK) { if (st[i] == KZG_HIP_ERR_HIP) g_last_error = errs[i]; return st[i]; }
     return KZG_HIP_OK;
 }
 
-// stream-ordered temporaries of one device of a sharded call; frees on that device whatever the calling thread's current device is
+// stream-ordered temporaries of one device of a sharded call (device-LOCAL data only: what crosses devices comes from exch_arena); frees on
+// that device whatever the calling thread's current device is
 struct mtmp {
     int device; hipStream_t s; std::vector<void *> ptrs;
     mtmp(int dev, hipStream_t st) : device(dev), s(st) {}
@@ -142,36 +211,146 @@ int cross_barrier(kzg_hip_multi *m) {
     return KZG_HIP_OK;
 }
 
-// In-place all-gather of bytes: device i holds its slice at buf[i] + i * bytes_each and ends with all D slices in buf[i].
-int all_gather_bytes(kzg_hip_multi *m, const std::vector<uint8_t *> &buf, size_t bytes_each) {
+// In-place all-gather of bytes: device i holds its slice at buf[i].p + i * bytes_each and ends with all D slices in buf[i].p.  The buffers are
+// arena memory (xbuf); `kind` is the transport to use (the handle's, or the one transport_self_test is probing).
+int all_gather_bytes(kzg_hip_multi *m, const std::vector<xbuf> &buf, size_t bytes_each, int kind) {
     const size_t D = m->d.size();
     m->n_allgather++;
-    if (m->nccl) {
+    if (kind == T_RCCL) {
+        if (m->fault & FAULT_RCCL) { g_last_error = "ncclAllGather failed: injected fault (KZG_HIP_MULTI_FAULT=rccl)"; return KZG_HIP_ERR_HIP; }
         rccl_api *n = m->nccl;
         ncclResult_t r = n->GroupStart();
         hipError_t he = hipSuccess;
         for (size_t i = 0; i < D && r == ncclSuccess && he == hipSuccess; i++) {   // one thread drives every communicator: the calls form one group
             he = hipSetDevice(m->d[i].device);
-            if (he == hipSuccess) r = n->AllGather(buf[i] + i * bytes_each, buf[i], bytes_each, ncclUint8, m->comms[i], m->d[i].s);
+            if (he == hipSuccess) r = n->AllGather(buf[i].p + i * bytes_each, buf[i].p, bytes_each, ncclUint8, m->comms[i], m->d[i].s);
         }
         ncclResult_t r2 = n->GroupEnd();   // always closed, also after a failure inside the group
         if (r == ncclSuccess) r = r2;
         HIPCHK(he);
         if (r != ncclSuccess) { g_last_error = std::string("ncclAllGather failed: ") + n->GetErrorString(r); return KZG_HIP_ERR_HIP; }
+        if (m->fault & FAULT_RCCL_CORRUPT) { HIPCHK(hipSetDevice(m->d[D - 1].device)); HIPCHK(hipMemsetAsync(buf[D - 1].p, 0x5a, 1, m->d[D - 1].s)); }
         return KZG_HIP_OK;
     }
+    if (kind == T_HOST) {
+        // device -> pinned host -> device: no peer mapping involved.  The staging area belongs to the handle (sharded calls are serialised).
+        const size_t total = D * bytes_each;
+        if (m->h_stage_cap < total) {
+            if (m->h_stage) { HIPCHK(hipHostFree(m->h_stage)); m->h_stage = nullptr; m->h_stage_cap = 0; }
+            size_t cap = std::max<size_t>(total, 1u << 20);
+            HIPCHK(hipHostMalloc((void **)&m->h_stage, cap, hipHostMallocPortable));
+            m->h_stage_cap = cap;
+        }
+        for (size_t i = 0; i < D; i++) {
+            HIPCHK(hipSetDevice(m->d[i].device));
+            HIPCHK(hipMemcpyAsync(m->h_stage + i * bytes_each, buf[i].p + i * bytes_each, bytes_each, hipMemcpyDeviceToHost, m->d[i].s));
+            HIPCHK(hipEventRecord(m->d[i].ev, m->d[i].s));
+        }
+        for (size_t j = 0; j < D; j++) {
+            HIPCHK(hipSetDevice(m->d[j].device));
+            for (size_t i = 0; i < D; i++) {
+                if (i == j) continue;
+                HIPCHK(hipStreamWaitEvent(m->d[j].s, m->d[i].ev, 0));
+                HIPCHK(hipMemcpyAsync(buf[j].p + i * bytes_each, m->h_stage + i * bytes_each, bytes_each, hipMemcpyHostToDevice, m->d[j].s));
+            }
+        }
+        return cross_barrier(m);   // the staging area is reused by the next exchange only after every reader is done
+    }
     // peer copies: device j pulls slice i from device i once i's stream has produced it
+    if (m->fault & FAULT_PEER) { g_last_error = "peer copy failed: injected fault (KZG_HIP_MULTI_FAULT=peer)"; return KZG_HIP_ERR_HIP; }
     for (auto &d : m->d) { HIPCHK(hipSetDevice(d.device)); HIPCHK(hipEventRecord(d.ev, d.s)); }
     for (size_t j = 0; j < D; j++) {
         HIPCHK(hipSetDevice(m->d[j].device));
         for (size_t i = 0; i < D; i++) {
             if (i == j) continue;
             HIPCHK(hipStreamWaitEvent(m->d[j].s, m->d[i].ev, 0));
-            if (m->d[i].device == m->d[j].device) HIPCHK(hipMemcpyAsync(buf[j] + i * bytes_each, buf[i] + i * bytes_each, bytes_each, hipMemcpyDeviceToDevice, m->d[j].s));
-            else HIPCHK(hipMemcpyPeerAsync(buf[j] + i * bytes_each, m->d[j].device, buf[i] + i * bytes_each, m->d[i].device, bytes_each, m->d[j].s));
+            if (m->d[i].device == m->d[j].device) HIPCHK(hipMemcpyAsync(buf[j].p + i * bytes_each, buf[i].p + i * bytes_each, bytes_each, hipMemcpyDeviceToDevice, m->d[j].s));
+            else HIPCHK(hipMemcpyPeerAsync(buf[j].p + i * bytes_each, m->d[j].device, buf[i].p + i * bytes_each, m->d[i].device, bytes_each, m->d[j].s));
         }
     }
-    return cross_barrier(m);   // a source buffer may be released (stream-ordered, on its own stream) only after every reader is done
+    if (m->fault & FAULT_PEER_CORRUPT) { HIPCHK(hipSetDevice(m->d[D - 1].device)); HIPCHK(hipMemsetAsync(buf[D - 1].p, 0x5a, 1, m->d[D - 1].s)); }
+    return cross_barrier(m);   // a source buffer may be reused only after every reader is done
+}
+inline int all_gather_bytes(kzg_hip_multi *m, const std::vector<xbuf> &buf, size_t bytes_each) { return all_gather_bytes(m, buf, bytes_each, m->tkind); }
+
+// One exchange with known contents on transport `kind`: entry i fills its slice with bytes that depend on (i, offset), one all_gather_bytes,
+// every entry's whole buffer is read back and compared on the host.  KZG_HIP_OK and *why empty when every byte arrived everywhere.
+int transport_probe(kzg_hip_multi *m, int kind, std::string *why) {
+    const size_t D = m->d.size(), each = 4096 + 144;            // not a power of two: a slice boundary inside a cache line
+    std::vector<xbuf> buf(D);
+    std::vector<uint8_t> pat(D * each), got(D * each);
+    for (size_t i = 0; i < D; i++) for (size_t b = 0; b < each; b++) pat[i * each + b] = (uint8_t)(0x31 * (i + 1) + 7 * b + (b >> 8));
+    auto fail = [&](int st) { *why = g_last_error; for (auto &d : m->d) { (void)hipSetDevice(d.device); (void)hipStreamSynchronize(d.s); } (void)hipGetLastError(); return st; };
+    for (size_t i = 0; i < D; i++) {
+        multi_dev &d = m->d[i];
+        int st = d.arena.reserve(D * each + 256); if (st) return fail(st);
+        st = d.arena.take(D * each, &buf[i]); if (st) return fail(st);
+        if (hipSetDevice(d.device) != hipSuccess || hipMemsetAsync(buf[i].p, 0, D * each, d.s) != hipSuccess ||
+            hipMemcpyAsync(buf[i].p + i * each, pat.data() + i * each, each, hipMemcpyHostToDevice, d.s) != hipSuccess) { g_last_error = "self-test: could not fill the pattern"; return fail(KZG_HIP_ERR_HIP); }
+    }
+    int st = all_gather_bytes(m, buf, each, kind);
+    if (st) return fail(st);
+    for (size_t i = 0; i < D; i++) {
+        multi_dev &d = m->d[i];
+        if (hipSetDevice(d.device) != hipSuccess || hipMemcpyAsync(got.data(), buf[i].p, D * each, hipMemcpyDeviceToHost, d.s) != hipSuccess ||
+            hipStreamSynchronize(d.s) != hipSuccess) { g_last_error = std::string("self-test: read-back failed: ") + hipGetErrorString(hipGetLastError()); return fail(KZG_HIP_ERR_HIP); }
+        if (got != pat) {
+            size_t at = 0; while (got[at] == pat[at]) at++;
+            char t[160]; snprintf(t, sizeof t, "self-test: entry %zu holds wrong bytes after the all-gather (first at slice %zu, offset %zu)", i, at / each, at % each);
+            g_last_error = t;
+            return fail(KZG_HIP_ERR_HIP);
+        }
+    }
+    for (auto &d : m->d) { (void)hipSetDevice(d.device); (void)hipStreamSynchronize(d.s); }
+    why->clear();
+    return KZG_HIP_OK;
+}
+
+const char *transport_name(int k) { return k == T_RCCL ? "rccl" : k == T_PEER ? "peer-copy" : "host-staged"; }
+
+// Creation-time proof of the exchange: probes the preferred transport and steps down (rccl -> peer-copy -> host-staged) until one delivers.
+int transport_self_test(kzg_hip_multi *m) {
+    std::lock_guard<std::mutex> lk(m->mu);
+    for (int kind = m->tkind; kind <= T_HOST; kind++) {
+        if (kind == T_RCCL && !m->nccl) continue;
+        std::string why;
+        int st = transport_probe(m, kind, &why);
+        if (st == KZG_HIP_OK) {
+            m->tkind = kind; m->transport = transport_name(kind);
+            char t[160]; snprintf(t, sizeof t, "ok: %s, %zu entries, %d B per slice, every byte verified on every entry", transport_name(kind), m->d.size(), 4096 + 144);
+            m->self_test = t;
+            return KZG_HIP_OK;
+        }
+        if (!m->transport_note.empty()) m->transport_note += "; ";
+        m->transport_note += std::string(transport_name(kind)) + " failed its self-test (" + why + ")";
+        if (kind == T_RCCL) {   // a communicator that failed once is not used again
+            for (ncclComm_t c : m->comms) if (c) (void)m->nccl->CommDestroy(c);
+            m->comms.clear(); m->nccl = nullptr;
+        }
+    }
+    m->self_test = "failed: no transport delivered";
+    g_last_error = "multi-device exchange: " + m->transport_note;
+    return KZG_HIP_ERR_HIP;
+}
+
+// peer access between every distinct pair of listed devices (both directions); what could not be granted goes into the note and the
+// exchange then runs host-staged at worst (the self-test decides)
+void enable_peer_access(kzg_hip_multi *m) {
+    std::vector<int> devs;
+    for (auto &d : m->d) if (std::find(devs.begin(), devs.end(), d.device) == devs.end()) devs.push_back(d.device);
+    for (int a : devs) for (int b : devs) {
+        if (a == b) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+        hipError_t e = hipErrorPeerAccessUnsupported;
+        if (can && hipSetDevice(a) == hipSuccess) e = hipDeviceEnablePeerAccess(b, 0);
+        if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); e = hipSuccess; }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            if (!m->transport_note.empty()) m->transport_note += "; ";
+            m->transport_note += "no peer access " + std::to_string(a) + " -> " + std::to_string(b) + " (" + hipGetErrorString(e) + ")";
+        }
+    }
 }
 
 // x[a] = src[D a + r], a < count: the residue class r of a sequence (decimation in time by D)
@@ -198,17 +377,18 @@ __global__ void k_multi_combine_operands(const g1j *Y, const fr *roots, uint64_t
 int sharded_g1_fft(kzg_hip_multi *m, std::vector<mtmp> &tmp, const std::vector<const g1j *> &x, uint64_t n_valid, uint64_t N, int inv, uint64_t n_out,
                    const std::vector<g1j *> &out) {
     const uint64_t D = m->d.size(), M = N / D, cnt = n_out / D;
-    std::vector<uint8_t *> ybuf(D);
+    std::vector<xbuf> ybuf(D);
     for (uint64_t r = 0; r < D; r++) {
         multi_dev &d = m->d[r];
-        g1j *xr = nullptr, *Y = nullptr;
+        g1j *xr = nullptr;
         const uint64_t valid_r = n_valid > r ? (n_valid - r + D - 1) / D : 0;   // elements D a + r below n_valid
-        CHK(tmp[r].alloc(&xr, std::max<uint64_t>(valid_r, 1))); CHK(tmp[r].alloc(&Y, N));
+        CHK(tmp[r].alloc(&xr, std::max<uint64_t>(valid_r, 1)));
+        CHK(d.arena.take(N * sizeof(g1j), &ybuf[r]));                           // exchanged: arena memory
+        g1j *Y = (g1j *)ybuf[r].p;
         HIPCHK(hipSetDevice(d.device));
         if (valid_r) hipLaunchKernelGGL(k_multi_gather_stride, dim3((uint32_t)((valid_r + 255) / 256)), dim3(256), 0, d.s, x[r], D, r, valid_r, xr);
         CHK(g1_fft_rows(d.fs, d.s, xr, valid_r, valid_r, Y + r * M, M, 1, inv));
         HIPCHK(hipGetLastError());
-        ybuf[r] = (uint8_t *)Y;
     }
     CHK(all_gather_bytes(m, ybuf, M * sizeof(g1j)));
     for (uint64_t r = 0; r < D; r++) {
@@ -217,7 +397,7 @@ int sharded_g1_fft(kzg_hip_multi *m, std::vector<mtmp> &tmp, const std::vector<c
         CHK(tmp[r].alloc(&pts, D * cnt)); CHK(tmp[r].alloc(&prod, D * cnt)); CHK(tmp[r].alloc(&sc, D * cnt));
         HIPCHK(hipSetDevice(d.device));
         const fr *roots = inv ? d.fs->d_reversed : d.fs->d_expanded;
-        hipLaunchKernelGGL(k_multi_combine_operands, dim3((uint32_t)((D * cnt + 255) / 256)), dim3(256), 0, d.s, (const g1j *)ybuf[r], roots, d.fs->W / N, N, M, D, r * cnt, cnt, pts, sc);
+        hipLaunchKernelGGL(k_multi_combine_operands, dim3((uint32_t)((D * cnt + 255) / 256)), dim3(256), 0, d.s, (const g1j *)ybuf[r].p, roots, d.fs->W / N, N, M, D, r * cnt, cnt, pts, sc);
         HIPCHK(hipMemcpyAsync(prod, pts, cnt * sizeof(g1j), hipMemcpyDeviceToDevice, d.s));           // the term of class 0 has twiddle one
         launch_g1_mul_vec(d.s, pts + cnt, (D - 1) * cnt, sc + cnt, 1, (D - 1) * cnt, prod + cnt);
         launch_g1_sum_files(d.s, prod, D, cnt, 1, out[r] + r * cnt);
@@ -241,31 +421,35 @@ int fk20_da_sharded(kzg_hip_multi *m, const std::vector<fk20_core *> &core, cons
     std::vector<mtmp> tmp; tmp.reserve(D);
     for (auto &d : m->d) tmp.emplace_back(d.device, d.s);
     drain_all drain(m);                                          // declared after tmp: streams drain before the temporaries go
-    std::vector<uint8_t *> hext(D);
+    // everything that crosses devices: hExtFFT (D cnt), two sub-transform files (2k each), h (k), the normalised proofs (2k) -- + alignment slack
+    const size_t arena_need = (D * cnt + 2 * k2 + k + k2) * sizeof(g1j) + 8 * 256;
+    for (auto &d : m->d) CHK(d.arena.reserve(arena_need));       // the previous sharded call drained every stream: the arena is idle
+    std::vector<xbuf> hext(D);
     // (1) Toeplitz stage, sharded by output position; every device needs the coefficients (n x 32 B)
     for (uint64_t i = 0; i < D; i++) {
         multi_dev &d = m->d[i];
-        fr *d_poly = nullptr; g1j *d_hext = nullptr;
-        CHK(tmp[i].alloc(&d_poly, n)); CHK(tmp[i].alloc(&d_hext, D * cnt));
+        fr *d_poly = nullptr;
+        CHK(tmp[i].alloc(&d_poly, n));
+        CHK(d.arena.take(D * cnt * sizeof(g1j), &hext[i]));
+        g1j *d_hext = (g1j *)hext[i].p;
         HIPCHK(hipSetDevice(d.device));
         HIPCHK(hipMemcpyAsync(d_poly, poly_fr, n * sizeof(fr), hipMemcpyHostToDevice, d.s));
         const uint64_t j0 = std::min(i * cnt, k2), j1 = std::min(j0 + cnt, k2);
         if (j1 > j0) CHK(fk20_hext(core[i], d.s, d_poly, n, n, 1, j0, j1 - j0, d_hext + j0));
-        hext[i] = (uint8_t *)d_hext;
     }
     CHK(all_gather_bytes(m, hext, cnt * sizeof(g1j)));           // all-gather #1: hExtFFT
     const bool pow2_devs = (D & (D - 1)) == 0;
     g1j *d_res = nullptr;                                        // the 2k proofs, reverse-bit order, Kilic images, on device 0
     if (D > 1 && pow2_devs && k2 >= 8 * D && sharded_fft_default(m)) {
         // (2) h = IFFT_G1(hExtFFT)[:k] (1 / 2k is folded into the Toeplitz coefficients): sub-transforms, all-gather #2, combine, all-gather #3
-        std::vector<const g1j *> x(D); std::vector<g1j *> hbuf(D); std::vector<uint8_t *> hb(D);
-        for (uint64_t i = 0; i < D; i++) { x[i] = (const g1j *)hext[i]; CHK(tmp[i].alloc(&hbuf[i], k)); hb[i] = (uint8_t *)hbuf[i]; }
+        std::vector<const g1j *> x(D); std::vector<g1j *> hbuf(D); std::vector<xbuf> hb(D);
+        for (uint64_t i = 0; i < D; i++) { x[i] = (const g1j *)hext[i].p; CHK(m->d[i].arena.take(k * sizeof(g1j), &hb[i])); hbuf[i] = (g1j *)hb[i].p; }
         CHK(sharded_g1_fft(m, tmp, x, k2, k2, 1, k, hbuf));
         CHK(all_gather_bytes(m, hb, (k / D) * sizeof(g1j)));
         // (3) proofs = FFT_G1(h || inf^k): sub-transforms on the k / D valid entries of each class, all-gather #4, combine,
         //     normalise the own slice, all-gather #5 of the proof points
-        std::vector<g1j *> pbuf(D), nbuf(D); std::vector<uint8_t *> nb(D);
-        for (uint64_t i = 0; i < D; i++) { x[i] = hbuf[i]; CHK(tmp[i].alloc(&pbuf[i], k2)); CHK(tmp[i].alloc(&nbuf[i], k2)); nb[i] = (uint8_t *)nbuf[i]; }
+        std::vector<g1j *> pbuf(D), nbuf(D); std::vector<xbuf> nb(D);
+        for (uint64_t i = 0; i < D; i++) { x[i] = hbuf[i]; CHK(tmp[i].alloc(&pbuf[i], k2)); CHK(m->d[i].arena.take(k2 * sizeof(g1j), &nb[i])); nbuf[i] = (g1j *)nb[i].p; }
         CHK(sharded_g1_fft(m, tmp, x, k, k2, 0, k2, pbuf));
         const uint64_t M = k2 / D;
         for (uint64_t i = 0; i < D; i++) {
@@ -281,7 +465,7 @@ int fk20_da_sharded(kzg_hip_multi *m, const std::vector<fk20_core *> &core, cons
     } else {
         CHK(tmp[0].alloc(&d_res, k2));
         HIPCHK(hipSetDevice(m->d[0].device));
-        CHK(fk20_finish(core[0], m->d[0].s, (const g1j *)hext[0], 1, 1, 1, d_res));
+        CHK(fk20_finish(core[0], m->d[0].s, (const g1j *)hext[0].p, 1, 1, 1, d_res));
     }
     HIPCHK(hipSetDevice(m->d[0].device));
     HIPCHK(hipMemcpyAsync(out_g1, d_res, k2 * sizeof(g1j), hipMemcpyDeviceToHost, m->d[0].s));
@@ -298,13 +482,35 @@ int kzg_hip_multi_settings_new(const int *devices, uint32_t n_devices, unsigned 
     if (!out) return KZG_HIP_ERR_BAD_ARG;
     *out = nullptr;
     if (!devices || !n_devices || n_devices > 64 || !secret_g1) return KZG_HIP_ERR_BAD_ARG;
-    const int visible = kzg_hip_device_count();
-    if (visible < 1) return KZG_HIP_ERR_NO_DEVICE;
-    for (uint32_t i = 0; i < n_devices; i++) if (devices[i] < 0 || devices[i] >= visible) return KZG_HIP_ERR_NO_DEVICE;
+    if (kzg_hip_device_count() < 1) return KZG_HIP_ERR_NO_DEVICE;
+    // ordinals are bounded by what the runtime enumerates (a mixed node may have a gfx950 device at ordinal 1 behind another architecture at
+    // ordinal 0); kzg_hip_fft_settings_new rejects a device that is not gfx950
+    int ordinals = 0;
+    if (hipGetDeviceCount(&ordinals) != hipSuccess) { (void)hipGetLastError(); return KZG_HIP_ERR_NO_DEVICE; }
+    for (uint32_t i = 0; i < n_devices; i++) if (devices[i] < 0 || devices[i] >= ordinals) return KZG_HIP_ERR_NO_DEVICE;
     KZG_TRY
     kzg_hip_multi *m = new kzg_hip_multi;
     m->d.resize(n_devices);
-    for (uint32_t i = 0; i < n_devices; i++) m->d[i].device = devices[i];
+    for (uint32_t i = 0; i < n_devices; i++) { m->d[i].device = devices[i]; m->d[i].arena.device = devices[i]; }
+    if (const char *f = getenv("KZG_HIP_MULTI_FAULT")) {   // tests: make a leg of the exchange fail so that the fall-backs run on one GPU
+        std::string fs(f);
+        auto has = [&](const char *w) { size_t at = 0; const size_t n = strlen(w); while ((at = fs.find(w, at)) != std::string::npos) { const size_t e = at + n; if ((at == 0 || fs[at - 1] == ',') && (e == fs.size() || fs[e] == ',')) return true; at = e; } return false; };
+        if (has("rccl")) m->fault |= FAULT_RCCL;
+        if (has("rccl-corrupt")) m->fault |= FAULT_RCCL_CORRUPT;
+        if (has("peer")) m->fault |= FAULT_PEER;
+        if (has("peer-corrupt")) m->fault |= FAULT_PEER_CORRUPT;
+    }
+    try {   // one host thread per further entry, for the lifetime of the handle; a thread that cannot be started fails the constructor cleanly
+        for (uint32_t i = 1; i < n_devices; i++) {
+            m->workers.emplace_back(new dev_worker);
+            dev_worker *w = m->workers.back().get();
+            w->th = std::thread([w] { w->loop(); });
+        }
+    } catch (const std::exception &e) {
+        g_last_error = std::string("multi-device handle: worker thread: ") + e.what();
+        kzg_hip_multi_settings_free(m);
+        return KZG_HIP_ERR_HIP;
+    }
     int st = per_device(m, [&](size_t i) -> int {
         multi_dev &d = m->d[i];
         CHK(kzg_hip_fft_settings_new(d.device, max_scale, &d.fs));
@@ -314,13 +520,15 @@ int kzg_hip_multi_settings_new(const int *devices, uint32_t n_devices, unsigned 
         HIPCHK(hipEventCreateWithFlags(&d.ev, hipEventDisableTiming));
         return KZG_HIP_OK;
     });
-    if (st) { kzg_hip_multi_settings_free(m); return st; }
+    if (st) { std::string keep = g_last_error; kzg_hip_multi_settings_free(m); g_last_error = keep; return st; }
     // exchange transport: RCCL when every device is listed once (KZG_HIP_MULTI_TRANSPORT=rccl also for a single device: the binding's own test;
-    // =peer never binds RCCL)
+    // =peer never binds RCCL, =host goes straight to the host-staged exchange)
     bool distinct = true;
     for (uint32_t i = 0; i < n_devices; i++) for (uint32_t j = 0; j < i; j++) if (devices[i] == devices[j]) distinct = false;
+    enable_peer_access(m);
     const char *force = getenv("KZG_HIP_MULTI_TRANSPORT");
     const bool want_rccl = force ? !strcmp(force, "rccl") && distinct : (distinct && n_devices >= 2);
+    if (force && !strcmp(force, "host")) m->tkind = T_HOST;
     if (want_rccl) {
         std::string why;
         rccl_api *api = rccl_bind(&why);
@@ -329,23 +537,31 @@ int kzg_hip_multi_settings_new(const int *devices, uint32_t n_devices, unsigned 
             m->comms.assign(n_devices, nullptr);
             ncclResult_t r = api->CommInitAll(m->comms.data(), (int)n_devices, devices);
             if (r != ncclSuccess) { m->transport_note = std::string("ncclCommInitAll: ") + api->GetErrorString(r); m->comms.clear(); }
-            else { m->nccl = api; m->transport = "rccl"; }
+            else { m->nccl = api; m->tkind = T_RCCL; }
         }
     } else if (!distinct) m->transport_note = "the device list repeats a device";
+    m->transport = transport_name(m->tkind);
+    // the handle proves its exchange before anyone relies on it: pattern -> all-gather -> verify on every entry; steps down on failure
+    st = transport_self_test(m);
+    m->n_allgather = 0;                      // kzg_hip_multi_exchanges counts the callers' exchanges
+    if (st) { std::string keep = g_last_error; kzg_hip_multi_settings_free(m); g_last_error = keep; return st; }
     *out = m;
     return KZG_HIP_OK;
     KZG_CATCH
 }
 void kzg_hip_multi_settings_free(kzg_hip_multi *m) {
     if (!m) return;
+    for (auto &w : m->workers) w->shutdown();
     if (m->nccl) for (ncclComm_t c : m->comms) if (c) (void)m->nccl->CommDestroy(c);
     for (auto &d : m->d) {
         (void)hipSetDevice(d.device);
         if (d.s) { (void)hipStreamSynchronize(d.s); (void)hipStreamDestroy(d.s); }
         if (d.ev) (void)hipEventDestroy(d.ev);
+        d.arena.release();
         if (d.ks) kzg_hip_kzg_settings_free(d.ks);
         if (d.fs) kzg_hip_fft_settings_free(d.fs);
     }
+    if (m->h_stage) (void)hipHostFree(m->h_stage);
     (void)hipGetLastError();
     delete m;
 }
@@ -355,6 +571,7 @@ kzg_hip_fft *kzg_hip_multi_fft(kzg_hip_multi *m, uint32_t i) { return (m && i < 
 kzg_hip_kzg *kzg_hip_multi_kzg(kzg_hip_multi *m, uint32_t i) { return (m && i < m->d.size()) ? m->d[i].ks : nullptr; }
 const char *kzg_hip_multi_transport(const kzg_hip_multi *m) { return m ? m->transport.c_str() : ""; }
 const char *kzg_hip_multi_transport_note(const kzg_hip_multi *m) { return m ? m->transport_note.c_str() : ""; }
+const char *kzg_hip_multi_transport_check(const kzg_hip_multi *m) { return m ? m->self_test.c_str() : ""; }
 uint64_t kzg_hip_multi_exchanges(const kzg_hip_multi *m) { return m ? m->n_allgather.load() : 0; }
 int kzg_hip_multi_set_fft_sharding(kzg_hip_multi *m, int mode) {
     if (!m || mode < -1 || mode > 1) return KZG_HIP_ERR_BAD_ARG;

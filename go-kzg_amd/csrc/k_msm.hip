@@ -16,6 +16,7 @@
 #include "internal.hpp"
 #include "g1_quad.hpp"
 #include <atomic>
+#include <cstring>
 
 namespace kzg {
 
@@ -587,7 +588,8 @@ void launch_msm(hipStream_t s, const msm_plan &p, const g1a *table, const fr *sc
         hipLaunchKernelGGL(k_msm_accumulate, dim3((uint32_t)((total + MSM_ACC_BLOCK - 1) / MSM_ACC_BLOCK)), dim3(MSM_ACC_BLOCK), 0, s, table, ws, L.per_blob,
                            L.entries_off, L.offsets_off, L.buckets_off, K, S, total);
     prof_end(s, "msm_accumulate");
-    if (balanced && batch * p.ngroups * 32 >= device_simd_lanes()) {   // (256 MSMs on a cached set: 37.7 k -> 40.7 k MSM/s, 512: 40.4 k -> 43.4 k; 64 MSMs are faster on the scan: 29.3 k vs 27.6 k)
+    static const int reduce_mode = [] { const char *e = getenv("KZG_HIP_MSM_REDUCE"); return !e ? -1 : !strcmp(e, "chunks") ? 1 : !strcmp(e, "scan") ? 0 : -1; }();   // tests / A/B runs: force a form at any batch size
+    if (reduce_mode == 1 || (reduce_mode < 0 && balanced && batch * p.ngroups * 32 >= device_simd_lanes())) {   // (256 MSMs on a cached set: 37.7 k -> 40.7 k MSM/s, 512: 40.4 k -> 43.4 k; 64 MSMs are faster on the scan: 29.3 k vs 27.6 k)
         const uint64_t tg = batch * p.ngroups;
         hipLaunchKernelGGL(k_msm_reduce_chunks, dim3((uint32_t)((tg + 3) / 4)), dim3(MSM_NB), 0, s, ws, L.per_blob, L.buckets_off, L.gsum_off, p.ngroups, tg);
     } else

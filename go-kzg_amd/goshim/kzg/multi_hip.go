@@ -53,8 +53,9 @@ func (m *MultiKZGSettings) Close() {
 	}
 }
 
-// Transport reports how one-polynomial calls exchange their slices: "rccl" (ncclAllGather between distinct devices) or "peer-copy"
-// (hipMemcpyPeerAsync: the list repeats a device, or librccl could not be bound -- TransportNote says which).
+// Transport reports how one-polynomial calls exchange their slices: "rccl" (ncclAllGather between distinct devices), "peer-copy"
+// (hipMemcpyPeerAsync: the list repeats a device, or librccl could not be bound) or "host-staged" (through pinned host memory: the
+// other two failed the exchange test the constructor runs) -- TransportNote says which and why.
 func (m *MultiKZGSettings) Transport() string {
 	defer runtime.KeepAlive(m)
 	return C.GoString(C.kzg_hip_multi_transport(m.h))
@@ -62,6 +63,13 @@ func (m *MultiKZGSettings) Transport() string {
 func (m *MultiKZGSettings) TransportNote() string {
 	defer runtime.KeepAlive(m)
 	return C.GoString(C.kzg_hip_multi_transport_note(m.h))
+}
+
+// TransportSelfTest is the outcome of the exchange the constructor ran before returning (every device writes a pattern, one all-gather,
+// every device verifies every byte): "ok: <transport>, ...".
+func (m *MultiKZGSettings) TransportSelfTest() string {
+	defer runtime.KeepAlive(m)
+	return C.GoString(C.kzg_hip_multi_transport_check(m.h))
 }
 
 // SetFFTSharding: 0 = one all-gather of the hExtFFT slices, both G1 transforms on the first device; 1 = both transforms sharded by

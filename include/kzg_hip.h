@@ -257,8 +257,13 @@ int kzg_hip_recover_poly_from_samples(kzg_hip_fft *fs, const void *samples_fr, c
  *     the five all-gathers of SURVEY.md 8e; default from 4 devices on, kzg_hip_multi_set_fft_sharding / KZG_HIP_MULTI_FFT=gather|sharded).
  * Exchange transport (kzg_hip_multi_transport): "rccl" = ncclAllGather on ncclUint8 over single-process communicators (ncclCommInitAll;
  * RCCL over xGMI), used when every listed device is distinct; "peer-copy" = hipMemcpyPeerAsync between the devices' streams, used when the
- * list repeats a device or librccl cannot be bound (kzg_hip_multi_transport_note says why).  Results are identical either way and
- * identical to the single-device calls (tests/test_multi_device.py). */
+ * list repeats a device or librccl cannot be bound; "host-staged" = device -> pinned host -> device, the last resort
+ * (kzg_hip_multi_transport_note says why a transport was not used).  Every buffer another device reads or writes is hipMalloc memory of a
+ * per-entry exchange arena (never the stream-ordered pool), peer access is enabled between all listed devices, and the constructor PROVES
+ * the transport before returning: every entry writes a pattern, one all-gather, every entry verifies every byte
+ * (kzg_hip_multi_transport_check); a transport that errs or delivers wrong bytes is replaced by the next one in the order above, and the
+ * constructor fails with KZG_HIP_ERR_HIP only if none delivers.  Results are identical whatever the transport and identical to the
+ * single-device calls (tests/test_multi_device.py). */
 typedef struct kzg_hip_multi kzg_hip_multi;
 typedef struct kzg_hip_multi_fk20s kzg_hip_multi_fk20s;
 typedef struct kzg_hip_multi_fk20m kzg_hip_multi_fk20m;
@@ -268,8 +273,9 @@ uint32_t kzg_hip_multi_device_count(const kzg_hip_multi *m);
 int kzg_hip_multi_device(const kzg_hip_multi *m, uint32_t i);          /* device ordinal of entry i (-1 out of range) */
 kzg_hip_fft *kzg_hip_multi_fft(kzg_hip_multi *m, uint32_t i);          /* entry i's settings, BORROWED (owned by the multi handle): */
 kzg_hip_kzg *kzg_hip_multi_kzg(kzg_hip_multi *m, uint32_t i);          /* any single-device call can be made on a chosen device     */
-const char *kzg_hip_multi_transport(const kzg_hip_multi *m);           /* "rccl" or "peer-copy" */
+const char *kzg_hip_multi_transport(const kzg_hip_multi *m);           /* "rccl", "peer-copy" or "host-staged" */
 const char *kzg_hip_multi_transport_note(const kzg_hip_multi *m);      /* why the transport is not "rccl" ("" otherwise) */
+const char *kzg_hip_multi_transport_check(const kzg_hip_multi *m); /* outcome of the creation-time exchange test: "ok: <transport>, ..." */
 uint64_t kzg_hip_multi_exchanges(const kzg_hip_multi *m);              /* all-gathers performed on this handle so far */
 int kzg_hip_multi_set_fft_sharding(kzg_hip_multi *m, int mode);        /* 0 gather, 1 sharded transforms, -1 default policy */
 int kzg_hip_multi_set_table_budget_gb(kzg_hip_multi *m, double gb);    /* kzg_hip_kzg_set_table_budget_gb on every entry */

@@ -213,7 +213,8 @@ class MultiKZGSettings {
     MultiKZGSettings(const MultiKZGSettings &) = delete;
     MultiKZGSettings &operator=(const MultiKZGSettings &) = delete;
     kzg_hip_multi *handle() const { return h_; }
-    std::string Transport() const { return kzg_hip_multi_transport(h_); }           // "rccl" or "peer-copy"
+    std::string Transport() const { return kzg_hip_multi_transport(h_); }           // "rccl", "peer-copy" or "host-staged"
+    std::string TransportSelfTest() const { return kzg_hip_multi_transport_check(h_); }   // "ok: <transport>, ..." -- the exchange test the constructor ran
     uint64_t Exchanges() const { return kzg_hip_multi_exchanges(h_); }
     void SetFFTSharding(int mode) const { detail::must(kzg_hip_multi_set_fft_sharding(h_, mode)); }   // 0 gather, 1 sharded transforms, -1 default
     void SetTableBudgetGB(double gb) const { detail::must(kzg_hip_multi_set_table_budget_gb(h_, gb)); }

@@ -172,6 +172,7 @@ int main(void) {
         expect_status(kzg_hip_multi_settings_new(devs, 2, 5, setup, 33, &m), KZG_HIP_OK, "NewMultiKZGSettings({0, 0}, scale 5)");
         check(kzg_hip_multi_device_count(m) == 2 && kzg_hip_multi_device(m, 1) == 0, "two entries, both on device 0");
         check(strcmp(kzg_hip_multi_transport(m), "peer-copy") == 0, "a repeated device exchanges by peer copies (RCCL needs distinct devices)");
+        check(strncmp(kzg_hip_multi_transport_check(m), "ok: peer-copy, 2 entries", 24) == 0, "the constructor proved the exchange (pattern, all-gather, verify)");
         memcpy(two_polys, poly, 16 * FR);
         memcpy(two_polys + 16 * FR, poly, 16 * FR);
         expect_status(kzg_hip_multi_commit_to_poly_batch(m, two_polys, 16, 2, two_out), KZG_HIP_OK, "multi CommitToPoly x 2");

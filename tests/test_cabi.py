@@ -59,6 +59,22 @@ def test_product_does_not_touch_the_oracle():
     assert "oracle" not in open(os.path.join(ROOT, "include", "kzg_hip.h")).read()
 
 
+def test_only_arena_memory_crosses_devices():
+    """capi_multi.hip: what ncclAllGather / a peer copy / the host-staged exchange reads or writes is an `xbuf`, and the only place that makes
+    one is exch_arena::take (hipMalloc memory with peer access granted) -- no hipMallocAsync pointer can reach the exchange"""
+    src = open(os.path.join(ROOT, "go-kzg_amd", "csrc", "capi_multi.hip")).read()
+    code = re.sub(r"//[^\n]*", "", src)
+    assert len(re.findall(r"(?:\.|->)p\s*=[^=]", code)) == 1 and "out->p = base + at" in code            # one producer of xbuf pointers: the arena
+    arena = code[code.index("struct exch_arena"):code.index("struct dev_worker")]
+    assert "hipMalloc((void **)&base" in arena and "hipMallocAsync" not in arena
+    ag = code[code.index("int all_gather_bytes(kzg_hip_multi *m, const std::vector<xbuf> &buf"):code.index("int transport_probe(")]
+    assert "AllGather(buf[i].p + i * bytes_each, buf[i].p," in ag and "hipMemcpyPeerAsync(buf[j].p" in ag
+    for call in re.findall(r"all_gather_bytes\(m, (\w+),", code):                                      # every call site passes a vector of xbuf
+        assert re.search(r"std::vector<xbuf> [^;]*\b%s\b" % call, code), call
+    assert "hipDeviceEnablePeerAccess" in code and "transport_self_test(m)" in code
+    assert "std::thread" not in code[code.index("template <class F> int per_device"):code.index("struct mtmp")]   # no thread creation per call
+
+
 def test_transcript_sha256_matches_hashlib_on_both_code_paths():
     """the SHA-256 behind eth.ComputeAggregateKZGProof's Fiat-Shamir transcript (go-kzg_amd/csrc/sha256.cpp): x86 SHA extensions where the CPU
     has them and the portable loop (forced with KZG_HIP_SHA256=portable in a child process), every length around the padding boundaries"""

@@ -482,21 +482,16 @@ def test_lincomb_edge_scalars_and_cached_points(kz, fs16, setup_1337):
     lag_set.close(); fs12.close()
 
 
-def test_bucket_pipeline_balanced_accumulate(kz, setup_1337):
-    """Batches that fill the GPU walk the sorted entries in segments of 64 (k_msm_accumulate_seg + k_msm_merge_segs; phi applied once per bucket
-    half): 80 linear combinations over 4096 caller-type points on the bucket pipeline (table budget 0) against the fixed-base walk of the same
-    points, with rows built to stress the segment logic -- one scalar for every point (a window's entries all fall into ONE bucket that spans 64
-    segments), a scalar whose halves have a single non-zero window, the zero row, a row of ones (only the plain half, only window 0), r - 1 (negated
-    halves), rows that stop short (ragged lengths through the coalesced one-row calls are covered elsewhere) -- plus oracle rows"""
-    fs = kz.FFTSettings(12)
+def _bucket_edge_case(setup_1337, B, seed=64):
+    """caller-type points with an infinity, P == Q and P == -Q among them, and B scalar rows built to stress the segment / chunk logic of the bucket
+    pipeline: one scalar for every point (a window's entries all fall into ONE bucket), halves with a single non-zero window, the zero row, ones,
+    r - 1 (negated halves), a short list (most buckets of a 4-bucket chunk empty: S_c == T_c takes the doubling branch of the merge), every other point"""
     pts = setup_1337.copy()
     pts[17] = ko.g1_zero()[0]                                  # an infinity among the points
     pts[19] = pts[18]                                          # P == Q inside a bucket whenever their digits agree
     pts[21] = ko.g1_sub(ko.g1_zero()[0], pts[20])              # ... and P == -Q
-    cached = kz.G1Points(fs, pts)
-    rng = np.random.default_rng(64)
+    rng = np.random.default_rng(seed)
     r = ko.R_MOD
-    B = 80
     rows = np.stack([rand_fr(rng, 4096) for _ in range(6)])
     rows = np.concatenate([rows] * (B // 6 + 1))[:B].copy()
     same = ko.fr_from_ints([0x1234567890abcdef1234567890abcdef1234567890abcdef1234567890abcdef % r])[0]
@@ -508,6 +503,17 @@ def test_bucket_pipeline_balanced_accumulate(kz, setup_1337):
     rows[8, 100:] = 0                                          # a short list: most segments are empty
     rows[9, :] = ko.fr_from_ints([(LAMBDA << 8) % r])[0]
     rows[10, ::2] = same
+    rows[11, 3:] = 0                                           # three entries per window: lone buckets inside otherwise empty chunks
+    return pts, rows
+
+
+def test_bucket_pipeline_balanced_accumulate(kz, setup_1337):
+    """Batches that fill the GPU walk the sorted entries in segments of 64 (k_msm_accumulate_seg + k_msm_merge_segs; phi applied once per bucket
+    half): 80 linear combinations over 4096 caller-type points on the bucket pipeline (table budget 0) against the fixed-base walk of the same
+    points, with the edge rows of _bucket_edge_case, plus oracle rows"""
+    fs = kz.FFTSettings(12)
+    pts, rows = _bucket_edge_case(setup_1337, 80)
+    cached = kz.G1Points(fs, pts)
     want = cached.lin_comb_batch(rows)                         # the set's own fixed-base table
     cached.set_table_budget_gb(0)
     got = cached.lin_comb_batch(rows)                          # bucket pipeline, 80 x 2048 segments: the balanced form
@@ -519,17 +525,38 @@ def test_bucket_pipeline_balanced_accumulate(kz, setup_1337):
     cached.close(); fs.close()
 
 
+def test_bucket_pipeline_reduce_chunks(kz, setup_1337):
+    """The throughput form of the bucket reduce (k_msm_reduce_chunks: a lane owns 4 buckets, double running sum, suffix scan over 32 lanes) is taken
+    from 256 MSMs on a cached set (8 window groups) and from 128 on the 16-group layout of one-shot points / a settings object without a table:
+    both thresholds crossed here, edge rows included, against the fixed-base walk of the same points (all rows) and the oracle (edge rows)"""
+    fs = kz.FFTSettings(12)
+    pts, rows = _bucket_edge_case(setup_1337, 256, seed=65)
+    cached = kz.G1Points(fs, pts)
+    want = cached.lin_comb_batch(rows)                         # the set's own fixed-base table (k_fb_accumulate)
+    cached.set_table_budget_gb(0)
+    got = cached.lin_comb_batch(rows)                          # 256 x 8 groups x 32 lanes = one round of SIMD lanes: reduce_chunks
+    assert np.array_equal(got, want), np.nonzero((got != want).any(axis=(1, 2)))[0][:8]
+    for b in (1, 3, 4, 5, 6, 7, 8, 9, 10, 11):
+        assert_points_equal(got[b], ko.lincomb_g1(pts, rows[b]))
+    cached.close()
+    ks = kz.KZGSettings(fs, pts)                               # CommitToPoly's no-table fallback: 16 window groups, no 2^64 rows
+    ks.set_table_budget_gb(0)
+    got2 = ks.commit_to_poly_batch(rows[:130])
+    assert np.array_equal(got2, want[:130]), np.nonzero((got2 != want[:130]).any(axis=(1, 2)))[0][:8]
+    ks.close(); fs.close()
+
+
 def test_bucket_pipeline_forms_in_fresh_processes():
     """the balanced accumulate forced at every batch size (KZG_HIP_MSM_SEG=1: lone MSMs on caller-supplied points, ragged lengths, edge scalars) and
     never (=0), through the linear-combination tests"""
     import subprocess
     import sys
-    for mode in ("1", "0"):
-        env = dict(os.environ, KZG_HIP_MSM_SEG=mode)
+    for mode, reduce in (("1", "chunks"), ("0", "scan"), ("1", "scan"), ("0", "chunks")):   # KZG_HIP_MSM_REDUCE forces a reduce form at every batch size, lone MSMs included
+        env = dict(os.environ, KZG_HIP_MSM_SEG=mode, KZG_HIP_MSM_REDUCE=reduce)
         res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k",
-                              "lincomb_matches_oracle or lincomb_edge or empty_lincomb or bucket_pipeline_balanced or commit_to_eval or proof_multi"],
+                              "lincomb_matches_oracle or lincomb_edge or empty_lincomb or bucket_pipeline_balanced or bucket_pipeline_reduce or commit_to_eval or proof_multi"],
                              env=env, capture_output=True, text=True, timeout=1200)
-        assert res.returncode == 0, (mode, res.stdout[-1500:])
+        assert res.returncode == 0, (mode, reduce, res.stdout[-1500:])
 
 
 def test_generate_testing_setup(kz, fs16):

@@ -62,6 +62,7 @@ def test_handle_shape_transport_and_misuse(kz, setup_1337):
     L = kz.lib()
     assert L.kzg_hip_multi_device_count(m.h) == 2 and L.kzg_hip_multi_device(m.h, 1) == 0 and L.kzg_hip_multi_device(m.h, 2) == -1
     assert m.transport == "peer-copy" and "repeats" in m.transport_note          # RCCL refuses two ranks on one device
+    assert m.transport_self_test.startswith("ok: peer-copy, 2 entries") and m.exchanges == 0   # the constructor proved the exchange
     assert L.kzg_hip_multi_kzg(m.h, 0) != L.kzg_hip_multi_kzg(m.h, 1)             # every entry owns its settings
     assert not L.kzg_hip_multi_kzg(m.h, 2)
     m.close()
@@ -112,6 +113,11 @@ def test_pinned_input_is_read_in_place(kz, setup_1337):
         assert np.array_equal(m.commit_to_poly_batch(blobs), want)
         assert np.array_equal(ks.commit_to_poly_batch(blobs[:, :1000].copy()), ks.commit_to_poly_batch(np.ascontiguousarray(blobs[:, :1000])))   # pageable beside it
     assert np.array_equal(ks.commit_to_poly_batch(blobs), want)                     # unregistered again: staged copy
+    with kz.pinned(blobs[:4]):                                                      # only the first rows are pinned: a batch that starts inside the
+        assert np.array_equal(ks.commit_to_poly_batch(blobs), want)                 # range and runs past its end must take the staged copy (in place
+        assert np.array_equal(ks.commit_to_poly_batch(blobs[2:]), want[2:])         # it would fault on the device); a batch inside it is still in place
+        assert np.array_equal(ks.commit_to_poly_batch(blobs[1:4]), want[1:4])
+        assert np.array_equal(m.commit_to_poly_batch(blobs), want)
     L = kz.lib()
     assert L.kzg_hip_host_register(None, 16) == kz.ERR_BAD_ARG and L.kzg_hip_host_unregister(None) == kz.ERR_BAD_ARG
     assert L.kzg_hip_host_unregister(blobs.ctypes.data) == kz.ERR_HIP              # not registered (any more)
@@ -246,3 +252,115 @@ def test_rccl_leg_on_a_single_device_communicator(kz, monkeypatch):
     assert m.exchanges == 1
     assert hashlib.sha256(ko.g1_compress(proofs).tobytes()).hexdigest() == DERIVED["C_da_using_fk20_scale5"]["sha256"]
     fk.close(); m.close()
+
+
+def _vector_C_through(kz, m):
+    """DAUsingFK20 of the reference's test polynomial over the entries of m: the exchange is on the path of every proof"""
+    fk = kz.MultiFK20SingleSettings(m, 32)
+    m.set_fft_sharding("sharded" if len(m.devices) in (2, 4) else "gather")
+    e0 = m.exchanges
+    proofs = fk.da_using_fk20(ko.fr_from_ints(TEST_POLY))
+    assert hashlib.sha256(ko.g1_compress(proofs).tobytes()).hexdigest() == DERIVED["C_da_using_fk20_scale5"]["sha256"]
+    n = m.exchanges - e0
+    fk.close()
+    return n
+
+
+@pytest.mark.parametrize("devices,force,fault,transport,why", [
+    ([0, 0], None, "peer", "host-staged", "peer-copy failed its self-test (peer copy failed: injected fault"),
+    ([0, 0], None, "peer-corrupt", "host-staged", "holds wrong bytes after the all-gather (first at slice 0, offset 0)"),
+    ([0, 0, 0, 0], "host", None, "host-staged", "repeats"),
+    ([0], "rccl", "rccl", "peer-copy", "rccl failed its self-test (ncclAllGather failed: injected fault"),
+    ([0], "rccl", "rccl-corrupt", "peer-copy", "rccl failed its self-test (self-test: entry 0 holds wrong bytes"),
+    ([0], "rccl", "rccl,peer", "host-staged", "peer-copy failed its self-test"),
+])
+def test_transport_self_test_steps_down_on_an_injected_fault(kz, monkeypatch, devices, force, fault, transport, why):
+    """kzg_hip_multi_settings_new proves its exchange before returning (pattern -> all-gather -> every byte verified on every entry) and replaces
+    a transport that errs or delivers wrong bytes: rccl -> peer-copy -> host-staged.  KZG_HIP_MULTI_FAULT makes the named leg fail on the one
+    GPU of a test box; the reason lands in transport_note and the proofs that then travel over the fall-back are still vector C."""
+    monkeypatch.setenv("KZG_HIP_FK20_FB_BUDGET_GB", "4")
+    if force:
+        monkeypatch.setenv("KZG_HIP_MULTI_TRANSPORT", force)
+    if fault:
+        monkeypatch.setenv("KZG_HIP_MULTI_FAULT", fault)
+    m = kz.MultiKZGSettings(devices, 5, ko.generate_testing_setup_g1(S_TEST, 33))
+    assert m.transport == transport, (m.transport, m.transport_note)
+    assert why in m.transport_note, m.transport_note
+    assert m.transport_self_test.startswith("ok: %s, %d entries" % (transport, len(devices))), m.transport_self_test
+    n = _vector_C_through(kz, m)
+    assert n == (0 if len(devices) == 1 else 5)          # one entry without RCCL: the single-device call, nothing to exchange
+    m.close()
+
+
+def test_forced_host_staged_and_out_of_range_ordinal(kz, monkeypatch):
+    """host-staged as the FIRST choice (KZG_HIP_MULTI_TRANSPORT=host) never touches the broken peer leg; ordinals are bounded by what the runtime
+    enumerates (hipGetDeviceCount), not by the number of gfx950 devices"""
+    monkeypatch.setenv("KZG_HIP_MULTI_FAULT", "peer")
+    monkeypatch.setenv("KZG_HIP_MULTI_TRANSPORT", "host")
+    m = kz.MultiKZGSettings([0, 0], 5, ko.generate_testing_setup_g1(S_TEST, 33))
+    assert m.transport == "host-staged" and m.transport_self_test.startswith("ok: host-staged")
+    m.close()
+    n_ord = kz.lib().kzg_hip_device_count()
+    with pytest.raises(kz.NoDeviceError):
+        kz.MultiKZGSettings([0, n_ord + 7], 5, ko.generate_testing_setup_g1(S_TEST, 33))
+
+
+def test_batch_calls_from_many_threads_share_the_workers(kz, setup_1337):
+    """the per-entry worker threads of a handle serve concurrent batch calls from several host threads (one queue per entry): every caller gets
+    its own rows back, equal to the single-device results"""
+    import threading
+    m = kz.MultiKZGSettings([0, 0, 0], 12, setup_1337)
+    m.set_table_budget_gb(10)
+    ks = m.kzg_settings(0)
+    rng = np.random.default_rng(5)
+    blobs = [np.stack([rand_fr(rng, 4096) for _ in range(3 + t)]) for t in range(6)]
+    want = [ks.commit_to_poly_batch(b) for b in blobs]
+    got, errs = [None] * 6, []
+
+    def run(t):
+        try:
+            for _ in range(3):
+                got[t] = m.commit_to_poly_batch(blobs[t])
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=run, args=(t,)) for t in range(6)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    assert all(np.array_equal(g, w) for g, w in zip(got, want))
+    m.close()
+
+
+def _distinct_devices(kz):
+    return list(range(kz.device_count()))
+
+
+@pytest.mark.parametrize("force", [None, "peer", "host"])
+@pytest.mark.parametrize("mode", ["gather", "sharded"])
+def test_distinct_devices_byte_pins(kz, monkeypatch, force, mode):
+    """What a one-GPU box cannot run: the exchange between DISTINCT devices -- ncclAllGather over xGMI (default), hipMemcpyPeerAsync ("peer"),
+    host-staged -- under vector C, vector E and the config-5 byte pin.  Skipped below two devices; the first multi-GPU box that runs the suite runs it."""
+    devs = _distinct_devices(kz)
+    if len(devs) < 2:
+        pytest.skip("needs two or more gfx950 devices")
+    devs = devs[:1 << (len(devs).bit_length() - 1)]        # a power of two: the sharded transforms
+    monkeypatch.setenv("KZG_HIP_FK20_FB_BUDGET_GB", "8")
+    if force:
+        monkeypatch.setenv("KZG_HIP_MULTI_TRANSPORT", force)
+    m = kz.MultiKZGSettings(devs, 5, ko.generate_testing_setup_g1(S_TEST, 33))
+    assert m.transport == {None: "rccl", "peer": "peer-copy", "host": "host-staged"}[force], m.transport_note
+    assert m.transport_self_test.startswith("ok: "), m.transport_self_test
+    if len(devs) <= 4:
+        _vector_C_through(kz, m)
+    m.close()
+    l, n = 16, 32768
+    fs = kz.FFTSettings(16)
+    setup = fs.generate_testing_setup_g1(ko.fr_from_ints([S_TEST]), 65536)
+    m = kz.MultiKZGSettings(devs, 16, setup)
+    m.set_fft_sharding(mode)
+    fk = kz.MultiFK20MultiSettings(m, 2 * n, l)
+    e0 = m.exchanges
+    proofs = fk.da_using_fk20_multi(ko.synthetic_blob(5, n))
+    assert m.exchanges - e0 == (5 if mode == "sharded" else 1)
+    assert sha(fs, proofs) == FK20_PINS["config5_da_using_fk20_multi_seed5"]["sha256"]
+    fk.close(); m.close(); fs.close()
