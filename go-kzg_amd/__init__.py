@@ -450,6 +450,10 @@ class KZGSettings:
             lib().kzg_hip_kzg_settings_free(self.h)
             self.h = None
 
+    def commit_to_poly_unoptimized(self, coeffs):
+        """KZGSettings.CommitToPolyUnoptimized (kzg_single_proofs.go:22-33): the same group element as CommitToPoly, hence the same call"""
+        return self.commit_to_poly(coeffs)
+
     def set_table_budget_gb(self, gb):
         """HBM budget of the fixed-base commitment table (default 64 GB; 210 opts into the 206 GB 16-bit-window table)"""
         _chk(lib().kzg_hip_kzg_set_table_budget_gb(self.h, float(gb)))

@@ -60,6 +60,7 @@ static bool device_is_gfx950(int device) {
 int kzg_hip_fft_settings_new(int device, unsigned max_scale, kzg_hip_fft **out) {
     if (!out || max_scale > 31) return KZG_HIP_ERR_BAD_ARG;
     *out = nullptr;
+    if (max_scale > KZG_HIP_MAX_SCALE) return KZG_HIP_ERR_UNSUPPORTED;   // refused, not attempted: the tables of scale 25+ are tens of GB per settings object
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0 || device < 0 || device >= ndev) return KZG_HIP_ERR_NO_DEVICE;
     if (!device_is_gfx950(device)) return KZG_HIP_ERR_NO_DEVICE;   // kernels are built for gfx950 only; there is no fallback

@@ -25,6 +25,12 @@ func (ks *KZGSettings) CommitToPoly(coeffs []bls.Fr) *bls.G1Point {
 	return out
 }
 
+// CommitToPolyUnoptimized replaces kzg_single_proofs.go:22-33 (a MulG1 / AddG1 loop over SecretG1[:len(coeffs)]): the same group element, so
+// it is the same call here -- a caller that used it as a cross-check of LinCombG1 now cross-checks nothing and should compare against the CPU backend.
+func (ks *KZGSettings) CommitToPolyUnoptimized(coeffs []bls.Fr) *bls.G1Point {
+	return ks.CommitToPoly(coeffs)
+}
+
 // CommitToPolyBatch is new API surface: many blobs per launch is what fills 256 CUs.
 func (ks *KZGSettings) CommitToPolyBatch(coeffs [][]bls.Fr) []bls.G1Point {
 	defer runtime.KeepAlive(ks) // the finalizer must not free the device handle under a running call

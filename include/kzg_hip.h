@@ -40,7 +40,7 @@ extern "C" {
 #define KZG_HIP_ERR_BAD_POINT 6     /* invalid compressed G1 */
 #define KZG_HIP_ERR_NO_DEVICE 7     /* no gfx950 device visible: the library has NO CPU fallback */
 #define KZG_HIP_ERR_HIP 8           /* HIP runtime error, see kzg_hip_last_error() */
-#define KZG_HIP_ERR_UNSUPPORTED 9
+#define KZG_HIP_ERR_UNSUPPORTED 9    /* a size class this library does not serve: kzg_hip_fft_settings_new with KZG_HIP_MAX_SCALE < max_scale <= 31 */
 #define KZG_HIP_ERR_RECOVERY 10      /* "failed to reconstruct data correctly" (recover_from_samples.go:103-107) */
 #define KZG_HIP_ERR_BAD_BLOB 11      /* "could not convert blobs to polynomials" (eth/eth.go:156-159,176-179): a field element >= r */
 
@@ -60,7 +60,12 @@ const char *kzg_hip_version(void);
 int kzg_hip_host_register(void *host, uint64_t bytes);
 int kzg_hip_host_unregister(void *host);
 
-/* ---- FFTSettings: NewFFTSettings (fft.go:44-61) ---- */
+/* ---- FFTSettings: NewFFTSettings (fft.go:44-61) ----
+ * max_scale <= KZG_HIP_MAX_SCALE (2^24 roots: 6 root tables of 0.5 GB + the G1 twiddles' digit rows, 8.9 GB); the reference's root table goes to
+ * scale 31 (bls/globals.go:27-60), whose tables would not fit any device: KZG_HIP_MAX_SCALE < max_scale <= 31 returns KZG_HIP_ERR_UNSUPPORTED, larger
+ * values KZG_HIP_ERR_BAD_ARG (the reference indexes past its table there).  Transforms are parity-tested up to 2^20 points
+ * (tests/test_gpu_parity.py::test_fft_fr_above_65536). */
+#define KZG_HIP_MAX_SCALE 24
 int kzg_hip_fft_settings_new(int device, unsigned max_scale, kzg_hip_fft **out);
 void kzg_hip_fft_settings_free(kzg_hip_fft *fs);
 uint64_t kzg_hip_fft_max_width(const kzg_hip_fft *fs);

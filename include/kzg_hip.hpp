@@ -149,6 +149,7 @@ class KZGSettings {
     G1Point CommitToPoly(const std::vector<Fr> &coeffs) const {                     // kzg_single_proofs.go:17-19
         G1Point out; detail::must(kzg_hip_commit_to_poly(h_, coeffs.data(), coeffs.size(), &out)); return out;
     }
+    G1Point CommitToPolyUnoptimized(const std::vector<Fr> &coeffs) const { return CommitToPoly(coeffs); }   // kzg_single_proofs.go:22-33: the same group element
     G1Point ComputeProofSingle(const std::vector<Fr> &poly, uint64_t x) const {     // kzg_single_proofs.go:36-54
         G1Point out; detail::must(kzg_hip_compute_proof_single(h_, poly.data(), poly.size(), x, &out)); return out;
     }

@@ -4,6 +4,7 @@ golden fixtures.  Every test here needs a real MI355X: run with `-m gpu`.  Integ
 The structure follows the reference's tests: fft_fr_test.go, das_extension_test.go, bls/bls_test.go,
 kzg_single_proofs_test.go, fk20_single_test.go, fk20_multi_test.go.
 """
+import ctypes as C
 import hashlib
 import json
 import os
@@ -89,6 +90,69 @@ def test_fft_fr_matches_oracle(kz, n):
     for inv in (False, True):
         assert np.array_equal(fs.fft(vals, inv), ofs.fft(vals, inv)), (n, inv)
     fs.close()
+
+
+@pytest.mark.parametrize("logn", [17, 20])
+def test_fft_fr_above_65536(kz, logn):
+    """sizes above 2^16 (bit-reversal copy, LDS-resident 4096-point tiles, one launch per remaining stage; fft.go:44-61 allows them, the reference's
+    benchmark loop stops at scale 15): forward, inverse and the round trip at 2^17 and 2^20 points vs the C oracle, one and three rows, a zero-padded
+    input (FFT pads to the next power of two, fft_fr.go:60), in a settings object of exactly that width and a wider one"""
+    n = 1 << logn
+    for max_scale in ((logn, logn + 1) if logn == 17 else (logn,)):
+        fs, ofs = kz.FFTSettings(max_scale), ko.FFTSettings(max_scale)
+        vals = ko.synthetic_blob(logn, n)
+        vals[:4] = ko.fr_from_ints([0, ko.R_MOD - 1, 1, ko.R_MOD - 2])
+        fwd = fs.fft(vals, False)
+        assert np.array_equal(fwd, ofs.fft(vals, False)), (logn, max_scale)
+        assert np.array_equal(fs.fft(fwd, True), vals)
+        assert np.array_equal(fs.fft(vals, True), ofs.fft(vals, True)), (logn, max_scale)
+        if logn == 17:
+            short = vals[:n - 12345]
+            assert np.array_equal(fs.fft(short, False), ofs.fft(short, False))
+            rows = np.stack([vals, fwd, np.roll(vals, 7, axis=0)])
+            for inv in (False, True):
+                got = fs.fft_batch(rows, inv=inv)
+                for b in range(3):
+                    assert np.array_equal(got[b], ofs.fft(rows[b], inv)), (inv, b)
+        fs.close()
+
+
+def test_das_extension_and_recovery_at_scale_17(kz):
+    """DASFFTExtension of 2^16 values in the exact-width scale-17 domain (one row and three) and RecoverPolyFromSamples / ZeroPolyViaMultiplication at
+    2^17 points with half of the samples missing: the odd values and the vanishing polynomial against the C oracle, the recovered data against the
+    transform of the known polynomial (recover_from_samples_test.go:62-137 at a size the reference's tests do not reach)"""
+    fs, ofs = kz.FFTSettings(17), ko.FFTSettings(17)
+    n = 1 << 17
+    even = ko.synthetic_blob(171, n // 2)
+    odd = fs.das_fft_extension(even)
+    assert np.array_equal(odd, ofs.das_fft_extension(even.copy()))
+    rows = np.stack([even, odd, np.roll(even, 3, axis=0)])
+    got = fs.das_fft_extension_batch(rows.copy())
+    for b in range(3):
+        assert np.array_equal(got[b], ofs.das_fft_extension(rows[b].copy())), b
+    data = np.empty((n, 4), dtype=np.uint64)
+    data[0::2], data[1::2] = even, odd
+    assert not fs.fft(data, inv=True)[n // 2:].any()                      # das_extension_test.go:59-77
+    rng = np.random.default_rng(17)
+    missing = sorted(rng.choice(n, size=n // 2, replace=False).tolist())
+    ze, zp = fs.zero_poly_via_multiplication(missing, n)
+    oze, ozp = ofs.zero_poly_via_multiplication(missing, n)
+    assert np.array_equal(ze, oze) and np.array_equal(zp, ozp)
+    present = np.ones(n, dtype=np.uint8)
+    present[missing] = 0
+    samples = np.where(present[:, None].astype(bool), data, 0)
+    assert np.array_equal(fs.recover_poly_from_samples(samples, present), data)
+    fs.close()
+
+
+def test_settings_scale_limits(kz):
+    """NewFFTSettings (fft.go:44-61): scales above KZG_HIP_MAX_SCALE = 24 are refused with their own status instead of attempting tables of tens of
+    GB; above 31 the reference indexes past its root table (panic)"""
+    h = C.c_void_p()
+    L = kz.lib()
+    assert L.kzg_hip_fft_settings_new(0, 25, C.byref(h)) == kz.ERR_UNSUPPORTED and not h.value
+    assert L.kzg_hip_fft_settings_new(0, 31, C.byref(h)) == kz.ERR_UNSUPPORTED and not h.value
+    assert L.kzg_hip_fft_settings_new(0, 32, C.byref(h)) == kz.ERR_BAD_ARG and not h.value
 
 
 def test_fr_lazy_kernels_4096_and_das2048(kz):
