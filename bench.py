@@ -20,7 +20,7 @@ Extra objects on the JSON line:
   roofline.secondary.fk20 -- the same for the FK20 half of the metric (dominant kernel k_g1_fft_stage).
   cpu_baseline  -- the oracle's restatement of bls.LinCombG1 (Kilic-style Pippenger) on the host: one core and all cores (one blob
                    per core), CPU model and core count stated; the Go toolchain probe (rank 0, N = 1).
-  table_sweep   -- commitments/s against the HBM budget of the fixed-base table (10 / 32 / 64 / 210 GB).
+  table_sweep   -- commitments/s against the HBM budget of the fixed-base table (5 / 9 / 17 / 60 / 110 GB).
   drop_in       -- the reference's ONE-blob-per-call API from 1 .. 256 native host threads (host buffers, coalesced in the library).
   lincomb       -- variable-base bls.LinCombG1 on a cached point set (GLV bucket MSM), batch 1 / 64 / 512.
   latency       -- single-call latencies of the reference-shaped entry points.
@@ -413,7 +413,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharded-fk20-multi", action="store_true", help="also time ONE FK20Multi through the sharded driver at world size 1")
     ap.add_argument("--no-fk20", action="store_true")
-    ap.add_argument("--table-gb", type=float, default=210.0, help="HBM budget of the commitment table for the headline (library default: 64)")
+    ap.add_argument("--table-gb", type=float, default=110.0, help="HBM budget of the commitment table for the headline (110 = the library default: 8 signed 16-bit windows walked by both GLV halves, 103 GB)")
     ap.add_argument("--no-extras", action="store_true", help="skip table_sweep / drop_in / lincomb / latency (profiling runs)")
     ap.add_argument("--fk20-4096-batch", type=int, default=512, help="polynomials per step of the fk20_4096 block (0: skip)")
     ap.add_argument("--no-in-process", action="store_true", help="skip the multi-device-handle leg (a child process at the end)")
@@ -457,7 +457,7 @@ def main():
     raw = np.frombuffer(open(os.path.join(ROOT, "tests", "golden", "trusted_setup_g1.bin"), "rb").read(), dtype=np.uint8)
     setup = fs.from_compressed_g1(raw)                      # 4096 x [1337^i]G1, decompressed on the device
     ks = kz.KZGSettings(fs, setup)
-    ks.set_table_budget_gb(args.table_gb)                   # explicit opt-in to the 16-bit-window table (206 GB); table_sweep has the others
+    ks.set_table_budget_gb(args.table_gb)                   # 110 GB = the library's default budget (c = 16 on 8 windows, 103 GB); table_sweep has the smaller ones
     cal_mad, cal_add, cal_fpmul = fs.calibrate()            # measured on THIS GPU: v_mad_u64_u32 / v_add_u32 lane-ops/s, lazy F_p products/s
     golden = os.path.join(ROOT, "tests", "golden")
     pins = json.load(open(os.path.join(golden, "fk20_pins.json")))
@@ -651,7 +651,9 @@ def main():
             # `mac` sets that against the v_mad_u64_u32 rate MEASURED in this run (8 waves per SIMD, independent chains); `issue` adds
             # the non-multiply instructions (SQ_INSTS_VALU of the committed counter pass) at the measured v_add_u32 rate: the share of
             # the launch time that pure instruction issue of this mix explains.
-            mads = B * N_COEFF * tab_w * (6 * 338 + 2 * 260 + 507)
+            adds_pt = ks.table_additions()                       # 2 x windows: both GLV halves of a scalar walk the same rows
+            roofline["table"]["additions_per_coefficient"] = adds_pt
+            mads = B * N_COEFF * adds_pt * (6 * 338 + 2 * 260 + 507)
             roofline["mac"] = {"mads_per_launch": mads, "achieved_Tmad_s": mads / avg_s * 1e-12, "measured_peak_Tmad_s": cal_mad * 1e-12,
                                "frac": mads / avg_s / cal_mad, "measured_v_add_u32_Tops_s": cal_add * 1e-12, "measured_fp_products_G_s": cal_fpmul * 1e-9,
                                "fp_product_equivalents_G_s": mads / 338.0 / avg_s * 1e-9,
@@ -674,17 +676,17 @@ def main():
         if os.environ.get("KZG_BENCH_FAIL_SECONDARY"):           # test hook (tests/test_bench_dist.py)
             raise RuntimeError("KZG_BENCH_FAIL_SECONDARY is set")
         if not args.no_extras and not args.no_fk20 and world == 1:   # single-GPU characterisations: not repeated by every rank of an N > 1 run
-            # --- commitments/s against the HBM budget of the fixed-base table (library default: 64 GB -> c = 14; the headline opts into 210)
+            # --- commitments/s against the HBM budget of the fixed-base table (library default: 110 GB -> c = 16 on 8 windows = 103 GB, the headline)
             table_sweep = {}
-            for gb in (10.0, 33.0, 64.0):
+            for gb in (5.0, 9.0, 17.0, 60.0):
                 ks.set_table_budget_gb(gb)
                 step()
                 torch.cuda.synchronize()
                 tsecs = timed_steps(step, 5, 1, torch.cuda.synchronize, barrier, max_over_ranks)
                 c_, w_, b_ = ks.table_info()
                 table_sweep["%g" % gb] = {"commitments_per_s": B * world * 5 / tsecs, "window_bits": c_, "windows": w_, "table_GB": b_ / 1e9}
-            # --- eth.ComputeKZGProof (eth/helpers.go:179-203) while the monomial settings hold the library-default 64 GB table, so that the
-            # eth settings get their own default table beside it (the co-residence the default budget is chosen for)
+            # --- eth.ComputeKZGProof (eth/helpers.go:179-203) while the monomial settings hold a 58 GB table; the eth settings build their own
+            # default table (103 GB) beside it
             eth_proof = None
             try:
                 lag_raw = np.frombuffer(open(os.path.join(ROOT, "tests", "golden", "trusted_setup_g1_lagrange.bin"), "rb").read(), dtype=np.uint8)
@@ -707,7 +709,7 @@ def main():
                     erates[str(T)] = eth.bench_drop_in_proof(blobs_h[:64], T, 100 if T == 1 else 40)[0]
                 eth_proof = {"entry": "kzg_hip_eth_compute_kzg_proof (host buffers, blocking, one polynomial per call; coalesced in the library)",
                              "device_resident_batch_%d_per_s" % EB: EB * 5 / esecs, "invalid_rows_in_batch": int((d_bad != 0).sum().item()),
-                             "threads_per_s": erates, "monomial_table_GB_beside_it": table_sweep["64"]["table_GB"]}
+                             "threads_per_s": erates, "monomial_table_GB_beside_it": table_sweep["60"]["table_GB"]}
                 # eth.ComputeAggregateKZGProof (eth/eth.go:175-182): the blobs of one block from host buffers -> commitments + aggregated proof,
                 # the SHA-256 transcript hashed on the host while the device commits
                 agg = {}
@@ -1208,7 +1210,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": secs / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "dtype_note": "30/32-bit limbs in u32 lanes, 64-bit accumulators (v_mad_u64_u32): 381-bit F_p and 255-bit F_r Montgomery arithmetic",
             "data": "synthetic",
-            "config": {"workload": "CommitToPoly, 4096-coeff blobs, eth/trusted_setup.json monomial setup (s=1337), %d blobs/step/GPU resident in HBM, fixed-base table budget %g GB (opt-in; library default 64 GB, see table_sweep)" % (B, args.table_gb),
+            "config": {"workload": "CommitToPoly, 4096-coeff blobs, eth/trusted_setup.json monomial setup (s=1337), %d blobs/step/GPU resident in HBM, fixed-base table budget %g GB (library default 110 GB: signed 16-bit windows, 8 of them walked by both GLV halves of every scalar, 103 GB; see table_sweep)" % (B, args.table_gb),
                        "global_batch": B * world, "parallelism": "dp%d (independent blobs, no data-path collective)" % world},
             "rccl": rccl, "roofline": roofline, "cpu_baseline": base, "self_check": self_check, "batch_sweep": batch_sweep, "table_sweep": table_sweep, "drop_in": drop_in,
             "lincomb": lincomb, "latency": latency, "fk20": fk20, "fk20_4096": fk20_4096, "fk20_multi": fk20m, "reference_benchmarks": ref_benches, "in_process": in_process,

@@ -227,7 +227,8 @@ msm_plan classic_plan(uint64_t n, bool folded = false);   // capi_core.hip
 void set_inf_image(void *out_g1);   // capi_core.hip
 int kzg_settings_build(kzg_hip_fft *fs, const void *points_g1, uint64_t n, kzg_hip_kzg **out);   // capi_kzg.hip
 int ensure_fixed_table(kzg_hip_kzg *ks, hipStream_t);   // capi_kzg.hip
-const void *host_mapped_pointer(const void *host, size_t bytes);   // capi_kzg.hip
+const void *host_mapped_pointer(const void *host, size_t bytes);
+int h2d_copy(void *dst, const void *src, size_t bytes, hipStream_t s);   // capi_kzg.hip: cut at the boundaries of registered ranges   // capi_kzg.hip
 int commit_rows(kzg_hip_kzg *ks, hipStream_t s, const fr *d_sc, uint64_t n, uint64_t batch, g1j *d_out, uint64_t sc_stride = 0);   // capi_kzg.hip
 double table_budget_gb(const char *env, double cap_gb, double headroom_gb);   // capi_kzg.hip
 int lincomb_points_rows(kzg_hip_points *pts, hipStream_t s, const fr *d_sc, uint64_t n, uint64_t batch, g1j *d_out, uint64_t sc_stride = 0, bool holds_mu = false);   // capi_core.hip

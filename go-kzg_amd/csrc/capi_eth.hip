@@ -94,7 +94,7 @@ int kzg_hip_eth_blob_to_kzg_commitment_batch(kzg_hip_eth *eth, const void *blobs
     const uint8_t *src = (const uint8_t *)host_mapped_pointer(blobs_le32, (size_t)batch * n * 32);     // pinned blobs (kzg_hip_host_register): the conversion kernel reads them in place over PCIe
     if (!src) {
         CHK(d_in.alloc(batch * n * 32));
-        HIPCHK(hipMemcpyAsync(d_in.p, blobs_le32, batch * n * 32, hipMemcpyHostToDevice, s));
+        CHK(h2d_copy(d_in.p, blobs_le32, batch * n * 32, s));
         src = d_in.p;
     }
     launch_fr_from_le32(s, src, d_poly.p, n, batch, d_bad.p);                    // BlobToPolynomial, eth/helpers.go:264-273

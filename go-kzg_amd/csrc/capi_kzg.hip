@@ -61,25 +61,41 @@ uint32_t fb_windows(uint32_t c) {
 }
 
 // Lazily builds the fixed-base table T[(w n + i) D + d - 1] = d 2^(c w) SecretG1[i] (k_msm.hip).  The window size is the
-// largest whose table fits the HBM budget.  Budget, in this order: kzg_hip_kzg_set_table_budget_gb (per handle, the opt-in for
-// the 206 GB c = 16 table), the KZG_HIP_FB_BUDGET_GB environment variable, else the DEFAULT of 64 GB (n = 4096: c = 14,
-// 19 windows, 61 GB) clipped to free HBM - 24 GB so that several settings objects (monomial + eth Lagrange + FK20) co-reside.
-// Measured, n = 4096, 512 blobs per launch: c = 11 (10 GB) ~39k, c = 13 (32 GB) ~55k, c = 14 (61 GB) ~77k, c = 16 (206 GB,
-// 16 windows) ~88k commitments/s (bench.py table_sweep).  If the allocation fails (another process on the GPU, fragmentation)
+// largest whose table fits the HBM budget.  Budget, in this order: kzg_hip_kzg_set_table_budget_gb (per handle), the KZG_HIP_FB_BUDGET_GB
+// environment variable, else the DEFAULT of 110 GB clipped to free HBM - 24 GB.  Since round 5 the walk uses the endomorphism (k_fb_accumulate_glv:
+// both GLV halves of a scalar walk the SAME rows), so n = 4096 gets c = 16 with 8 windows = 103 GB and 16 additions per point by default -- what
+// took the 206 GB opt-in before -- and the monomial setup (103 GB), eth's Lagrange setup (103 GB) and FK20 settings (32-48 GB) still co-reside in
+// 288 GB.  Smaller budgets: 58 GB c = 15 (2 x 9 additions), 16 GB c = 13 (2 x 10), 8.9 GB c = 12 (2 x 11), 4.8 GB c = 11 (2 x 12).
+// (KZG_HIP_FB_GLV=0 restores the plain layout: 206 GB c = 16 / 61 GB c = 14 (19) / 32 GB c = 13 (20) / 9.7 GB c = 11 (24).)
+// If the allocation fails (another process on the GPU, fragmentation)
 // the next smaller window is tried, and finally the bucket path, which needs no table: a commitment never fails for lack of HBM.
 // The build runs on the HANDLE's stream and only that stream is waited for (by the host thread that found no table): a caller's stream
 // passed to a _dev entry point is never synchronised here -- its work already enqueued keeps running under the build.  Callers hold fs->mu.
+#ifndef FB_DEFAULT_BUDGET_GB
+#define FB_DEFAULT_BUDGET_GB 110.0
+#endif
+// windows of the GLV walk: both halves of a split scalar are below 2^126.5 (glv_split_signed), so the top signed digit cannot carry out as soon as
+// c * nwin >= 128
+uint32_t fb_windows_glv(uint32_t c) { return (128 + c - 1) / c; }
+bool fb_glv_enabled() {
+    static const bool on = [] { const char *e = getenv("KZG_HIP_FB_GLV"); return !(e && !strcmp(e, "0")); }();   // "0": the round-1..4 layout (one window per c bits of the whole scalar), A/B runs and tests
+    return on;
+}
 int ensure_fixed_table(kzg_hip_kzg *ks, hipStream_t) {
     if (ks->d_fixed || ks->fixed_plan.c == 0xffffffffu) return KZG_HIP_OK;
     hipStream_t s = ks->fs->stream;
-    double budget_gb = ks->budget_gb >= 0.0 ? ks->budget_gb : table_budget_gb("KZG_HIP_FB_BUDGET_GB", 64.0, 24.0);
+    double budget_gb = ks->budget_gb >= 0.0 ? ks->budget_gb : table_budget_gb("KZG_HIP_FB_BUDGET_GB", FB_DEFAULT_BUDGET_GB, 24.0);
     if (ks->n_setup < 64) { ks->fixed_plan.c = 0xffffffffu; return KZG_HIP_OK; }   // classic path only
+    const bool glv = fb_glv_enabled();
     for (uint32_t c = 16; c >= 5; c--) {
-        if (c == 15) continue;                               // measured slower than c = 14 (18 windows, 116 GB)
-        double bytes = (double)fb_windows(c) * (double)ks->n_setup * (double)(1u << (c - 1)) * sizeof(g1a);
+        // window sizes that are dominated by a smaller table with the same number of additions per point are skipped: GLV c = 14 (2 x 10 windows, 32 GB)
+        // against c = 13 (2 x 10, 16 GB); plain c = 15 (18 windows, 116 GB) measured slower than c = 14 (19 windows, 61 GB)
+        if (glv ? (c == 14) : (c == 15)) continue;
+        const uint32_t nwin = glv ? fb_windows_glv(c) : fb_windows(c);
+        double bytes = (double)nwin * (double)ks->n_setup * (double)(1u << (c - 1)) * sizeof(g1a);
         if (bytes > budget_gb * 1e9) continue;
         msm_plan p{};
-        p.c = c; p.nwin = fb_windows(c); p.nb = 1u << (c - 1); p.ngroups = 1; p.fixed = 1; p.table_n = ks->n_setup;
+        p.c = c; p.nwin = nwin; p.nb = 1u << (c - 1); p.ngroups = 1; p.fixed = 1; p.glv = glv ? 1 : 0; p.table_n = ks->n_setup;
         size_t entries = (size_t)p.nwin * ks->n_setup * p.nb;
         g1a *tab = nullptr;
         if (hipMalloc((void **)&tab, entries * sizeof(g1a)) != hipSuccess) { (void)hipGetLastError(); continue; }   // retry smaller
@@ -105,7 +121,7 @@ int commit_rows(kzg_hip_kzg *ks, hipStream_t s, const fr *d_sc, uint64_t n, uint
     size_t ws_main = fixed ? fb_partials_bytes(n, batch) : msm_workspace_bytes(p, n, batch);
     dtmp<uint8_t> d_ws(s);
     CHK(d_ws.alloc(ws_main));
-    if (fixed) launch_fb_msm(s, ks->d_fixed, p.table_n, p.c, p.nwin, d_sc, sc_stride, n, batch, d_ws.p, d_out, true);   // sums, normalises, converts
+    if (fixed) launch_fb_msm(s, ks->d_fixed, p.table_n, p.c, p.nwin, d_sc, sc_stride, n, batch, d_ws.p, d_out, true, p.glv != 0);   // sums, normalises, converts
     else launch_msm(s, p, ks->d_secret_a, d_sc, sc_stride, n, batch, d_ws.p, d_out, true);
     HIPCHK(hipGetLastError());
     return KZG_HIP_OK;
@@ -155,6 +171,26 @@ const void *host_mapped_pointer(const void *host, size_t bytes) {
     const uintptr_t d = (uintptr_t)a.devicePointer, b = (uintptr_t)base;
     return (d >= b && d + bytes <= b + size) ? a.devicePointer : nullptr;
 }
+// Host -> device copy of a range that may STRADDLE the end (or the start) of a range pinned through kzg_hip_host_register: the runtime refuses one
+// hipMemcpyAsync over pinned and pageable pages together ("invalid argument"), so the copy is cut at the registered boundaries.
+int h2d_copy(void *dst, const void *src, size_t bytes, hipStream_t s) {
+    uintptr_t p = (uintptr_t)src; uint8_t *d = (uint8_t *)dst;
+    while (bytes) {
+        size_t chunk = bytes;
+        {
+            std::lock_guard<std::mutex> lk(g_reg_mu);
+            auto it = g_registered.upper_bound(p);                         // first range that starts after p
+            if (it != g_registered.end() && it->first - p < chunk) chunk = it->first - p;
+            if (it != g_registered.begin()) {
+                --it;
+                if (p < it->first + it->second && it->first + it->second - p < chunk) chunk = it->first + it->second - p;   // p lies inside this range: stop at its end
+            }
+        }
+        HIPCHK(hipMemcpyAsync(d, (const void *)p, chunk, hipMemcpyHostToDevice, s));
+        p += chunk; d += chunk; bytes -= chunk;
+    }
+    return KZG_HIP_OK;
+}
 int kzg_hip_host_register(void *host, uint64_t bytes) {
     if (!host || !bytes) return KZG_HIP_ERR_BAD_ARG;
     KZG_TRY
@@ -202,13 +238,13 @@ int kzg_hip_commit_to_poly_batch(kzg_hip_kzg *ks, const void *coeffs_fr, uint64_
         int slot = 0;
         for (uint64_t b0 = 0; b0 < batch; b0 += chunk, slot ^= 1) {
             uint64_t cnt = batch - b0 < chunk ? batch - b0 : chunk;
-            HIPCHK(hipMemcpyAsync(d_sc.p + b0 * n, (const fr *)coeffs_fr + b0 * n, n * cnt * sizeof(fr), hipMemcpyHostToDevice, ks->copy_stream));
+            CHK(h2d_copy(d_sc.p + b0 * n, (const fr *)coeffs_fr + b0 * n, n * cnt * sizeof(fr), ks->copy_stream));
             HIPCHK(hipEventRecord(ks->copy_done[slot], ks->copy_stream));
             HIPCHK(hipStreamWaitEvent(s, ks->copy_done[slot], 0));
             CHK(commit_rows(ks, s, d_sc.p + b0 * n, n, cnt, d_out.p + b0));
         }
     } else {
-        HIPCHK(hipMemcpyAsync(d_sc.p, coeffs_fr, n * batch * sizeof(fr), hipMemcpyHostToDevice, s));
+        CHK(h2d_copy(d_sc.p, coeffs_fr, n * batch * sizeof(fr), s));
         CHK(commit_rows(ks, s, d_sc.p, n, batch, d_out.p));
     }
     HIPCHK(hipMemcpyAsync(out_g1, d_out.p, batch * sizeof(g1j), hipMemcpyDeviceToHost, s));
@@ -455,4 +491,9 @@ int kzg_hip_kzg_table_info(kzg_hip_kzg *ks, uint32_t *window_bits, uint32_t *win
     *window_bits = have ? ks->fixed_plan.c : 0; *windows = have ? ks->fixed_plan.nwin : 0;
     *table_bytes = have ? (uint64_t)ks->fixed_plan.nwin * ks->fixed_plan.table_n * ks->fixed_plan.nb * sizeof(g1a) : 0;
     return KZG_HIP_OK;
+}
+// mixed additions per coefficient of a commitment on that table: 2 x windows when both GLV halves of a scalar walk it (the default), else windows; 0 without a table
+uint32_t kzg_hip_kzg_table_additions(kzg_hip_kzg *ks) {
+    if (!ks || !ks->d_fixed) return 0;
+    return ks->fixed_plan.glv ? 2 * ks->fixed_plan.nwin : ks->fixed_plan.nwin;
 }

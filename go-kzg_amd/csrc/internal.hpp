@@ -100,6 +100,7 @@ struct msm_plan {
     uint32_t nb;       // 2^(c-1)
     uint32_t ngroups;  // bucket MSM: 16 window groups (points only) or 8 (table also holds 2^64 P_i at [table_n + i])
     uint32_t fixed;    // 1: plan of a fixed-base table (k_fb_*), 0: bucket MSM
+    uint32_t glv;      // fixed-base walk: 1 = the table holds ceil(128 / c) windows and both GLV halves of a scalar walk them (k_fb_accumulate_glv)
     uint64_t table_n;  // points per row of the table
 };
 // the bucket pipeline packs (point index << 2 | half | sign) into 32 bits and counts entries (32 per scalar) in 32 bits: both must fit
@@ -116,7 +117,7 @@ void launch_msm_window_table(hipStream_t s, const g1a *pts, uint64_t n, uint32_t
 size_t fb_partials_bytes(uint64_t n, uint64_t batch);
 hipError_t launch_fb_build(hipStream_t s, const g1a *pts, uint64_t n, uint32_t c, uint32_t nwin, g1a *table);
 void launch_fb_msm(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, uint64_t sc_stride, uint64_t n,
-                   uint64_t batch, void *partials, g1j *out, bool to_kilic);
+                   uint64_t batch, void *partials, g1j *out, bool to_kilic, bool glv = false);
 
 // out[(b, f, jj)] = scalars[b][f * row + j0 + jj] * P[f * row + j0 + jj] over a fixed-base table of table_n = nfiles * row points
 void launch_fb_mul_vec(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, uint64_t row, uint64_t j0,

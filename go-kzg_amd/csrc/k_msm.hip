@@ -775,6 +775,72 @@ template <bool SPLIT> __global__ __launch_bounds__(FB_ACC_BLOCK, FB_ACC_WAVES) v
     fb_block_reduce_coop(acc, buf, &lds, tid);
     if (tid == 0) fb_partial_store(partials[blockIdx.x], acc);
 }
+// The same walk over a table HALF as large (round 5): every scalar is split on the device, k = s1 |k1| + s2 |k2| lambda with both magnitudes below
+// 2^126.5 (glv_split_signed), and BOTH halves walk the same rows -- phi(d 2^(c w) P) = (beta x, y) of the entry d 2^(c w) P -- so a table of
+// nwin = ceil(128 / c) windows serves 2 nwin additions per point: c = 16 is 8 windows = 103 GB for the 16 additions per point that took 16 windows =
+// 206 GB.  phi costs nothing per entry: a lane first sums the phi halves of all its points UN-mapped, maps the sum once (phi is an endomorphism:
+// X <- beta X on the XYZZ accumulator, one product per lane and blob), then continues with the plain halves.  Virtual points v in [0, nvh) are
+// phi halves, v in [nvh, 2 nvh) plain halves (nvh = n, or n * wsplit when the windows of a half are divided among wsplit lanes: small batches).
+__device__ __forceinline__ uint32_t mag_bits(const uint32_t (&m)[4], uint32_t off, uint32_t c) {
+    const uint32_t idx = off >> 5, sh = off & 31;
+    if (idx >= 4) return 0;
+    uint64_t v = m[idx];
+    if (idx + 1 < 4) v |= (uint64_t)m[idx + 1] << 32;
+    return (uint32_t)(v >> sh) & ((1u << c) - 1u);
+}
+template <bool SPLIT> __global__ __launch_bounds__(FB_ACC_BLOCK, FB_ACC_WAVES) void k_fb_accumulate_glv(const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, uint32_t D, const fr *scalars,
+                                                            uint64_t sc_stride, uint64_t n, uint32_t blocks_per_blob, uint32_t wsplit, fb_partial *partials) {
+    __shared__ fb_partial buf[64];
+    __shared__ coop_lds lds;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t blob = blockIdx.x / blocks_per_blob; const uint32_t blk = blockIdx.x % blocks_per_blob;
+    const uint64_t L = (uint64_t)blocks_per_blob * FB_ACC_BLOCK;
+    const fr *sc = scalars + blob * sc_stride;
+    g1x_acc acc; acc.init();
+    const uint32_t wpg = SPLIT ? (nwin + wsplit - 1) / wsplit : nwin;
+    const uint64_t nvh = SPLIT ? n * wsplit : n;
+    bool in_phi = false;                                  // acc holds an un-mapped sum of phi-half entries
+    for (uint64_t v = (uint64_t)blk * FB_ACC_BLOCK + tid; v < 2 * nvh; v += L) {
+        const bool phi = v < nvh;
+        const uint64_t vh = phi ? v : v - nvh;
+        const uint64_t i = SPLIT ? vh % n : vh;
+        const uint32_t w0 = SPLIT ? (uint32_t)(vh / n) * wpg : 0u;
+        const uint32_t w1 = SPLIT ? (w0 + wpg < nwin ? w0 + wpg : nwin) : nwin;
+        if (SPLIT && w0 >= w1) continue;
+        if (in_phi && !phi) { if (!acc.inf) acc.v.x = mulq(acc.v.x, unpackq(glv_beta())); in_phi = false; }   // the lane crosses into its plain halves: map the phi sum
+        const glv_halves h = glv_split_signed(from_mont<FrP>(sc[i]));
+        uint32_t m[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) m[j] = phi ? h.k2[j] : h.k1[j];
+        const uint32_t sgn = phi ? h.neg2 : h.neg1;
+        uint32_t raw, carry = 0, mag, ng;
+        if (SPLIT) {
+#pragma nounroll
+            for (uint32_t w = 0; w < w0; w++) carry = (mag_bits(m, w * c, c) + carry > D) ? 1u : 0u;
+        }
+        raw = mag_bits(m, w0 * c, c) + carry;
+        if (raw > D) { carry = 1; mag = (1u << c) - raw; ng = 1; } else { carry = 0; mag = raw; ng = 0; }
+        g1a qn = table[((uint64_t)w0 * table_n + i) * D + (mag ? mag - 1 : 0)];
+#pragma nounroll
+        for (uint32_t w = w0; w < w1; w++) {
+            g1a q = qn;
+            const uint32_t cmag = mag, cng = ng;
+            if (w + 1 < w1) {
+                raw = mag_bits(m, (w + 1) * c, c) + carry;
+                if (raw > D) { carry = 1; mag = (1u << c) - raw; ng = 1; } else { carry = 0; mag = raw; ng = 0; }
+                qn = table[((uint64_t)(w + 1) * table_n + i) * D + (mag ? mag - 1 : 0)];
+            }
+            if (cmag) {
+                if (cng ^ sgn) q.y = neg<FpP>(q.y);
+                acc.add(q);
+                in_phi = phi;
+            }
+        }
+    }
+    if (in_phi && !acc.inf) acc.v.x = mulq(acc.v.x, unpackq(glv_beta()));   // a lane that only held phi halves
+    fb_block_reduce_coop(acc, buf, &lds, tid);
+    if (tid == 0) fb_partial_store(partials[blockIdx.x], acc);
+}
 // one workgroup of four cooperating wavefronts per blob (lane column j = partial sum j): the blob's partial sums are added by a
 // tree of wave-cooperative XYZZ additions (4 products deep instead of 13; a lone commitment has 32 partials: 5 levels), then
 // column 0 normalises (one inversion: 1 / (ZZ ZZZ)) and converts.  This kernel is pure latency: ~100 us instead of ~230.
@@ -1085,6 +1151,7 @@ uint64_t device_simd_lanes() {
     }
     return lanes;
 }
+// n = virtual points of a blob (the points themselves, or 2 x points for the GLV walk: a phi half and a plain half each)
 static uint32_t fb_blocks_per_blob(uint64_t n, uint64_t batch, uint32_t *wsplit = nullptr) {
     // 131072 lanes = 2048 wavefronts = exactly the resident capacity at 2 waves per SIMD: ONE round.  Measured (512 blobs):
     // 131072 lanes 5.7 ms, 262144 lanes (two rounds) 6.4 ms, 98304 / 65536 lanes 10.4 ms.  KZG_HIP_FB_LANES overrides.
@@ -1103,18 +1170,24 @@ static uint32_t fb_blocks_per_blob(uint64_t n, uint64_t batch, uint32_t *wsplit 
     if (bpb < 1) bpb = 1;
     return (uint32_t)bpb;
 }
-size_t fb_partials_bytes(uint64_t n, uint64_t batch) { return (((size_t)fb_blocks_per_blob(n, batch) * batch * sizeof(fb_partial)) + 15) / 16 * 16; }
+// (the GLV walk has 2 n virtual points and half the windows per virtual point: its lanes per blob, and so its partial sums, equal the plain walk's)
+size_t fb_partials_bytes(uint64_t n, uint64_t batch) { return (((size_t)std::max(fb_blocks_per_blob(n, batch), fb_blocks_per_blob(2 * n, batch)) * batch * sizeof(fb_partial)) + 15) / 16 * 16; }
 
 // out[b] = the NORMALISED sum (Z = one), as Kilic images when to_kilic: the per-blob partial sums are added and inverted in one
-// latency-bound kernel instead of two
+// latency-bound kernel instead of two.  glv: the table holds ceil(128 / c) windows and both GLV halves of every scalar walk them (k_fb_accumulate_glv).
 void launch_fb_msm(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, uint64_t sc_stride, uint64_t n,
-                   uint64_t batch, void *partials, g1j *out, bool to_kilic) {
+                   uint64_t batch, void *partials, g1j *out, bool to_kilic, bool glv) {
     if (!batch) return;
     uint32_t split = 1;
-    uint32_t bpb = fb_blocks_per_blob(n, batch, &split);
+    uint32_t bpb = fb_blocks_per_blob(glv ? 2 * n : n, batch, &split);   // (glv: `split` lanes per HALF, so up to 16 lanes per point with one window each)
     if (split > nwin) split = nwin;
     prof_begin(s, "fb_accumulate");
-    if (split > 1) hipLaunchKernelGGL(k_fb_accumulate<true>, dim3((uint32_t)(batch * bpb)), dim3(FB_ACC_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars, sc_stride, n,
+    if (glv) {
+        if (split > 1) hipLaunchKernelGGL(k_fb_accumulate_glv<true>, dim3((uint32_t)(batch * bpb)), dim3(FB_ACC_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars, sc_stride, n,
+                                          bpb, split, (fb_partial *)partials);
+        else hipLaunchKernelGGL(k_fb_accumulate_glv<false>, dim3((uint32_t)(batch * bpb)), dim3(FB_ACC_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars, sc_stride, n, bpb,
+                                1u, (fb_partial *)partials);
+    } else if (split > 1) hipLaunchKernelGGL(k_fb_accumulate<true>, dim3((uint32_t)(batch * bpb)), dim3(FB_ACC_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars, sc_stride, n,
                                       bpb, split, (fb_partial *)partials);
     else hipLaunchKernelGGL(k_fb_accumulate<false>, dim3((uint32_t)(batch * bpb)), dim3(FB_ACC_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars, sc_stride, n, bpb,
                             1u, (fb_partial *)partials);

@@ -186,6 +186,12 @@ func (ks *KZGSettings) TableInfo() (windowBits, windows uint32, tableBytes uint6
 	return uint32(c), uint32(w), uint64(b)
 }
 
+// TableAdditions: mixed additions per coefficient of a commitment on that table (2 x windows: both GLV halves of a scalar walk the same rows).
+func (ks *KZGSettings) TableAdditions() uint32 {
+	defer runtime.KeepAlive(ks)
+	return uint32(C.kzg_hip_kzg_table_additions(ks.hip()))
+}
+
 // FK20SingleBatch: FK20Single (fk20_single.go:122-137) on every row; out[b] holds the n proofs of polynomials[b].
 func (fk *FK20SingleSettings) FK20SingleBatch(polynomials [][]bls.Fr) [][]bls.G1Point {
 	defer runtime.KeepAlive(fk)

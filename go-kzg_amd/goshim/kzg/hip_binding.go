@@ -30,7 +30,7 @@ import (
 
 // One device handle per Go settings object, created on first use (settings are immutable after construction).
 // The side tables are keyed by the object's ADDRESS as a uintptr, not by the pointer: they do not keep the settings object
-// alive.  A finalizer on the settings object (and the explicit Close methods below) frees the device handle -- up to 206 GB of
+// alive.  A finalizer on the settings object (and the explicit Close methods below) frees the device handle -- up to 103 GB of
 // HBM for a KZGSettings -- and removes the entry.  KZGSettings points to its FFTSettings and the FK20 settings to their
 // KZGSettings, so the runtime runs the finalizers outermost first (runtime.SetFinalizer: "if A points to B, A's runs first"),
 // which is the order the C side needs (a kzg handle refers to its fft handle).

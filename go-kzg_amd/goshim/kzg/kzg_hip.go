@@ -80,8 +80,9 @@ func (ks *KZGSettings) ComputeProofSingleBatch(polys [][]bls.Fr, xs []uint64) []
 	return out
 }
 
-// SetTableBudgetGB opts this settings object into a bigger (or smaller) fixed-base commitment table than the 64 GB default;
-// 210 selects the 16-bit-window table (206 GB, 16 additions per coefficient).  Call before the first commitment.
+// SetTableBudgetGB gives this settings object a smaller (or bigger) fixed-base commitment table than the 110 GB default budget (4096 points:
+// signed 16-bit windows, 8 of them walked by both GLV halves of a scalar, 103 GB, 16 additions per coefficient); 60 selects 15-bit windows
+// (58 GB, 18 additions), 17 selects 13-bit windows (16 GB, 20 additions).  Call before the first commitment.
 func (ks *KZGSettings) SetTableBudgetGB(gb float64) {
 	defer runtime.KeepAlive(ks) // the finalizer must not free the device handle under a running call
 	hipMust(C.kzg_hip_kzg_set_table_budget_gb(ks.hip(), C.double(gb)))

@@ -137,8 +137,9 @@ int kzg_hip_trusted_setup_from_json(kzg_hip_fft *fs, const char *json, uint64_t 
 int kzg_hip_kzg_settings_new(kzg_hip_fft *fs, const void *secret_g1, uint64_t n_setup, kzg_hip_kzg **out);
 void kzg_hip_kzg_settings_free(kzg_hip_kzg *ks);
 /* HBM budget (GB, decimal) of the fixed-base commitment table of this settings object; call before the first commitment (a
- * later call frees the table, which is rebuilt lazily).  Default without this call: KZG_HIP_FB_BUDGET_GB, else 64 GB
- * (n = 4096: signed 14-bit windows, 61 GB); 210 selects the 16-bit-window table (206 GB, 16 additions per coefficient). */
+ * later call frees the table, which is rebuilt lazily).  Default without this call: KZG_HIP_FB_BUDGET_GB, else 110 GB
+ * clipped to free HBM - 24 GB (n = 4096: signed 16-bit windows, 8 of them walked by both GLV halves of a scalar: 103 GB, 16 additions per
+ * coefficient); 60 selects 15-bit windows (58 GB, 18 additions), 17 selects 13-bit windows (16 GB, 20 additions). */
 int kzg_hip_kzg_set_table_budget_gb(kzg_hip_kzg *ks, double gb);
 /* KZGSettings.CommitToPoly (kzg_single_proofs.go:17-19) */
 int kzg_hip_commit_to_poly(kzg_hip_kzg *ks, const void *coeffs_fr, uint64_t n, void *out_g1);
@@ -310,8 +311,11 @@ int kzg_hip_multi_da_using_fk20_multi_batch(kzg_hip_multi_fk20m *fk, const void 
 int kzg_hip_multi_da_using_fk20_multi(kzg_hip_multi_fk20m *fk, const void *poly_fr, uint64_t n, void *out_g1 /* 2n / chunk_len */);
 
 /* shape of the fixed-base table CommitToPoly walks (built lazily by the first commitment): signed window bits c, window count and
- * bytes of HBM; all zero before the first commitment or when the setup is too small for a table (classic bucket path) */
+ * bytes of HBM; all zero before the first commitment or when the setup is too small for a table (classic bucket path).  Both GLV halves of a
+ * scalar (k = k1 + k2 lambda, |k1|, |k2| < 2^127) walk the same rows, so `windows` = ceil(128 / c) and a coefficient costs 2 x windows mixed
+ * additions (kzg_hip_kzg_table_additions): 4096 points at c = 16 are 8 windows = 103 GB, the default budget (110 GB; kzg_hip_kzg_set_table_budget_gb). */
 int kzg_hip_kzg_table_info(kzg_hip_kzg *ks, uint32_t *window_bits, uint32_t *windows, uint64_t *table_bytes);
+uint32_t kzg_hip_kzg_table_additions(kzg_hip_kzg *ks);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

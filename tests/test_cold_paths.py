@@ -12,6 +12,13 @@ blob can be built whose partial sums collide:
 * other offsets put the two equal / opposite partial sums in two lanes of one wavefront column, two wavefronts of a workgroup, two
   workgroups of a blob (the cooperative trees of k_fb_accumulate and k_fb_finish / k_fb_finish_lanes), whatever the launch shape.
 
+Since round 5 the walk splits every scalar, k = +-|k1| +- |k2| lambda (glv_split_signed), and a lane sums the phi halves of its points un-mapped, maps
+the sum (X <- beta X) and continues with the plain halves.  Rows for that order: pairs whose PHI halves collide before the map (k = lambda m for small
+m splits into (0, m)), pairs where a phi-only lane meets a mixed lane with the same sum, and rows built backwards from the kernel's iteration order
+(lane t of the unsplit walk owns points t + 256 j; its LAST addition is the top non-zero window of the plain half of its last point): the scalars of a
+lane are chosen so that everything summed before that addition equals the entry it adds (doubling) or its negative (infinity), for the window sizes
+of every table in use and for the plain layout (KZG_HIP_FB_GLV=0), which test_plain_layout_in_a_fresh_process re-runs.
+
 Expected values do not come from any MSM code: the commitment of a blob is [sum k_i 1337^i mod r]G, one scalar multiplication of the
 oracle.  All-zero rows sit at the first, middle and last position of every batch.  Runs at the table sizes bench.py uses (signed 11-, 14-
 and 16-bit windows) and at batch sizes 1 / 16 / 32 / 130 / 4096 (window-split walk, plain walk with 16 / 3 / 1 workgroups per blob).
@@ -27,6 +34,67 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 R = ko.R_MOD
 S = 1337
 N = 4096
+LAMBDA = 0xac45a4010001a40200000000ffffffff
+GLV_WALK = os.environ.get("KZG_HIP_FB_GLV") != "0"
+
+
+def glv_split(k):
+    """glv_split_signed (go-kzg_amd/csrc/g1.hpp) on Python integers: (|k1|, k2, neg1, neg2)"""
+    sg = k > (R - 1) // 2
+    a = R - k if sg else k
+    q = (a + LAMBDA // 2) // LAMBDA
+    k1 = a - q * LAMBDA
+    return abs(k1), q, sg ^ (k1 < 0), sg
+
+
+def signed_digits(mag, c, nwin):
+    """the walk's recoding: digits in [-2^(c-1), 2^(c-1)] with sum d_w 2^(c w) == mag"""
+    out, carry = [], 0
+    for w in range(nwin):
+        raw = ((mag >> (c * w)) & ((1 << c) - 1)) + carry
+        if raw > (1 << (c - 1)):
+            out.append(raw - (1 << c)); carry = 1
+        else:
+            out.append(raw); carry = 0
+    assert carry == 0 and sum(d << (c * w) for w, d in enumerate(out)) == mag
+    return out
+
+
+def plain_windows(c):
+    """fb_windows (capi_kzg.hip): signed c-bit windows of a canonical scalar"""
+    nw = (255 + c - 1) // c
+    top = ((R - 1) >> (c * (nw - 1))) + 1
+    return nw + 1 if top > (1 << (c - 1)) else nw
+
+
+def last_addition_rows(rng):
+    """rows built backwards from the unsplit walk's order at one workgroup per blob (batches >= 512): lane t owns the points t + 256 j, j = 0 .. 15; with
+    the endomorphism it sums their phi halves, maps, then their plain halves, windows ascending -- so its last addition is the top non-zero window of the
+    plain half (of the whole scalar in the plain layout) of point t + 3840.  k_(t) is solved so that the lane's sum before that addition equals the entry
+    (doubling) or its negative (the lane ends at infinity).  In other launch shapes these are ordinary rows."""
+    out = []
+    for glv, cs in ((True, (16, 15, 12)), (False, (16, 14, 11))):
+        for c in cs:
+            for t, sign in ((5, 1), (77, -1), (255, 1)):
+                pts = [t + 256 * j for j in range(16)]
+                ks = {p: int.from_bytes(rng.bytes(32), "little") % R for p in pts}
+                last = pts[-1]
+                if glv:
+                    k1, _, neg1, _ = glv_split(ks[last])
+                    dig = signed_digits(k1, c, (128 + c - 1) // c)
+                    flip = -1 if neg1 else 1
+                else:
+                    dig = signed_digits(ks[last], c, plain_windows(c))
+                    flip = 1
+                w = max(i for i, d in enumerate(dig) if d)
+                e = flip * dig[w] << (c * w)                               # the last entry added is e S_last
+                total = (2 * e if sign > 0 else 0) * pow(S, last, R) % R    # what the lane must sum to: e + e, or -e + e
+                rest = sum(ks[p] * pow(S, p, R) for p in pts[1:]) % R
+                ks[pts[0]] = (total - rest) * pow(S, -pts[0], R) % R
+                row, dlog = sparse_row(ks)
+                assert dlog == total
+                out.append(("last addition of lane %d %s (%s layout, c = %d)" % (t, "doubles" if sign > 0 else "cancels", "glv" if glv else "plain", c), row, dlog))
+    return out
 
 
 @pytest.fixture(scope="module")
@@ -60,8 +128,8 @@ def crafted_rows():
             for d in digits:
                 for sign in (1, -1):
                     e = {i: sign * d * pow(S, off, R) % R, i + off: d}
-                    if i + 2 * off < N:                   # the walk continues after the doubling / from the point at infinity
-                        e[i + 2 * off] = int.from_bytes(rng.bytes(32), "little") % R
+                    if i + 2 * off < N:                   # the walk continues after the doubling / from the point at infinity (below 2^125: no phi half,
+                        e[i + 2 * off] = int.from_bytes(rng.bytes(15), "little")   # which the GLV walk would sum BEFORE the pair meets)
                     row, dlog = sparse_row(e)
                     out.append(("off=%d i=%d d=%#x sign=%+d" % (off, i, d, sign), row, dlog))
     # the bare pairs: the commitment itself is 2 d S_(i+off) resp. the point at infinity
@@ -69,6 +137,19 @@ def crafted_rows():
         for sign in (1, -1):
             row, dlog = sparse_row({i: sign * pow(S, off, R) % R, i + off: 1})
             out.append(("bare off=%d i=%d sign=%+d" % (off, i, sign), row, dlog))
+    # the same pairs in the PHI halves: k = lambda m (m < 2^125) splits into (0, m), so both entries are summed un-mapped and meet before / at the map
+    for off in (1, 64, 256, 2048):
+        for i in (0, 255):
+            for m in (1, 1 << 100):
+                for sign in (1, -1):
+                    e = {i: sign * LAMBDA * m * pow(S, off, R) % R, i + off: LAMBDA * m % R}   # a mixed lane (both halves) against a phi-only lane
+                    row, dlog = sparse_row(e)
+                    out.append(("phi off=%d i=%d m=%#x sign=%+d" % (off, i, m, sign), row, dlog))
+    for c, w in ((16, 0), (16, 7), (15, 3), (12, 0), (12, 9)):                                  # single digits on both sides: 1337 d and d in window w, phi halves only
+        for sign in (1, -1):
+            row, dlog = sparse_row({40: sign * LAMBDA * (S << (c * w)) % R, 41: LAMBDA * (1 << (c * w)) % R})
+            out.append(("phi digits c=%d w=%d sign=%+d" % (c, w, sign), row, dlog))
+    out += last_addition_rows(rng)
     # three equal partial sums in lanes of one column, and a full workgroup of them
     row, dlog = sparse_row({i: pow(S, 192 - i, R) for i in (0, 64, 128, 192)})
     out.append(("four equal sums, one per wavefront of a workgroup", row, dlog))
@@ -133,9 +214,10 @@ def material(setup_1337):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(1200)
-@pytest.mark.parametrize("budget_gb,want_c", [(210.0, 16), (64.0, 14), (10.0, 11)])
-def test_walk_exceptional_cases_crafted_blobs(kz, setup_1337, material, budget_gb, want_c):
+@pytest.mark.parametrize("budget_gb,want_c,want_c_plain", [(210.0, 16, 16), (64.0, 15, 14), (10.0, 12, 11)])
+def test_walk_exceptional_cases_crafted_blobs(kz, setup_1337, material, budget_gb, want_c, want_c_plain):
     crafted, want_crafted, fillers, want_fill = material
+    want_c = want_c if GLV_WALK else want_c_plain
     fs = kz.FFTSettings(12)
     ks = kz.KZGSettings(fs, setup_1337)
     try:
@@ -157,3 +239,30 @@ def test_crafted_rows_really_collide():
     b = ko.g1_mul(g, ko.fr_from_ints([d * pow(S, i + off, R) % R])[0])
     assert ko.g1_equal(a, b)
     assert ko.g1_equal(ko.g1_add(a, ko.g1_mul(b, ko.fr_from_ints([R - 1])[0])), ko.g1_zero(1))
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(2400)
+def test_plain_layout_in_a_fresh_process():
+    """KZG_HIP_FB_GLV=0: the table layout of rounds 1-4 (one window per c bits of the whole scalar, k_fb_accumulate) stays selectable for A/B runs; the
+    crafted blobs and the table-size tests run against it in a child process (the library reads the variable once)"""
+    import subprocess
+    import sys
+    if not GLV_WALK:
+        pytest.skip("already the plain-layout child")
+    here = os.path.dirname(os.path.abspath(__file__))
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_cold_paths.py"), os.path.join(here, "test_gpu_parity.py"), "-m", "gpu", "-x", "-q", "-k",
+                          "crafted_blobs or every_table_size or table_budget_setter or c16_table or vector_F or batch_shapes"],
+                         env=dict(os.environ, KZG_HIP_FB_GLV="0"), capture_output=True, text=True, timeout=2300)
+    assert res.returncode == 0, res.stdout[-2000:]
+
+
+def test_python_split_matches_the_composition():
+    """CPU: the Python restatement of the split used to build the rows: k == +-|k1| +- k2 lambda mod r, both halves below 2^126.5"""
+    rng = np.random.default_rng(3)
+    for _ in range(2000):
+        k = int.from_bytes(rng.bytes(32), "little") % R
+        k1, k2, n1, n2 = glv_split(k)
+        assert ((-k1 if n1 else k1) + (-k2 if n2 else k2) * LAMBDA) % R == k and k1 < 2 ** 126.5 and k2 < 2 ** 126.5
+    assert glv_split(LAMBDA * 12345)[:2] == (0, 12345) and glv_split(R - LAMBDA * 12345) == (0, 12345, True, True)
+    assert len(last_addition_rows(np.random.default_rng(1))) == 18

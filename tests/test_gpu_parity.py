@@ -679,8 +679,13 @@ def setup_1337():
     return ko.g1_decompress(raw)
 
 
+GLV_WALK = os.environ.get("KZG_HIP_FB_GLV") != "0"   # the table layout of this process (read once by the library): both GLV halves of a scalar walk one
+                                                      # table of ceil(128 / c) windows (default), or the plain layout of rounds 1-4 (one window per c bits of the scalar)
+
+
 def test_commit_c16_table_opt_in(kz, setup_1337):
-    """the 206 GB table (signed 16-bit windows, 16 additions per coefficient) is an explicit opt-in: set_table_budget_gb(210).
+    """the table of signed 16-bit windows, 16 additions per coefficient: 8 windows = 103 GB with the endomorphism (the default budget reaches it),
+    16 windows = 206 GB in the plain layout (an explicit opt-in: set_table_budget_gb(210)).
     Runs before the module's shared 4096-point settings exist, so the device is empty enough for it."""
     fs = kz.FFTSettings(12)
     ks = kz.KZGSettings(fs, setup_1337)
@@ -688,7 +693,7 @@ def test_commit_c16_table_opt_in(kz, setup_1337):
     blobs = np.stack([ko.synthetic_blob(1 + b) for b in range(3)])
     got = ks.commit_to_poly_batch(blobs)
     c, w, nbytes = ks.table_info()
-    assert (c, w) == (16, 16) and 200e9 < nbytes < 210e9
+    assert (c, w) == ((16, 8) if GLV_WALK else (16, 16)) and (100e9 < nbytes < 105e9 if GLV_WALK else 200e9 < nbytes < 210e9)
     assert comp_hex(got[:1])[0] == DERIVED["F_blob_seed1"]["commit_monomial_s1337"]
     assert_points_equal(got[2], ko.lincomb_g1(setup_1337, blobs[2]))
     ks.close(); fs.close()
@@ -698,6 +703,8 @@ def test_commit_c16_table_opt_in(kz, setup_1337):
 def ks4096(kz, setup_1337):
     fs = kz.FFTSettings(12)
     ks = kz.KZGSettings(fs, setup_1337)
+    ks.set_table_budget_gb(62.0)     # 58 GB (c = 15, 2 x 9 windows; plain layout: c = 14, 61 GB): the module's shared settings leave room for the tests that build the
+                                     # default 103 GB tables of their own (test_table_budget_setter_and_default, test_commit_c16_table_opt_in, tests/test_cold_paths.py)
     yield ks
     ks.close()
     fs.close()
@@ -718,16 +725,21 @@ def test_vector_F_and_batch_commit_4096(kz, ks4096, setup_1337):
     assert comp_hex(c)[0] == DERIVED["F_blob_seed1"]["commit_eth_bitrev_lagrange"]
 
 
-@pytest.mark.parametrize("budget_gb,want_c", [(0.05, 0), (0.4, 5), (1.0, 7), (6.0, 10), (20.0, 12), (70.0, 14), (120.0, 14)])
-def test_commit_with_every_table_size(kz, setup_1337, budget_gb, want_c, monkeypatch):
+@pytest.mark.parametrize("budget_gb,want_c,want_c_plain", [(0.05, 0, 0), (0.2, 5, 0), (0.4, 6, 5), (0.6, 7, 6), (1.0, 8, 7), (2.0, 9, 8), (3.0, 10, 9), (6.0, 11, 10), (10.0, 12, 11),
+                                                           (20.0, 13, 12), (40.0, 13, 13), (70.0, 15, 14), (120.0, 16, 14)])
+def test_commit_with_every_table_size(kz, setup_1337, budget_gb, want_c, want_c_plain, monkeypatch):
     # the fixed-base table adapts to the HBM budget: every window size must give the same commitments (incl. edge scalars:
-    # zero digits, digits that carry through several windows, r - 1); 0.05 GB fits no table (bucket path), 120 GB would fit
-    # c = 15, which the sizing rule skips
+    # zero digits, digits that carry through several windows, r - 1, scalars around the GLV split's boundaries); 0.05 GB fits no table (bucket
+    # path); the sizing rule skips window sizes that are dominated (GLV c = 14: 2 x 10 additions like c = 13 at twice the size; plain c = 15)
     monkeypatch.setenv("KZG_HIP_FB_BUDGET_GB", str(budget_gb))
+    want_c = want_c if GLV_WALK else want_c_plain
     fs = kz.FFTSettings(12)
     ks = kz.KZGSettings(fs, setup_1337)
     try:
         edge = [0, 1, 2**14, 2**15, 2**16 - 1, 2**16, (1 << 255) % ko.R_MOD, ko.R_MOD - 1, ko.R_MOD - 2**15, 0x8000800080008000, int("7fff" * 15, 16), int("8000" * 15, 16)]
+        hl = LAMBDA // 2
+        edge += [LAMBDA, LAMBDA - 1, LAMBDA + 1, hl, hl + 1, hl - 1, ko.R_MOD - LAMBDA, ko.R_MOD - hl, ko.R_MOD // 2, ko.R_MOD // 2 + 1, (LAMBDA * (2**126 + 12345)) % ko.R_MOD,
+                 (LAMBDA * int("7fff" * 7, 16) + int("8000" * 7, 16)) % ko.R_MOD, (LAMBDA << 64) % ko.R_MOD, 2**127 - 1, 2**127, 2**128 - 1]
         blob = ko.synthetic_blob(77)[:256].copy()
         blob[:len(edge)] = ko.fr_from_ints(edge)
         got = ks.commit_to_poly(blob)
@@ -1563,17 +1575,18 @@ def test_trusted_setup_from_json(kz, setup_1337):
 
 
 def test_table_budget_setter_and_default(kz, setup_1337, monkeypatch):
-    """default budget 64 GB -> c = 14 for n = 4096; the setter rebuilds at another size; results identical"""
+    """default budget 110 GB -> c = 16 on 8 windows (103 GB) for n = 4096 with the endomorphism (plain layout: c = 14, 61 GB -- c = 15 is skipped);
+    the setter rebuilds at another size; results identical"""
     monkeypatch.delenv("KZG_HIP_FB_BUDGET_GB", raising=False)
     fs = kz.FFTSettings(12)
     ks = kz.KZGSettings(fs, setup_1337)
     blob = ko.synthetic_blob(1)
     c0 = ks.commit_to_poly(blob)
-    assert ks.table_info()[0] == 14 and ks.table_info()[2] <= 64e9
+    assert ks.table_info()[:2] == ((16, 8) if GLV_WALK else (14, 19)) and ks.table_info()[2] <= 110e9
     ks.set_table_budget_gb(1.0)
     assert ks.table_info() == (0, 0, 0)
     c1 = ks.commit_to_poly(blob)
-    assert ks.table_info()[0] == 7
+    assert ks.table_info()[0] == (8 if GLV_WALK else 7)
     assert np.array_equal(c0, c1)
     assert comp_hex(c0[None])[0] == DERIVED["F_blob_seed1"]["commit_monomial_s1337"]
     ks.close(); fs.close()
