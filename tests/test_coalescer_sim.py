@@ -1,0 +1,42 @@
+"""The request coalescer (go-kzg_amd/csrc/coalesce.hpp) against a simulated device -- CPU only.
+
+The reference's API is one polynomial per call from many goroutines (kzg_single_proofs.go:17-19, fk20_single.go:176-196); the library merges
+concurrent calls into batched launches.  The protocol (row tickets, leader = row 0, device slots, futex sleeps) has no GPU in it, so it is
+exercised here with threads against an executor that sleeps like a device: every caller must get ITS result (rows are tagged, lengths are
+ragged), whatever the number of callers, with callers leaving early, with one device slot and with three."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def sim():
+    bdir = os.path.join(ROOT, "tests", "host", "_build")
+    os.makedirs(bdir, exist_ok=True)
+    exe = os.path.join(bdir, "coalesce_sim")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-Wall", "-Wextra", "-Werror", os.path.join(ROOT, "tests", "host", "coalesce_sim.cpp"), "-o", exe])
+    return exe
+
+
+@pytest.mark.parametrize("threads,calls", [(1, 200), (2, 200), (7, 200), (64, 100), (300, 40)])
+def test_every_caller_gets_its_own_result(sim, threads, calls):
+    res = subprocess.run([sim, str(threads), str(calls), "120", "3"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "wrong results: 0" in res.stdout, res.stdout + res.stderr
+
+
+@pytest.mark.parametrize("env", [{"KZG_HIP_COALESCE_EXEC": "1"}, {"KZG_HIP_COALESCE_US": "0"}, {"KZG_HIP_COALESCE_SPIN_US": "0"}, {"KZG_HIP_COALESCE_EXEC": "3", "KZG_HIP_COALESCE_US": "1000"}])
+def test_policies(sim, env):
+    """one batch in flight at a time; no gather window; no spinning before a follower parks; a long window"""
+    res = subprocess.run([sim, "96", "60", "120", "3"], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+    assert res.returncode == 0 and "wrong results: 0" in res.stdout, res.stdout + res.stderr
+
+
+def test_a_lone_caller_is_never_batched_with_a_wait(sim):
+    """one caller: 200 batches of one row, and no gather wait on its path (a_us = 100: the run must stay near 200 x 0.1 ms, far from 200 x the 150 us window on top)"""
+    res = subprocess.run([sim, "1", "200", "100", "1"], capture_output=True, text=True, timeout=120, env=dict(os.environ, KZG_HIP_COALESCE_STATS="1"))
+    assert res.returncode == 0 and "200 batches (avg 1.0 rows, max 1)" in res.stdout, res.stdout
+    gather_ms = float(res.stderr.split("ms waiting for a device slot,")[1].split("ms gathering callers")[0])
+    assert gather_ms < 0.02, res.stderr

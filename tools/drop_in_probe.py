@@ -37,6 +37,7 @@ def main():
         rate, out = ks.bench_drop_in(blobs, t, 100)
         print("native threads %3d: %8.0f commitments/s" % (t, rate))
     if os.environ.get("ONLY"):
+        ks.close(); fs.close()
         return
     print("python threads %3d: %8.0f commitments/s (GIL-bound harness)" % (T, run(ks, blobs, T, 20)))
     prate, _ = ks.bench_drop_in(blobs, T, 50, op=1)
