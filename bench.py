@@ -52,354 +52,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-R_MOD = 52435875175126190479447740508185965837690552500527637822603658699938581184513
-HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8.0 TB/s spec
-N_COEFF = 4096
-# algorithmic bytes of one commitment with the setup resident (scalars 131072 + 96 out), and the
-# setup itself (4096 affine points = 393216 B) counted once per launch.
-BYTES_PER_COMMIT = 131072 + 96
-BYTES_SETUP = 393216
-FK20_BYTES = 851968
-FK20_4096_BYTES = 1310720                  # 131 072 poly + 786 432 xExtFFT + 393 216 proofs
-S_TEST = 1927409816240961209460912649124   # the reference's test secret (kzg_single_proofs_test.go:15): setups longer than eth/trusted_setup.json
-
-
-def splitmix_blobs(base_seed, batch, n=N_COEFF):
-    """SURVEY.md 8(d) synthetic scalars -> Montgomery images, shape (batch, n, 4) uint64 (host-side input synthesis)."""
-    out = np.empty((batch, n, 4), dtype=np.uint64)
-    mask = (1 << 64) - 1
-    rmont = (1 << 256) % R_MOD
-    for b in range(batch):
-        idx = np.arange(1, 4 * n + 1, dtype=np.uint64)
-        with np.errstate(over="ignore"):
-            z = np.uint64((base_seed + b) & mask) + idx * np.uint64(0x9E3779B97F4A7C15)
-            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-            z = z ^ (z >> np.uint64(31))
-        limbs = z.reshape(n, 4)
-        raw = limbs.tobytes()
-        row = bytearray(n * 32)
-        for i in range(n):
-            v = int.from_bytes(raw[32 * i:32 * i + 32], "little") % R_MOD
-            row[32 * i:32 * i + 32] = (v * rmont % R_MOD).to_bytes(32, "little")
-        out[b] = np.frombuffer(bytes(row), dtype=np.uint64).reshape(n, 4)
-    return out
-
-
-_R_LIMBS = [(R_MOD >> (64 * i)) & ((1 << 64) - 1) for i in range(4)]
-
-
-def splitmix_blobs_le32(base_seed, batch, n=N_COEFF):
-    """The same scalars as splitmix_blobs, in STANDARD form as 32 little-endian bytes each (batch, n, 32) uint8, fully
-    vectorised (the 256-bit value is < 2^256 < 3 r: at most two conditional subtractions of r).  The Montgomery conversion
-    is then done on the device with kzg_hip_fr_from_le32 (bls.FrFrom32 over a slice)."""
-    seeds = (np.uint64(base_seed & ((1 << 64) - 1)) + np.arange(batch, dtype=np.uint64))[:, None]
-    idx = np.arange(1, 4 * n + 1, dtype=np.uint64)[None, :]
-    with np.errstate(over="ignore"):
-        z = seeds + idx * np.uint64(0x9E3779B97F4A7C15)
-        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        z = z ^ (z >> np.uint64(31))
-        v = z.reshape(batch, n, 4)
-        r = np.array(_R_LIMBS, dtype=np.uint64)
-        for _ in range(2):
-            ge = np.ones(v.shape[:2], dtype=bool)          # v >= r, lexicographic from the top limb
-            decided = np.zeros(v.shape[:2], dtype=bool)
-            for k in (3, 2, 1, 0):
-                gt, lt = v[..., k] > r[k], v[..., k] < r[k]
-                ge = np.where(~decided & lt, False, ge)
-                decided |= gt | lt
-            borrow = np.zeros(v.shape[:2], dtype=np.uint64)
-            out = v.copy()
-            for k in range(4):
-                d = v[..., k] - r[k] - borrow
-                borrow = ((v[..., k] < r[k] + borrow) | ((r[k] + borrow) < r[k])).astype(np.uint64)
-                out[..., k] = d
-            v = np.where(ge[..., None], out, v)
-    return np.ascontiguousarray(v).view(np.uint8).reshape(batch, n, 32)
-
-
-def dist_env():
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    return rank, world, local
-
-
-def timed_steps(step_fn, steps, warmup, sync_fn, barrier_fn, max_over_ranks_fn):
-    """W untimed steps, then exactly K steps bracketed by barrier + device sync; returns max-over-ranks seconds.
-    Backend-agnostic so that tests/test_bench_dist.py can drive it with gloo on CPU."""
-    for _ in range(warmup):
-        step_fn()
-    sync_fn()
-    barrier_fn()
-    sync_fn()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step_fn()
-    sync_fn()
-    barrier_fn()
-    t1 = time.perf_counter()
-    return max_over_ranks_fn(t1 - t0)
-
-
-def shard_units(total_units, world, rank):
-    """contiguous shard [lo, hi) of `total_units` for `rank` (used for strong-scaling workloads and FK20Multi positions)"""
-    base, rem = divmod(total_units, world)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
-
-
-def _cpu_worker(seconds_budget):
-    """one host core: as many oracle LinCombG1(4096) as fit the budget; returns (count, seconds)"""
-    from oracle import koracle as ko
-    raw = np.frombuffer(open(os.path.join(ROOT, "tests", "golden", "trusted_setup_g1.bin"), "rb").read(), dtype=np.uint8)
-    setup = ko.g1_decompress(raw)
-    blobs = [ko.synthetic_blob(1 + b) for b in range(4)]
-    ko.lincomb_g1(setup, blobs[0])
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < seconds_budget:
-        ko.lincomb_g1(setup, blobs[n % 4])
-        n += 1
-    return n, time.perf_counter() - t0
-
-
-def _port_vs_published():
-    """the oracle port timed on the three transforms the reference PUBLISHES numbers for (BENCH.md, Kilic column, Ryzen 9 5950X, 1 thread),
-    so that a reader can rescale the port's commitments/s: ratio = port time / published time (> 1: the port is slower than Go + Kilic's
-    assembly on that CPU).  FFT over G1 is estimated from the oracle's scalar multiplication: 12 x 2048 butterflies, each one MulG1
-    (fft_g1.go:44-55 multiplies every butterfly) -- timing a whole transform would take a minute of the bench."""
-    from oracle import koracle as ko
-    fs = ko.FFTSettings(12)
-    blob = ko.synthetic_blob(12)
-
-    def per_call(fn, min_s=1.0):
-        fn()
-        n, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < min_s:
-            fn()
-            n += 1
-        return (time.perf_counter() - t0) / n
-    t_fft = per_call(lambda: fs.fft(blob))
-    half = blob[:2048].copy()
-    t_das = per_call(lambda: fs.das_fft_extension(half.copy()))
-    gen = ko.g1_generator()
-    ks_ = [ko.fr_from_ints([int.from_bytes(os.urandom(32), "little") % R_MOD])[0] for _ in range(8)]
-    it = iter(range(1 << 30))
-    t_mul = per_call(lambda: ko.g1_mul(gen, ks_[next(it) % 8]), 1.5)
-    pub = {"fft_fr_scale12_ns": 1911871, "das_fft_extension_scale12_ns": 1169011, "fft_g1_scale12_ns": 3745748396}
-    mine = {"fft_fr_scale12_ns": t_fft * 1e9, "das_fft_extension_scale12_ns": t_das * 1e9, "fft_g1_scale12_ns": 12 * 2048 * t_mul * 1e9}
-    return {"port_ns": mine, "published_ns": pub, "port_over_published": {k: mine[k] / pub[k] for k in pub},
-            "sources": "BENCH.md:43 (FFT over F_r), :31 (DAS FFT extension), :55 (FFT over G1), scale 12",
-            "mul_g1_port_us": t_mul * 1e6, "fft_g1_is_estimate": "12 x 2048 x MulG1 of the port (additions not counted)"}
-
-
-def cpu_baseline(seconds_budget=6.0):
-    """oracle (kind 'port'): Kilic-style bls.LinCombG1 on 4096 points.  `value` = ONE thread (the reference is single-threaded);
-    `all_cores` = one blob per core on every host core (the metric is a per-second throughput).  Must run before the
-    process initialises HIP (the all-cores leg forks)."""
-    import multiprocessing as mp
-    nproc = os.cpu_count() or 1
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else nproc
-    try:   # a container's CPU quota (cgroup v2) bounds what "all cores" can mean here
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            cores = max(1, min(cores, int(float(quota) / float(period) + 0.999)))
-    except (OSError, ValueError):
-        pass
-    model = "unknown"
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                model = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
-    go = shutil.which("go")
-    go_version = None
-    if go:
-        try:
-            go_version = subprocess.run([go, "version"], capture_output=True, text=True, timeout=20).stdout.strip()
-        except (OSError, subprocess.SubprocessError):
-            go_version = "present, `go version` failed"
-    n1, dt1 = _cpu_worker(seconds_budget)
-    try:
-        calib = _port_vs_published()
-    except Exception as e:                                  # noqa: BLE001
-        calib = {"error": "%s: %s" % (type(e).__name__, e)}
-    t0 = time.perf_counter()
-    with mp.get_context("fork").Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [seconds_budget] * cores)
-    wall = time.perf_counter() - t0
-    total = sum(r[0] for r in res)
-    return {"value": n1 / dt1, "unit": "commitments/s", "cores": 1, "kind": "port",
-            "sample": "%d x LinCombG1(n=4096) in %.1f s, oracle/kzg_oracle.c (Kilic-style Pippenger c=9), 1 thread" % (n1, dt1),
-            "cpu_model": model, "nproc": nproc, "usable_cores": cores,
-            "all_cores": {"value": sum(r[0] / r[1] for r in res), "unit": "commitments/s", "cores": cores,
-                          "sample": "%d x LinCombG1(n=4096), one blob per core on %d processes, %.1f s wall" % (total, cores, wall)},
-            "go_toolchain": go_version or "absent (`go`: command not found): the Go/Kilic reference cannot be timed on this host (BASELINE.md 3)",
-            "port_vs_published": calib,
-            "reference_published": "BENCH.md Kilic column, Ryzen 9 5950X, 1 thread: see reference_benchmarks and port_vs_published"}
-
-
-def self_launch(n_ranks):
-    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run (one process per GPU,
-    rendezvous on 127.0.0.1 with a kernel-chosen port), pass their stderr through, and print exactly ONE line on stdout: rank 0's
-    JSON line.  Anything else a rank or the launcher wrote to stdout goes to stderr.  Returns the exit code for sys.exit."""
-    import signal
-    import socket
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KZG_BENCH_SELF_LAUNCHED="1")
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this driver
-    env.setdefault("OMP_NUM_THREADS", "1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    sys.stderr.write("[bench.py] no WORLD_SIZE in the environment: launching %d ranks: %s\n" % (n_ranks, " ".join(cmd)))
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
-    try:
-        out, _ = proc.communicate()
-    except BaseException:
-        os.killpg(proc.pid, signal.SIGKILL)                  # the launcher AND its ranks (own session), nothing else
-        proc.wait()
-        raise
-    lines = [l for l in out.splitlines() if l.startswith('{"metric"')]
-    for l in out.splitlines():
-        if not l.startswith('{"metric"'):
-            sys.stderr.write(l + "\n")
-    if proc.returncode != 0 or len(lines) != 1:
-        sys.stderr.write("[bench.py] the %d-rank run ended with exit code %d and %d JSON lines\n" % (n_ranks, proc.returncode, len(lines)))
-        return proc.returncode or 1
-    print(lines[0])
-    return 0
-
-
-def run_in_process_child(devices, timeout=300):
-    """the multi-device leg in a child process (a crash or a hang there must not cost the bench line): returns its `in_process` object"""
-    cmd = [sys.executable, os.path.abspath(__file__), "--in-process-child", "--devices", ",".join(str(d) for d in devices)]
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK")}
-    try:
-        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
-        for line in reversed(res.stdout.splitlines()):
-            if line.startswith('{"in_process"'):
-                return json.loads(line)["in_process"]
-        return {"error": "child exit code %d, no result line" % res.returncode, "stderr_tail": res.stderr[-600:]}
-    except subprocess.TimeoutExpired:
-        return {"error": "child timed out after %d s" % timeout}
-    except Exception as e:                                    # noqa: BLE001
-        return {"error": "%s: %s" % (type(e).__name__, e)}
-
-
-def in_process_child(devices):
-    """Times the multi-device handle of the C ABI (kzg_hip_multi_*: what a Go caller gets from NewMultiKZGSettings) on `devices`: host-buffer
-    batches divided among the devices (PCIe-inclusive, the only form a Go slice can take) and ONE polynomial sharded inside the library.
-    On a single device the one-polynomial legs also run on the list [d, d] (two entries, one GPU): that measures the orchestration and the
-    exchange, not a speed-up.  Prints one line {"in_process": {...}}."""
-    import gokzg_amd as kz
-    golden = os.path.join(ROOT, "tests", "golden")
-    pins = json.load(open(os.path.join(golden, "fk20_pins.json")))
-    out = {"devices": devices, "entry": "kzg_hip_multi_* (include/kzg_hip.h), host buffers, blocking calls"}
-
-    def med(fn, reps=5, warm=2):
-        for _ in range(warm):
-            fn()
-        ts = []
-        for _ in range(reps):
-            t0 = time.perf_counter()
-            fn()
-            ts.append((time.perf_counter() - t0) * 1e3)
-        return float(np.median(ts))
-
-    try:
-        D = len(devices)
-        fs0 = kz.FFTSettings(12, device=devices[0])
-        raw = np.frombuffer(open(os.path.join(golden, "trusted_setup_g1.bin"), "rb").read(), dtype=np.uint8)
-        setup = fs0.from_compressed_g1(raw)
-
-        def mont(seed, batch, n=N_COEFF):
-            o, ok = fs0.fr_from_32(splitmix_blobs_le32(seed, batch, n).reshape(-1, 32))
-            assert ok
-            return o.reshape(batch, n, 4)
-
-        def sha(fsx, pts):
-            return hashlib.sha256(fsx.to_compressed_g1(pts).tobytes()).hexdigest()
-        m = kz.MultiKZGSettings(devices, 12, setup)
-        out["transport"], out["transport_note"], out["transport_self_test"] = m.transport, m.transport_note, m.transport_self_test
-        per = 1024
-        blobs = mont(1, per * D)
-        exp_f = json.load(open(os.path.join(golden, "derived_vectors.json")))["F_blob_seed1"]["commit_monomial_s1337"]
-        got = m.commit_to_poly_batch(blobs)
-        ks0 = m.kzg_settings(0)
-        one_dev = ks0.commit_to_poly_batch(blobs[:per])
-        ms_all = med(lambda: m.commit_to_poly_batch(blobs), 3, 1)
-        ms_one = med(lambda: ks0.commit_to_poly_batch(blobs[:per]), 3, 1)
-        with kz.pinned(blobs):                                  # kzg_hip_host_register: every device reads its share of the range in place over PCIe
-            ms_pin = med(lambda: m.commit_to_poly_batch(blobs), 3, 1)
-            pin_same = bool(np.array_equal(m.commit_to_poly_batch(blobs), got))
-        out["commit_to_poly_batch"] = {"blobs_per_device": per, "table": "library default (64 GB, 14-bit windows) on every device",
-                                       "commitments_per_s": per * D / ms_all * 1e3, "one_device_same_call_per_s": per / ms_one * 1e3,
-                                       "commitments_per_s_pinned_input": per * D / ms_pin * 1e3, "pinned_same_results": pin_same,
-                                       "scaling_vs_one_device": (per * D / ms_all) / (per / ms_one),
-                                       "vector_F": fs0.to_compressed_g1(got[:1])[0].tobytes().hex() == exp_f, "first_share_equals_one_device": bool(np.array_equal(got[:per], one_dev))}
-        # FK20 (config 4a): batches divided among the devices, and ONE polynomial sharded inside the library
-        mfk = kz.MultiFK20SingleSettings(m, 4096)
-        fper = 32
-        polys = mont(4, fper * D)[:, :2048, :].copy()
-        pr = mfk.da_using_fk20_batch(polys)
-        ms_fk = med(lambda: mfk.da_using_fk20_batch(polys), 2, 1)
-        fk0 = kz.FK20SingleSettings(ks0, 4096)
-        ms_fk1 = med(lambda: fk0.da_using_fk20_batch(polys[:fper]), 2, 1)
-        out["da_using_fk20_batch"] = {"polynomials_per_device": fper, "all_proofs_per_s": fper * D / ms_fk * 1e3, "one_device_same_call_per_s": fper / ms_fk1 * 1e3,
-                                      "byte_pin_row0": sha(fs0, pr[0]) == pins["config4a_da_using_fk20_seed4"]["sha256"]}
-        one = {"unsharded_one_device_ms": med(lambda: fk0.da_using_fk20(polys[0]))}
-        for mode in ("gather", "sharded"):
-            if D == 1 and mode == "sharded":
-                continue
-            m.set_fft_sharding(mode)
-            e0 = m.exchanges
-            okp = sha(fs0, mfk.da_using_fk20(polys[0])) == pins["config4a_da_using_fk20_seed4"]["sha256"]
-            one[mode] = {"ms": med(lambda: mfk.da_using_fk20(polys[0])), "all_gathers_per_call": None, "byte_pin": okp}
-            e1 = m.exchanges
-            mfk.da_using_fk20(polys[0])
-            one[mode]["all_gathers_per_call"] = m.exchanges - e1
-        out["da_using_fk20_one_polynomial"] = one
-        fk0.close(); mfk.close(); m.close()
-
-        # config 5: ONE DAUsingFK20Multi (scale 16, chunk 16) over the devices; on a single device also over two entries of it
-        fs16 = kz.FFTSettings(16, device=devices[0])
-        sec = np.frombuffer((S_TEST * ((1 << 256) % R_MOD) % R_MOD).to_bytes(32, "little"), dtype=np.uint64).reshape(1, 4)
-        setup16 = fs16.generate_testing_setup_g1(sec, 65536)
-        poly5 = mont(5, 1, 32768)[0]
-        pin5 = pins["config5_da_using_fk20_multi_seed5"]["sha256"]
-        cfg5 = {}
-        for devs in ([devices] if D > 1 else [devices, devices * 2]):
-            m16 = kz.MultiKZGSettings(devs, 16, setup16)
-            mfkm = kz.MultiFK20MultiSettings(m16, 65536, 16)
-            row = {"devices": devs, "transport": m16.transport}
-            if "unsharded_one_device_ms" not in cfg5:
-                fkm0 = kz.FK20MultiSettings(m16.kzg_settings(0), 65536, 16)
-                cfg5["unsharded_one_device_ms"] = med(lambda: fkm0.da_using_fk20_multi(poly5), 5, 4)   # (the first calls after building 47 GB of tables run at a lower clock)
-                fkm0.close()
-            for mode in ("gather", "sharded"):
-                if len(devs) == 1 and mode == "sharded":
-                    continue
-                m16.set_fft_sharding(mode)
-                okp = sha(fs16, mfkm.da_using_fk20_multi(poly5)) == pin5
-                e1 = m16.exchanges
-                row[mode] = {"ms": med(lambda: mfkm.da_using_fk20_multi(poly5), 5, 2), "byte_pin": okp}
-                row[mode]["all_gathers_per_call"] = (m16.exchanges - e1) // 7
-            cfg5["%d_entries" % len(devs)] = row
-            mfkm.close(); m16.close()
-        cfg5["note"] = ("entries of ONE device share its SIMDs: the figures there are orchestration + exchange cost, not a speed-up" if D == 1 else
-                        "Toeplitz stage by output position on every device; gather = transforms on the first device, sharded = five all-gathers")
-        out["da_using_fk20_multi_one_polynomial_scale16"] = cfg5
-        fs16.close(); fs0.close()
-    except Exception as e:                                    # noqa: BLE001
-        import traceback
-        out["error"] = "%s: %s | %s" % (type(e).__name__, e, traceback.format_exc().strip().splitlines()[-3:])
-    print(json.dumps({"in_process": out}))
-    return 0
+from benchlib.workload import *  # noqa: E402,F401,F403  (constants, splitmix_blobs[_le32], dist_env, timed_steps, shard_units: tests and tools use them as bench.X)
+from benchlib.workload import R_MOD, HBM_PEAK_GBS, N_COEFF, BYTES_PER_COMMIT, BYTES_SETUP, FK20_BYTES, FK20_4096_BYTES, S_TEST  # noqa: E402,F401
+from benchlib.cpu import cpu_baseline  # noqa: E402
+from benchlib.launch import self_launch  # noqa: E402
+from benchlib.in_process import run_in_process_child, in_process_child  # noqa: E402
 
 
 def main():
@@ -1205,8 +862,20 @@ def main():
         except (KeyError, TypeError):
             pass
     if rank == 0:
+        # BASELINE's metric has two halves; `value` is the commitments half, the FK20 half on the metric's literal 4096-element blob (config 4b)
+        # rides at top level beside it with its own roofline, and once more as plain numbers inside `roofline` (a reader that keeps only the
+        # contract's keys still sees both halves)
+        fk_half = fk20_4096["value"] if isinstance(fk20_4096, dict) and "value" in fk20_4096 else None
+        if roofline is not None:
+            roofline["second_half_of_metric"] = {"metric": "FK20 all-proofs/s, 4096-element blob (FK20Single, 4096 coefficients -> 4096 proofs)", "value": fk_half,
+                                                 "unit": "all-proofs/s", "roofline_frac": (roofline_fk20_4096 or {}).get("frac"),
+                                                 "mac_frac": ((roofline_fk20_4096 or {}).get("mac") or {}).get("frac"),
+                                                 "fk20_2048_to_4096_all_proofs_per_s": fk20["value"] if isinstance(fk20, dict) and "value" in fk20 else None}
+        if isinstance(base, dict) and isinstance(base.get("all_cores"), dict):   # flat copies: nested objects of cpu_baseline are dropped by some readers
+            base["value_all_cores"], base["cores_all"] = base["all_cores"].get("value"), base["all_cores"].get("cores")
         print(json.dumps({
-            "metric": "KZG commitments/sec (CommitToPoly, 4096-element blob)", "value": value, "unit": "commitments/s",
+            "metric": "KZG commitments/sec (CommitToPoly, 4096-element blob); FK20 half: value_fk20_4096", "value": value, "unit": "commitments/s",
+            "value_fk20_4096": fk_half, "unit_fk20_4096": "all-proofs/s", "roofline_fk20_4096": roofline_fk20_4096,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": secs / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "dtype_note": "30/32-bit limbs in u32 lanes, 64-bit accumulators (v_mad_u64_u32): 381-bit F_p and 255-bit F_r Montgomery arithmetic",
             "data": "synthetic",
