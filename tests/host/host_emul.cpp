@@ -98,6 +98,52 @@ uint32_t he_fr_fft4096(const fr *in, uint64_t n_in, fr *out, const fr *roots, ui
     for (uint32_t t = 0; t < 1024; t++) { if (scale) fr4::pass_last<true>(t, lds.data(), tw.data(), sc, out); else fr4::pass_last<false>(t, lds.data(), tw.data(), sc, out); }
     return worst;
 }
+// k_fr_fft4096_r16 lane by lane: 256 lanes x 16 register values, the two transpositions through an LDS area of HALF the transform in two stages
+// each (a barrier == finishing the loop over the lanes).  Reports the largest word seen in the LDS area; *conflicts receives the number of
+// (stage, access, half wavefront, limb) groups of 32 lanes that did NOT hit 32 different banks (the address maps a1 / a2 promise zero).
+uint32_t he_fr_fft4096_r16(const fr *in, uint64_t n_in, fr *out, const fr *roots, uint64_t W, const fr *scale, uint32_t *conflicts) {
+    std::vector<uint32_t> tw(fr4::TW_WORDS), lds(9 * fr16::HALF, 0);
+    fr4::build_twiddles(roots, W, tw.data());
+    struct lane { frl a[16], b[16]; };
+    std::vector<lane> L(256);
+    uint32_t worst = 0, bad = 0;
+    auto scan = [&]() { for (uint32_t v : lds) if (v > worst) worst = v; };
+    // bank check of one access of one half wavefront: the 32 word addresses of limb 0
+    auto banks = [&](int which, uint32_t t0, auto posfn) {
+        uint32_t seen = 0;
+        for (uint32_t t = t0; t < t0 + 32; t++) { const uint32_t p = posfn(t), a = which == 1 ? fr16::a1(p) : fr16::a2(p); seen |= 1u << (a & 31u); }
+        if (seen != 0xffffffffu) bad++;
+    };
+    for (uint32_t t = 0; t < 256; t++) { fr x[16]; fr16::load(t, in, n_in, 1, 0, x); fr16::pass_a(x, L[t].b, tw.data()); }
+    for (uint32_t s = 0; s < 2; s++) {
+        for (uint32_t t = 0; t < 256; t++) fr16::stage_put<1>(lds.data(), L[t].b, 16u * fr16::bitrev8(fr16::lane_a_nat(t)), 1u, s ^ ((t >> 6) & 1u));
+        scan();
+        for (uint32_t t = 0; t < 256; t++) { uint32_t g, j; fr16::lane_b(t, g, j); fr16::stage_get<1>(lds.data(), L[t].a, 256u * g + j, 16u, s ^ (t >> 7)); }
+        for (uint32_t t0 = 0; t0 < 256; t0 += 32)
+            for (uint32_t r = 0; r < 8; r++) {
+                const uint32_t kw = 8u * (s ^ ((t0 >> 6) & 1u)) + r, kr = 8u * (s ^ (t0 >> 7)) + r;
+                banks(1, t0, [&](uint32_t t) { return 16u * fr16::bitrev8(fr16::lane_a_nat(t)) + kw; });
+                banks(1, t0, [&](uint32_t t) { uint32_t g, j; fr16::lane_b(t, g, j); return 256u * g + j + 16u * kr; });
+            }
+    }
+    for (uint32_t t = 0; t < 256; t++) { uint32_t g, j; fr16::lane_b(t, g, j); fr16::pass_b(L[t].a, j, tw.data()); }
+    for (uint32_t s = 0; s < 2; s++) {
+        for (uint32_t t = 0; t < 256; t++) { uint32_t g, j; fr16::lane_b(t, g, j); fr16::stage_put<2>(lds.data(), L[t].a, 256u * g + j, 16u, s ^ ((t >> 6) & 1u)); }
+        scan();
+        for (uint32_t t = 0; t < 256; t++) fr16::stage_get<2>(lds.data(), L[t].b, t, 256u, s ^ (t >> 7));
+        for (uint32_t t0 = 0; t0 < 256; t0 += 32)
+            for (uint32_t r = 0; r < 8; r++) {
+                const uint32_t kw = 8u * (s ^ ((t0 >> 6) & 1u)) + r, kr = 8u * (s ^ (t0 >> 7)) + r;
+                banks(2, t0, [&](uint32_t t) { uint32_t g, j; fr16::lane_b(t, g, j); return 256u * g + j + 16u * kw; });
+                banks(2, t0, [&](uint32_t t) { return t + 256u * kr; });
+            }
+    }
+    frl sc = frl_zero();
+    if (scale) sc = frl_const_from_kilic(*scale);
+    for (uint32_t t = 0; t < 256; t++) { fr16::pass_c(L[t].b, t, tw.data()); if (scale) fr16::store<true>(t, L[t].b, sc, out); else fr16::store<false>(t, L[t].b, sc, out); }
+    if (conflicts) *conflicts = bad;
+    return worst;
+}
 uint32_t he_fr_fft_small(uint32_t logm, const fr *in, uint64_t in_stride, uint64_t n_in, uint64_t batch, fr *out, const fr *roots, uint64_t W, const fr *scale) {
     std::vector<uint32_t> tw(fr4::TW_WORDS);
     fr4::build_twiddles(roots, W, tw.data());

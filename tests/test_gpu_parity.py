@@ -258,6 +258,21 @@ def test_fr_radix2_kernels_in_a_fresh_process():
     assert res.returncode == 0, res.stdout[-1500:]
 
 
+def test_fr_fft4096_both_forms_in_fresh_processes():
+    """the 4096-point transform has a 1024-lane form (k_fr_fft4096_r4: one workgroup per CU) and a 256-lane form (k_fr_fft4096_r16: 16 values per
+    lane in registers, two workgroups per CU); whichever is the default, BOTH are forced in child processes (KZG_HIP_FR_FFT=r4 / r16) through the
+    tests that reach a 4096-point transform: the reference KATs, every oracle comparison, rows of longer transforms, FK20 vectors, the DAS flow"""
+    import subprocess
+    import sys
+    if os.environ.get("KZG_HIP_FR_FFT"):
+        pytest.skip("already a forced child")
+    for form in ("r16", "r4"):
+        res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k",
+                              "fft_fr or inv_fft or fr_lazy or above_65536 or scale_17 or vector_C or vector_D or full_das_flow or zero_poly_and_recover or config1"],
+                             env=dict(os.environ, KZG_HIP_FR_FFT=form), capture_output=True, text=True, timeout=1500)
+        assert res.returncode == 0, (form, res.stdout[-1500:])
+
+
 def test_fft_fr_batch_and_config1_roundtrip(kz):
     # BASELINE config 1: FFT_Fr scale 12 forward + inverse round trip on blob(seed 12)
     fs, ofs = kz.FFTSettings(12), ko.FFTSettings(12)

@@ -359,6 +359,31 @@ def test_fr_fft4096_radix4_emulation_matches_oracle(he, n_in, inv):
     assert worst < 6 * 2**29
 
 
+@pytest.mark.parametrize("n_in,inv", [(4096, False), (4096, True), (2048, False), (1, False), (0, False), (3000, True)])
+def test_fr_fft4096_r16_emulation_matches_oracle(he, n_in, inv):
+    """k_fr_fft4096_r16 (256 lanes x 16 register-resident values, two transpositions through an LDS area of half the transform) lane by lane on the
+    host == the oracle's FFT (fft_fr.go:30-105), bit for bit; what crosses the LDS stays below 6 * 2^29; every half wavefront hits 32 different
+    banks in every write and every read of both transpositions (the address maps a1 / a2)"""
+    rng = np.random.default_rng(1600 + n_in + inv)
+    fs = ko.FFTSettings(13)
+    vals = rand_fr(rng, 4096)
+    if n_in >= 8:
+        vals[:3] = ko.fr_from_ints([0, ko.R_MOD - 1, 1])
+    padded = vals.copy()
+    padded[n_in:] = 0
+    want = fs.fft(padded, inv=inv)
+    roots = fs.reverse_roots() if inv else fs.expanded_roots()
+    out = ko.fr_empty(4096)
+    scale = ko.fr_from_ints([pow(4096, -1, ko.R_MOD)]) if inv else None
+    conflicts = C.c_uint32(99)
+    he.he_fr_fft4096_r16.restype = C.c_uint32
+    he.he_fr_fft4096_r16.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    worst = he.he_fr_fft4096_r16(p(np.ascontiguousarray(vals[:max(n_in, 1)])), n_in, p(out), p(roots), 8192, p(scale) if inv else None, C.byref(conflicts))
+    assert np.array_equal(out, want)
+    assert worst < 6 * 2**29
+    assert conflicts.value == 0
+
+
 @pytest.mark.parametrize("logm", list(range(2, 12)))
 def test_fr_fft_small_emulation_matches_oracle(he, logm):
     """k_fr_fft_small lane by lane on the host: 4096 / m transforms of m = 4 .. 2048 points through the first passes of the 4096-point network (odd
