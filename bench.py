@@ -119,7 +119,7 @@ def main():
     golden = os.path.join(ROOT, "tests", "golden")
     pins = json.load(open(os.path.join(golden, "fk20_pins.json")))
     pmc = {}
-    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):   # counters of the committed rocprofv3 passes (tools/profile_round.sh)
+    for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):   # counters of the committed rocprofv3 passes (tools/profile_round.sh)
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             pmc["_file"] = "profiles/" + name
@@ -128,7 +128,7 @@ def main():
             continue
 
     shapes, shapes_file = [], None
-    for name in ("r04_kernel_shapes.json",):                 # (kernel, grid, workgroup) rows of the committed rocprofv3 kernel trace (tools/rocprof_summary.py)
+    for name in ("r05_kernel_shapes.json", "r04_kernel_shapes.json"):                 # (kernel, grid, workgroup) rows of the committed rocprofv3 kernel trace (tools/rocprof_summary.py)
         try:
             shapes = json.load(open(os.path.join(ROOT, "profiles", name)))["rows"]
             shapes_file = "profiles/" + name
@@ -142,8 +142,8 @@ def main():
         calls = sum(r["calls"] for r in rows_)
         if not calls:
             return None, None
-        return sum(r["avg_us"] * r["calls"] for r in rows_) / calls * 1e-3, "profiles/r04_kernel_stats.md (rows: %s): %s, grid %d, workgroup %d (%d launches)" % (
-            shapes_file, " + ".join(sorted(set(r["kernel"] for r in rows_))), grid, wg, calls)
+        return sum(r["avg_us"] * r["calls"] for r in rows_) / calls * 1e-3, "%s (rows: %s): %s, grid %d, workgroup %d (%d launches)" % (
+            shapes_file.replace("kernel_shapes.json", "kernel_stats.md"), shapes_file, " + ".join(sorted(set(r["kernel"] for r in rows_))), grid, wg, calls)
 
     def mont_blobs(seed, batch, n=N_COEFF):
         """synthetic scalars as Montgomery images: vectorised splitmix + mod r on the host, FrFrom32 on the device"""
@@ -283,7 +283,7 @@ def main():
         try:   # HBM bytes per launch from the committed PMC passes (profiles/), only when the workload matches that measurement; the counter
             # passes ran 512-blob launches: the work per blob is identical at every batch of 512 and more (one workgroup per blob), so the
             # per-launch counts scale with the batch (stated in traffic_source)
-            if pm["kernel"] == "k_" + dominant.decode() and pm["n"] == N_COEFF and pm["table_c"] == tab_c and B >= pm["batch"] and B % pm["batch"] == 0:
+            if pm["kernel"] == "k_" + dominant.decode() and pm["n"] == N_COEFF and pm["table_c"] == tab_c and pm.get("table_windows", tab_w) == tab_w and B >= pm["batch"] and B % pm["batch"] == 0:
                 pm_sc = B / pm["batch"]
                 traffic = (pm["fetch_bytes_per_launch"] + pm["write_bytes_per_launch"]) * pm_sc
                 pm_ok = True
