@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Builds profiles/r05_pmc.json from the output of tools/profile_round4.sh
+"""Builds profiles/r05_pmc.json from the output of tools/profile_round5.sh
 (gpurun_out/prof_r05/{pmc_rows.jsonl, kernel_stats.md, bench_line.json}): counters at the launch shapes bench.py times by default."""
 import collections
 import json
@@ -32,7 +32,7 @@ def entry(k, units, unit_name, per_launch_units, fetch_x2, extra=None):
 
 L = bl["roofline"]["secondary"]["fk20"]["launches_per_step"]
 pm = {
-    "source": "rocprofv3 --pmc <pass> --kernel-trace --output-format csv (tools/profile_round4.sh r05), 1x MI355X, passes FETCH_SIZE | WRITE_SIZE | SQ group 1 + GRBM | SQ group 2; "
+    "source": "rocprofv3 --pmc <pass> --kernel-trace --output-format csv (tools/profile_round5.sh r05), 1x MI355X, passes FETCH_SIZE | WRITE_SIZE | SQ group 1 + GRBM | SQ group 2; "
               "launch shapes = bench.py's defaults (4096 blobs, 1024 polynomials, 1024 F_r transforms per launch); FETCH_SIZE / WRITE_SIZE in KiB as reported; SQ_INSTS_* count wave64 "
               "instructions; SQ_WAVE_CYCLES = SQ_ACTIVE_INST_ANY + SQ_WAIT_INST_ANY + SQ_WAIT_ANY in quad-cycles summed over waves; GRBM_GUI_ACTIVE summed over the 8 XCDs",
     "k_fb_accumulate": entry("k_fb_accumulate", 4096, "batch", "4096 blobs of 4096 coefficients", False, {"n": 4096, "table_c": 16, "table_windows": 8, "additions_per_coefficient": 16, "walk": "k_fb_accumulate_glv: both GLV halves of a scalar walk the same 8 windows", "vgprs": 256}),
@@ -53,14 +53,14 @@ print("ok", {k: v.get("fetch_bytes_per_launch") for k, v in pm.items() if isinst
 
 
 def kernel_stats(trace_dir):
-    """profiles/r05_kernel_stats.md + r05_kernel_shapes.json from the trace step of tools/profile_round4.sh (gpurun_out/<trace_dir>)"""
+    """profiles/r05_kernel_stats.md + r05_kernel_shapes.json from the trace step of tools/profile_round5.sh (gpurun_out/<trace_dir>)"""
     src_ = os.path.join(R, "gpurun_out", trace_dir)
     d_ = json.loads(open(os.path.join(src_, "bench_line.json")).read())
     t_ = json.loads(open(os.path.join(src_, "trace_bench.json")).read().strip().splitlines()[-1])
     rows_ = json.load(open(os.path.join(src_, "kernel_shapes.json")))["rows"]
     r_ = [x for x in rows_ if x["kernel"].startswith("k_fb_accumulate") and x["grid"] == 1048576 and x["workgroup"] == 256][0]
     avg = r_["avg_us"] / 1e3
-    hdr = """# r05 -- kernel trace of `python bench.py --no-cpu-baseline --no-extras --no-in-process` at its default step sizes (rocprofv3 --kernel-trace --stats, tools/profile_round4.sh), 1x MI355X
+    hdr = """# r05 -- kernel trace of `python bench.py --no-cpu-baseline --no-extras --no-in-process` at its default step sizes (rocprofv3 --kernel-trace --stats, tools/profile_round5.sh), 1x MI355X
 
 One row per LAUNCH SHAPE (kernel, grid, workgroup) -- tools/rocprof_summary.py; `r05_kernel_shapes.json` holds the same rows for bench.py, which prints the
 row of the launch it puts on its roofline line as `roofline.profile_avg_ms` beside its own HIP-event figure.
@@ -78,7 +78,7 @@ Profiled line: %d commitments/s (%.2f ms per 4096-blob step), FK20 %d all-proofs
        t_["fk20_4096"]["value"], d_["value"], d_["ms_per_step"], d_["fk20"]["value"], d_["fk20_4096"]["value"],
        d_["reference_benchmarks"]["fft_fr_scale12_per_s"]["value"] / 1e6, d_["reference_benchmarks"]["das_fft_extension_scale12_per_s"]["value"] / 1e6)
     open(os.path.join(R, "profiles", "r05_kernel_stats.md"), "w").write(hdr + open(os.path.join(src_, "kernel_stats.md")).read())
-    json.dump({"source": "rocprofv3 --kernel-trace --stats of `python bench.py --no-cpu-baseline --no-extras --no-in-process` (tools/profile_round4.sh); one row per (kernel, grid, workgroup)",
+    json.dump({"source": "rocprofv3 --kernel-trace --stats of `python bench.py --no-cpu-baseline --no-extras --no-in-process` (tools/profile_round5.sh); one row per (kernel, grid, workgroup)",
                "rows": rows_}, open(os.path.join(R, "profiles", "r05_kernel_shapes.json"), "w"), indent=0)
     print("kernel stats ok: k_fb_accumulate %.2f ms" % avg)
 
