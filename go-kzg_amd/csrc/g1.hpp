@@ -165,6 +165,22 @@ struct g1x_acc {
         // branch weights: the compiler lays the (never taken) generic path out of the straight line of the walk loop: +2.7 % measured
         if (KZG_UNLIKELY(is_inf(q))) return;
         if (KZG_UNLIKELY(inf)) { v = g1xq_from_affine(q); inf = false; return; }
+#ifdef KZG_AB_FAKE_AFFINE   // TIMING-ONLY A/B (wrong results): the multiply-adds of a BATCH-AFFINE addition whose shared inversion, prefix-product storage and
+        // result storage came for free -- the ceiling of that scheme for the walk (profiles/r05_batch_affine.md): prefix product (1M), two products to unwind
+        // the inverse of the denominator (2M), lambda (1M), x3 (1S), y3 (1M) = 5M + 1S against the 8M + 2S (one reduction saved) of the XYZZ mixed addition
+        {
+            const fq x2 = unpackq(q.x), y2 = unpackq(q.y);
+            const fq d = subq<12>(x2, v.x);
+            const fq pre = mulq(v.zz, d);
+            const fq invd = mulq(v.zzz, pre);
+            v.zzz = mulq(v.zzz, d);
+            const fq lam = mulq(subq<6>(y2, v.y), invd);
+            const fq x3 = subq<3>(subq<12>(sqrq(lam), v.x), x2);
+            v.y = subq<6>(mulq(lam, subq<12>(v.x, x3)), v.y);
+            v.zz = pre; v.x = x3;
+            return;
+        }
+#endif
 #ifdef KZG_AB_FAKE_UNPACK   // TIMING-ONLY A/B (wrong results): what the walk would cost if table entries arrived as 13 limbs (profiles/r04_walk_ab.md)
         fq fx_, fy_;
 #pragma unroll
