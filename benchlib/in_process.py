@@ -78,7 +78,7 @@ def in_process_child(devices):
         with kz.pinned(blobs):                                  # kzg_hip_host_register: every device reads its share of the range in place over PCIe
             ms_pin = med(lambda: m.commit_to_poly_batch(blobs), 3, 1)
             pin_same = bool(np.array_equal(m.commit_to_poly_batch(blobs), got))
-        out["commit_to_poly_batch"] = {"blobs_per_device": per, "table": "library default (64 GB, 14-bit windows) on every device",
+        out["commit_to_poly_batch"] = {"blobs_per_device": per, "table": "library default (budget 110 GB: 16-bit windows x 8, 103 GB) on every device",
                                        "commitments_per_s": per * D / ms_all * 1e3, "one_device_same_call_per_s": per / ms_one * 1e3,
                                        "commitments_per_s_pinned_input": per * D / ms_pin * 1e3, "pinned_same_results": pin_same,
                                        "scaling_vs_one_device": (per * D / ms_all) / (per / ms_one),
