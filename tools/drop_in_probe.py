@@ -27,7 +27,7 @@ def main():
     fs = kz.FFTSettings(12)
     raw = np.frombuffer(open(os.path.join(bench.ROOT, "tests", "golden", "trusted_setup_g1.bin"), "rb").read(), dtype=np.uint8)
     ks = kz.KZGSettings(fs, fs.from_compressed_g1(raw))
-    ks.set_table_budget_gb(float(os.environ.get("TABLE_GB", "210")))
+    ks.set_table_budget_gb(float(os.environ.get("TABLE_GB", "110")))
     std = bench.splitmix_blobs_le32(1, 64)
     blobs, ok = fs.fr_from_32(std.reshape(-1, 32))
     blobs = blobs.reshape(64, 4096, 4)

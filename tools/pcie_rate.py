@@ -15,7 +15,7 @@ import gokzg_amd as kz  # noqa: E402
 fs = kz.FFTSettings(12)
 raw = np.frombuffer(open(os.path.join(ROOT, "tests", "golden", "trusted_setup_g1.bin"), "rb").read(), dtype=np.uint8)
 ks = kz.KZGSettings(fs, fs.from_compressed_g1(raw))
-ks.set_table_budget_gb(float(os.environ.get("TABLE_GB", "210")))     # the headline's table (library default: 64 GB)
+ks.set_table_budget_gb(float(os.environ.get("TABLE_GB", "110")))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 blobs, ok = fs.fr_from_32(bench.splitmix_blobs_le32(1, B, 4096).reshape(-1, 32))
 blobs = blobs.reshape(B, 4096, 4)
