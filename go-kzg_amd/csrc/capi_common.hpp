@@ -54,56 +54,6 @@ inline uint32_t ilog2(uint64_t v) { uint32_t r = 0; while ((1ull << r) < v) r++;
 // ---------------------------------------------------------------------------------------------------------
 // handles
 // ---------------------------------------------------------------------------------------------------------
-// A few host threads that copy slices of one large buffer side by side (pageable caller memory -> pinned staging): one thread moves ~10 GB/s, the table
-// walk consumes 13 GB/s at 100 k commitments/s.  Created on first use by a call that holds the handle's mutex (one user at a time); if a thread cannot
-// be started the pool stays smaller (down to the calling thread alone).
-struct copy_pool {
-    struct job { uint8_t *dst = nullptr; const uint8_t *src = nullptr; size_t bytes = 0; };
-    std::vector<std::thread> th;
-    std::mutex mu; std::condition_variable cv_work, cv_done;
-    std::vector<job> jobs; size_t next = 0, pending = 0; bool stop = false;
-    explicit copy_pool(int helpers) {
-        for (int i = 0; i < helpers; i++) {
-            try { th.emplace_back([this] { loop(); }); } catch (...) { break; }
-        }
-    }
-    ~copy_pool() {
-        { std::lock_guard<std::mutex> lk(mu); stop = true; }
-        cv_work.notify_all();
-        for (auto &t : th) if (t.joinable()) t.join();
-    }
-    void loop() {
-        std::unique_lock<std::mutex> lk(mu);
-        for (;;) {
-            cv_work.wait(lk, [&] { return stop || next < jobs.size(); });
-            if (stop) return;
-            const job j = jobs[next++];
-            lk.unlock();
-            memcpy(j.dst, j.src, j.bytes);
-            lk.lock();
-            if (--pending == 0) cv_done.notify_one();
-        }
-    }
-    // dst <- src, cut into one slice per thread (the caller copies a slice too); returns when every byte has been copied
-    void copy(void *dst, const void *src, size_t bytes) {
-        const size_t parts = th.size() + 1, slice = ((bytes / parts) + 4095) & ~(size_t)4095;
-        if (parts == 1 || bytes < (4u << 20)) { memcpy(dst, src, bytes); return; }
-        size_t mine_off = 0, mine_bytes = 0;
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            jobs.clear(); next = 0;
-            for (size_t i = 0, off = 0; i < parts && off < bytes; i++, off += slice) {
-                const size_t b = std::min(slice, bytes - off);
-                if (i == 0) { mine_off = off; mine_bytes = b; } else jobs.push_back(job{(uint8_t *)dst + off, (const uint8_t *)src + off, b});
-            }
-            pending = jobs.size();
-        }
-        cv_work.notify_all();
-        memcpy((uint8_t *)dst + mine_off, (const uint8_t *)src + mine_off, mine_bytes);
-        std::unique_lock<std::mutex> lk(mu);
-        cv_done.wait(lk, [&] { return pending == 0; });
-    }
-};
 struct kzg_hip_fft {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -118,9 +68,6 @@ struct kzg_hip_fft {
     fr *d_glv_expanded = nullptr, *d_glv_reversed = nullptr;   // twiddles as GLV pairs for the G1 FFT (g1_mul_glv)
     int8_t *d_wnaf_expanded = nullptr, *d_wnaf_reversed = nullptr;   // ... and their width-5 NAF digit strings (KZG_WNAF_ROW bytes per twiddle)
     uint8_t *h_stage = nullptr; size_t h_stage_cap = 0;   // pinned staging for large results of calls that hold `mu` (d2h_staged)
-    std::unique_ptr<copy_pool> copiers;                  // host threads that stage large pageable inputs side by side (calls that hold `mu`)
-    uint8_t *h_in_stage[2] = {nullptr, nullptr}; size_t h_in_stage_cap = 0;   // two pinned, mapped input staging areas (double buffer) of those calls
-    hipEvent_t in_stage_read[2] = {nullptr, nullptr};    // "the kernels that read staging area i have finished"
     std::mutex mu;
     struct pool_slot { hipStream_t s = nullptr; uint8_t *h_pin = nullptr; size_t pin_cap = 0; };   // a stream + its pinned staging area (stream_lease)
     std::mutex pool_mu; std::condition_variable pool_cv; std::vector<pool_slot> pool_idle; int pool_total = 0;

@@ -131,8 +131,6 @@ void kzg_hip_fft_settings_free(kzg_hip_fft *fs) {
     hipFree(fs->d_expanded); hipFree(fs->d_reversed); hipFree(fs->d_expanded_l); hipFree(fs->d_reversed_l); hipFree(fs->d_inv_pow2); hipFree(fs->d_tw4096[0]); hipFree(fs->d_tw4096[1]); hipFree(fs->d_tw_das2048); hipFree(fs->d_glv_expanded); hipFree(fs->d_glv_reversed); hipFree(fs->d_wnaf_expanded); hipFree(fs->d_wnaf_reversed);
     if (fs->stream) hipStreamDestroy(fs->stream);
     if (fs->h_stage) hipHostFree(fs->h_stage);
-    fs->copiers.reset();
-    for (int i = 0; i < 2; i++) { if (fs->h_in_stage[i]) hipHostFree(fs->h_in_stage[i]); if (fs->in_stage_read[i]) hipEventDestroy(fs->in_stage_read[i]); }
     for (auto &ps : fs->pool_idle) { hipStreamSynchronize(ps.s); hipStreamDestroy(ps.s); if (ps.h_pin) hipHostFree(ps.h_pin); }
     (void)hipGetLastError();
     delete fs;

@@ -224,44 +224,10 @@ int kzg_hip_commit_to_poly_batch(kzg_hip_kzg *ks, const void *coeffs_fr, uint64_
         HIPCHK(hipStreamSynchronize(s));
         return KZG_HIP_OK;
     }
-    // Large batches from PAGEABLE memory (what a Go slice is unless the caller pinned it): a few host threads copy chunk k + 1 into a pinned, mapped staging
-    // area side by side while the GPU walks chunk k IN PLACE over PCIe out of the other area (round 5; one staging thread moved ~10 GB/s and the walk
-    // needs 13: 68-78 k commitments/s from pageable memory against ~100 k resident).  Chunks keep >= 256 blobs so that a walk still fills one round of waves.
-    static const bool par_stage = [] { const char *e = getenv("KZG_HIP_PARALLEL_STAGE"); return !(e && e[0] == '0'); }();
-    const uint64_t chunk = batch >= 1024 ? 512 : (batch >= 512 ? 256 : batch);
-    kzg_hip_fft *fs = ks->fs;
-    if (par_stage && chunk < batch && n * sizeof(fr) >= (64u << 10)) {
-        const size_t chunk_bytes = (size_t)chunk * n * sizeof(fr);
-        bool have = true;
-        if (fs->h_in_stage_cap < chunk_bytes) {
-            for (int i = 0; i < 2; i++) { if (fs->h_in_stage[i]) { (void)hipHostFree(fs->h_in_stage[i]); fs->h_in_stage[i] = nullptr; } }
-            fs->h_in_stage_cap = 0;
-            for (int i = 0; i < 2 && have; i++) have = hipHostMalloc((void **)&fs->h_in_stage[i], chunk_bytes, hipHostMallocMapped) == hipSuccess;
-            if (have) fs->h_in_stage_cap = chunk_bytes;
-            else { (void)hipGetLastError(); for (int i = 0; i < 2; i++) { if (fs->h_in_stage[i]) { (void)hipHostFree(fs->h_in_stage[i]); fs->h_in_stage[i] = nullptr; } } }
-        }
-        for (int i = 0; i < 2 && have; i++)
-            if (!fs->in_stage_read[i]) have = hipEventCreateWithFlags(&fs->in_stage_read[i], hipEventDisableTiming) == hipSuccess;
-        if (have && !fs->copiers) { try { fs->copiers.reset(new copy_pool(3)); } catch (...) { have = false; } }
-        if (have) {
-            CHK(ensure_fixed_table(ks, s));
-            int slot = 0;
-            for (uint64_t b0 = 0; b0 < batch; b0 += chunk, slot ^= 1) {
-                const uint64_t cnt = batch - b0 < chunk ? batch - b0 : chunk;
-                HIPCHK(hipEventSynchronize(fs->in_stage_read[slot]));                   // the walk that last read this area (chunk k - 2, or an earlier call's) has finished
-                fs->copiers->copy(fs->h_in_stage[slot], (const fr *)coeffs_fr + b0 * n, (size_t)cnt * n * sizeof(fr));
-                void *dp = nullptr;
-                HIPCHK(hipHostGetDevicePointer(&dp, fs->h_in_stage[slot], 0));
-                CHK(commit_rows(ks, s, (const fr *)dp, n, cnt, d_out.p + b0));
-                HIPCHK(hipEventRecord(fs->in_stage_read[slot], s));
-            }
-            HIPCHK(hipMemcpyAsync(out_g1, d_out.p, batch * sizeof(g1j), hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
-            return KZG_HIP_OK;
-        }
-    }
     CHK(d_sc.alloc(n * batch));
-    // (fallback: chunks uploaded on a second stream by the calling thread, the copy of chunk i + 1 under the walk of chunk i)
+    // Large batches are uploaded in chunks on a second stream: the copy of chunk i + 1 (from pageable host memory it occupies the
+    // calling thread) runs while the GPU walks chunk i.  Chunks keep >= 256 blobs so that a walk still fills one round of waves.
+    uint64_t chunk = batch >= 1024 ? 512 : (batch >= 512 ? 256 : batch);
     if (chunk < batch && n * sizeof(fr) >= (64u << 10)) {
         if (!ks->copy_stream) {
             HIPCHK(hipStreamCreateWithFlags(&ks->copy_stream, hipStreamNonBlocking));

@@ -782,18 +782,6 @@ def test_commit_batch_shapes_fuzz(kz, ks4096, setup_1337):
             assert ko.g1_equal(got[b], want), (batch, n, b)
 
 
-def test_host_batches_without_parallel_staging_in_a_fresh_process():
-    """large host-buffer batches from pageable memory are staged by a few host threads into pinned areas that the walk reads in place (default); the
-    single-threaded chunked upload they replace stays as the fall-back (no pinned memory, no threads) and is forced here: KZG_HIP_PARALLEL_STAGE=0"""
-    import subprocess
-    import sys
-    if os.environ.get("KZG_HIP_PARALLEL_STAGE") == "0":
-        pytest.skip("already the forced child")
-    res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", "batch_shapes_fuzz or vector_F"],
-                         env=dict(os.environ, KZG_HIP_PARALLEL_STAGE="0"), capture_output=True, text=True, timeout=1200)
-    assert res.returncode == 0, res.stdout[-1500:]
-
-
 def test_commit_carry_chains_through_every_launch_shape(kz, ks4096, setup_1337):
     """signed-window recoding carries from window to window; below 32 polynomials the windows of a point are divided among lanes and each
     lane re-derives the carry into its first window from the lower digits (k_fb_accumulate<true>).  Scalars whose windows sit on the
