@@ -55,6 +55,7 @@ sys.path.insert(0, ROOT)
 from benchlib.workload import *  # noqa: E402,F401,F403  (constants, splitmix_blobs[_le32], dist_env, timed_steps, shard_units: tests and tools use them as bench.X)
 from benchlib.workload import R_MOD, HBM_PEAK_GBS, N_COEFF, BYTES_PER_COMMIT, BYTES_SETUP, FK20_BYTES, FK20_4096_BYTES, S_TEST  # noqa: E402,F401
 from benchlib.cpu import cpu_baseline  # noqa: E402
+from benchlib.roofline import walk_roofline, walk_mac, issue_model  # noqa: E402
 from benchlib.launch import self_launch  # noqa: E402
 from benchlib.in_process import run_in_process_child, in_process_child  # noqa: E402
 
@@ -277,52 +278,23 @@ def main():
     if cnt.value:
         avg_s = tot.value / cnt.value * 1e-3
         alg_bytes = B * BYTES_PER_COMMIT + BYTES_SETUP
-        ach = alg_bytes / avg_s * 1e-9
         tab_c, tab_w, tab_bytes = ks.table_info()
-        traffic, pm, pm_ok, pm_sc = None, pmc.get("k_fb_accumulate", pmc), False, 1.0
-        try:   # HBM bytes per launch from the committed PMC passes (profiles/), only when the workload matches that measurement; the counter
-            # passes ran 512-blob launches: the work per blob is identical at every batch of 512 and more (one workgroup per blob), so the
-            # per-launch counts scale with the batch (stated in traffic_source)
-            if pm["kernel"] == "k_" + dominant.decode() and pm["n"] == N_COEFF and pm["table_c"] == tab_c and pm.get("table_windows", tab_w) == tab_w and B >= pm["batch"] and B % pm["batch"] == 0:
-                pm_sc = B / pm["batch"]
-                traffic = (pm["fetch_bytes_per_launch"] + pm["write_bytes_per_launch"]) * pm_sc
-                pm_ok = True
-        except (KeyError, TypeError):
-            pass
-        roofline = {"bound": "hbm", "kernel": "k_" + dominant.decode(), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_s * 1e3,
-                    "algorithmic_bytes_per_launch": alg_bytes,
-                    "table": {"window_bits": tab_c, "windows": tab_w, "GB": tab_bytes / 1e9},
-                    "secondary": {},
-                    "traffic_source": (pmc.get("_file") if pm_sc == 1.0 else "%s (counters of the %d-blob launch x %g)" % (pmc.get("_file"), pm["batch"], pm_sc)) if pm_ok else None,
-                    "note": "integer-issue-bound kernel (see mac / issue); traffic (PMC passes committed under profiles/) exceeds the algorithmic bytes by design: fixed-base table gathers trade HBM bandwidth for integer work (DESIGN.md 4)"}
-
+        # HBM bytes per launch come from the committed PMC passes (profiles/) only when the workload matches that measurement (benchlib/roofline.py)
+        roofline, pm, pm_sc = walk_roofline("k_" + dominant.decode(), B, avg_s, (tab_c, tab_w, tab_bytes), pmc, pmc.get("_file"))
+        pm_ok = pm is not None
         if dominant == b"fb_accumulate" and B >= 512:           # one 256-lane workgroup per blob from 512 blobs on: the row of this launch shape
             pa_, ps_ = profile_avg_ms("k_fb_accumulate", B * 256, 256)
             roofline["profile_avg_ms"], roofline["profile_source"] = pa_, ps_
             if pa_:
                 roofline["profile_frac"] = alg_bytes / (pa_ * 1e-3) * 1e-9 / HBM_PEAK_GBS
         if tab_w:
-            # What bounds the walk is integer issue, not HBM.  One XYZZ mixed addition = 6 products (338 v_mad_u64_u32 each) + 2 squarings
-            # (260) + one two-product reduction (507) = 3055 multiply-adds; B * n * windows of them per launch (zero digits: < 2^-15).
-            # `mac` sets that against the v_mad_u64_u32 rate MEASURED in this run (8 waves per SIMD, independent chains); `issue` adds
-            # the non-multiply instructions (SQ_INSTS_VALU of the committed counter pass) at the measured v_add_u32 rate: the share of
-            # the launch time that pure instruction issue of this mix explains.
+            # What bounds the walk is integer issue, not HBM: `mac` sets the multiply-adds against the v_mad_u64_u32 rate MEASURED in this run, `issue` adds the
+            # non-multiply instructions (SQ_INSTS_VALU of the committed counter pass) at the measured v_add_u32 rate
             adds_pt = ks.table_additions()                       # 2 x windows: both GLV halves of a scalar walk the same rows
             roofline["table"]["additions_per_coefficient"] = adds_pt
-            mads = B * N_COEFF * adds_pt * (6 * 338 + 2 * 260 + 507)
-            roofline["mac"] = {"mads_per_launch": mads, "achieved_Tmad_s": mads / avg_s * 1e-12, "measured_peak_Tmad_s": cal_mad * 1e-12,
-                               "frac": mads / avg_s / cal_mad, "measured_v_add_u32_Tops_s": cal_add * 1e-12, "measured_fp_products_G_s": cal_fpmul * 1e-9,
-                               "fp_product_equivalents_G_s": mads / 338.0 / avg_s * 1e-9,
-                               "note": "peak = kzg_hip_calibrate on this GPU in this run (tools/microbench.hip loops); the guide's SIMD-32 figure "
-                                       "(one wave64 VALU instruction per 2 cycles) holds for v_add_u32 / v_mov, the 64-bit multiply-add issues at ~5.3 cycles"}
+            roofline["mac"] = walk_mac(B, adds_pt, avg_s, cal_mad, cal_add, cal_fpmul)
             if pm_ok and "valu_insts_per_launch" in pm:
-                valu = pm["valu_insts_per_launch"] * pm_sc
-                other = valu * 64.0 - mads
-                model_s = mads / cal_mad + max(other, 0.0) / cal_add
-                roofline["issue"] = {"valu_wave_insts_per_launch": valu, "mad_share_of_insts": mads / 64.0 / valu,
-                                     "issue_model_ms": model_s * 1e3, "frac_of_launch_explained": model_s / avg_s,
-                                     "note": "mads / measured mad rate + other VALU / measured add rate; the rest is dependency / memory stalls at 2 waves per SIMD"}
+                roofline["issue"] = issue_model(roofline["mac"]["mads_per_launch"], pm["valu_insts_per_launch"] * pm_sc, avg_s, cal_mad, cal_add)
 
     # Everything below is secondary to the headline measured above.  On one GPU a failure in a secondary leg is recorded in
     # `secondary_error` and the line is still printed; with several ranks it is raised (a rank that skipped ahead would leave the others

@@ -238,3 +238,29 @@ def test_bench_line_survives_a_failing_secondary_leg():
     d = json.loads(lines[0])
     assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["roofline"]["mac"]["frac"] > 0
     assert "KZG_BENCH_FAIL_SECONDARY" in d["secondary_error"] and d["fk20"] is None
+
+
+def test_roofline_arithmetic_reproduces_the_committed_profile():
+    """benchlib/roofline.py on the numbers of profiles/r05_*: the contract's `achieved` = algorithmic bytes / average launch time of the dominant kernel (the row of
+    that launch shape in the committed kernel trace), counters matched on kernel, length and table shape, the multiply-add and issue fractions from the same inputs"""
+    import json
+    from benchlib import roofline as rl
+    shapes = json.load(open(os.path.join(ROOT, "profiles", "r05_kernel_shapes.json")))["rows"]
+    row, = [r for r in shapes if r["kernel"].startswith("k_fb_accumulate") and r["grid"] == 4096 * 256 and r["workgroup"] == 256]
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_line_unprofiled.json")))
+    avg_s = row["avg_us"] * 1e-6
+    table = (16, 8, 8 * 4096 * 32768 * 96)
+    r, pm, sc = rl.walk_roofline("k_fb_accumulate", 4096, avg_s, table, pmc, "profiles/r05_pmc.json")
+    assert r["algorithmic_bytes_per_launch"] == 4096 * 131168 + 393216 == 537657344
+    assert abs(r["achieved"] - 0.537657344 / avg_s) < 1e-9 and 0.0015 < r["frac"] < 0.0018           # 13 GB/s of 8 TB/s: the kernel is issue-bound
+    assert pm is not None and sc == 1.0 and r["traffic"] == pm["fetch_bytes_per_launch"] + pm["write_bytes_per_launch"] > 50 * r["algorithmic_bytes_per_launch"]
+    assert abs(row["avg_us"] * 1e-3 - line["roofline"]["avg_launch_ms"]) / line["roofline"]["avg_launch_ms"] < 0.03     # trace row and HIP events of the un-profiled run agree
+    # a plain-layout table (16 windows) must NOT pick up the counters of the 8-window walk; neither may a batch that is no multiple of the profiled one
+    assert rl.walk_roofline("k_fb_accumulate", 4096, avg_s, (16, 16, 2 * table[2]), pmc, "x")[1] is None
+    assert rl.walk_roofline("k_fb_accumulate", 1000, avg_s, table, pmc, "x")[1] is None
+    mac = rl.walk_mac(4096, 16, avg_s, line["roofline"]["mac"]["measured_peak_Tmad_s"] * 1e12, line["roofline"]["mac"]["measured_v_add_u32_Tops_s"] * 1e12, 6.8e10)
+    assert mac["mads_per_launch"] == 4096 * 4096 * 16 * 3055 and 0.6 < mac["frac"] < 0.75
+    iss = rl.issue_model(mac["mads_per_launch"], pm["valu_insts_per_launch"], avg_s, line["roofline"]["mac"]["measured_peak_Tmad_s"] * 1e12,
+                         line["roofline"]["mac"]["measured_v_add_u32_Tops_s"] * 1e12)
+    assert 0.5 < iss["mad_share_of_insts"] < 0.65 and 0.8 < iss["frac_of_launch_explained"] < 1.05
