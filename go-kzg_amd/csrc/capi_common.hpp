@@ -90,7 +90,7 @@ struct fk20_core {
     uint64_t n2 = 0, l = 1, k = 0;   // n2 = 2n, chunk length l, k = n / l
     g1j *d_files = nullptr;          // l x 2k points: xExtFFT (single) / xExtFFTFiles (multi)
     g1a *d_files_fb = nullptr;       // fixed-base table over the l x 2k file points (k_fb_mul_vec); null -> double-and-add path
-    uint32_t fb_c = 0, fb_nwin = 0;
+    uint32_t fb_c = 0, fb_nwin = 0; bool fb_glv = false;   // window bits, windows, layout (glv: ceil(128 / c) windows walked by both halves of every scalar)
     std::unique_ptr<coalescer> co_da;   // concurrent DAUsingFK20 / DAUsingFK20Multi calls
 };
 struct kzg_hip_fk20s { fk20_core c; };
@@ -251,6 +251,8 @@ double table_budget_gb(const char *env, double cap_gb, double headroom_gb);   //
 int lincomb_points_rows(kzg_hip_points *pts, hipStream_t s, const fr *d_sc, uint64_t n, uint64_t batch, g1j *d_out, uint64_t sc_stride = 0, bool holds_mu = false);   // capi_core.hip
 int lincomb_points_coalesced(kzg_hip_points *pts, const void *scalars_fr, uint64_t n, void *out_g1);   // capi_kzg.hip
 uint32_t fb_windows(uint32_t c);   // capi_kzg.hip
+uint32_t fb_windows_glv(uint32_t c);   // capi_kzg.hip
+bool fb_glv_enabled();   // capi_kzg.hip
 bool coalescing_enabled();   // capi_kzg.hip
 coalescer *get_coalescer(kzg_hip_fft *fs, std::unique_ptr<coalescer> &slot, size_t in_row, size_t out_row);   // capi_kzg.hip
 int coalesce_upload_rows(coalesce_buf &b, uint64_t batch, size_t in_row_bytes, uint64_t n_max, fr *d_rows, uint64_t *d_meta);   // capi_kzg.hip

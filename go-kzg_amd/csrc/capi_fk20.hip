@@ -25,22 +25,28 @@ static int fk20_core_new(kzg_hip_kzg *ks, uint64_t n2, uint64_t l, fk20_core *c)
     CHK(g1_fft_rows(fs, s, d_x.p, k, k, d_f.p, k2, l, 0));   // toeplitzPart1: FFTG1(x || inf^k), fk20_single.go:40-56
     launch_g1_normalize(s, d_f.p, c->d_files, l * k2);
     HIPCHK(hipGetLastError());
-    {   // fixed-base table over the file points, sized by KZG_HIP_FK20_FB_BUDGET_GB (default: min(48 GB, free HBM - 12 GB)):
-        // scale 12, l = 1: c = 13, 20 windows, 32 GB;  scale 16, l = 16 (65 536 file points): c = 9, 29 windows, 47 GB.
+    {   // fixed-base table over the file points, sized by KZG_HIP_FK20_FB_BUDGET_GB (default: min(48 GB, free HBM - 12 GB)).  Both GLV halves of a coefficient
+        // walk one table of ceil(128 / c) windows (round 5; KZG_HIP_FB_GLV=0: the plain layout): scale 12, l = 1 (4096 file points): c = 13, 2 x 10 additions, 16 GB
+        // (plain: c = 13, 20, 32 GB);  scale 13 (8192 points): c = 13, 2 x 10, 32 GB (plain: c = 12, 22, 35 GB);  scale 16, l = 16 (65 536 points): c = 10, 2 x 13, 42 GB
+        // (plain: c = 9, 29, 47 GB).
         // An allocation failure falls back to the next smaller window and finally to the table-free double-and-add path.
         double budget_gb = table_budget_gb("KZG_HIP_FK20_FB_BUDGET_GB", 48.0, 12.0);
         uint64_t npts = l * k2;
+        const bool glv = fb_glv_enabled();
         dtmp<g1a> d_fa(s);
         if (npts >= 64) { CHK(d_fa.alloc(npts)); launch_g1_to_affine(s, c->d_files, d_fa.p, npts); }
-        for (uint32_t cc = 14; cc >= 4 && npts >= 64; cc--) {
-            double bytes = (double)fb_windows(cc) * (double)npts * (double)(1u << (cc - 1)) * sizeof(g1a);
+        for (uint32_t cc = glv ? 16 : 14; cc >= 4 && npts >= 64; cc--) {
+            const uint32_t nwin = glv ? fb_windows_glv(cc) : fb_windows(cc);
+            // (GLV: a window size whose additions per coefficient a smaller table also reaches is skipped)
+            if (glv && cc > 4 && fb_windows_glv(cc - 1) == nwin) continue;
+            double bytes = (double)nwin * (double)npts * (double)(1u << (cc - 1)) * sizeof(g1a);
             if (bytes > budget_gb * 1e9) continue;
             g1a *tab = nullptr;
-            if (hipMalloc((void **)&tab, (size_t)fb_windows(cc) * npts * (1u << (cc - 1)) * sizeof(g1a)) != hipSuccess) { (void)hipGetLastError(); continue; }
-            hipError_t e = launch_fb_build(s, d_fa.p, npts, cc, fb_windows(cc), tab);
+            if (hipMalloc((void **)&tab, (size_t)nwin * npts * (1u << (cc - 1)) * sizeof(g1a)) != hipSuccess) { (void)hipGetLastError(); continue; }
+            hipError_t e = launch_fb_build(s, d_fa.p, npts, cc, nwin, tab);
             if (e == hipSuccess) e = hipStreamSynchronize(s);
             if (e != hipSuccess) { (void)hipGetLastError(); hipFree(tab); continue; }
-            c->d_files_fb = tab; c->fb_c = cc; c->fb_nwin = fb_windows(cc);
+            c->d_files_fb = tab; c->fb_c = cc; c->fb_nwin = nwin; c->fb_glv = glv;
             break;
         }
     }
@@ -58,12 +64,12 @@ int fk20_hext(fk20_core *c, hipStream_t s, const fr *d_poly, uint64_t poly_strid
     launch_toeplitz_coeffs(s, d_poly, poly_stride, n, l, batch, d_tc.p, fs->d_inv_pow2 + ilog2(k2));
     fr_fft_rows(fs, s, d_tc.p, k2, k2, d_cf.p, k2, batch * l, 0);
     if (c->d_files_fb) {
-        if (l == 1) launch_fb_mul_vec(s, c->d_files_fb, l * k2, c->fb_c, c->fb_nwin, d_cf.p, k2, j0, cnt, batch, d_hext);
-        else if (batch * cnt >= device_simd_lanes()) launch_fb_mul_vec_files(s, c->d_files_fb, l * k2, c->fb_c, c->fb_nwin, d_cf.p, k2, j0, cnt, batch, d_hext);   // enough output positions to fill the GPU: one lane sums all files
+        if (l == 1) launch_fb_mul_vec(s, c->d_files_fb, l * k2, c->fb_c, c->fb_nwin, d_cf.p, k2, j0, cnt, batch, d_hext, c->fb_glv);
+        else if (batch * cnt >= device_simd_lanes()) launch_fb_mul_vec_files(s, c->d_files_fb, l * k2, c->fb_c, c->fb_nwin, d_cf.p, k2, j0, cnt, batch, d_hext, c->fb_glv);   // enough output positions to fill the GPU: one lane sums all files
         else {   // few positions (one polynomial, a shard): a lane per (file, position), then the sum over the files
             dtmp<g1j> d_tmp(s);
             CHK(d_tmp.alloc(batch * l * cnt));
-            launch_fb_mul_vec(s, c->d_files_fb, l * k2, c->fb_c, c->fb_nwin, d_cf.p, k2, j0, cnt, batch, d_tmp.p);
+            launch_fb_mul_vec(s, c->d_files_fb, l * k2, c->fb_c, c->fb_nwin, d_cf.p, k2, j0, cnt, batch, d_tmp.p, c->fb_glv);
             launch_g1_sum_files(s, d_tmp.p, l, cnt, batch, d_hext);
         }
     } else if (l == 1 && j0 == 0 && cnt == k2) launch_g1_mul_vec(s, c->d_files, k2, d_cf.p, 1, batch * k2, d_hext);
@@ -108,7 +114,7 @@ static int fk20_run_pass1_fused(fk20_core *c, hipStream_t s, const fr *d_poly, u
     CHK(d_tc.alloc(batch * k2)); CHK(d_cf.alloc(batch * k2)); CHK(d_p1.alloc(batch * k2)); CHK(d_a.alloc(batch * k2)); CHK(d_tmp.alloc(batch * k2));
     launch_toeplitz_coeffs(s, d_poly, poly_stride, n, 1, batch, d_tc.p, fs->d_inv_pow2 + ilog2(k2));   // 1 / 2k folded into the scalars
     fr_fft_rows(fs, s, d_tc.p, k2, k2, d_cf.p, k2, batch, 0);
-    launch_fb_direct_pass1(s, c->d_files_fb, k2, c->fb_c, c->fb_nwin, d_cf.p, fs->d_reversed, fs->W, batch, 4, d_p1.p);
+    launch_fb_direct_pass1(s, c->d_files_fb, k2, c->fb_c, c->fb_nwin, d_cf.p, fs->d_reversed, fs->W, batch, 4, d_p1.p, c->fb_glv);
     launch_g1_fft_direct(s, d_p1.p, k2, k2, d_a.p, d_tmp.p, k2, batch, fs->d_reversed, fs->W, nullptr, 4, g1_fft_direct_lanes(k2, batch), 4, c->k);   // only h[:k] is read below
     HIPCHK(hipGetLastError());
     return fk20_finish_from_h(c, s, d_a.p, batch, da, bit_reverse, d_out);
@@ -131,7 +137,7 @@ static int fk20_run_fused(fk20_core *c, hipStream_t s, const fr *d_poly, uint64_
     CHK(d_tc.alloc(batch * k2)); CHK(d_cf.alloc(batch * k2)); CHK(d_a.alloc(batch * k2)); CHK(d_b.alloc(batch * k2));
     launch_toeplitz_coeffs(s, d_poly, poly_stride, n, 1, batch, d_tc.p, fs->d_inv_pow2 + ilog2(k2));   // 1 / 2k folded into the scalars
     fr_fft_rows(fs, s, d_tc.p, k2, k2, d_cf.p, k2, batch, 0);
-    launch_fb_mul_vec_dif2(s, c->d_files_fb, k2, c->fb_c, c->fb_nwin, d_cf.p, fs->d_reversed, fs->W, batch, d_a.p);
+    launch_fb_mul_vec_dif2(s, c->d_files_fb, k2, c->fb_c, c->fb_nwin, d_cf.p, fs->d_reversed, fs->W, batch, d_a.p, c->fb_glv);
     for (uint64_t m = k2 / 8; m >= 1; m >>= 1) launch_g1_fft_stage_dif(s, d_a.p, k2, batch, m, fs->d_glv_reversed, fs->d_wnaf_reversed, fs->W);
     if (!da) {                                                  // FK20Single: transform of k points on h[:k]
         const uint64_t k = c->k;

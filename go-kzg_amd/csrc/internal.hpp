@@ -72,7 +72,7 @@ void launch_g1_take_even(hipStream_t s, const g1j *in, g1j *out, uint64_t total)
 bool g1_quad_enabled();   // the stage launchers put four lanes on a butterfly for launches of at most 16 384 butterflies (g1_quad.hpp) unless KZG_HIP_G1_QUAD=0
 // latency mode: Stockham passes of radix 16 evaluated directly (k_g1.hip); result in data, tmp = batch x n scratch, scale optional
 void launch_fb_direct_pass1(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, const fr *roots, uint64_t W, uint64_t batch,
-                            uint32_t logR, g1j *out);   // FK20 Toeplitz stage + first direct pass of the inverse transform (a lone polynomial)
+                            uint32_t logR, g1j *out, bool glv = false);   // FK20 Toeplitz stage + first direct pass of the inverse transform (a lone polynomial)
 // several lanes per multiplication (g1_coop_kernels.hpp; translation units of their own)
 void launch_g1_stage_coop_dif(hipStream_t s, int lanes, g1j *data, uint64_t n, uint64_t batch, uint64_t m, const fr *roots, const int8_t *wnaf, uint64_t W, uint64_t total);
 void launch_g1_stage_coop_dit(hipStream_t s, int lanes, g1j *data, uint64_t n, uint64_t batch, uint64_t m, const fr *roots, const int8_t *wnaf, uint64_t W, uint64_t total);
@@ -120,15 +120,16 @@ void launch_fb_msm(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c
                    uint64_t batch, void *partials, g1j *out, bool to_kilic, bool glv = false);
 
 // out[(b, f, jj)] = scalars[b][f * row + j0 + jj] * P[f * row + j0 + jj] over a fixed-base table of table_n = nfiles * row points
+// (glv, here and below: the table holds ceil(128 / c) windows and both GLV halves of every scalar walk them)
 void launch_fb_mul_vec(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, uint64_t row, uint64_t j0,
-                       uint64_t cnt, uint64_t batch, g1j *out);
+                       uint64_t cnt, uint64_t batch, g1j *out, bool glv = false);
 // the same stage fused with the first two decimation-in-frequency stages of the inverse G1 transform (single-file tables, N >= 4):
 // out[b][.] = two DIF stages applied to (scalars[b][j] * P_j)_j; roots = ReverseRootsOfUnity (Montgomery) of width W
 void launch_fb_mul_vec_dif2(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, const fr *roots, uint64_t W,
-                            uint64_t batch, g1j *out);
+                            uint64_t batch, g1j *out, bool glv = false);
 // all files of an output position summed in one lane: out[b][jj] = sum_f scalars[b][f * row + j0 + jj] * P[f * row + j0 + jj]
 void launch_fb_mul_vec_files(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, uint64_t row, uint64_t j0,
-                             uint64_t cnt, uint64_t batch, g1j *out);
+                             uint64_t cnt, uint64_t batch, g1j *out, bool glv = false);
 void launch_g1_sum_files(hipStream_t s, const g1j *tmp, uint64_t nfiles, uint64_t cnt, uint64_t batch, g1j *out);
 
 // profiling hook (HIP events around the dominant kernel), see capi.hip

@@ -922,28 +922,40 @@ __global__ __launch_bounds__(64) void k_fb_finish_lanes(const fb_partial *partia
     out[b] = to_kilic ? g1_to_kilic(r) : r;
 }
 
-// element-wise fixed-base products over the same table layout: out[b][i] = scalars[b][i] * P_i  (the FK20 Toeplitz stage,
-// ToeplitzPart2's loop fk20_single.go:72-74, where P = xExtFFT is fixed per settings): nwin mixed adds instead of a
-// 255-bit double-and-add per element.
-__global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_mul_vec(const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, uint32_t D, const fr *scalars,
-                                                         uint64_t i0, uint64_t cnt, uint64_t row, uint64_t total, g1j *out) {
-    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    // t enumerates (b, f, jj): point index i = f * k2 + j0 + jj is supplied through (row = k2, i0 = j0, cnt) by the caller
-    uint64_t jj = t % cnt, f = (t / cnt) % (table_n / row), b = t / (cnt * (table_n / row));
-    uint64_t i = f * row + i0 + jj;
-    fr k = from_mont<FrP>(scalars[b * table_n + i]);
-    g1x_acc acc; acc.init();
-    // same software pipeline as k_fb_accumulate: gather of window w + 1 before the addition of window w
-    uint32_t raw = scalar_bits(k, 0, c), carry, mag, ng;
+// One fixed-base product added into an accumulator: the walk of point i's rows with the signed c-bit digits of a scalar (standard form), sign sg folded in.
+//   GLV = false: the plain layout, nwin windows over the whole scalar (phi is ignored, one call per term);
+//   GLV = true : the table holds ceil(128 / c) windows; the call walks ONE half of the split scalar -- phi ? |k2| : |k1| -- so a caller sums the phi halves of all
+//                its terms first, maps the sum once (acc_apply_phi: X <- beta X), then adds the plain halves (the order of k_fb_accumulate_glv).
+template <bool GLV> __device__ __forceinline__ void fb_walk_term(g1x_acc &acc, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, uint32_t D, uint64_t i,
+                                                                const fr &k, uint32_t sg, bool phi) {
+    uint32_t m[8];
+    uint32_t sgn = sg;
+    if (GLV) {
+        const glv_halves h = glv_split_signed(k);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { m[j] = phi ? h.k2[j] : h.k1[j]; m[4 + j] = 0; }
+        sgn ^= phi ? h.neg2 : h.neg1;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) m[j] = k.l[j];
+    }
+    auto bits = [&](uint32_t off) -> uint32_t {
+        const uint32_t idx = off >> 5, sh = off & 31;
+        if (idx >= (GLV ? 4u : 8u)) return 0u;
+        uint64_t v = m[idx];
+        if (idx + 1 < (GLV ? 4u : 8u)) v |= (uint64_t)m[idx + 1] << 32;
+        return (uint32_t)(v >> sh) & ((1u << c) - 1u);
+    };
+    // software pipeline as in k_fb_accumulate: the gather of window w + 1 is issued before the addition of window w
+    uint32_t raw = bits(0), carry, mag, ng;
     if (raw > D) { carry = 1; mag = (1u << c) - raw; ng = 1; } else { carry = 0; mag = raw; ng = 0; }
     g1a qn = table[((uint64_t)0 * table_n + i) * D + (mag ? mag - 1 : 0)];
 #pragma nounroll
     for (uint32_t w = 0; w < nwin; w++) {
         g1a q = qn;
-        const uint32_t cmag = mag, cng = ng;
+        const uint32_t cmag = mag, cng = ng ^ sgn;
         if (w + 1 < nwin) {
-            raw = scalar_bits(k, (w + 1) * c, c) + carry;
+            raw = bits((w + 1) * c) + carry;
             if (raw > D) { carry = 1; mag = (1u << c) - raw; ng = 1; } else { carry = 0; mag = raw; ng = 0; }
             qn = table[((uint64_t)(w + 1) * table_n + i) * D + (mag ? mag - 1 : 0)];
         }
@@ -952,6 +964,21 @@ __global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_mul_vec(const g1a *table, ui
             acc.add(q);
         }
     }
+}
+// element-wise fixed-base products over the same table layout: out[b][i] = scalars[b][i] * P_i  (the FK20 Toeplitz stage,
+// ToeplitzPart2's loop fk20_single.go:72-74, where P = xExtFFT is fixed per settings): nwin mixed adds instead of a
+// 255-bit double-and-add per element.
+template <bool GLV> __global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_mul_vec(const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, uint32_t D, const fr *scalars,
+                                                         uint64_t i0, uint64_t cnt, uint64_t row, uint64_t total, g1j *out) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    // t enumerates (b, f, jj): point index i = f * k2 + j0 + jj is supplied through (row = k2, i0 = j0, cnt) by the caller
+    uint64_t jj = t % cnt, f = (t / cnt) % (table_n / row), b = t / (cnt * (table_n / row));
+    uint64_t i = f * row + i0 + jj;
+    const fr k = from_mont<FrP>(scalars[b * table_n + i]);
+    g1x_acc acc; acc.init();
+    if (GLV) { fb_walk_term<true>(acc, table, table_n, c, nwin, D, i, k, 0u, true); acc_apply_phi(acc); }
+    fb_walk_term<GLV>(acc, table, table_n, c, nwin, D, i, k, 0u, false);
     out[t] = acc.to_jac();
 }
 // The FK20 Toeplitz stage fused with the FIRST direct pass of the inverse G1 transform of a LONE polynomial (fk20_single.go:72-74 + the first
@@ -960,7 +987,7 @@ __global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_mul_vec(const g1a *table, ui
 // 128 doublings + 66 additions of a variable-base multiplication -- then the R terms of an output are summed as in the direct pass.  One lane per
 // (output, term); one-wavefront workgroups.  roots = ReverseRootsOfUnity (Montgomery), W = its width.
 struct fbp_slot { uint32_t w[39]; uint32_t inf; uint32_t pad; };
-__global__ __launch_bounds__(64, 2) void k_fb_direct_pass1(const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, uint32_t D, const fr *scalars, const fr *roots,
+template <bool GLV> __global__ __launch_bounds__(64, 2) void k_fb_direct_pass1(const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, uint32_t D, const fr *scalars, const fr *roots,
                                                            uint64_t W, uint32_t logn, uint32_t logR, uint64_t total, g1j *out) {
     __shared__ fbp_slot buf[64];
     const uint32_t tid = threadIdx.x;
@@ -976,23 +1003,8 @@ __global__ __launch_bounds__(64, 2) void k_fb_direct_pass1(const g1a *table, uin
         if (e) kmont = mul(kmont, roots[e * (W >> logn)]);
         const fr k = from_mont<FrP>(kmont);
         g1x_acc xa; xa.init();
-        uint32_t raw = scalar_bits(k, 0, c), carry, mag, ng;
-        if (raw > D) { carry = 1; mag = (1u << c) - raw; ng = 1; } else { carry = 0; mag = raw; ng = 0; }
-        g1a qn = table[((uint64_t)0 * table_n + i) * D + (mag ? mag - 1 : 0)];
-#pragma nounroll
-        for (uint32_t w = 0; w < nwin; w++) {
-            g1a q = qn;
-            const uint32_t cmag = mag, cng = ng;
-            if (w + 1 < nwin) {
-                raw = scalar_bits(k, (w + 1) * c, c) + carry;
-                if (raw > D) { carry = 1; mag = (1u << c) - raw; ng = 1; } else { carry = 0; mag = raw; ng = 0; }
-                qn = table[((uint64_t)(w + 1) * table_n + i) * D + (mag ? mag - 1 : 0)];
-            }
-            if (cmag) {
-                if (cng) q.y = neg<FpP>(q.y);
-                xa.add(q);
-            }
-        }
+        if (GLV) { fb_walk_term<true>(xa, table, table_n, c, nwin, D, i, k, 0u, true); acc_apply_phi(xa); }
+        fb_walk_term<GLV>(xa, table, table_n, c, nwin, D, i, k, 0u, false);
         if (!xa.inf) { acc.v = g1jq_unpack(xa.to_jac()); acc.inf = false; }
     }
 #define FBP_STORE(i_) do { _Pragma("unroll") for (int q_ = 0; q_ < 13; q_++) { buf[i_].w[q_] = acc.v.x.l[q_]; buf[i_].w[13 + q_] = acc.v.y.l[q_]; buf[i_].w[26 + q_] = acc.v.z.l[q_]; } \
@@ -1014,13 +1026,15 @@ __global__ __launch_bounds__(64, 2) void k_fb_direct_pass1(const g1a *table, uin
     if (live && tt == 0) out[b * n + j * R + u] = acc.inf ? g1_inf() : g1jq_pack(acc.v);
 }
 void launch_fb_direct_pass1(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, const fr *roots, uint64_t W, uint64_t batch,
-                            uint32_t logR, g1j *out) {
+                            uint32_t logR, g1j *out, bool glv) {
     uint32_t logn = 0;
     while ((1ull << logn) < table_n) logn++;
     const uint64_t total = (batch * table_n) << logR, wgs = (total + 63) / 64;
     prof_begin(s, "fb_mul_vec");
-    hipLaunchKernelGGL(k_fb_direct_pass1, dim3((uint32_t)wgs), dim3(64), wgs <= device_simds() ? 24 * 1024 : 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars, roots, W, logn, logR,
-                       total, out);
+    if (glv) hipLaunchKernelGGL(k_fb_direct_pass1<true>, dim3((uint32_t)wgs), dim3(64), wgs <= device_simds() ? 24 * 1024 : 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars, roots, W, logn, logR,
+                                total, out);
+    else hipLaunchKernelGGL(k_fb_direct_pass1<false>, dim3((uint32_t)wgs), dim3(64), wgs <= device_simds() ? 24 * 1024 : 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars, roots, W, logn, logR,
+                            total, out);
     prof_end(s, "fb_mul_vec");
 }
 
@@ -1035,7 +1049,7 @@ void launch_fb_direct_pass1(hipStream_t s, const g1a *table, uint64_t table_n, u
 // additions (~720 product-equivalents) replace one table walk + two butterfly levels (~1640), the twiddle multiplications of the two
 // widest stages of the transform (a fifth of all of them) disappear.  Lane = (polynomial, output); scalars in Montgomery form;
 // roots = ReverseRootsOfUnity (Montgomery), W = its width.
-__global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_mul_vec_dif2(const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, uint32_t D, const fr *scalars,
+template <bool GLV> __global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_mul_vec_dif2(const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, uint32_t D, const fr *scalars,
                                                               const fr *roots, uint64_t W, uint64_t total, g1j *out) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= total) return;
@@ -1043,97 +1057,79 @@ __global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_mul_vec_dif2(const g1a *tabl
     const uint64_t i = t % q, o = (t / q) & 3u, b = t / N;
     const uint64_t rs = W / N;                              // stride of the order-N roots inside the width-W table
     g1x_acc acc; acc.init();
+    // GLV: the phi halves of the four terms first, the map once, then the plain halves (the scalar of a term is formed in both passes: one F_r product)
 #pragma nounroll
-    for (uint32_t term = 0; term < 4; term++) {
-        const uint64_t pi = i + term * q;
-        // exponent and sign of the root that multiplies C[pi] in output o (table above)
-        uint64_t e; uint32_t sg;
-        if (o == 0) { e = 0; sg = 0; }
-        else if (o == 1) { e = 2 * i; sg = term & 1u; }
-        else if (o == 2) { e = i + ((term & 1u) ? q : 0); sg = term >> 1; }
-        else { e = 3 * i + ((term & 1u) ? q : 0); sg = (term == 1 || term == 2) ? 1u : 0u; }
-        fr kmont = scalars[b * N + pi];
-        if (e) kmont = mul(kmont, roots[(e & (N - 1)) * rs]);
-        const fr k = from_mont<FrP>(kmont);
-        // the table walk of k_fb_mul_vec for point pi, sign folded into the digits
-        uint32_t raw = scalar_bits(k, 0, c), carry, mag, ng;
-        if (raw > D) { carry = 1; mag = (1u << c) - raw; ng = 1; } else { carry = 0; mag = raw; ng = 0; }
-        g1a qn = table[((uint64_t)0 * table_n + pi) * D + (mag ? mag - 1 : 0)];
+    for (uint32_t pass = GLV ? 0u : 1u; pass < 2; pass++) {
 #pragma nounroll
-        for (uint32_t w = 0; w < nwin; w++) {
-            g1a qq = qn;
-            const uint32_t cmag = mag, cng = ng ^ sg;
-            if (w + 1 < nwin) {
-                raw = scalar_bits(k, (w + 1) * c, c) + carry;
-                if (raw > D) { carry = 1; mag = (1u << c) - raw; ng = 1; } else { carry = 0; mag = raw; ng = 0; }
-                qn = table[((uint64_t)(w + 1) * table_n + pi) * D + (mag ? mag - 1 : 0)];
-            }
-            if (cmag) {
-                if (cng) qq.y = neg<FpP>(qq.y);
-                acc.add(qq);
-            }
+        for (uint32_t term = 0; term < 4; term++) {
+            const uint64_t pi = i + term * q;
+            // exponent and sign of the root that multiplies C[pi] in output o (table above)
+            uint64_t e; uint32_t sg;
+            if (o == 0) { e = 0; sg = 0; }
+            else if (o == 1) { e = 2 * i; sg = term & 1u; }
+            else if (o == 2) { e = i + ((term & 1u) ? q : 0); sg = term >> 1; }
+            else { e = 3 * i + ((term & 1u) ? q : 0); sg = (term == 1 || term == 2) ? 1u : 0u; }
+            fr kmont = scalars[b * N + pi];
+            if (e) kmont = mul(kmont, roots[(e & (N - 1)) * rs]);
+            const fr k = from_mont<FrP>(kmont);
+            fb_walk_term<GLV>(acc, table, table_n, c, nwin, D, pi, k, sg, pass == 0);   // the table walk of k_fb_mul_vec for point pi, sign folded into the digits
         }
+        if (GLV && pass == 0) acc_apply_phi(acc);
     }
     out[b * N + o * q + i] = acc.to_jac();
 }
 void launch_fb_mul_vec_dif2(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, const fr *roots, uint64_t W,
-                            uint64_t batch, g1j *out) {
+                            uint64_t batch, g1j *out, bool glv) {
     uint64_t total = batch * table_n;
     if (!total) return;
     prof_begin(s, "fb_mul_vec");
-    hipLaunchKernelGGL(k_fb_mul_vec_dif2, dim3((uint32_t)((total + FB_BLOCK - 1) / FB_BLOCK)), dim3(FB_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars,
-                       roots, W, total, out);
+    if (glv) hipLaunchKernelGGL(k_fb_mul_vec_dif2<true>, dim3((uint32_t)((total + FB_BLOCK - 1) / FB_BLOCK)), dim3(FB_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars,
+                                roots, W, total, out);
+    else hipLaunchKernelGGL(k_fb_mul_vec_dif2<false>, dim3((uint32_t)((total + FB_BLOCK - 1) / FB_BLOCK)), dim3(FB_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars,
+                            roots, W, total, out);
     prof_end(s, "fb_mul_vec");
 }
 // FK20Multi's Toeplitz stage (fk20_multi.go:79-91): out[b][jj] = sum over the files f of scalars[b][f * row + j0 + jj] * X_f[j0 + jj],
 // all files of an output position in ONE lane's accumulator (nfiles x nwin mixed additions): no per-file temporaries and no
 // summation pass with generic additions afterwards.
-__global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_mul_vec_files(const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, uint32_t D, const fr *scalars,
+template <bool GLV> __global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_mul_vec_files(const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, uint32_t D, const fr *scalars,
                                                                uint64_t i0, uint64_t cnt, uint64_t row, uint64_t total, g1j *out) {
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= total) return;
     const uint64_t jj = t % cnt, b = t / cnt, nfiles = table_n / row;
     g1x_acc acc; acc.init();
 #pragma nounroll
-    for (uint64_t f = 0; f < nfiles; f++) {
-        const uint64_t i = f * row + i0 + jj;
-        fr k = from_mont<FrP>(scalars[b * table_n + i]);
-        uint32_t raw = scalar_bits(k, 0, c), carry, mag, ng;
-        if (raw > D) { carry = 1; mag = (1u << c) - raw; ng = 1; } else { carry = 0; mag = raw; ng = 0; }
-        g1a qn = table[((uint64_t)0 * table_n + i) * D + (mag ? mag - 1 : 0)];
+    for (uint32_t pass = GLV ? 0u : 1u; pass < 2; pass++) {       // GLV: phi halves of every file, the map once, then the plain halves
 #pragma nounroll
-        for (uint32_t w = 0; w < nwin; w++) {
-            g1a q = qn;
-            const uint32_t cmag = mag, cng = ng;
-            if (w + 1 < nwin) {
-                raw = scalar_bits(k, (w + 1) * c, c) + carry;
-                if (raw > D) { carry = 1; mag = (1u << c) - raw; ng = 1; } else { carry = 0; mag = raw; ng = 0; }
-                qn = table[((uint64_t)(w + 1) * table_n + i) * D + (mag ? mag - 1 : 0)];
-            }
-            if (cmag) {
-                if (cng) q.y = neg<FpP>(q.y);
-                acc.add(q);
-            }
+        for (uint64_t f = 0; f < nfiles; f++) {
+            const uint64_t i = f * row + i0 + jj;
+            const fr k = from_mont<FrP>(scalars[b * table_n + i]);
+            fb_walk_term<GLV>(acc, table, table_n, c, nwin, D, i, k, 0u, pass == 0);
         }
+        if (GLV && pass == 0) acc_apply_phi(acc);
     }
     out[t] = acc.to_jac();
 }
 void launch_fb_mul_vec_files(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, uint64_t row, uint64_t j0,
-                             uint64_t cnt, uint64_t batch, g1j *out) {
+                             uint64_t cnt, uint64_t batch, g1j *out, bool glv) {
     uint64_t total = batch * cnt;
     if (!total) return;
     prof_begin(s, "fb_mul_vec");
-    hipLaunchKernelGGL(k_fb_mul_vec_files, dim3((uint32_t)((total + FB_BLOCK - 1) / FB_BLOCK)), dim3(FB_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars,
-                       j0, cnt, row, total, out);
+    if (glv) hipLaunchKernelGGL(k_fb_mul_vec_files<true>, dim3((uint32_t)((total + FB_BLOCK - 1) / FB_BLOCK)), dim3(FB_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars,
+                                j0, cnt, row, total, out);
+    else hipLaunchKernelGGL(k_fb_mul_vec_files<false>, dim3((uint32_t)((total + FB_BLOCK - 1) / FB_BLOCK)), dim3(FB_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars,
+                            j0, cnt, row, total, out);
     prof_end(s, "fb_mul_vec");
 }
 void launch_fb_mul_vec(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, uint64_t row, uint64_t j0,
-                       uint64_t cnt, uint64_t batch, g1j *out) {
+                       uint64_t cnt, uint64_t batch, g1j *out, bool glv) {
     uint64_t total = batch * (table_n / row) * cnt;
     if (!total) return;
     prof_begin(s, "fb_mul_vec");
-    hipLaunchKernelGGL(k_fb_mul_vec, dim3((uint32_t)((total + FB_BLOCK - 1) / FB_BLOCK)), dim3(FB_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars,
-                       j0, cnt, row, total, out);
+    if (glv) hipLaunchKernelGGL(k_fb_mul_vec<true>, dim3((uint32_t)((total + FB_BLOCK - 1) / FB_BLOCK)), dim3(FB_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars,
+                                j0, cnt, row, total, out);
+    else hipLaunchKernelGGL(k_fb_mul_vec<false>, dim3((uint32_t)((total + FB_BLOCK - 1) / FB_BLOCK)), dim3(FB_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars,
+                            j0, cnt, row, total, out);
     prof_end(s, "fb_mul_vec");
 }
 

@@ -244,15 +244,17 @@ def test_crafted_rows_really_collide():
 @pytest.mark.gpu
 @pytest.mark.timeout(2400)
 def test_plain_layout_in_a_fresh_process():
-    """KZG_HIP_FB_GLV=0: the table layout of rounds 1-4 (one window per c bits of the whole scalar, k_fb_accumulate) stays selectable for A/B runs; the
-    crafted blobs and the table-size tests run against it in a child process (the library reads the variable once)"""
+    """KZG_HIP_FB_GLV=0: the table layout of rounds 1-4 (one window per c bits of the whole scalar: k_fb_accumulate and the <false> instantiations of the FK20
+    Toeplitz kernels) stays selectable for A/B runs; the crafted blobs, the table-size tests and the FK20 vectors / byte pins run against it in a child process
+    (the library reads the variable once)"""
     import subprocess
     import sys
     if not GLV_WALK:
         pytest.skip("already the plain-layout child")
     here = os.path.dirname(os.path.abspath(__file__))
     res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_cold_paths.py"), os.path.join(here, "test_gpu_parity.py"), "-m", "gpu", "-x", "-q", "-k",
-                          "crafted_blobs or every_table_size or table_budget_setter or c16_table or vector_F or batch_shapes"],
+                          "crafted_blobs or every_table_size or table_budget_setter or c16_table or vector_F or batch_shapes or vector_C or vectors_D_E or config4a or "
+                          "file_accumulation or config5 or config4b or da_using_fk20_batch_host"],
                          env=dict(os.environ, KZG_HIP_FB_GLV="0"), capture_output=True, text=True, timeout=2300)
     assert res.returncode == 0, res.stdout[-2000:]
 
