@@ -266,8 +266,14 @@ class coalescer {
         uint32_t peak;
         {
             std::lock_guard<std::mutex> lk(mu_);
-            const uint32_t decayed = peak_ - (peak_ + 3) / 4;              // rounds up: 3 -> 2 -> 1 -> 0
-            const uint32_t seen_max = inside_max_.exchange(inside_.load(std::memory_order_relaxed), std::memory_order_relaxed);
+            // (after an idle gap -- no batch formed for 2 ms and for four batch times -- the estimate is forgotten at once: a lone caller that follows a burst
+            // of 64 must not pay the burst's gather window for the dozen calls the decay takes)
+            const long idle_ns = s1 - last_close_ns_;
+            const bool idle = last_close_ns_ != 0 && idle_ns > 2000000L && idle_ns > 4 * exec_ema_ns_.load(std::memory_order_relaxed);
+            last_close_ns_ = s1;
+            const uint32_t decayed = idle ? 0u : peak_ - (peak_ + 3) / 4;  // rounds up: 3 -> 2 -> 1 -> 0
+            uint32_t seen_max = inside_max_.exchange(inside_.load(std::memory_order_relaxed), std::memory_order_relaxed);
+            if (idle) seen_max = inside_.load(std::memory_order_relaxed);  // (the maximum since the last batch is the burst's tail: forgotten with the rest)
             peak_ = seen_max > decayed ? seen_max : decayed;
             peak = peak_;
             // Batches in flight: ONE up to ~48 concurrent callers (a table walk over fewer than ~50 polynomials leaves lanes idle and pays its
@@ -339,6 +345,7 @@ class coalescer {
     std::atomic<uint32_t> inside_{0};    // callers currently inside submit()
     std::atomic<uint32_t> inside_max_{0};// its maximum since the last batch was formed
     uint32_t peak_ = 0;                  // decaying maximum of inside_: the concurrency the gather targets are derived from (under mu_)
+    long last_close_ns_ = 0;             // when the previous batch's leader got its slot (under mu_)
     std::atomic<int> spinners_{0};
     long window_us_ = 150;               // upper bound of the gather wait (KZG_HIP_COALESCE_US; 0 disables)
     long spin_us_ = 40;                  // a follower's spin before it parks (KZG_HIP_COALESCE_SPIN_US; 0 disables)

@@ -59,6 +59,15 @@ int main(int argc, char **argv) {
             }
         });
     for (auto &th : ts) th.join();
+    if (argc > 5) {   // "lone-after-burst": the burst above is followed, after an idle gap, by one caller: it must not pay the burst's gather window
+        std::this_thread::sleep_for(std::chrono::milliseconds(atoi(argv[5])));
+        std::vector<uint64_t> in(in_row / 8, 7);
+        const auto l0 = std::chrono::steady_clock::now();
+        for (int c = 0; c < 20; c++) { uint64_t out[4]; in[0] = 1000 + c; if (co.submit(in.data(), 64, 8, 0, out, sizeof out, exec, 8) || out[0] != (1000ull + c) * 0x9e3779b97f4a7c15ull) bad++; }
+        const double per = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - l0).count() / 20;
+        printf("lone caller after the burst: %.0f us per call (device model: %.0f us)\n", per, a_us + b_us);
+        g_rows -= 20;
+    }
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     uint64_t total = 0;
     for (unsigned t = 0; t < T; t++) total += calls - (t % 3 == 2 ? calls / 2 : 0);
