@@ -45,12 +45,17 @@ def test_a_lone_caller_is_never_batched_with_a_wait(sim):
 def test_a_lone_caller_after_a_burst_does_not_pay_the_bursts_gather_window(sim):
     """64 callers, an idle gap of 10 ms, then one caller: the concurrency estimate is forgotten after the gap, so its calls cost what a lone caller's calls
     cost (measured in the same harness: the simulated device sleeps coarsely) and not that + the 150 us gather window (twelve calls' worth of decay otherwise)"""
-    base = subprocess.run([sim, "1", "100", "100", "1"], capture_output=True, text=True, timeout=300)
-    assert base.returncode == 0, base.stdout + base.stderr
-    base_us = float(base.stdout.split(" calls in ")[1].split(" s = ")[0]) / 100 * 1e6
-    # a 3 ms window makes the difference unmistakable in a harness whose simulated device sleeps coarsely: un-forgotten, the estimate of 64 costs the lone caller
-    # ~12 waits of 3 ms over its 20 calls (+1.8 ms per call on average)
-    res = subprocess.run([sim, "64", "30", "100", "1", "30"], capture_output=True, text=True, timeout=300, env=dict(os.environ, KZG_HIP_COALESCE_US="3000"))
-    assert res.returncode == 0 and "wrong results: 0" in res.stdout, res.stdout + res.stderr
-    per = float(res.stdout.split("lone caller after the burst: ")[1].split(" us per call")[0])
-    assert per < base_us + 1000, (per, base_us, res.stdout)
+    last = None
+    for attempt in range(3):          # a timing comparison on a shared host: one clean attempt out of three is the evidence, three noisy ones are a failure
+        base = subprocess.run([sim, "1", "100", "100", "1"], capture_output=True, text=True, timeout=300)
+        assert base.returncode == 0, base.stdout + base.stderr
+        base_us = float(base.stdout.split(" calls in ")[1].split(" s = ")[0]) / 100 * 1e6
+        # a 3 ms window makes the difference unmistakable in a harness whose simulated device sleeps coarsely: un-forgotten, the estimate of 64 costs the lone caller
+        # ~12 waits of 3 ms over its 20 calls (+1.8 ms per call on average)
+        res = subprocess.run([sim, "64", "30", "100", "1", "30"], capture_output=True, text=True, timeout=300, env=dict(os.environ, KZG_HIP_COALESCE_US="3000"))
+        assert res.returncode == 0 and "wrong results: 0" in res.stdout, res.stdout + res.stderr
+        per = float(res.stdout.split("lone caller after the burst: ")[1].split(" us per call")[0])
+        last = (per, base_us, res.stdout)
+        if per < base_us + 1000:
+            return
+    raise AssertionError(last)
