@@ -254,7 +254,7 @@ uint32_t fb_windows(uint32_t c);   // capi_kzg.hip
 uint32_t fb_windows_glv(uint32_t c);   // capi_kzg.hip
 bool fb_glv_enabled();   // capi_kzg.hip
 bool coalescing_enabled();   // capi_kzg.hip
-coalescer *get_coalescer(kzg_hip_fft *fs, std::unique_ptr<coalescer> &slot, size_t in_row, size_t out_row);   // capi_kzg.hip
+coalescer *get_coalescer(kzg_hip_fft *fs, std::unique_ptr<coalescer> &slot, size_t in_row, size_t out_row, int callers_per_batch = 0);   // capi_kzg.hip
 int coalesce_upload_rows(coalesce_buf &b, uint64_t batch, size_t in_row_bytes, uint64_t n_max, fr *d_rows, uint64_t *d_meta);   // capi_kzg.hip
 int proof_single_rows(kzg_hip_kzg *ks, hipStream_t s, const fr *d_poly, uint64_t n, uint64_t batch, const uint64_t *d_x_u64, uint64_t x_stride, g1j *d_out);   // capi_kzg.hip
 int fk20_hext(fk20_core *c, hipStream_t s, const fr *d_poly, uint64_t poly_stride, uint64_t n, uint64_t batch, uint64_t j0, uint64_t cnt, g1j *d_hext);   // capi_fk20.hip

@@ -285,7 +285,7 @@ int kzg_hip_da_using_fk20_batch(kzg_hip_fk20s *fk, const void *poly_fr, uint64_t
 static int fk20_da_coalesced(fk20_core *c, const void *poly_fr, uint64_t n, void *out_g1) {
     KZG_TRY
     const uint64_t on = 2 * c->k;
-    coalescer *co = get_coalescer(c->ks->fs, c->co_da, n * sizeof(fr), on * sizeof(g1j));
+    coalescer *co = get_coalescer(c->ks->fs, c->co_da, n * sizeof(fr), on * sizeof(g1j), 48);   // two half batches side by side from 48 callers on (r04: 930/s from 64 threads; one batch of 64: 760-840/s)
     auto exec = [c, co, n, on](coalesce_buf &b, uint64_t batch) -> int {
         hipSetDevice(c->ks->fs->device);
         hipStream_t s = b.stream;

@@ -262,9 +262,9 @@ static uint64_t coalesce_rows(size_t in_row, size_t out_row) {
     uint64_t r = (64u << 20) / (row ? row : 1);          // 64 MiB of pinned rows per staging buffer: 113 rows of 4096 proofs (a 56-row cap split 64 callers 56 + 8)
     return r < 4 ? 4 : (r > 256 ? 256 : r);
 }
-coalescer *get_coalescer(kzg_hip_fft *fs, std::unique_ptr<coalescer> &slot, size_t in_row, size_t out_row) {
+coalescer *get_coalescer(kzg_hip_fft *fs, std::unique_ptr<coalescer> &slot, size_t in_row, size_t out_row, int callers_per_batch) {
     std::lock_guard<std::mutex> lk(fs->mu);
-    if (!slot) slot.reset(new coalescer(fs->device, in_row, out_row, coalesce_rows(in_row, out_row)));
+    if (!slot) slot.reset(new coalescer(fs->device, in_row, out_row, coalesce_rows(in_row, out_row), callers_per_batch));
     return slot.get();
 }
 // uploads the batch's rows (pinned, row stride in_row_bytes) as dense n_max-wide rows and zero-fills the tails

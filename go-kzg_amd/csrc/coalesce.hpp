@@ -97,8 +97,11 @@ class coalescer {
     // must block until the results are in host memory; returns a status that every request of the batch receives
     using exec_fn = std::function<int(coalesce_buf &, uint64_t batch)>;
 
-    coalescer(int device, size_t in_row_bytes, size_t out_row_bytes, uint64_t max_batch)
+    // callers_per_batch: concurrent callers per batch in flight (0: KZG_COALESCE_CALLERS_PER_BATCH).  The table walk of a commitment wants ONE batch for 64 callers
+    // (96); pipelines whose launches fill the chip from ~32 polynomials on and whose batches take tens of milliseconds (FK20) run two half batches side by side (48).
+    coalescer(int device, size_t in_row_bytes, size_t out_row_bytes, uint64_t max_batch, int callers_per_batch = 0)
         : device_(device), in_row_(in_row_bytes), out_row_(out_row_bytes), max_batch_(max_batch) {
+        if (callers_per_batch > 0) per_batch_ = callers_per_batch;
         if (const char *e = getenv("KZG_HIP_COALESCE_US")) window_us_ = atol(e);
         if (const char *e = getenv("KZG_HIP_COALESCE_EXEC")) { max_exec_ = atoi(e); if (max_exec_ < 1) max_exec_ = 1; if (max_exec_ > NBUF - 1) max_exec_ = NBUF - 1; }
         if (const char *e = getenv("KZG_HIP_COALESCE_SPIN_US")) spin_us_ = atol(e);
