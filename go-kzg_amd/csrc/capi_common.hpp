@@ -172,23 +172,6 @@ inline int d2h_staged(kzg_hip_fft *fs, hipStream_t s, void *host_dst, const void
     memcpy(host_dst, fs->h_stage, bytes);
     return KZG_HIP_OK;
 }
-// Waits for a stream whose work is SHORT (a coalesced batch, a lone commitment: tens of microseconds to a few milliseconds): polls hipStreamQuery
-// for up to KZG_HIP_SYNC_SPIN_US microseconds (default below) before falling back to the blocking hipStreamSynchronize, whose wake-up costs the
-// caller a scheduler round trip after the device is done.  One polling thread per batch (its leader), never the followers.
-inline hipError_t stream_wait_short(hipStream_t s) {
-    static const long spin_us = [] { const char *e = getenv("KZG_HIP_SYNC_SPIN_US"); return e ? atol(e) : 0L; }();
-    if (spin_us > 0) {
-        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us);
-        for (int i = 0;; i++) {
-            const hipError_t q = hipStreamQuery(s);
-            if (q == hipSuccess) return hipSuccess;
-            if (q != hipErrorNotReady) { (void)hipGetLastError(); break; }
-            if ((i & 15) == 15 && std::chrono::steady_clock::now() > until) break;
-        }
-        (void)hipGetLastError();                      // hipErrorNotReady is sticky in hipGetLastError
-    }
-    return hipStreamSynchronize(s);
-}
 // coalesced executors enqueue kernels that read and write a batch's PINNED rows in place: whatever way the executor returns (an error
 // status after some kernels were already enqueued included), the stream has drained before the rows are handed back to their callers
 struct drain_on_exit {

@@ -316,7 +316,7 @@ int kzg_hip_commit_to_poly(kzg_hip_kzg *ks, const void *coeffs_fr, uint64_t n, v
         CHK(commit_rows(ks, s, d_src, n_max, batch, d_out, stride));
         if (trace) hipStreamSynchronize(s);
         const auto t2 = std::chrono::steady_clock::now();
-        HIPCHK(stream_wait_short(s));
+        HIPCHK(hipStreamSynchronize(s));
         if (trace) {
             auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::micro>(c - a).count(); };
             fprintf(stderr, "[commit batch %llu] upload %.0f us, kernels %.0f us, final synchronisation %.0f us\n", (unsigned long long)batch, us(t0, t1), us(t1, t2),
@@ -357,7 +357,7 @@ int lincomb_points_coalesced(kzg_hip_points *pts, const void *scalars_fr, uint64
             d_src = d_rows.p; stride = n_max;
         }
         CHK(lincomb_points_rows(pts, s, d_src, n_max, batch, (g1j *)dp_out, stride));
-        HIPCHK(stream_wait_short(s));
+        HIPCHK(hipStreamSynchronize(s));
         return KZG_HIP_OK;
     };
     return co->submit(scalars_fr, n * sizeof(fr), n, 0, out_g1, sizeof(g1j), exec, KZG_HIP_ERR_HIP);
@@ -417,7 +417,7 @@ int kzg_hip_compute_proof_single(kzg_hip_kzg *ks, const void *poly_fr, uint64_t 
         CHK(coalesce_upload_rows(b, batch, co->in_row_bytes(), n_max, d_rows.p, d_meta.p));
         // a shorter polynomial padded with zero high coefficients has the same quotient (followed by zeros)
         CHK(proof_single_rows(ks, s, d_rows.p, n_max, batch, d_meta.p + 1, 2, (g1j *)dp_out));
-        HIPCHK(stream_wait_short(s));
+        HIPCHK(hipStreamSynchronize(s));
         return KZG_HIP_OK;
     };
     return co->submit(poly_fr, n * sizeof(fr), n, x, out_g1, sizeof(g1j), exec, KZG_HIP_ERR_HIP);
