@@ -441,6 +441,20 @@ def main():
                        "LinCombG1_4096_cached_points_ms": lat("LinCombG1_cached", lambda: pts.lin_comb(one), 10),
                        "FFTG1_4096_ms": lat("FFTG1", lambda: fs.fft_g1(setup, False), 7)}
             latency["statistic"] = "median of the timed calls after 3 warm-up calls"
+            # the reference's functions return Jacobian points with whatever Z the additions left; with kzg_hip_kzg_set_projective_outputs the library does the same
+            # (no inversion per result).  Default (above): normalised, Z = one.  Checked here: the projective results are the same group elements.
+            want_c, want_p = ks.commit_to_poly(one), ks.compute_proof_single(one, 17)
+            ks.set_projective_outputs(True)
+            try:
+                latency["projective_outputs"] = {
+                    "CommitToPoly_4096_ms": lat("CommitToPoly_projective", lambda: ks.commit_to_poly(one), 30),
+                    "ComputeProofSingle_4096_ms": lat("ComputeProofSingle_projective", lambda: ks.compute_proof_single(one, 17), 30),
+                    "one_blob_per_call_from_64_threads_per_s": ks.bench_drop_in(blobs_h[:64].copy(), 64, 40)[0],
+                    "same_group_elements": bool(np.array_equal(fs.to_compressed_g1(np.stack([ks.commit_to_poly(one), ks.compute_proof_single(one, 17)]).reshape(2, 3, 6)),
+                                                               fs.to_compressed_g1(np.stack([want_c, want_p]).reshape(2, 3, 6)))),
+                    "note": "kzg_hip_kzg_set_projective_outputs(ks, 1): results leave as un-normalised Jacobian images, the reference's own return type"}
+            finally:
+                ks.set_projective_outputs(False)
             latency["slowest_call_ms"] = lat_max
             pts.close()
 

@@ -121,7 +121,7 @@ def lib():
         "kzg_hip_recover_poly_from_samples": (i32, [vp, vp, vp, u64, vp]),
         "kzg_hip_calibrate": (i32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "kzg_hip_bench_drop_in": (i32, [vp, i32, vp, u64, u64, u32, u32, vp, C.POINTER(C.c_double)]),
-        "kzg_hip_kzg_table_info": (i32, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(u64)]), "kzg_hip_kzg_table_additions": (u32, [vp]),
+        "kzg_hip_kzg_table_info": (i32, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(u64)]), "kzg_hip_kzg_table_additions": (u32, [vp]), "kzg_hip_kzg_set_projective_outputs": (i32, [vp, i32]),
         "kzg_hip_da_using_fk20_multi_batch": (i32, [vp, vp, u64, u64, vp]),
         "kzg_hip_multi_settings_new": (i32, [C.POINTER(i32), u32, u32, vp, u64, pp]), "kzg_hip_multi_settings_free": (None, [vp]),
         "kzg_hip_multi_device_count": (u32, [vp]), "kzg_hip_multi_device": (i32, [vp, u32]),
@@ -470,6 +470,10 @@ class KZGSettings:
         c, w, b = C.c_uint32(0), C.c_uint32(0), C.c_uint64(0)
         _chk(lib().kzg_hip_kzg_table_info(self.h, C.byref(c), C.byref(w), C.byref(b)))
         return c.value, w.value, b.value
+
+    def set_projective_outputs(self, on=True):
+        """CommitToPoly / ComputeProofSingle return un-normalised Jacobian images (the reference's own return type): no inversion per result"""
+        _chk(lib().kzg_hip_kzg_set_projective_outputs(self.h, 1 if on else 0))
 
     def table_additions(self):
         """mixed additions per coefficient on that table (2 x windows: both GLV halves of a scalar walk the same rows)"""

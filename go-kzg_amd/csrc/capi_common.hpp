@@ -11,6 +11,7 @@
 #include "sha256.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -80,6 +81,7 @@ struct kzg_hip_kzg {
     g1a *d_fixed = nullptr;      // fixed-base window table (lazily built)
     msm_plan fixed_plan{};
     double budget_gb = -1.0;             // fixed-base table budget; < 0: default policy (ensure_fixed_table)
+    std::atomic<bool> projective{false}; // kzg_hip_kzg_set_projective_outputs: table-walk results leave as Jacobian images with Z != 1 (no inversion per result)
     hipStream_t copy_stream = nullptr;   // uploads of the host-buffer batch entry point, overlapped with the walk of the previous chunk
     hipEvent_t copy_done[2] = {nullptr, nullptr};
     std::unique_ptr<coalescer> co_commit, co_proof;   // merge concurrent one-polynomial calls into batched launches (coalesce.hpp)

@@ -121,7 +121,7 @@ int commit_rows(kzg_hip_kzg *ks, hipStream_t s, const fr *d_sc, uint64_t n, uint
     size_t ws_main = fixed ? fb_partials_bytes(n, batch) : msm_workspace_bytes(p, n, batch);
     dtmp<uint8_t> d_ws(s);
     CHK(d_ws.alloc(ws_main));
-    if (fixed) launch_fb_msm(s, ks->d_fixed, p.table_n, p.c, p.nwin, d_sc, sc_stride, n, batch, d_ws.p, d_out, true, p.glv != 0);   // sums, normalises, converts
+    if (fixed) launch_fb_msm(s, ks->d_fixed, p.table_n, p.c, p.nwin, d_sc, sc_stride, n, batch, d_ws.p, d_out, true, p.glv != 0, ks->projective.load(std::memory_order_relaxed));   // sums, normalises (unless projective), converts
     else launch_msm(s, p, ks->d_secret_a, d_sc, sc_stride, n, batch, d_ws.p, d_out, true);
     HIPCHK(hipGetLastError());
     return KZG_HIP_OK;
@@ -490,6 +490,16 @@ int kzg_hip_kzg_table_info(kzg_hip_kzg *ks, uint32_t *window_bits, uint32_t *win
     bool have = ks->d_fixed != nullptr;
     *window_bits = have ? ks->fixed_plan.c : 0; *windows = have ? ks->fixed_plan.nwin : 0;
     *table_bytes = have ? (uint64_t)ks->fixed_plan.nwin * ks->fixed_plan.table_n * ks->fixed_plan.nb * sizeof(g1a) : 0;
+    return KZG_HIP_OK;
+}
+// The reference's G1Point IS a Jacobian triple (bls/bls_kilic.go:30-35) and CommitToPoly / ComputeProofSingle return whatever Z their additions left; this
+// library normalises every result (Z = one) by default, which costs one F_p inversion per result: ~110 us of pure latency on one lane, a third of a lone
+// CommitToPoly.  on != 0: results of the fixed-base table walk on THIS settings object (CommitToPoly, ComputeProofSingle, their batch, _dev and coalesced
+// forms) leave as (X ZZ, Y ZZZ, ZZ) -- the same group element, Z != one; the bucket fallback (no table) still normalises.  eth and cached point sets hold
+// settings objects of their own and are not affected.
+int kzg_hip_kzg_set_projective_outputs(kzg_hip_kzg *ks, int on) {
+    if (!ks) return KZG_HIP_ERR_BAD_ARG;
+    ks->projective.store(on != 0, std::memory_order_relaxed);
     return KZG_HIP_OK;
 }
 // mixed additions per coefficient of a commitment on that table: 2 x windows when both GLV halves of a scalar walk it (the default), else windows; 0 without a table

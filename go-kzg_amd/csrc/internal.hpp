@@ -117,7 +117,7 @@ void launch_msm_window_table(hipStream_t s, const g1a *pts, uint64_t n, uint32_t
 size_t fb_partials_bytes(uint64_t n, uint64_t batch);
 hipError_t launch_fb_build(hipStream_t s, const g1a *pts, uint64_t n, uint32_t c, uint32_t nwin, g1a *table);
 void launch_fb_msm(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, uint64_t sc_stride, uint64_t n,
-                   uint64_t batch, void *partials, g1j *out, bool to_kilic, bool glv = false);
+                   uint64_t batch, void *partials, g1j *out, bool to_kilic, bool glv = false, bool projective = false);
 
 // out[(b, f, jj)] = scalars[b][f * row + j0 + jj] * P[f * row + j0 + jj] over a fixed-base table of table_n = nfiles * row points
 // (glv, here and below: the table holds ceil(128 / c) windows and both GLV halves of every scalar walk them)

@@ -885,6 +885,7 @@ __global__ __launch_bounds__(256) void k_fb_finish(const fb_partial *partials, u
     if (c.wave == 0 && col == 0) {
         g1j r;
         if (acc.inf) r = g1_inf();
+        else if (to_kilic & 2) r = g1x_to_jac(g1xq_pack(acc.v));   // projective output (kzg_hip_kzg_set_projective_outputs): (X ZZ, Y ZZZ, ZZ), no inversion
         else {   // x = X / ZZ, y = Y / ZZZ with ONE inversion: i = 1 / (ZZ ZZZ), 1 / ZZ = i ZZZ, 1 / ZZZ = i ZZ
             g1x px = g1xq_pack(acc.v);
 #ifdef KZG_FINISH_NOINV                                      // timing experiment only (wrong results): what the inversion costs
@@ -894,7 +895,7 @@ __global__ __launch_bounds__(256) void k_fb_finish(const fb_partial *partials, u
 #endif
             r.x = mul(px.x, mul(i, px.zzz)); r.y = mul(px.y, mul(i, px.zz)); r.z = one<FpP>();
         }
-        out[b] = to_kilic ? g1_to_kilic(r) : r;
+        out[b] = (to_kilic & 1) ? g1_to_kilic(r) : r;
     }
 }
 
@@ -914,12 +915,13 @@ __global__ __launch_bounds__(64) void k_fb_finish_lanes(const fb_partial *partia
     }
     g1j r;
     if (acc.inf) r = g1_inf();
+    else if (to_kilic & 2) r = g1x_to_jac(g1xq_pack(acc.v));       // projective output: no inversion
     else {
         g1x px = g1xq_pack(acc.v);
         fp i = inv<FpP>(mul(px.zz, px.zzz));
         r.x = mul(px.x, mul(i, px.zzz)); r.y = mul(px.y, mul(i, px.zz)); r.z = one<FpP>();
     }
-    out[b] = to_kilic ? g1_to_kilic(r) : r;
+    out[b] = (to_kilic & 1) ? g1_to_kilic(r) : r;
 }
 
 // One fixed-base product added into an accumulator: the walk of point i's rows with the signed c-bit digits of a scalar (standard form), sign sg folded in.
@@ -1172,8 +1174,9 @@ size_t fb_partials_bytes(uint64_t n, uint64_t batch) { return (((size_t)std::max
 // out[b] = the NORMALISED sum (Z = one), as Kilic images when to_kilic: the per-blob partial sums are added and inverted in one
 // latency-bound kernel instead of two.  glv: the table holds ceil(128 / c) windows and both GLV halves of every scalar walk them (k_fb_accumulate_glv).
 void launch_fb_msm(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, const fr *scalars, uint64_t sc_stride, uint64_t n,
-                   uint64_t batch, void *partials, g1j *out, bool to_kilic, bool glv) {
+                   uint64_t batch, void *partials, g1j *out, bool to_kilic, bool glv, bool projective) {
     if (!batch) return;
+    const int fin = (to_kilic ? 1 : 0) | (projective ? 2 : 0);
     uint32_t split = 1;
     uint32_t bpb = fb_blocks_per_blob(glv ? 2 * n : n, batch, &split);   // (glv: `split` lanes per HALF, so up to 16 lanes per point with one window each)
     if (split > nwin) split = nwin;
@@ -1188,8 +1191,8 @@ void launch_fb_msm(hipStream_t s, const g1a *table, uint64_t table_n, uint32_t c
     else hipLaunchKernelGGL(k_fb_accumulate<false>, dim3((uint32_t)(batch * bpb)), dim3(FB_ACC_BLOCK), 0, s, table, table_n, c, nwin, 1u << (c - 1), scalars, sc_stride, n, bpb,
                             1u, (fb_partial *)partials);
     prof_end(s, "fb_accumulate");
-    if (bpb <= FB_FINISH_LANES_MAX) hipLaunchKernelGGL(k_fb_finish_lanes, dim3((uint32_t)((batch + 63) / 64)), dim3(64), 0, s, (const fb_partial *)partials, bpb, batch, out, to_kilic ? 1 : 0);
-    else hipLaunchKernelGGL(k_fb_finish, dim3((uint32_t)batch), dim3(256), 0, s, (const fb_partial *)partials, bpb, batch, out, to_kilic ? 1 : 0);
+    if (bpb <= FB_FINISH_LANES_MAX) hipLaunchKernelGGL(k_fb_finish_lanes, dim3((uint32_t)((batch + 63) / 64)), dim3(64), 0, s, (const fb_partial *)partials, bpb, batch, out, fin);
+    else hipLaunchKernelGGL(k_fb_finish, dim3((uint32_t)batch), dim3(256), 0, s, (const fb_partial *)partials, bpb, batch, out, fin);
 }
 // builds the table for `n` affine points: rows (2^(c w) P_i) first, then all multiples window-slab by window-slab
 hipError_t launch_fb_build(hipStream_t s, const g1a *pts, uint64_t n, uint32_t c, uint32_t nwin, g1a *table) {

@@ -186,6 +186,17 @@ func (ks *KZGSettings) TableInfo() (windowBits, windows uint32, tableBytes uint6
 	return uint32(c), uint32(w), uint64(b)
 }
 
+// SetProjectiveOutputs: CommitToPoly / ComputeProofSingle on this object return un-normalised Jacobian points, as the reference's own functions do (no F_p inversion
+// per result: a lone CommitToPoly 0.30 -> ~0.19 ms).  Compare with bls.EqualG1; bls.ToCompressedG1 normalises as always.
+func (ks *KZGSettings) SetProjectiveOutputs(on bool) {
+	defer runtime.KeepAlive(ks)
+	v := C.int(0)
+	if on {
+		v = 1
+	}
+	hipMust(C.kzg_hip_kzg_set_projective_outputs(ks.hip(), v))
+}
+
 // TableAdditions: mixed additions per coefficient of a commitment on that table (2 x windows: both GLV halves of a scalar walk the same rows).
 func (ks *KZGSettings) TableAdditions() uint32 {
 	defer runtime.KeepAlive(ks)

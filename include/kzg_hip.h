@@ -316,6 +316,11 @@ int kzg_hip_multi_da_using_fk20_multi(kzg_hip_multi_fk20m *fk, const void *poly_
  * additions (kzg_hip_kzg_table_additions): 4096 points at c = 16 are 8 windows = 103 GB, the default budget (110 GB; kzg_hip_kzg_set_table_budget_gb). */
 int kzg_hip_kzg_table_info(kzg_hip_kzg *ks, uint32_t *window_bits, uint32_t *windows, uint64_t *table_bytes);
 uint32_t kzg_hip_kzg_table_additions(kzg_hip_kzg *ks);
+/* Projective outputs (off by default).  The reference's G1Point is a Jacobian triple and CommitToPoly / ComputeProofSingle return it with whatever Z the
+ * additions left (kzg_single_proofs.go:17-19,36-54; bls/bls_kilic.go:30-35); this library normalises every result to Z = one, one F_p inversion per result:
+ * ~0.11 ms of latency, a third of a lone CommitToPoly.  on != 0: CommitToPoly / ComputeProofSingle on this settings object (single, batch, _dev forms) return the
+ * same group element as an un-normalised Jacobian image (Z != one; infinity stays (0, 1, 0)); callers compare with bls.EqualG1 / compress as they would the reference's. */
+int kzg_hip_kzg_set_projective_outputs(kzg_hip_kzg *ks, int on);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

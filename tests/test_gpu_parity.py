@@ -765,6 +765,39 @@ def test_commit_with_every_table_size(kz, setup_1337, budget_gb, want_c, want_c_
         fs.close()
 
 
+def test_projective_outputs_are_the_same_group_elements(kz, setup_1337):
+    """kzg_hip_kzg_set_projective_outputs: CommitToPoly / ComputeProofSingle (single = coalesced, batch, one workgroup per blob and several) return un-normalised
+    Jacobian images -- the reference's own return type (bls/bls_kilic.go:30-35) -- of exactly the points the default, normalised outputs are; infinity keeps its
+    image; switching back restores Z = one; a settings object without a table (bucket path) is unaffected"""
+    fs = kz.FFTSettings(12)
+    ks = kz.KZGSettings(fs, setup_1337)
+    ks.set_table_budget_gb(10)
+    rng = np.random.default_rng(77)
+    blobs = np.stack([rand_fr(rng, 4096) for _ in range(6)])
+    blobs[4] = 0
+    big = np.concatenate([blobs] * 100)[:520].copy()                     # one workgroup per blob, one lane finishes each
+    xs = np.arange(3, 9, dtype=np.uint64)
+    want_c, want_p, want_big = ks.commit_to_poly_batch(blobs), ks.compute_proof_single_batch(blobs, xs), ks.commit_to_poly_batch(big)
+    one_k = ko.g1_affine(ko.g1_generator())[0][2]                        # Kilic image of Z = one
+    assert all(np.array_equal(w[2], one_k) for i, w in enumerate(want_c) if i != 4)
+    ks.set_projective_outputs(True)
+    got_c, got_p, got_big = ks.commit_to_poly_batch(blobs), ks.compute_proof_single_batch(blobs, xs), ks.commit_to_poly_batch(big)
+    singles = np.stack([ks.commit_to_poly(b) for b in blobs]).reshape(6, 3, 6)
+    single_p = ks.compute_proof_single(blobs[1], 4)
+    for got, want in ((got_c, want_c), (got_p, want_p), (got_big, want_big), (singles, want_c)):
+        assert np.array_equal(fs.to_compressed_g1(got), fs.to_compressed_g1(want))
+        assert all(ko.g1_equal(got[i], want[i]) for i in range(4))        # bls.EqualG1 on the oracle's side: projective equality
+    assert np.array_equal(fs.to_compressed_g1(single_p.reshape(1, 3, 6)), fs.to_compressed_g1(want_p[1:2]))
+    assert not np.array_equal(got_c[0], want_c[0]) and not np.array_equal(got_c[0][2], one_k)      # really un-normalised
+    assert np.array_equal(got_c[4], want_c[4])                                                      # infinity: (0, 1, 0) either way
+    ks.set_projective_outputs(False)
+    assert np.array_equal(ks.commit_to_poly_batch(blobs), want_c) and np.array_equal(ks.commit_to_poly(blobs[2]).reshape(3, 6), want_c[2])
+    ks.set_table_budget_gb(0)                                             # bucket path: normalised whatever the flag says
+    ks.set_projective_outputs(True)
+    assert np.array_equal(ks.commit_to_poly_batch(blobs), want_c)
+    ks.close(); fs.close()
+
+
 def test_commit_batch_shapes_fuzz(kz, ks4096, setup_1337):
     # batch sizes that exercise every launch shape (blocks per blob 32 .. 1, the chunked upload of the host-buffer form at >= 512
     # blobs, ragged last chunk) and ragged polynomial lengths; the first five rows are random (oracle MSM each), the others are
