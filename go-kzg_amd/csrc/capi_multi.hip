@@ -236,7 +236,10 @@ int all_gather_bytes(kzg_hip_multi *m, const std::vector<xbuf> &buf, size_t byte
         // device -> pinned host -> device: no peer mapping involved.  The staging area belongs to the handle (sharded calls are serialised).
         const size_t total = D * bytes_each;
         if (m->h_stage_cap < total) {
-            if (m->h_stage) { HIPCHK(hipHostFree(m->h_stage)); m->h_stage = nullptr; m->h_stage_cap = 0; }
+            if (m->h_stage) {   // copies of an earlier exchange may still be reading the old area: drain before it goes
+                for (auto &d : m->d) { HIPCHK(hipSetDevice(d.device)); HIPCHK(hipStreamSynchronize(d.s)); }
+                HIPCHK(hipHostFree(m->h_stage)); m->h_stage = nullptr; m->h_stage_cap = 0;
+            }
             size_t cap = std::max<size_t>(total, 1u << 20);
             HIPCHK(hipHostMalloc((void **)&m->h_stage, cap, hipHostMallocPortable));
             m->h_stage_cap = cap;
