@@ -200,8 +200,15 @@ def main():
                 "self_launched": bool(os.environ.get("KZG_BENCH_SELF_LAUNCHED")),
                 "tables_per_rank": [{"rank": r[0], "window_bits": r[2], "windows": r[3], "GB": r[4] / 1e9} for r in seen],
                 "all_gather_proofs_ms": None, "sharded_one_polynomial_ms": None}
+    # HIP events around every kernel of the TIMED steps (on the launch stream): the roofline's launch duration is taken from the very launches `value` is made of
+    secs = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, barrier, max_over_ranks, before_timed=lambda: lib.kzg_hip_prof_reset(fs.h, 1))
+    tot, cnt = C.c_double(0), C.c_uint64(0)
+    dominant = b"fb_accumulate"
+    lib.kzg_hip_prof_read(fs.h, dominant, C.byref(tot), C.byref(cnt))
+    if not cnt.value:
+        dominant = b"msm_accumulate"
+        lib.kzg_hip_prof_read(fs.h, dominant, C.byref(tot), C.byref(cnt))
     lib.kzg_hip_prof_reset(fs.h, 0)
-    secs = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, barrier, max_over_ranks)
     value = B * world * args.steps / secs
 
     def poly_lincomb(d_rows, stride, rho_h, count, n):
@@ -262,18 +269,7 @@ def main():
             batch_sweep[str(bs)] = {"commitments_per_s": bs * world * reps / ssecs, "ms_per_step": ssecs / reps * 1e3}
         del d_big, d_big_out
 
-    # roofline leg: HIP events around the dominant kernel on the launch stream, separate (un-timed) pass
-    lib.kzg_hip_prof_reset(fs.h, 1)
-    for _ in range(max(3, min(args.steps, 10))):
-        step()
-    torch.cuda.synchronize()
-    tot, cnt = C.c_double(0), C.c_uint64(0)
-    dominant = b"fb_accumulate"
-    lib.kzg_hip_prof_read(fs.h, dominant, C.byref(tot), C.byref(cnt))
-    if not cnt.value:
-        dominant = b"msm_accumulate"
-        lib.kzg_hip_prof_read(fs.h, dominant, C.byref(tot), C.byref(cnt))
-    lib.kzg_hip_prof_reset(fs.h, 0)
+    # roofline leg: the HIP-event records of the timed steps above (tot, cnt)
     roofline = None
     if cnt.value:
         avg_s = tot.value / cnt.value * 1e-3
@@ -282,6 +278,12 @@ def main():
         # HBM bytes per launch come from the committed PMC passes (profiles/) only when the workload matches that measurement (benchlib/roofline.py)
         roofline, pm, pm_sc = walk_roofline("k_" + dominant.decode(), B, avg_s, (tab_c, tab_w, tab_bytes), pmc, pmc.get("_file"))
         pm_ok = pm is not None
+        # measured on the args.steps timed launches themselves: a launch cannot be longer than the step it is part of
+        roofline["launches_timed"], roofline["timed_in"] = int(cnt.value), "the %d timed steps (HIP events on the launch stream; nothing of the warm-up)" % args.steps
+        roofline["launch_over_step"] = avg_s * (cnt.value / args.steps) / (secs / args.steps)
+        if roofline["launch_over_step"] > 1.002:
+            raise SystemExit("bench self-check failed: the dominant kernel's launches (%.3f ms per step) exceed the step (%.3f ms)" % (
+                avg_s * 1e3 * cnt.value / args.steps, secs / args.steps * 1e3))
         if dominant == b"fb_accumulate" and B >= 512:           # one 256-lane workgroup per blob from 512 blobs on: the row of this launch shape
             pa_, ps_ = profile_avg_ms("k_fb_accumulate", B * 256, 256)
             roofline["profile_avg_ms"], roofline["profile_source"] = pa_, ps_
@@ -862,6 +864,7 @@ def main():
         print(json.dumps({
             "metric": "KZG commitments/sec (CommitToPoly, 4096-element blob); FK20 half: value_fk20_4096", "value": value, "unit": "commitments/s",
             "value_fk20_4096": fk_half, "unit_fk20_4096": "all-proofs/s", "roofline_fk20_4096": roofline_fk20_4096,
+            "cpu_baseline_fk20_4096": base.get("fk20_4096") if isinstance(base, dict) else None,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": secs / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "dtype_note": "30/32-bit limbs in u32 lanes, 64-bit accumulators (v_mad_u64_u32): 381-bit F_p and 255-bit F_r Montgomery arithmetic",
             "data": "synthetic",

@@ -83,14 +83,18 @@ def dist_env():
     return rank, world, local
 
 
-def timed_steps(step_fn, steps, warmup, sync_fn, barrier_fn, max_over_ranks_fn):
+def timed_steps(step_fn, steps, warmup, sync_fn, barrier_fn, max_over_ranks_fn, before_timed=None):
     """W untimed steps, then exactly K steps bracketed by barrier + device sync; returns max-over-ranks seconds.
-    Backend-agnostic so that tests/test_bench_dist.py can drive it with gloo on CPU."""
+    Backend-agnostic so that tests/test_bench_dist.py can drive it with gloo on CPU.  `before_timed` runs after the warm-up
+    has drained and before the clock starts (bench.py switches the per-kernel HIP-event records on there, so that the
+    roofline's launch durations are those of the TIMED steps and nothing of the warm-up)."""
     for _ in range(warmup):
         step_fn()
     sync_fn()
     barrier_fn()
     sync_fn()
+    if before_timed is not None:
+        before_timed()
     t0 = time.perf_counter()
     for _ in range(steps):
         step_fn()

@@ -6,6 +6,7 @@ compare the full hash (tests/test_gpu_parity.py), so a permutation / offset erro
 sampled coset identity does not visit cannot hide.
 
     python tests/golden/make_fk20_pins.py            # ~10 minutes of single-core oracle time (scale-16 settings dominate)
+    python tests/golden/make_fk20_pins.py --only-l128   # just config 5's second variant (chunk length 128), merged into the file
 
 Inputs are the synthetic blobs of SURVEY.md 8(d) (splitmix64, seed = config seed); setups are GenerateTestingSetup with
 the reference's test secret (kzg_single_proofs_test.go) except config 4a, which uses the s = 1337 monomial setup of
@@ -32,7 +33,28 @@ def digest(points):
             "first": c[0].tobytes().hex(), "last": c[-1].tobytes().hex()}
 
 
+def config5_l128(out, ks16, t0):
+    # config 5, second variant ("also l = 128 (integration_test.go:74)"): the same 32768 coefficients of seed 5,
+    # chunk length 128 -> k = 256, 512 coset proofs
+    fkm128 = ko.FK20MultiSettings(ks16, 65536, 128)
+    print("scale-16 l=128 settings done %.0f s" % (time.time() - t0), flush=True)
+    out["config5_l128_da_using_fk20_multi_seed5"] = digest(fkm128.da_using_fk20_multi(ko.synthetic_blob(5, 32768)))
+    print("5 (l=128) done %.0f s" % (time.time() - t0), flush=True)
+
+
 def main():
+    if "--only-l128" in sys.argv:
+        path = os.path.join(HERE, "fk20_pins.json")
+        out = json.load(open(path))
+        t0 = time.time()
+        ks16 = ko.KZGSettings(ko.FFTSettings(16), ko.generate_testing_setup_g1(S_TEST, 65536))
+        config5_l128(out, ks16, t0)
+        out["oracle_seconds_l128"] = round(time.time() - t0)
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+            f.write("\n")
+        print(json.dumps(out["config5_l128_da_using_fk20_multi_seed5"], indent=1))
+        return
     out = {"note": "SHA-256 over the concatenated 48-byte compressed proofs in returned order; produced by the CPU oracle "
                    "(tests/golden/make_fk20_pins.py), not by running the reference (no Go toolchain in the image)"}
     t0 = time.time()
@@ -65,6 +87,7 @@ def main():
     print("scale-16 settings done %.0f s" % (time.time() - t0), flush=True)
     out["config5_da_using_fk20_multi_seed5"] = digest(fkm.da_using_fk20_multi(ko.synthetic_blob(5, 32768)))
     print("5 done %.0f s" % (time.time() - t0), flush=True)
+    config5_l128(out, ks16, t0)
     out["oracle_seconds"] = round(time.time() - t0)
     with open(os.path.join(HERE, "fk20_pins.json"), "w") as f:
         json.dump(out, f, indent=1)

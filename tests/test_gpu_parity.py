@@ -1054,29 +1054,56 @@ def test_fk20_multi_scale16_config5(kz):
     for j in range(4096):                                                      # linearity, every position
         L.ko_g1_add(tmp.ctypes.data, pa[j].ctypes.data, pb[j].ctypes.data)
         assert L.ko_g1_equal(tmp.ctypes.data, ps[j].ctypes.data), j
-    w2n = pyref.root_of_unity(16)
     gen = ko.g1_generator()
-    # coset-proof identity at EVERY position: proof = [(p(s) - I(s)) / (s^l - x^l)] G with I = p mod (X^l - x^l).  The l coefficients of I at all
-    # 4096 cosets at once: I_i = sum_t p[i + t l] (x^l)^t, and x^l runs over the 4096-th roots of unity, so coefficient i of every coset is one
-    # 4096-point transform (the oracle's) of the stride-l subsequence p[i::l]
-    R = ko.R_MOD
-    ofs12 = ko.FFTSettings(12)
-    sub = [ko.fr_to_ints(ofs12.fft(ko.fr_from_ints(ai[i::l] + [0] * 2048))) for i in range(l)]
-    spow = [pow(S_TEST, i, R) for i in range(l + 1)]
-    ps_ = pyref.eval_poly(ai, S_TEST)
-    w4096 = pyref.root_of_unity(12)
-    dl = []
-    for pos in range(4096):
-        k = pyref.rev_bits(pos, 12)                                             # domainStride = MaxWidth / n2 = 1: x = w_2n^bitrev(pos)
-        i_s = sum(spow[i] * sub[i][k] for i in range(l)) % R
-        dl.append((ps_ - i_s) * pow(spow[l] - pow(w4096, k, R), -1, R) % R)
-    for pos in (0, 1, 2, 777, 2048, 4095):                                      # the vectorised form against the plain restatement
-        assert dl[pos] == pyref.coset_proof_dlog(ai, S_TEST, pow(w2n, pyref.rev_bits(pos, 12), R), l), pos
-    want = ko.g1_empty(1)
+    dl = _coset_proof_dlogs_scale16(ai, l)
     dfr = ko.fr_from_ints(dl)
     for pos in range(4096):
         assert ko.g1_equal(pa[pos], ko.g1_mul(gen, dfr[pos])), pos
-    fk.close(); ks.close(); fs.close()
+    fk.close()
+    # config 5's second variant ("also l = 128 (integration_test.go:74)"): the same 32 768 coefficients, chunk length 128 -> k = 256, 512 coset proofs.
+    # Byte pin of the oracle's full-size run + the coset identity at all 512 positions + linearity
+    l2 = 128
+    fk2 = kz.FK20MultiSettings(ks, 2 * n, l2)
+    qa, qb, qs = fk2.da_using_fk20_multi(a), fk2.da_using_fk20_multi(b), fk2.da_using_fk20_multi(s)
+    assert qa.shape == (512, 3, 6)
+    pin2 = FK20_PINS["config5_l128_da_using_fk20_multi_seed5"]
+    assert pin2["count"] == 512 and proofs_sha256(fs, qa) == pin2["sha256"]
+    assert comp_hex(qa[:1])[0] == pin2["first"] and comp_hex(qa[-1:])[0] == pin2["last"]
+    for j in range(512):
+        L.ko_g1_add(tmp.ctypes.data, qa[j].ctypes.data, qb[j].ctypes.data)
+        assert L.ko_g1_equal(tmp.ctypes.data, qs[j].ctypes.data), j
+    dfr2 = ko.fr_from_ints(_coset_proof_dlogs_scale16(ai, l2))
+    for pos in range(512):
+        assert ko.g1_equal(qa[pos], ko.g1_mul(gen, dfr2[pos])), pos
+    # batch rows == single calls on the l = 128 settings
+    qq = fk2.da_using_fk20_multi_batch(np.stack([a, b]))
+    assert np.array_equal(qq[0], qa) and np.array_equal(qq[1], qb)
+    fk2.close(); ks.close(); fs.close()
+
+
+def _coset_proof_dlogs_scale16(ai, l):
+    """discrete logs (known test secret) of all 2 k = 65536 / l coset proofs of the 32768-coefficient polynomial `ai` in DAUsingFK20Multi's returned (bit-reversed)
+    order: proof = [(p(s) - I(s)) / (s^l - x^l)] G with I = p mod (X^l - x^l) (pairing-free form of CheckProofMulti, fk20_multi_test.go:86).  The l coefficients of I
+    at all cosets at once: I_i = sum_t p[i + t l] (x^l)^t, and x^l runs over the 2k-th roots of unity, so coefficient i of every coset is one 2k-point transform
+    (the oracle's) of the stride-l subsequence p[i::l]."""
+    R = ko.R_MOD
+    n = len(ai)
+    k2 = 2 * n // l
+    lg = k2.bit_length() - 1
+    ofs = ko.FFTSettings(lg)
+    sub = [ko.fr_to_ints(ofs.fft(ko.fr_from_ints(ai[i::l] + [0] * (k2 // 2)))) for i in range(l)]
+    spow = [pow(S_TEST, i, R) for i in range(l + 1)]
+    ps_ = pyref.eval_poly(ai, S_TEST)
+    wk2 = pyref.root_of_unity(lg)
+    w2n = pyref.root_of_unity(16)
+    dl = []
+    for pos in range(k2):
+        k = pyref.rev_bits(pos, lg)                                             # domainStride = MaxWidth / n2 = 1: x = w_2n^bitrev(pos)
+        i_s = sum(spow[i] * sub[i][k] for i in range(l)) % R
+        dl.append((ps_ - i_s) * pow(spow[l] - pow(wk2, k, R), -1, R) % R)
+    for pos in (0, 1, 2, k2 // 5, k2 // 2, k2 - 1):                             # the vectorised form against the plain restatement
+        assert dl[pos] == pyref.coset_proof_dlog(ai, S_TEST, pow(w2n, pyref.rev_bits(pos, lg), R), l), pos
+    return dl
 
 
 # ------------------------------------------------------------------ eth/ byte-level path (SURVEY.md 8f row f1)

@@ -237,7 +237,16 @@ def test_config5_one_polynomial_byte_pin(kz, devices, mode, monkeypatch):
     assert m.exchanges - e0 == (5 if mode == "sharded" else 1)
     pin = FK20_PINS["config5_da_using_fk20_multi_seed5"]
     assert sha(fs, proofs) == pin["sha256"]
-    fk.close(); m.close(); fs.close()
+    fk.close()
+    if len(devices) == 2:
+        # config 5's second variant (integration_test.go:74): chunk length 128 -> 512 coset proofs, 256 output positions per entry
+        fk2 = kz.MultiFK20MultiSettings(m, 2 * n, 128)
+        e0 = m.exchanges
+        proofs2 = fk2.da_using_fk20_multi(ko.synthetic_blob(5, n))
+        assert proofs2.shape[0] == 512 and m.exchanges - e0 == (5 if mode == "sharded" else 1)
+        assert sha(fs, proofs2) == FK20_PINS["config5_l128_da_using_fk20_multi_seed5"]["sha256"]
+        fk2.close()
+    m.close(); fs.close()
 
 
 def test_rccl_leg_on_a_single_device_communicator(kz, monkeypatch):
@@ -363,4 +372,7 @@ def test_distinct_devices_byte_pins(kz, monkeypatch, force, mode):
     proofs = fk.da_using_fk20_multi(ko.synthetic_blob(5, n))
     assert m.exchanges - e0 == (5 if mode == "sharded" else 1)
     assert sha(fs, proofs) == FK20_PINS["config5_da_using_fk20_multi_seed5"]["sha256"]
-    fk.close(); m.close(); fs.close()
+    fk.close()
+    fk2 = kz.MultiFK20MultiSettings(m, 2 * n, 128)                                  # the l = 128 variant: 512 coset proofs
+    assert sha(fs, fk2.da_using_fk20_multi(ko.synthetic_blob(5, n))) == FK20_PINS["config5_l128_da_using_fk20_multi_seed5"]["sha256"]
+    fk2.close(); m.close(); fs.close()
