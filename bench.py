@@ -89,7 +89,7 @@ def main():
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            base = cpu_baseline()                           # first: the all-cores leg forks, which must precede HIP initialisation
+            base = cpu_baseline(float(os.environ.get("KZG_BENCH_CPU_BUDGET_S", "6")))   # first: the all-cores leg forks, which must precede HIP initialisation
         except Exception as e:                              # noqa: BLE001  (a missing / unbuildable oracle must not cost the GPU measurement)
             base = {"value": None, "unit": "commitments/s", "cores": 0, "kind": "port", "sample": "failed: %s: %s" % (type(e).__name__, e)}
 
@@ -365,10 +365,28 @@ def main():
             host_blobs = blobs_h[:64].copy()
             drop_in = {"entry": "kzg_hip_commit_to_poly (host buffers, blocking, one 4096-coefficient blob per call)", "threads": {}}
             ks.bench_drop_in(host_blobs, 8, 4)
+            # every thread count three times (min / median / max: a cold box and a warm one have differed by 30 % at 256 callers); `commitments_per_s` is the median.
+            # The coalescer's own counters over the three 256-caller runs (batches, rows per batch, where a batch's time goes) make a discrepancy diagnosable from the line alone
             for T in (1, 8, 64, 256):
-                rate_, outs = ks.bench_drop_in(host_blobs, T, 200 if T == 1 else 60)
-                drop_in["threads"][str(T)] = {"commitments_per_s": rate_, "frac_of_device_resident_batch": rate_ / (value / world),
+                before = ks.coalesce_stats(0)
+                runs = []
+                for _rep in range(3):
+                    rate_, outs = ks.bench_drop_in(host_blobs, T, 200 if T == 1 else 60)
+                    runs.append(rate_)
+                runs.sort()
+                rate_ = runs[1]
+                drop_in["threads"][str(T)] = {"commitments_per_s": rate_, "min": runs[0], "median": runs[1], "max": runs[2], "runs": 3,
+                                              "frac_of_device_resident_batch": rate_ / (value / world),
                                               "frac_of_512_blob_resident_rate": rate_ / (batch_sweep["512"]["commitments_per_s"] / world)}
+                after = ks.coalesce_stats(0)
+                nb = after["batches"] - before["batches"]
+                if nb > 0:
+                    ms = {k: (after["ms_per_batch"][k] * after["batches"] - before["ms_per_batch"][k] * before["batches"]) / nb for k in after["ms_per_batch"]}
+                    drop_in["threads"][str(T)]["coalescer"] = {"batches": nb, "avg_batch": (after["requests"] - before["requests"]) / nb, "ms_per_batch": ms,
+                                                               "largest_concurrency_estimate": after["largest_concurrency_estimate"],
+                                                               "batches_in_flight_limit": after["batches_in_flight_limit"]}
+            drop_in["coalescer_256"] = drop_in["threads"]["256"].get("coalescer")
+            drop_in["host_cores"] = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
             want0 = d_out[(T - 1 + 59) % 64].cpu().numpy().view(np.uint64).reshape(3, 6)      # thread T-1's last call used blob (T-1 + 59) % 64
             drop_in["bit_exact_vs_batched_path"] = bool(np.array_equal(outs[T - 1], want0))
             prate_, _ = ks.bench_drop_in(host_blobs, 64, 40, op=1)

@@ -70,16 +70,16 @@ def fft_g1_muls(m, full_width_only=False):
 
 def fk20_single_muls(n_coeff):
     """bls.MulG1 calls of one FK20Single on n_coeff coefficients (fk20_single.go:122-134): the Toeplitz product over 2 n points (:63-70), FFTG1(2 n, inv), FFTG1(n)"""
-    return 2 * n_coeff + fft_g1_muls(2 * n_coeff) + fft_g1_muls(n_coeff)
+    return 2 * n_coeff + (fft_g1_muls(2 * n_coeff) + 2 * n_coeff) + fft_g1_muls(n_coeff)   # the inverse transform scales every output by 1 / len (fft_g1.go:85-93)
 
 
 def fk20_single_full_width_muls(n_coeff):
-    return 2 * n_coeff + fft_g1_muls(2 * n_coeff, True) + fft_g1_muls(n_coeff, True)
+    return 2 * n_coeff + (fft_g1_muls(2 * n_coeff, True) + 2 * n_coeff) + fft_g1_muls(n_coeff, True)
 
 
 def cpu_baseline_fk20(n_sample=512, full=False):
     """The FK20 half of the metric on the host: the oracle's FK20Single (kind 'port'; restates kzg.go:43-64, fk20_single.go:122-134), ONE thread.
-    A whole 4096-coefficient run is ~1 minute of port time (122 880 MulG1 + 8192-point settings), too long for the default bench: the bounded sample is ONE
+    A whole 4096-coefficient run is ~1 minute of port time (131 072 MulG1 + 8192-point settings), too long for the default bench: the bounded sample is ONE
     FK20Single on `n_sample` coefficients (scale log2(2 n_sample), GenerateTestingSetup with the test secret), and the 4096-coefficient figure is that time scaled by
     the reference's MulG1 count (the run is > 99 % MulG1) -- labelled an estimate.  KZG_BENCH_FK20_CPU_FULL=1 (or full=True) times the real thing instead."""
     from oracle import koracle as ko
@@ -135,11 +135,11 @@ def cpu_baseline(seconds_budget=6.0):
             go_version = "present, `go version` failed"
     n1, dt1 = _cpu_worker(seconds_budget)
     try:
-        calib = _port_vs_published()
+        calib = _port_vs_published(min(1.0, seconds_budget / 6.0))
     except Exception as e:                                  # noqa: BLE001
         calib = {"error": "%s: %s" % (type(e).__name__, e)}
     try:
-        fk20_cpu = cpu_baseline_fk20()
+        fk20_cpu = cpu_baseline_fk20(512 if seconds_budget >= 6.0 else 64)
     except Exception as e:                                  # noqa: BLE001
         fk20_cpu = {"error": "%s: %s" % (type(e).__name__, e)}
     t0 = time.perf_counter()

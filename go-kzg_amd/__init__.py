@@ -121,6 +121,7 @@ def lib():
         "kzg_hip_recover_poly_from_samples": (i32, [vp, vp, vp, u64, vp]),
         "kzg_hip_calibrate": (i32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "kzg_hip_bench_drop_in": (i32, [vp, i32, vp, u64, u64, u32, u32, vp, C.POINTER(C.c_double)]),
+        "kzg_hip_coalesce_stats": (i32, [vp, i32, C.POINTER(u64)]),
         "kzg_hip_kzg_table_info": (i32, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(u64)]), "kzg_hip_kzg_table_additions": (u32, [vp]), "kzg_hip_kzg_set_projective_outputs": (i32, [vp, i32]),
         "kzg_hip_da_using_fk20_multi_batch": (i32, [vp, vp, u64, u64, vp]),
         "kzg_hip_multi_settings_new": (i32, [C.POINTER(i32), u32, u32, vp, u64, pp]), "kzg_hip_multi_settings_free": (None, [vp]),
@@ -464,6 +465,16 @@ class KZGSettings:
         out, secs = g1_empty(threads), C.c_double(0)
         _chk(lib().kzg_hip_bench_drop_in(self.h, op, _p(blobs), blobs.shape[1], blobs.shape[0], threads, calls, _p(out), C.byref(secs)))
         return threads * calls / secs.value, out
+
+    def coalesce_stats(self, op=0):
+        """cumulative statistics of the coalescer behind the one-polynomial calls (op 0 CommitToPoly, 1 ComputeProofSingle)"""
+        a = (C.c_uint64 * 8)()
+        _chk(lib().kzg_hip_coalesce_stats(self.h, op, a))
+        req, bat = a[0], a[1]
+        return {"requests": req, "batches": bat, "avg_batch": req / bat if bat else 0.0,
+                "ms_per_batch": {"executing": a[2] * 1e-6 / bat if bat else 0.0, "waiting_for_a_device_slot": a[3] * 1e-6 / bat if bat else 0.0,
+                                 "gathering_callers": a[4] * 1e-6 / bat if bat else 0.0, "waiting_for_row_copies": a[5] * 1e-6 / bat if bat else 0.0},
+                "largest_concurrency_estimate": a[6], "batches_in_flight_limit": a[7]}
 
     def table_info(self):
         """(window bits, windows, bytes) of the fixed-base table the commitments walk; zeros before the first commitment"""

@@ -187,6 +187,14 @@ int kzg_hip_calibrate(kzg_hip_fft *fs, double *mad_per_s, double *add_per_s, dou
     HIPCHK(hipGetLastError());
     return KZG_HIP_OK;
 }
+int kzg_hip_coalesce_stats(kzg_hip_kzg *ks, int op, uint64_t out[8]) {
+    if (!ks || !out || op < 0 || op > 1) return KZG_HIP_ERR_BAD_ARG;
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    std::lock_guard<std::mutex> lk(ks->fs->mu);                  // get_coalescer creates the object under the settings' mutex
+    coalescer *co = op == 0 ? ks->co_commit.get() : ks->co_proof.get();
+    if (co) co->stats(out);
+    return KZG_HIP_OK;
+}
 void kzg_hip_prof_reset(kzg_hip_fft *fs, int enable) {
     (void)fs;
     std::lock_guard<std::mutex> lk(g_prof_mu);

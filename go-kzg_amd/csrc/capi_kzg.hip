@@ -194,6 +194,14 @@ int h2d_copy(void *dst, const void *src, size_t bytes, hipStream_t s) {
 int kzg_hip_host_register(void *host, uint64_t bytes) {
     if (!host || !bytes) return KZG_HIP_ERR_BAD_ARG;
     KZG_TRY
+    {   // a range that overlaps a live registration is refused before the runtime sees it: overwriting the tracked extent of a live base (or nesting two extents)
+        // would make h2d_copy cut copies at the wrong boundary and host_mapped_pointer vouch for pages that are not pinned
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        const uintptr_t h = (uintptr_t)host;
+        auto it = g_registered.lower_bound(h);
+        if (it != g_registered.end() && it->first < h + bytes) { g_last_error = "kzg_hip_host_register: the range overlaps a registered one (unregister it first)"; return KZG_HIP_ERR_BAD_ARG; }
+        if (it != g_registered.begin()) { --it; if (it->first + it->second > h) { g_last_error = "kzg_hip_host_register: the range overlaps a registered one (unregister it first)"; return KZG_HIP_ERR_BAD_ARG; } }
+    }
     HIPCHK(hipHostRegister(host, bytes, hipHostRegisterPortable | hipHostRegisterMapped));
     std::lock_guard<std::mutex> lk(g_reg_mu);
     g_registered[(uintptr_t)host] = bytes;
@@ -202,9 +210,14 @@ int kzg_hip_host_register(void *host, uint64_t bytes) {
 }
 int kzg_hip_host_unregister(void *host) {
     if (!host) return KZG_HIP_ERR_BAD_ARG;
-    { std::lock_guard<std::mutex> lk(g_reg_mu); g_registered.erase((uintptr_t)host); }
+    KZG_TRY
+    // the extent is forgotten only once the runtime has let go of the pages: after a failed hipHostUnregister they are still pinned, and h2d_copy /
+    // host_mapped_pointer must keep cutting and checking at this range's boundaries
     HIPCHK(hipHostUnregister(host));
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    g_registered.erase((uintptr_t)host);
     return KZG_HIP_OK;
+    KZG_CATCH
 }
 int kzg_hip_commit_to_poly_batch(kzg_hip_kzg *ks, const void *coeffs_fr, uint64_t n, uint64_t batch, void *out_g1) {
     if (!ks || !out_g1) return KZG_HIP_ERR_BAD_ARG;

@@ -19,14 +19,22 @@
 // transport when it is created (transport_self_test): every entry writes a pattern into its slice, one all_gather_bytes, every entry's
 // buffer is read back and compared; a transport that errs or delivers wrong bytes is replaced by the next one -- rccl -> peer-copy ->
 // host-staged (device -> pinned host -> device, no peer mapping involved) -- with the reason in kzg_hip_multi_transport_note.
-// KZG_HIP_MULTI_FAULT (tests only; comma list of "rccl", "rccl-corrupt", "peer", "peer-corrupt") makes the named leg fail so that the
-// fall-backs run on a one-GPU box.
+// KZG_HIP_MULTI_FAULT (tests only; comma list of "rccl", "rccl-corrupt", "rccl-hang", "peer", "peer-corrupt", "peer-hang") makes the named leg fail so
+// that the fall-backs run on a one-GPU box.
+//
+// A transport that HANGS (round 6).  The usual failure of a misconfigured RCCL / P2P path is not an error code but a collective that never completes.  The
+// probe therefore never blocks on a stream: it polls hipStreamQuery on every entry's stream against a deadline (KZG_HIP_MULTI_PROBE_TIMEOUT_MS, default
+// 10 000).  On a timeout the communicators are aborted (ncclCommAbort, on a helper thread that is itself given the deadline), the entries' streams, events
+// and arenas that the stuck work may still touch are ABANDONED (never synchronised, freed only if they have drained by the time the handle is freed) and
+// replaced, and the next transport is probed on the fresh ones; the note names the timeout.  "rccl-hang" / "peer-hang" enqueue a kernel that spins on a
+// host flag nobody sets (bounded by its own clock: at most ~2 x the probe deadline, so it cannot wedge a box) in front of the exchange.
 #include "capi_common.hpp"
 #include <rccl/rccl.h>   // types and prototypes; the functions are resolved at run time (rccl_api)
 #include <dlfcn.h>
 #include <atomic>
 #include <deque>
 #include <functional>
+#include <future>
 
 namespace {
 
@@ -34,6 +42,7 @@ struct rccl_api {
     void *h = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;     // optional: without it a timed-out communicator is leaked instead of aborted
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
@@ -58,6 +67,7 @@ rccl_api *rccl_bind(std::string *why) {
         if (api.h) {
             api.CommInitAll = (decltype(api.CommInitAll))dlsym(api.h, "ncclCommInitAll");
             api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.h, "ncclCommDestroy");
+            api.CommAbort = (decltype(api.CommAbort))dlsym(api.h, "ncclCommAbort");
             api.AllGather = (decltype(api.AllGather))dlsym(api.h, "ncclAllGather");
             api.GroupStart = (decltype(api.GroupStart))dlsym(api.h, "ncclGroupStart");
             api.GroupEnd = (decltype(api.GroupEnd))dlsym(api.h, "ncclGroupEnd");
@@ -97,6 +107,7 @@ struct exch_arena {
         return KZG_HIP_OK;
     }
     void release() { if (base) { (void)hipSetDevice(device); (void)hipFree(base); base = nullptr; cap = used = 0; } }
+    uint8_t *abandon() { uint8_t *b = base; base = nullptr; cap = used = 0; return b; }   // stuck work may still write it: never reused, freed by the handle if that work ever drains
 };
 // a host thread bound to one entry of the handle for its lifetime: batch calls hand it that entry's share (no thread creation per call)
 struct dev_worker {
@@ -129,11 +140,15 @@ struct kzg_hip_multi {
     std::string transport = "peer-copy", transport_note, self_test;
     uint8_t *h_stage = nullptr; size_t h_stage_cap = 0;   // pinned, portable: the host-staged exchange
     unsigned fault = 0;                    // KZG_HIP_MULTI_FAULT bits (tests)
+    long probe_timeout_ms = 10000;         // deadline of one self-test exchange (KZG_HIP_MULTI_PROBE_TIMEOUT_MS)
+    struct abandoned_t { int device; hipStream_t s; hipEvent_t ev; uint8_t *arena; };
+    std::vector<abandoned_t> abandoned;    // streams / events / arenas of entries whose probe timed out: never synchronised
+    uint32_t *h_spin_flag = nullptr;       // pinned, mapped: what the injected "hang" kernels spin on
     int fft_mode = -1;                     // -1 default policy, 0 gather, 1 sharded transforms
     std::mutex mu;                         // sharded calls (collectives) on a handle run one at a time
     std::atomic<uint64_t> n_allgather{0};  // exchanges performed (tests and bench read it)
 };
-enum { FAULT_RCCL = 1, FAULT_RCCL_CORRUPT = 2, FAULT_PEER = 4, FAULT_PEER_CORRUPT = 8 };
+enum { FAULT_RCCL = 1, FAULT_RCCL_CORRUPT = 2, FAULT_PEER = 4, FAULT_PEER_CORRUPT = 8, FAULT_RCCL_HANG = 16, FAULT_PEER_HANG = 32 };
 struct kzg_hip_multi_eth { kzg_hip_multi *m = nullptr; std::vector<kzg_hip_eth *> eth; uint64_t n = 0; };
 struct kzg_hip_multi_fk20s { kzg_hip_multi *m = nullptr; std::vector<kzg_hip_fk20s *> fk; uint64_t n2 = 0; };
 struct kzg_hip_multi_fk20m { kzg_hip_multi *m = nullptr; std::vector<kzg_hip_fk20m *> fk; uint64_t n2 = 0, l = 1; };
@@ -276,14 +291,93 @@ int all_gather_bytes(kzg_hip_multi *m, const std::vector<xbuf> &buf, size_t byte
 }
 inline int all_gather_bytes(kzg_hip_multi *m, const std::vector<xbuf> &buf, size_t bytes_each) { return all_gather_bytes(m, buf, bytes_each, m->tkind); }
 
+// fault injection: holds a stream until the host sets *flag -- or until its own clock runs out, so that a test can never wedge the device
+__global__ void k_multi_spin(uint32_t *flag, uint64_t max_ticks) {
+    const uint64_t t0 = wall_clock64();                        // constant 100 MHz counter
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0 && wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(127);
+}
+int enqueue_injected_hang(kzg_hip_multi *m, size_t entry) {
+    if (!m->h_spin_flag) {
+        HIPCHK(hipHostMalloc((void **)&m->h_spin_flag, sizeof(uint32_t), hipHostMallocPortable | hipHostMallocMapped));
+        *m->h_spin_flag = 0;
+    }
+    __atomic_store_n(m->h_spin_flag, 0u, __ATOMIC_SEQ_CST);
+    uint32_t *dflag = nullptr;
+    HIPCHK(hipSetDevice(m->d[entry].device));
+    HIPCHK(hipHostGetDevicePointer((void **)&dflag, m->h_spin_flag, 0));
+    const uint64_t ticks = (uint64_t)(2 * m->probe_timeout_ms + 500) * 100000ull;          // 100 MHz: 1e5 ticks per millisecond
+    k_multi_spin<<<1, 1, 0, m->d[entry].s>>>(dflag, ticks);
+    HIPCHK(hipGetLastError());
+    return KZG_HIP_OK;
+}
+inline void release_injected_hang(kzg_hip_multi *m) { if (m->h_spin_flag) __atomic_store_n(m->h_spin_flag, 1u, __ATOMIC_SEQ_CST); }
+
+// Polls every entry's stream until all have drained: 0 = drained, 1 = the deadline passed (some stream still has work), -1 = a stream reports an error
+// (g_last_error set).  Never blocks in the runtime: hipStreamQuery returns at once.
+int wait_streams_deadline(kzg_hip_multi *m, long timeout_ms) {
+    const auto until = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms);
+    for (long spins = 0;; spins++) {
+        bool all = true;
+        for (auto &d : m->d) {
+            (void)hipSetDevice(d.device);
+            hipError_t e = hipStreamQuery(d.s);
+            if (e == hipErrorNotReady) { (void)hipGetLastError(); all = false; continue; }
+            if (e != hipSuccess) { (void)hipGetLastError(); g_last_error = std::string("stream of device ") + std::to_string(d.device) + ": " + hipGetErrorString(e); return -1; }
+        }
+        if (all) return 0;
+        if (std::chrono::steady_clock::now() >= until) return 1;
+        if (spins < 200) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+}
+// The entries' streams hold work that will not finish: give every entry a fresh stream, event and (empty) arena; the old ones go to `abandoned`
+// (nothing here waits for them).  False when a replacement could not be created (g_last_error set).
+bool abandon_streams(kzg_hip_multi *m) {
+    for (auto &d : m->d) {
+        m->abandoned.push_back({d.device, d.s, d.ev, d.arena.abandon()});
+        d.s = nullptr; d.ev = nullptr;
+        if (hipSetDevice(d.device) != hipSuccess || hipStreamCreateWithFlags(&d.s, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&d.ev, hipEventDisableTiming) != hipSuccess) {
+            g_last_error = std::string("could not replace the stream of device ") + std::to_string(d.device) + ": " + hipGetErrorString(hipGetLastError());
+            return false;
+        }
+    }
+    return true;
+}
+// ncclCommAbort on every communicator, on a helper thread that gets the same deadline (an abort that blocks -- it synchronises RCCL's internal streams -- must
+// not wedge the constructor either); the communicators are gone afterwards whatever happened
+std::string abort_communicators(kzg_hip_multi *m) {
+    std::string how;
+    rccl_api *api = m->nccl;
+    std::vector<ncclComm_t> comms; comms.swap(m->comms);
+    m->nccl = nullptr;
+    if (!api || comms.empty()) return "no communicator to abort";
+    if (!api->CommAbort) return "librccl has no ncclCommAbort: communicators leaked";
+    auto done = std::make_shared<std::promise<int>>();
+    std::future<int> fut = done->get_future();
+    try {
+        std::thread([api, comms, done] { int bad = 0; for (ncclComm_t c : comms) if (c && api->CommAbort(c) != ncclSuccess) bad++; done->set_value(bad); }).detach();
+    } catch (const std::exception &) { return "could not start the abort thread: communicators leaked"; }
+    if (fut.wait_for(std::chrono::milliseconds(m->probe_timeout_ms)) != std::future_status::ready) return "ncclCommAbort did not return within the deadline either (left behind on its thread)";
+    const int bad = fut.get();
+    return bad ? "ncclCommAbort reported an error on " + std::to_string(bad) + " communicator(s)" : "communicators aborted";
+}
+
 // One exchange with known contents on transport `kind`: entry i fills its slice with bytes that depend on (i, offset), one all_gather_bytes,
-// every entry's whole buffer is read back and compared on the host.  KZG_HIP_OK and *why empty when every byte arrived everywhere.
-int transport_probe(kzg_hip_multi *m, int kind, std::string *why) {
+// every entry's whole buffer is read back and compared on the host.  KZG_HIP_OK and *why empty when every byte arrived everywhere.  *timed_out: the
+// exchange did not complete within the deadline -- the entries' streams still hold it and must not be waited for (the caller abandons them).
+int transport_probe(kzg_hip_multi *m, int kind, std::string *why, bool *timed_out) {
     const size_t D = m->d.size(), each = 4096 + 144;            // not a power of two: a slice boundary inside a cache line
     std::vector<xbuf> buf(D);
     std::vector<uint8_t> pat(D * each), got(D * each);
+    *timed_out = false;
     for (size_t i = 0; i < D; i++) for (size_t b = 0; b < each; b++) pat[i * each + b] = (uint8_t)(0x31 * (i + 1) + 7 * b + (b >> 8));
-    auto fail = [&](int st) { *why = g_last_error; for (auto &d : m->d) { (void)hipSetDevice(d.device); (void)hipStreamSynchronize(d.s); } (void)hipGetLastError(); return st; };
+    // every way out drains the streams -- against the deadline, never with a blocking synchronise
+    auto fail = [&](int st) {
+        *why = g_last_error;
+        if (wait_streams_deadline(m, m->probe_timeout_ms) == 1) { *timed_out = true; *why += " [and the streams did not drain within the deadline]"; }
+        (void)hipGetLastError();
+        return st;
+    };
     for (size_t i = 0; i < D; i++) {
         multi_dev &d = m->d[i];
         int st = d.arena.reserve(D * each + 256); if (st) return fail(st);
@@ -291,9 +385,20 @@ int transport_probe(kzg_hip_multi *m, int kind, std::string *why) {
         if (hipSetDevice(d.device) != hipSuccess || hipMemsetAsync(buf[i].p, 0, D * each, d.s) != hipSuccess ||
             hipMemcpyAsync(buf[i].p + i * each, pat.data() + i * each, each, hipMemcpyHostToDevice, d.s) != hipSuccess) { g_last_error = "self-test: could not fill the pattern"; return fail(KZG_HIP_ERR_HIP); }
     }
+    // (the pattern upload from pageable memory has completed on return of hipMemcpyAsync or is stream-ordered: either way the streams are idle or short here)
+    if ((kind == T_RCCL && (m->fault & FAULT_RCCL_HANG)) || (kind == T_PEER && (m->fault & FAULT_PEER_HANG))) {
+        int st = enqueue_injected_hang(m, D - 1); if (st) return fail(st);
+    }
     int st = all_gather_bytes(m, buf, each, kind);
     if (st) return fail(st);
-    for (size_t i = 0; i < D; i++) {
+    const int w = wait_streams_deadline(m, m->probe_timeout_ms);
+    if (w == 1) {
+        char t[200]; snprintf(t, sizeof t, "self-test: the all-gather did not complete within %ld ms (KZG_HIP_MULTI_PROBE_TIMEOUT_MS): timeout", m->probe_timeout_ms);
+        *why = t; g_last_error = t; *timed_out = true;
+        return KZG_HIP_ERR_HIP;
+    }
+    if (w < 0) return fail(KZG_HIP_ERR_HIP);
+    for (size_t i = 0; i < D; i++) {      // the streams are idle: these copies cannot queue behind anything
         multi_dev &d = m->d[i];
         if (hipSetDevice(d.device) != hipSuccess || hipMemcpyAsync(got.data(), buf[i].p, D * each, hipMemcpyDeviceToHost, d.s) != hipSuccess ||
             hipStreamSynchronize(d.s) != hipSuccess) { g_last_error = std::string("self-test: read-back failed: ") + hipGetErrorString(hipGetLastError()); return fail(KZG_HIP_ERR_HIP); }
@@ -304,7 +409,6 @@ int transport_probe(kzg_hip_multi *m, int kind, std::string *why) {
             return fail(KZG_HIP_ERR_HIP);
         }
     }
-    for (auto &d : m->d) { (void)hipSetDevice(d.device); (void)hipStreamSynchronize(d.s); }
     why->clear();
     return KZG_HIP_OK;
 }
@@ -317,7 +421,8 @@ int transport_self_test(kzg_hip_multi *m) {
     for (int kind = m->tkind; kind <= T_HOST; kind++) {
         if (kind == T_RCCL && !m->nccl) continue;
         std::string why;
-        int st = transport_probe(m, kind, &why);
+        bool timed_out = false;
+        int st = transport_probe(m, kind, &why, &timed_out);
         if (st == KZG_HIP_OK) {
             m->tkind = kind; m->transport = transport_name(kind);
             char t[160]; snprintf(t, sizeof t, "ok: %s, %zu entries, %d B per slice, every byte verified on every entry", transport_name(kind), m->d.size(), 4096 + 144);
@@ -326,7 +431,17 @@ int transport_self_test(kzg_hip_multi *m) {
         }
         if (!m->transport_note.empty()) m->transport_note += "; ";
         m->transport_note += std::string(transport_name(kind)) + " failed its self-test (" + why + ")";
-        if (kind == T_RCCL) {   // a communicator that failed once is not used again
+        if (timed_out) {
+            // injected hang: what ncclCommAbort does to RCCL's kernels (they poll the abort flag) the test does to its own spinning kernel -- BEFORE the abort, which
+            // synchronises internal streams that wait for the user stream; a peer copy cannot be cancelled at all: its stream is simply left behind
+            if (kind == T_RCCL && (m->fault & FAULT_RCCL_HANG)) release_injected_hang(m);
+            if (kind == T_RCCL) m->transport_note += "; " + abort_communicators(m);
+            bool drained = kind == T_RCCL && wait_streams_deadline(m, m->probe_timeout_ms) == 0;      // aborted collectives return: the streams are usable again
+            if (!drained) {
+                if (!abandon_streams(m)) { m->self_test = "failed: a transport hung and its streams could not be replaced"; g_last_error = "multi-device exchange: " + m->transport_note + "; " + g_last_error; return KZG_HIP_ERR_HIP; }
+                m->transport_note += "; streams and arenas of the hung exchange abandoned";
+            }
+        } else if (kind == T_RCCL) {   // a communicator that failed once is not used again
             for (ncclComm_t c : m->comms) if (c) (void)m->nccl->CommDestroy(c);
             m->comms.clear(); m->nccl = nullptr;
         }
@@ -492,8 +607,12 @@ int kzg_hip_multi_settings_new(const int *devices, uint32_t n_devices, unsigned 
     if (hipGetDeviceCount(&ordinals) != hipSuccess) { (void)hipGetLastError(); return KZG_HIP_ERR_NO_DEVICE; }
     for (uint32_t i = 0; i < n_devices; i++) if (devices[i] < 0 || devices[i] >= ordinals) return KZG_HIP_ERR_NO_DEVICE;
     KZG_TRY
-    kzg_hip_multi *m = new kzg_hip_multi;
+    // owned until it is handed out: whatever throws below (std::bad_alloc in a resize, a string concatenation, the probe's vectors) frees the handle with its worker
+    // threads, streams, arenas and per-device settings on the way to KZG_CATCH
+    std::unique_ptr<kzg_hip_multi, void (*)(kzg_hip_multi *)> owner(new kzg_hip_multi, kzg_hip_multi_settings_free);
+    kzg_hip_multi *m = owner.get();
     m->d.resize(n_devices);
+    if (const char *t = getenv("KZG_HIP_MULTI_PROBE_TIMEOUT_MS")) { long v = atol(t); if (v >= 10 && v <= 600000) m->probe_timeout_ms = v; }
     for (uint32_t i = 0; i < n_devices; i++) { m->d[i].device = devices[i]; m->d[i].arena.device = devices[i]; }
     if (const char *f = getenv("KZG_HIP_MULTI_FAULT")) {   // tests: make a leg of the exchange fail so that the fall-backs run on one GPU
         std::string fs(f);
@@ -502,6 +621,8 @@ int kzg_hip_multi_settings_new(const int *devices, uint32_t n_devices, unsigned 
         if (has("rccl-corrupt")) m->fault |= FAULT_RCCL_CORRUPT;
         if (has("peer")) m->fault |= FAULT_PEER;
         if (has("peer-corrupt")) m->fault |= FAULT_PEER_CORRUPT;
+        if (has("rccl-hang")) m->fault |= FAULT_RCCL_HANG;
+        if (has("peer-hang")) m->fault |= FAULT_PEER_HANG;
     }
     try {   // one host thread per further entry, for the lifetime of the handle; a thread that cannot be started fails the constructor cleanly
         for (uint32_t i = 1; i < n_devices; i++) {
@@ -511,7 +632,6 @@ int kzg_hip_multi_settings_new(const int *devices, uint32_t n_devices, unsigned 
         }
     } catch (const std::exception &e) {
         g_last_error = std::string("multi-device handle: worker thread: ") + e.what();
-        kzg_hip_multi_settings_free(m);
         return KZG_HIP_ERR_HIP;
     }
     int st = per_device(m, [&](size_t i) -> int {
@@ -523,7 +643,7 @@ int kzg_hip_multi_settings_new(const int *devices, uint32_t n_devices, unsigned 
         HIPCHK(hipEventCreateWithFlags(&d.ev, hipEventDisableTiming));
         return KZG_HIP_OK;
     });
-    if (st) { std::string keep = g_last_error; kzg_hip_multi_settings_free(m); g_last_error = keep; return st; }
+    if (st) { std::string keep = g_last_error; owner.reset(); g_last_error = keep; return st; }
     // exchange transport: RCCL when every device is listed once (KZG_HIP_MULTI_TRANSPORT=rccl also for a single device: the binding's own test;
     // =peer never binds RCCL, =host goes straight to the host-staged exchange)
     bool distinct = true;
@@ -547,13 +667,14 @@ int kzg_hip_multi_settings_new(const int *devices, uint32_t n_devices, unsigned 
     // the handle proves its exchange before anyone relies on it: pattern -> all-gather -> verify on every entry; steps down on failure
     st = transport_self_test(m);
     m->n_allgather = 0;                      // kzg_hip_multi_exchanges counts the callers' exchanges
-    if (st) { std::string keep = g_last_error; kzg_hip_multi_settings_free(m); g_last_error = keep; return st; }
-    *out = m;
+    if (st) { std::string keep = g_last_error; owner.reset(); g_last_error = keep; return st; }
+    *out = owner.release();
     return KZG_HIP_OK;
     KZG_CATCH
 }
 void kzg_hip_multi_settings_free(kzg_hip_multi *m) {
     if (!m) return;
+    release_injected_hang(m);
     for (auto &w : m->workers) w->shutdown();
     if (m->nccl) for (ncclComm_t c : m->comms) if (c) (void)m->nccl->CommDestroy(c);
     for (auto &d : m->d) {
@@ -565,6 +686,22 @@ void kzg_hip_multi_settings_free(kzg_hip_multi *m) {
         if (d.fs) kzg_hip_fft_settings_free(d.fs);
     }
     if (m->h_stage) (void)hipHostFree(m->h_stage);
+    // what a hung exchange left behind is freed only if ALL of it has drained by now (hipFree synchronises the device: with one stream still stuck it would block);
+    // otherwise it is leaked -- never waited for.  (An injected spin was released at the top and ends within microseconds.)
+    bool drained = true;
+    if (!m->abandoned.empty()) {
+        const auto until = std::chrono::steady_clock::now() + std::chrono::milliseconds(m->h_spin_flag ? 2000 : 0);
+        for (auto &a : m->abandoned) {
+            (void)hipSetDevice(a.device);
+            hipError_t e = hipStreamQuery(a.s);
+            while (e == hipErrorNotReady && std::chrono::steady_clock::now() < until) { std::this_thread::sleep_for(std::chrono::microseconds(200)); e = hipStreamQuery(a.s); }
+            if (e != hipSuccess) drained = false;
+            (void)hipGetLastError();
+        }
+        if (drained)
+            for (auto &a : m->abandoned) { (void)hipSetDevice(a.device); (void)hipStreamDestroy(a.s); if (a.ev) (void)hipEventDestroy(a.ev); if (a.arena) (void)hipFree(a.arena); }
+    }
+    if (m->h_spin_flag && drained) (void)hipHostFree(m->h_spin_flag);
     (void)hipGetLastError();
     delete m;
 }

@@ -17,7 +17,7 @@
 // (64 threads 51 k commitments/s, 256 threads 38 k/s).  Now a call is: fetch_add on the open buffer's state word, memcpy, fetch_add on its
 // `ready` counter, futex sleep -- the mutex is taken twice per BATCH (close + open the next buffer; recycle).
 //
-// One batch is in flight up to ~48 concurrent callers, up to MAX_EXEC (on separate streams) beyond: the end of a batch (reduction
+// One batch is in flight up to ~96 concurrent callers (KZG_COALESCE_CALLERS_PER_BATCH; 48 for the FK20 pipelines), up to MAX_EXEC (on separate streams) beyond: the end of a batch (reduction
 // trees, one inversion per polynomial) is latency-bound and uses a fraction of the CUs, so with hundreds of callers the next batch's
 // table walk overlaps it.  The executing function is supplied by the handle (commit / proof / FK20); everything here is host-side C++.
 //
@@ -114,6 +114,12 @@ class coalescer {
                     slot_ns_.load() * 1e-6 / batches_.load(), gather_ns_.load() * 1e-6 / batches_.load(), ready_ns_.load() * 1e-6 / batches_.load());
         for (auto &b : bufs_) free_buf(b);
     }
+    // cumulative statistics since the handle's first call: {requests, batches, ns executing, ns waiting for a device slot, ns gathering callers, ns waiting for row copies,
+    // most callers seen inside submit() at once (decaying estimate), batches allowed in flight right now}
+    void stats(uint64_t out[8]) const {
+        out[0] = requests_.load(); out[1] = batches_.load(); out[2] = (uint64_t)exec_ns_.load(); out[3] = (uint64_t)slot_ns_.load();
+        out[4] = (uint64_t)gather_ns_.load(); out[5] = (uint64_t)ready_ns_.load(); out[6] = peak_seen_.load(); out[7] = (uint64_t)exec_limit_.load();
+    }
     size_t in_row_bytes() const { return in_row_; }
     size_t out_row_bytes() const { return out_row_; }
 
@@ -138,7 +144,10 @@ class coalescer {
             }
             if (bi < 0) { futex_wait_u32(&open_seq_, seq); continue; }           // every buffer busy: the next recycle opens one
             coalesce_buf &b = bufs_[bi];
-            const uint64_t old = b.state.fetch_add(1, std::memory_order_acq_rel);
+            // seq_cst: with the gathering leader this is a store-buffering (Dekker) pair -- leader: target.store; state.load -- follower: state.fetch_add; target.load --
+            // and only a total order over all four accesses excludes "leader reads the old state AND follower reads target == 0" (a missed wake-up that costs the batch
+            // its whole gather window)
+            const uint64_t old = b.state.fetch_add(1, std::memory_order_seq_cst);
             if (!(old & coalesce_buf::CLOSED) && (uint32_t)old < max_batch_) { bp = &b; row = (uint32_t)old; break; }
             if (!(old & coalesce_buf::CLOSED) && (uint32_t)old == max_batch_) bump_and_wake(b.lead_word);   // full: its leader need not wait for more
             if (open_seq_.load(std::memory_order_acquire) == seq) futex_wait_u32(&open_seq_, seq);      // closed or full: until another buffer opens
@@ -151,7 +160,7 @@ class coalescer {
         if (row == 0) lead(b, exec, alloc_error_status);
         else {
             // the leader sleeps until its target is reached and, after closing, until the last taken row is filled
-            const uint32_t cnt = b.count.load(std::memory_order_seq_cst), tgt = b.target.load(std::memory_order_relaxed);
+            const uint32_t cnt = b.count.load(std::memory_order_seq_cst), tgt = b.target.load(std::memory_order_seq_cst);
             if ((cnt && filled >= cnt) || (tgt && row + 1 == tgt)) bump_and_wake(b.lead_word);
             wait_done(b, row);
         }
@@ -196,24 +205,40 @@ class coalescer {
             return false;
         }
 #else
+        // (simulation: KZG_COALESCE_SIM_MAX_BUFS staging buffers can be allocated, the next allocation fails -- pinned-memory pressure)
+        if (const char *e = getenv("KZG_COALESCE_SIM_MAX_BUFS")) {
+            int have = 0;
+            for (auto &x : bufs_) have += x.h_in != nullptr;
+            if (have >= atoi(e)) return false;
+        }
         b.h_in = (uint8_t *)malloc(in_row_ * max_batch_); b.h_out = (uint8_t *)malloc(out_row_ * max_batch_); b.h_meta = (coalesce_row *)malloc(sizeof(coalesce_row) * max_batch_);
 #endif
         return true;
     }
-    // mu_ held.  Makes a FREE buffer (not `except`) the open one; false if its staging memory cannot be allocated (open_ = OPEN_UNINIT: the next
-    // caller tries again and reports the failure itself) -- with every buffer busy open_ = -1 and the next recycle opens one.
+    // mu_ held.  Makes a FREE buffer (not `except`) the open one, preferring one whose staging memory exists: a new one is allocated only when no allocated buffer
+    // is free, and a failed allocation is an error only when nothing allocated is left to recycle either (then open_ = OPEN_UNINIT: the next caller tries again and
+    // reports the failure itself).  With every usable buffer busy open_ = -1 and the next recycle opens one: under pinned-memory pressure the handle runs with fewer
+    // staging buffers instead of failing calls.
     bool open_next_locked(int except) {
+        int pick = -1, fresh = -1, busy_allocated = 0;
         for (int k = 0; k < NBUF; k++) {
             const int o = (except < 0 ? k : (except + 1 + k) % NBUF);
-            if (o == except) continue;
             coalesce_buf &c = bufs_[o];
-            if (c.phase != coalesce_buf::FREE) continue;
-            if (!alloc_buf(c)) { open_.store(OPEN_UNINIT, std::memory_order_release); bump_open_seq(); return false; }
+            if (o == except || c.phase != coalesce_buf::FREE) { if (c.h_in) busy_allocated++; continue; }
+            if (c.h_in) { pick = o; break; }
+            if (fresh < 0) fresh = o;
+        }
+        if (pick < 0 && fresh >= 0) {
+            if (alloc_buf(bufs_[fresh])) pick = fresh;
+            else if (!busy_allocated) { open_.store(OPEN_UNINIT, std::memory_order_release); bump_open_seq(); return false; }
+        }
+        if (pick >= 0) {
+            coalesce_buf &c = bufs_[pick];
             c.phase = coalesce_buf::OPEN;
             c.ready.store(0, std::memory_order_relaxed); c.count.store(0, std::memory_order_relaxed); c.target.store(0, std::memory_order_relaxed);
             c.done_flag.store(0, std::memory_order_relaxed); c.status = 0;
             c.state.store(0, std::memory_order_release);
-            open_.store(o, std::memory_order_release);
+            open_.store(pick, std::memory_order_release);
             bump_open_seq();
             return true;
         }
@@ -279,6 +304,7 @@ class coalescer {
             if (idle) seen_max = inside_.load(std::memory_order_relaxed);  // (the maximum since the last batch is the burst's tail: forgotten with the rest)
             peak_ = seen_max > decayed ? seen_max : decayed;
             peak = peak_;
+            if (peak > peak_seen_.load(std::memory_order_relaxed)) peak_seen_.store(peak, std::memory_order_relaxed);
             // Batches in flight: ONE up to ~48 concurrent callers (a table walk over fewer than ~50 polynomials leaves lanes idle and pays its
             // reduction tree in full, so two half-size walks take 1.3 times one full-size walk), a second and third one beyond, where a batch
             // is large enough to walk efficiently and the host side of a batch (hundreds of wake-ups and 128 KiB row copies) is worth overlapping.
@@ -355,6 +381,7 @@ class coalescer {
     int per_batch_ = KZG_COALESCE_CALLERS_PER_BATCH;   // concurrent callers per batch in flight (KZG_HIP_COALESCE_PER_BATCH)
     std::atomic<uint64_t> batches_{0}, requests_{0};   // statistics (KZG_HIP_COALESCE_STATS=1 prints them when the handle is freed)
     std::atomic<long> exec_ns_{0}, slot_ns_{0}, gather_ns_{0}, ready_ns_{0};
+    std::atomic<uint64_t> peak_seen_{0}; // largest concurrency estimate a leader ever used (statistics)
     std::atomic<long> exec_ema_ns_{0};   // recent execution time of a batch (the gather window scales with it)
     int device_;
     size_t in_row_, out_row_;

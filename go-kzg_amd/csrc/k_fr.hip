@@ -108,47 +108,6 @@ __global__ __launch_bounds__(1024) void k_fr_fft4096_r4(const fr *in, uint64_t i
     if (SCALE) sc = frl_const_from_kilic(*scale);
     fr4::pass_last<SCALE>(t, smem, tw, sc, dst);
 }
-// The same transform on 256 lanes x 16 register-resident values (fr16 in fr_fft4096.hpp): 72 KiB of LDS, two workgroups per CU.
-template <bool SCALE>
-__global__ __launch_bounds__(256, 2) void k_fr_fft4096_r16(const fr *in, uint64_t in_stride, uint64_t n_in, fr *out, const uint32_t *__restrict__ tw,
-                                                           const fr *scale, uint32_t rows_log) {
-    extern __shared__ uint32_t smem[];
-    const uint32_t t = threadIdx.x, w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const uint32_t rows = 1u << rows_log, row = blockIdx.x & (rows - 1);
-    const fr *src = in + (uint64_t)(blockIdx.x >> rows_log) * in_stride;
-    fr *dst = out + (uint64_t)blockIdx.x * fr4::N;
-    frl a[16], b[16];
-    {
-        fr x[16];
-        fr16::load(t, src, n_in, rows, rows_log ? bitrev32(row, rows_log) : 0u, x);
-        fr16::pass_a(x, b, tw);
-    }
-    // A -> B: lane (block u, registers k) -> lane (g, j, registers k')
-    const uint32_t u = fr16::bitrev8(fr16::lane_a_nat(t));
-    uint32_t g, j;
-    fr16::lane_b(t, g, j);
-    fr16::stage_put<1>(smem, b, 16u * u, 1u, 0u ^ (w & 1u));
-    __syncthreads();
-    fr16::stage_get<1>(smem, a, 256u * g + j, 16u, 0u ^ (w >> 1));
-    __syncthreads();
-    fr16::stage_put<1>(smem, b, 16u * u, 1u, 1u ^ (w & 1u));
-    __syncthreads();
-    fr16::stage_get<1>(smem, a, 256u * g + j, 16u, 1u ^ (w >> 1));
-    fr16::pass_b(a, j, tw);
-    __syncthreads();                                       // every lane has read its last stage before the area is written again
-    // B -> C: lane (g, j, registers k') -> lane t = 16 k' + j, registers g
-    fr16::stage_put<2>(smem, a, 256u * g + j, 16u, 0u ^ (w & 1u));
-    __syncthreads();
-    fr16::stage_get<2>(smem, b, t, 256u, 0u ^ (w >> 1));
-    __syncthreads();
-    fr16::stage_put<2>(smem, a, 256u * g + j, 16u, 1u ^ (w & 1u));
-    __syncthreads();
-    fr16::stage_get<2>(smem, b, t, 256u, 1u ^ (w >> 1));
-    fr16::pass_c(b, t, tw);
-    frl sc = frl_zero();
-    if (SCALE) sc = frl_const_from_kilic(*scale);
-    fr16::store<SCALE>(t, b, sc, dst);
-}
 // 4 .. 2048 points: 4096 / m transforms per workgroup through the first passes of the 4096-point network (fr_fft4096.hpp)
 template <int LOGM, bool SCALE>
 __global__ __launch_bounds__(1024) void k_fr_fft_small(const fr *in, uint64_t in_stride, uint64_t n_in, fr *out, uint64_t batch, const uint32_t *__restrict__ tw,
@@ -215,30 +174,11 @@ __global__ void k_fr_fft_stage_glob(fr *data, uint32_t logn, uint64_t m, const f
 }
 
 static uint32_t ilog2(uint64_t v) { uint32_t r = 0; while ((1ull << r) < v) r++; return r; }
-#ifndef KZG_FR_FFT_R16_DEFAULT
-#define KZG_FR_FFT_R16_DEFAULT false
-#endif
-
 void launch_fr_fft(hipStream_t s, const fr *in, uint64_t in_stride, uint64_t n_in, fr *out, uint64_t n, uint64_t batch, const fr *roots,
                    uint64_t W, const fr *scale, const uint32_t *tw4096, const fr *roots_l) {
     if (n == 0 || batch == 0) return;
     uint32_t logn = ilog2(n);
     static const bool radix2_forced = [] { const char *e = getenv("KZG_HIP_FR_FFT"); return e && !strcmp(e, "radix2"); }();   // A/B and test hook
-    // KZG_HIP_FR_FFT=r4 / r16 selects the 1024-lane / the 256-lane form of the 4096-point kernel (A/B runs, tests); default below
-    static const int r16_mode = [] { const char *e = getenv("KZG_HIP_FR_FFT"); return !e ? -1 : !strcmp(e, "r16") ? 1 : !strcmp(e, "r4") ? 0 : -1; }();
-    const bool use_r16 = r16_mode < 0 ? KZG_FR_FFT_R16_DEFAULT : r16_mode == 1;
-    if (n == fr4::N && tw4096 && !radix2_forced && use_r16) {
-        prof_begin(s, "fr_fft4096");
-        if (scale) {
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fr_fft4096_r16<true>), hipFuncAttributeMaxDynamicSharedMemorySize, fr16::LDS_BYTES);
-            hipLaunchKernelGGL(k_fr_fft4096_r16<true>, dim3((uint32_t)batch), dim3(fr16::LANES), fr16::LDS_BYTES, s, in, in_stride, n_in, out, tw4096, scale, 0u);
-        } else {
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fr_fft4096_r16<false>), hipFuncAttributeMaxDynamicSharedMemorySize, fr16::LDS_BYTES);
-            hipLaunchKernelGGL(k_fr_fft4096_r16<false>, dim3((uint32_t)batch), dim3(fr16::LANES), fr16::LDS_BYTES, s, in, in_stride, n_in, out, tw4096, scale, 0u);
-        }
-        prof_end(s, "fr_fft4096");
-        return;
-    }
     if (n == fr4::N && tw4096 && !radix2_forced) {
         prof_begin(s, "fr_fft4096");
         if (scale) {

@@ -32,6 +32,10 @@ int kzg_hip_bench_threads_fft_fr(kzg_hip_fft *fs, const void *vals_fr, uint64_t 
  * linear combination of a timed step's input polynomials with it when it checks ALL outputs of the step */
 int kzg_hip_bench_poly_lincomb_dev(kzg_hip_fft *fs, const void *d_vectors_fr, uint64_t stride, const void *d_scalars_fr, uint64_t count, uint64_t n, void *d_out_fr,
                                    void *stream);
+/* statistics of the request coalescer behind the one-polynomial calls of a KZG handle (op 0: CommitToPoly, 1: ComputeProofSingle), cumulative since its first call:
+ * out[0..7] = requests, batches, ns executing, ns waiting for a device slot, ns gathering callers, ns waiting for row copies, largest concurrency estimate, batches
+ * allowed in flight; all zero before the first call.  bench.py prints the 256-caller run's figures with it (drop_in.coalescer_256) */
+int kzg_hip_coalesce_stats(kzg_hip_kzg *ks, int op, uint64_t out[8]);
 /* test hook: SHA-256 of a host buffer through the transcript's implementation (x86 SHA extensions or the portable loop; no device needed) */
 void kzg_hip_test_sha256(const void *data, uint64_t len, void *out32);
 

@@ -4,6 +4,7 @@
 #include "field.hpp"
 #include "g1.hpp"
 #include "fr_fft4096.hpp"
+#include "../../tools/ab_fr_r16/fr16.hpp"   // the 256-lane form: an A/B artefact since round 6, its emulation stays tested
 #include "fr_das2048.hpp"
 #include <vector>
 #include <string.h>

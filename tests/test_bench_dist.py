@@ -240,6 +240,75 @@ def test_bench_line_survives_a_failing_secondary_leg():
     assert "KZG_BENCH_FAIL_SECONDARY" in d["secondary_error"] and d["fk20"] is None
 
 
+def _error_paths(obj, path=""):
+    """every place in a bench line where a leg swallowed an exception into {"error": ...}"""
+    found = []
+    if isinstance(obj, dict):
+        if "error" in obj and obj["error"]:
+            found.append("%s: %s" % (path or "<line>", obj["error"]))
+        for k, v in obj.items():
+            found += _error_paths(v, path + "/" + str(k))
+    elif isinstance(obj, list):
+        for i, v in enumerate(obj):
+            found += _error_paths(v, "%s[%d]" % (path, i))
+    return found
+
+
+def test_port_vs_published_runs_and_carries_the_three_ratios():
+    """the calibration of the CPU port against the reference's published transforms (BENCH.md:31,43,55): in round 5 a missing import turned it into a swallowed
+    NameError and nothing noticed; it is called here directly (tiny budget), and through cpu_baseline's own try/except the result must carry no `error`"""
+    from benchlib import cpu
+    r = cpu._port_vs_published(0.05)
+    assert set(r["port_over_published"]) == {"fft_fr_scale12_ns", "das_fft_extension_scale12_ns", "fft_g1_scale12_ns"}
+    assert all(0.05 < v < 100 for v in r["port_over_published"].values()), r["port_over_published"]
+    assert r["mul_g1_port_us"] > 10
+
+
+def test_cpu_baseline_fk20_estimate():
+    """the FK20 half of the metric on the host: one oracle FK20Single on a small polynomial, scaled by the reference's MulG1 count"""
+    from benchlib import cpu
+    assert cpu.fft_g1_muls(4096) == 36864                                   # BASELINE.md 2: 1024 leaves x 16 + 10 levels x 2048
+    assert cpu.fk20_single_muls(4096) == 131072                             # BASELINE.md 2: FK20Single on 4096 coefficients
+    r = cpu.cpu_baseline_fk20(n_sample=16)
+    assert r["is_estimate"] and r["cores"] == 1 and r["kind"] == "port" and r["value"] > 0
+    assert r["mul_g1_per_fk20_4096"] == 131072
+    assert not _error_paths(r)
+
+
+def test_cpu_baseline_carries_no_swallowed_error():
+    """cpu_baseline() end to end with a sub-second budget: every nested leg (one core, all cores, port_vs_published, fk20_4096) present, none an {"error": ...}"""
+    import subprocess
+    code = ("import json, sys; sys.path.insert(0, %r); from benchlib.cpu import cpu_baseline; print(json.dumps(cpu_baseline(0.3)))" % ROOT)
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)       # own process: the all-cores leg forks
+    assert res.returncode == 0, res.stderr[-2000:]
+    import json
+    d = json.loads(res.stdout.strip().splitlines()[-1])
+    assert not _error_paths(d), _error_paths(d)
+    assert d["value"] > 0 and d["all_cores"]["value"] > 0 and d["fk20_4096"]["value"] > 0 and "port_over_published" in d["port_vs_published"]
+
+
+@pytest.mark.gpu
+def test_bench_line_has_no_failed_leg():
+    """the whole default bench (every leg, reduced sizes) on a box where everything should work: no leg may have swallowed an exception into an
+    {"error": ...} object, `secondary_error` is null, and the dominant kernel's launches -- timed on the timed steps -- fit inside the steps"""
+    import json
+    import subprocess
+    env = dict(os.environ, KZG_BENCH_CPU_BUDGET_S="0.5", KZG_HIP_FK20_FB_BUDGET_GB="8")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "512", "--table-gb", "9", "--fk20-batch", "16",
+           "--fk20-multi-batch", "2", "--fk20-4096-batch", "4"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["secondary_error"] is None, d["secondary_error"]
+    assert not _error_paths(d), _error_paths(d)
+    r = d["roofline"]
+    assert r["launches_timed"] == 3 and r["launch_over_step"] <= 1.002 and r["avg_launch_ms"] <= d["ms_per_step"] * 1.002
+    assert d["cpu_baseline"]["port_vs_published"]["port_over_published"]["fft_fr_scale12_ns"] > 0
+    assert d["cpu_baseline_fk20_4096"]["value"] > 0 and d["value_fk20_4096"] > 0
+
+
 def test_roofline_arithmetic_reproduces_the_committed_profile():
     """benchlib/roofline.py on the numbers of profiles/r05_*: the contract's `achieved` = algorithmic bytes / average launch time of the dominant kernel (the row of
     that launch shape in the committed kernel trace), counters matched on kernel, length and table shape, the multiply-add and issue fractions from the same inputs"""

@@ -34,6 +34,19 @@ def test_policies(sim, env):
     assert res.returncode == 0 and "wrong results: 0" in res.stdout, res.stdout + res.stderr
 
 
+@pytest.mark.parametrize("max_bufs", [1, 2])
+def test_staging_allocation_failure_degrades_to_fewer_buffers(sim, max_bufs):
+    """pinned-memory pressure: only `max_bufs` of the 4 staging buffers can be allocated.  Callers must keep running on the buffers that exist (waiting for a recycle)
+    instead of receiving allocation errors because the first FREE buffer in index order happened to be an unallocated one"""
+    res = subprocess.run([sim, "64", "60", "120", "3"], capture_output=True, text=True, timeout=300, env=dict(os.environ, KZG_COALESCE_SIM_MAX_BUFS=str(max_bufs)))
+    assert res.returncode == 0 and "wrong results: 0" in res.stdout, res.stdout + res.stderr
+
+
+def test_no_staging_memory_at_all_is_reported_to_every_caller(sim):
+    res = subprocess.run([sim, "8", "5", "120", "3"], capture_output=True, text=True, timeout=60, env=dict(os.environ, KZG_COALESCE_SIM_MAX_BUFS="0"))
+    assert res.returncode != 0 and "36 calls" in res.stdout and "0 batches" in res.stdout and "wrong results: 36" in res.stdout, res.stdout + res.stderr   # every call: the status
+
+
 def test_a_lone_caller_is_never_batched_with_a_wait(sim):
     """one caller: 200 batches of one row, and no gather wait on its path (a_us = 100: the run must stay near 200 x 0.1 ms, far from 200 x the 150 us window on top)"""
     res = subprocess.run([sim, "1", "200", "100", "1"], capture_output=True, text=True, timeout=120, env=dict(os.environ, KZG_HIP_COALESCE_STATS="1"))

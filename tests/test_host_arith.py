@@ -18,7 +18,7 @@ OUT = os.path.join(HERE, "host", "_build", "libhost_emul.so")
 def he():
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     inc = os.path.join(ROOT, "go-kzg_amd", "csrc")
-    deps = [SRC] + [os.path.join(inc, h) for h in ("field.hpp", "g1.hpp", "fr_lazy.hpp", "fr_fft4096.hpp", "fr_das2048.hpp")]
+    deps = [SRC] + [os.path.join(inc, h) for h in ("field.hpp", "g1.hpp", "fr_lazy.hpp", "fr_fft4096.hpp", "fr_das2048.hpp")] + [os.path.join(ROOT, "tools", "ab_fr_r16", "fr16.hpp")]
     if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-I", inc, "-o", OUT, SRC])   # -O1: half the build time of -O2 (the unrolled passes of ten transform sizes), same run time within seconds
     return C.CDLL(OUT)

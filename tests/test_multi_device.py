@@ -121,6 +121,14 @@ def test_pinned_input_is_read_in_place(kz, setup_1337):
     L = kz.lib()
     assert L.kzg_hip_host_register(None, 16) == kz.ERR_BAD_ARG and L.kzg_hip_host_unregister(None) == kz.ERR_BAD_ARG
     assert L.kzg_hip_host_unregister(blobs.ctypes.data) == kz.ERR_HIP              # not registered (any more)
+    # a live registration cannot be re-registered or overlapped (its tracked extent would be overwritten): refused before the runtime sees it, the first extent stays
+    with kz.pinned(blobs[:4]):
+        assert L.kzg_hip_host_register(blobs.ctypes.data, blobs.nbytes) == kz.ERR_BAD_ARG and b"overlaps" in L.kzg_hip_last_error()
+        assert L.kzg_hip_host_register(blobs[2:].ctypes.data, blobs[2:].nbytes) == kz.ERR_BAD_ARG
+        assert np.array_equal(ks.commit_to_poly_batch(blobs), want)                 # still cut at the boundary of the first four rows
+        # a failed unregister (an address inside the range is not a registered base) must not forget the extent
+        assert L.kzg_hip_host_unregister(blobs[1:].ctypes.data) == kz.ERR_HIP
+        assert np.array_equal(ks.commit_to_poly_batch(blobs), want) and np.array_equal(ks.commit_to_poly_batch(blobs[1:4]), want[1:4])
     m.close()
 
 
@@ -282,6 +290,10 @@ def _vector_C_through(kz, m):
     ([0], "rccl", "rccl", "peer-copy", "rccl failed its self-test (ncclAllGather failed: injected fault"),
     ([0], "rccl", "rccl-corrupt", "peer-copy", "rccl failed its self-test (self-test: entry 0 holds wrong bytes"),
     ([0], "rccl", "rccl,peer", "host-staged", "peer-copy failed its self-test"),
+    # a transport that HANGS instead of failing (a kernel spinning on a flag nobody sets sits in front of the exchange): the probe's deadline fires, the communicator
+    # is aborted resp. the stuck streams and arenas are abandoned, and the next transport is proven on fresh ones
+    ([0], "rccl", "rccl-hang", "peer-copy", "rccl failed its self-test (self-test: the all-gather did not complete within 400 ms (KZG_HIP_MULTI_PROBE_TIMEOUT_MS): timeout)"),
+    ([0, 0], None, "peer-hang", "host-staged", "peer-copy failed its self-test (self-test: the all-gather did not complete within 400 ms (KZG_HIP_MULTI_PROBE_TIMEOUT_MS): timeout); streams and arenas of the hung exchange abandoned"),
 ])
 def test_transport_self_test_steps_down_on_an_injected_fault(kz, monkeypatch, devices, force, fault, transport, why):
     """kzg_hip_multi_settings_new proves its exchange before returning (pattern -> all-gather -> every byte verified on every entry) and replaces
@@ -292,7 +304,20 @@ def test_transport_self_test_steps_down_on_an_injected_fault(kz, monkeypatch, de
         monkeypatch.setenv("KZG_HIP_MULTI_TRANSPORT", force)
     if fault:
         monkeypatch.setenv("KZG_HIP_MULTI_FAULT", fault)
-    m = kz.MultiKZGSettings(devices, 5, ko.generate_testing_setup_g1(S_TEST, 33))
+    hang = bool(fault) and "hang" in fault
+    if hang:
+        monkeypatch.setenv("KZG_HIP_MULTI_PROBE_TIMEOUT_MS", "400")
+    import time
+    setup33 = ko.generate_testing_setup_g1(S_TEST, 33)
+    t0 = time.time()
+    m = kz.MultiKZGSettings(devices, 5, setup33)
+    if hang:
+        # the constructor returns within a few deadlines (probe + abort / drain + the next probes), not when the spinning kernel's own clock runs out (2 x deadline + 0.5 s
+        # AFTER which a blocking synchronise would have returned) and never "never"
+        assert time.time() - t0 < 10.0, time.time() - t0
+        assert "timeout" in m.transport_note
+        if fault == "rccl-hang":
+            assert "communicators aborted" in m.transport_note or "ncclCommAbort" in m.transport_note, m.transport_note
     assert m.transport == transport, (m.transport, m.transport_note)
     assert why in m.transport_note, m.transport_note
     assert m.transport_self_test.startswith("ok: %s, %d entries" % (transport, len(devices))), m.transport_self_test
