@@ -187,6 +187,30 @@ int kzg_hip_calibrate(kzg_hip_fft *fs, double *mad_per_s, double *add_per_s, dou
     HIPCHK(hipGetLastError());
     return KZG_HIP_OK;
 }
+int kzg_hip_test_fp_inv(kzg_hip_fft *fs, const void *in_fp, uint64_t n, void *out_coop, void *out_lane, double *ms_coop, double *ms_lane) {
+    if (!fs || !in_fp || !n || n > (1u << 20)) return KZG_HIP_ERR_BAD_ARG;
+    dev_guard g(fs);
+    hipStream_t s = fs->stream;
+    dtmp<fp> d_in(s), d_a(s), d_b(s);
+    CHK(d_in.alloc(n)); CHK(d_a.alloc(n)); CHK(d_b.alloc(n));
+    HIPCHK(hipMemcpyAsync(d_in.p, in_fp, n * sizeof(fp), hipMemcpyHostToDevice, s));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    for (int which = 0; which < 2; which++) {
+        void *out = which ? out_lane : out_coop; double *ms = which ? ms_lane : ms_coop;
+        if (!out) continue;
+        hipEventRecord(e0, s);
+        launch_fp_inv_both(s, d_in.p, d_a.p, d_b.p, n, which ? 2 : 1);
+        hipEventRecord(e1, s);
+        HIPCHK(hipMemcpyAsync(out, which ? d_b.p : d_a.p, n * sizeof(fp), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        float t = 0; hipEventElapsedTime(&t, e0, e1);
+        if (ms) *ms = t;
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    HIPCHK(hipGetLastError());
+    return KZG_HIP_OK;
+}
 int kzg_hip_coalesce_stats(kzg_hip_kzg *ks, int op, uint64_t out[8]) {
     if (!ks || !out || op < 0 || op > 1) return KZG_HIP_ERR_BAD_ARG;
     for (int i = 0; i < 8; i++) out[i] = 0;

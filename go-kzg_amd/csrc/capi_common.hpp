@@ -37,6 +37,7 @@ extern thread_local std::string g_last_error;   // defined in capi_core.hip
             char buf_[512];                                                                                  \
             snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
             g_last_error = buf_;                                                                             \
+            (void)hipGetLastError(); /* consumed: a later hipGetLastError() after a launch must not see it */ \
             return KZG_HIP_ERR_HIP;                                                                          \
         }                                                                                                    \
     } while (0)

@@ -212,7 +212,17 @@ int kzg_hip_host_unregister(void *host) {
     if (!host) return KZG_HIP_ERR_BAD_ARG;
     KZG_TRY
     // the extent is forgotten only once the runtime has let go of the pages: after a failed hipHostUnregister they are still pinned, and h2d_copy /
-    // host_mapped_pointer must keep cutting and checking at this range's boundaries
+    // host_mapped_pointer must keep cutting and checking at this range's boundaries.  An address INSIDE a tracked range that is not its base never reaches the
+    // runtime (ROCm 7.2 aborts the process on it instead of returning an error)
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        const uintptr_t h = (uintptr_t)host;
+        auto it = g_registered.upper_bound(h);
+        if (it != g_registered.begin()) {
+            --it;
+            if (h > it->first && h < it->first + it->second) { g_last_error = "kzg_hip_host_unregister: the address lies inside a registered range but is not its base"; return KZG_HIP_ERR_BAD_ARG; }
+        }
+    }
     HIPCHK(hipHostUnregister(host));
     std::lock_guard<std::mutex> lk(g_reg_mu);
     g_registered.erase((uintptr_t)host);

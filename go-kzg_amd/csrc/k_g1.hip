@@ -3,6 +3,7 @@
 // fk20_single.go:72-74 (ToeplitzPart2), fk20_multi.go:86-89 and bls.To/FromCompressedG1 (bls/bls_kilic.go:114-121).
 #define KZG_MULQ_NOINLINE 1   // many mulq call sites in this translation unit: keep the product out of line (I-cache)
 #include "internal.hpp"
+#include "coop_inv.hpp"
 #include <stdlib.h>
 
 namespace kzg {
@@ -385,6 +386,28 @@ __global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_normalize(const g1j *in, g1j
     g1j p = g1_normalize(in[t]);
     out[t] = to_kilic ? g1_to_kilic(p) : p;
 }
+// Few points (a lone commitment, a lone proof, the handful of results of a small batch): ONE WAVEFRONT per point, its inversion spread over the lanes
+// (coop_inv.hpp: ~25 us instead of the ~100 us of one lane's binary GCD -- this kernel is pure latency).  Every lane computes the (wave-uniform) result; lane 0 stores.
+__global__ __launch_bounds__(64) void k_g1_normalize_wave(const g1j *in, g1j *out, uint64_t n, int to_kilic) {
+    const uint64_t t = blockIdx.x;
+    const g1j p = in[t];
+    g1j o;
+    if (is_inf(p)) o = g1_inf();                            // (wave-uniform: every lane holds the same point)
+    else {
+        const fp zi = wave_inv_fp(p.z, 0), zi2 = sqr(zi);
+        o.x = mul(p.x, zi2); o.y = mul(p.y, mul(zi2, zi)); o.z = one<FpP>();
+    }
+    if (threadIdx.x == 0) out[t] = to_kilic ? g1_to_kilic(o) : o;
+}
+// test / measurement hook: element i inverted by wavefront i cooperatively (out_coop) and by lane 0 of that wavefront alone (out_lane); mode bit 0 / bit 1 select which
+__global__ __launch_bounds__(64) void k_fp_inv_both(const fp *in, fp *out_coop, fp *out_lane, int mode) {
+    const fp x = in[blockIdx.x];
+    if (mode & 1) { const fp y = wave_inv_fp(x, 0); if (threadIdx.x == 0) out_coop[blockIdx.x] = y; }
+    if ((mode & 2) && threadIdx.x == 0) out_lane[blockIdx.x] = inv<FpP>(x);
+}
+void launch_fp_inv_both(hipStream_t s, const fp *in, fp *out_coop, fp *out_lane, uint64_t n, int mode) {
+    if (n) hipLaunchKernelGGL(k_fp_inv_both, dim3((uint32_t)n), dim3(64), 0, s, in, out_coop, out_lane, mode);
+}
 // Same result with ONE F_p inversion per NB points (Montgomery's trick inside a lane): a Fermat inversion is ~570 products,
 // so normalising the 4096 proofs of an FK20 run drops from ~575 to ~80 products per point.  Points are strided by `lanes`
 // so that the loads of a wavefront stay adjacent.  Z = 0 entries are skipped in the running product.
@@ -419,7 +442,12 @@ __global__ __launch_bounds__(G1_BLOCK, 2) void k_g1_normalize_batched(const g1j 
 }
 void launch_g1_normalize(hipStream_t s, const g1j *in, g1j *out, uint64_t n, bool to_kilic) {
     if (!n) return;
-    if (n < 1024 || in == out) {   // small outputs (one commitment) or in-place use: one inversion per point
+    static const bool coop_off = [] { const char *e = getenv("KZG_HIP_COOP_INV"); return e && e[0] == '0'; }();   // A/B and test hook: the lane form everywhere
+    if (n < 1024 && !coop_off) {   // small outputs (one commitment, one proof): a wavefront per point, cooperative inversion (in place is fine: a point is read before it is written)
+        hipLaunchKernelGGL(k_g1_normalize_wave, dim3((uint32_t)n), dim3(64), 0, s, in, out, n, to_kilic ? 1 : 0);
+        return;
+    }
+    if (n < 1024 || in == out) {   // in-place use of a large array: one inversion per point
         hipLaunchKernelGGL(k_g1_normalize, dim3((uint32_t)((n + G1_BLOCK - 1) / G1_BLOCK)), dim3(G1_BLOCK), 0, s, in, out, n, to_kilic ? 1 : 0);
         return;
     }

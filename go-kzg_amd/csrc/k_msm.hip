@@ -15,6 +15,7 @@
 // normalised afterwards, so the output bytes do not depend on that order.
 #include "internal.hpp"
 #include "g1_quad.hpp"
+#include "coop_inv.hpp"
 #include <atomic>
 #include <cstring>
 
@@ -546,15 +547,17 @@ __global__ __launch_bounds__(256) void k_msm_combine(uint8_t *ws, size_t per_blo
         if (winf) w = acc.v; else fb_partial_load(gsum[g], w);
         quad_acc_add(acc, w, winf, role);
     }
-    if (live && role == 0) {
-        g1j r;
-        if (acc.inf) r = g1_inf();
-        else {   // x = X / ZZ, y = Y / ZZZ with one inversion
-            g1x px = g1xq_pack(acc.v);
-            fp i = inv<FpP>(mul(px.zz, px.zzz));
-            r.x = mul(px.x, mul(i, px.zzz)); r.y = mul(px.y, mul(i, px.zz)); r.z = one<FpP>();
+    {   // x = X / ZZ, y = Y / ZZZ with one inversion per blob; a wavefront with up to three live blobs (a lone LinCombG1: one) inverts them cooperatively over its
+        // lanes, a full one (16 blobs) in its lanes side by side (wave_inv_any decides; every lane of the wavefront is here)
+        const bool own = live && role == 0;
+        const g1x px = g1xq_pack(acc.v);
+        const fp i = wave_inv_any(mul(px.zz, px.zzz), own && !acc.inf);
+        if (own) {
+            g1j r;
+            if (acc.inf) r = g1_inf();
+            else { r.x = mul(px.x, mul(i, px.zzz)); r.y = mul(px.y, mul(i, px.zz)); r.z = one<FpP>(); }
+            out[b] = to_kilic ? g1_to_kilic(r) : r;
         }
-        out[b] = to_kilic ? g1_to_kilic(r) : r;
     }
 }
 #endif
@@ -882,20 +885,26 @@ __global__ __launch_bounds__(256) void k_fb_finish(const fb_partial *partials, u
 #endif
         coop_acc_add(acc, w, winf, c);
     }
-    if (c.wave == 0 && col == 0) {
-        g1j r;
-        if (acc.inf) r = g1_inf();
-        else if (to_kilic & 2) r = g1x_to_jac(g1xq_pack(acc.v));   // projective output (kzg_hip_kzg_set_projective_outputs): (X ZZ, Y ZZZ, ZZ), no inversion
-        else {   // x = X / ZZ, y = Y / ZZZ with ONE inversion: i = 1 / (ZZ ZZZ), 1 / ZZ = i ZZZ, 1 / ZZZ = i ZZ
-            g1x px = g1xq_pack(acc.v);
+    if (c.wave == 0) {                                      // wave-uniform: the whole first wavefront takes part in the inversion, its lane 0 (column 0) owns the result
+        const bool own = col == 0;
+        const g1x px = g1xq_pack(acc.v);                    // (defined limbs in every column: empty accumulators hold the affine image of infinity)
+        // x = X / ZZ, y = Y / ZZZ with ONE inversion: i = 1 / (ZZ ZZZ), 1 / ZZ = i ZZZ, 1 / ZZZ = i ZZ -- spread over the wavefront's lanes (coop_inv.hpp)
+        const bool need = own && !acc.inf && !(to_kilic & 2);
 #ifdef KZG_FINISH_NOINV                                      // timing experiment only (wrong results): what the inversion costs
-            fp i = mul(px.zz, px.zzz);
+        const fp i = mul(px.zz, px.zzz);
+#elif defined(KZG_NO_COOP_INV)
+        fp i = zero<FpP>();
+        if (need) i = inv<FpP>(mul(px.zz, px.zzz));
 #else
-            fp i = inv<FpP>(mul(px.zz, px.zzz));
+        const fp i = wave_inv_any(mul(px.zz, px.zzz), need);
 #endif
-            r.x = mul(px.x, mul(i, px.zzz)); r.y = mul(px.y, mul(i, px.zz)); r.z = one<FpP>();
+        if (own) {
+            g1j r;
+            if (acc.inf) r = g1_inf();
+            else if (to_kilic & 2) r = g1x_to_jac(px);       // projective output (kzg_hip_kzg_set_projective_outputs): (X ZZ, Y ZZZ, ZZ), no inversion
+            else { r.x = mul(px.x, mul(i, px.zzz)); r.y = mul(px.y, mul(i, px.zz)); r.z = one<FpP>(); }
+            out[b] = (to_kilic & 1) ? g1_to_kilic(r) : r;
         }
-        out[b] = (to_kilic & 1) ? g1_to_kilic(r) : r;
     }
 }
 

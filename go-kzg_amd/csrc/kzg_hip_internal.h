@@ -36,6 +36,10 @@ int kzg_hip_bench_poly_lincomb_dev(kzg_hip_fft *fs, const void *d_vectors_fr, ui
  * out[0..7] = requests, batches, ns executing, ns waiting for a device slot, ns gathering callers, ns waiting for row copies, largest concurrency estimate, batches
  * allowed in flight; all zero before the first call.  bench.py prints the 256-caller run's figures with it (drop_in.coalescer_256) */
 int kzg_hip_coalesce_stats(kzg_hip_kzg *ks, int op, uint64_t out[8]);
+/* test / measurement hook for the F_p inversion (device-internal Montgomery images, 48 bytes each, host buffers): element i is inverted by wavefront i cooperatively
+ * (coop_inv.hpp) into out_coop and by one lane alone (inv<FpP>, field.hpp) into out_lane; either output may be null.  *ms_coop / *ms_lane (nullable): HIP-event time of
+ * the respective launch */
+int kzg_hip_test_fp_inv(kzg_hip_fft *fs, const void *in_fp, uint64_t n, void *out_coop, void *out_lane, double *ms_coop, double *ms_lane);
 /* test hook: SHA-256 of a host buffer through the transcript's implementation (x86 SHA extensions or the portable loop; no device needed) */
 void kzg_hip_test_sha256(const void *data, uint64_t len, void *out32);
 

@@ -258,6 +258,33 @@ def test_fr_radix2_kernels_in_a_fresh_process():
     assert res.returncode == 0, res.stdout[-1500:]
 
 
+def test_cooperative_fp_inversion_matches_the_lane_form(kz):
+    """wave_inv_fp (coop_inv.hpp: one wavefront per inversion, limbs across lanes, safegcd divsteps on the scalar unit) against inv<FpP>() on one lane, on the device:
+    word for word equal on edge values and 4096 random elements, and equal to Python's pow(x, -1, p) in the device's Montgomery domain (R' = 2^390)"""
+    import ctypes as C
+    P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+    R = 1 << 390
+    rng = np.random.default_rng(606)
+    xs = [0, 1, 2, 3, P - 1, P - 2, (P + 1) // 2, 1 << 380, 5, 1 << 200, (1 << 30) - 1, 1 << 30, (1 << 360) + 1]
+    xs += [int.from_bytes(rng.bytes(48), "little") % P for _ in range(4096 - len(xs))]
+    img = np.frombuffer(b"".join((x * R % P).to_bytes(48, "little") for x in xs), dtype=np.uint8).copy()
+    a, b = np.zeros_like(img), np.zeros_like(img)
+    fs = kz.FFTSettings(4)
+    tc, tl = C.c_double(0), C.c_double(0)
+    st = kz.lib().kzg_hip_test_fp_inv(fs.h, img.ctypes.data, len(xs), a.ctypes.data, b.ctypes.data, C.byref(tc), C.byref(tl))
+    assert st == 0, kz.lib().kzg_hip_last_error()
+    assert np.array_equal(a, b)
+    got = [int.from_bytes(a[48 * i:48 * i + 48].tobytes(), "little") for i in range(len(xs))]
+    for x, y in zip(xs[:64], got[:64]):
+        assert y == (pow(x, -1, P) * R % P if x else 0), hex(x)
+    # one element: the latency of ONE inversion either way (the launch's HIP-event time)
+    st = kz.lib().kzg_hip_test_fp_inv(fs.h, img[48 * 20:].ctypes.data, 1, a.ctypes.data, b.ctypes.data, C.byref(tc), C.byref(tl))
+    assert st == 0 and np.array_equal(a[:48], b[:48])
+    print("one F_p inversion alone on the chip: wave-cooperative %.1f us, one lane %.1f us" % (tc.value * 1e3, tl.value * 1e3))
+    assert tc.value < tl.value
+    fs.close()
+
+
 def test_fr_fft4096_r16_ab_artefact_is_bit_exact():
     """the 256-lane x 16-register form of the 4096-point transform left the library in round 6 (25 % slower: profiles/r05_fr_fft_ab.md, r06_fr_r16_fate.md); its kernel
     lives on as a stand-alone A/B harness (tools/ab_fr_r16) that sends the same rows through it and through the library's kernel: still word for word the same"""

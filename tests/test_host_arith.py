@@ -18,7 +18,7 @@ OUT = os.path.join(HERE, "host", "_build", "libhost_emul.so")
 def he():
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     inc = os.path.join(ROOT, "go-kzg_amd", "csrc")
-    deps = [SRC] + [os.path.join(inc, h) for h in ("field.hpp", "g1.hpp", "fr_lazy.hpp", "fr_fft4096.hpp", "fr_das2048.hpp")] + [os.path.join(ROOT, "tools", "ab_fr_r16", "fr16.hpp")]
+    deps = [SRC] + [os.path.join(inc, h) for h in ("field.hpp", "g1.hpp", "fr_lazy.hpp", "fr_fft4096.hpp", "fr_das2048.hpp", "coop_inv.hpp")] + [os.path.join(ROOT, "tools", "ab_fr_r16", "fr16.hpp")]
     if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-I", inc, "-o", OUT, SRC])   # -O1: half the build time of -O2 (the unrolled passes of ten transform sizes), same run time within seconds
     return C.CDLL(OUT)
@@ -77,6 +77,30 @@ def test_binary_gcd_inversion_matches_fermat_and_bigint(he):
             want = (pow(x, -1, mod) * R) % mod if x else 0
             assert int.from_bytes(got.tobytes(), "little") == want, (name, hex(x))
             assert np.array_equal(got, ferm), (name, hex(x))
+
+
+def test_cooperative_inversion_emulation_matches_the_lane_form(he):
+    """wave_inv_fp (coop_inv.hpp: limbs across 16 lanes, safegcd divsteps on the low limb, two carry hand-overs per round) replayed lane by lane on the host with the
+    device's own scalar pieces: word for word inv<FpP>() -- which is pinned to Fermat and to Python integers above -- on edge values and on 20 000 structured / random
+    elements, with the invariants the device code relies on (centred limbs within 2^29 + 2, products within 2^61, unique zero) checked in every round"""
+    P = ko.P_MOD if hasattr(ko, "P_MOD") else 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+    R = 1 << 390
+    edge = [0, 1, 2, 3, P - 1, P - 2, (P + 1) // 2, 1 << 380, (1 << 381) - 1 - ((1 << 381) - P), 5, 1 << 200, (1 << 30) - 1, 1 << 30, (1 << 360) + 1]
+    for x in edge:
+        img = np.frombuffer((x * R % P).to_bytes(48, "little"), dtype=np.uint32).copy()
+        got, want = np.zeros(12, dtype=np.uint32), np.zeros(12, dtype=np.uint32)
+        rounds, bad = C.c_uint32(0), C.c_uint32(0)
+        he.he_fp_inv_coop(p(got), p(img), C.byref(rounds), C.byref(bad))
+        he.he_fp_inv(p(want), p(img))
+        assert bad.value == 0 and np.array_equal(got, want), hex(x)
+        if x % P:
+            assert int.from_bytes(got.tobytes(), "little") == pow(x, -1, P) * R % P, hex(x)
+            assert 1 <= rounds.value <= 30, (hex(x), rounds.value)
+    he.he_fp_inv_coop_stress.restype = C.c_uint64
+    he.he_fp_inv_coop_stress.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+    mx, sm = C.c_uint32(0), C.c_uint64(0)
+    assert he.he_fp_inv_coop_stress(20000, 2026, C.byref(mx), C.byref(sm)) == 0
+    assert mx.value <= 30 and 20 < sm.value / 20000 < 28.5, (mx.value, sm.value / 20000)
 
 
 def test_binary_gcd_inversion_stress(he):

@@ -10,6 +10,7 @@
 #include <stdint.h>
 #include <vector>
 #include "../go-kzg_amd/csrc/field.hpp"
+#include "../go-kzg_amd/csrc/coop_inv.hpp"
 using namespace kzg;
 
 template <int CTRL> __device__ __forceinline__ uint32_t dppc(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false); }
@@ -78,6 +79,55 @@ __global__ __launch_bounds__(64) void k_chain_quad(uint32_t *io, int iters) {
     for (int s = 0; s < 4; s++) if (4 * q + s < 13) io[chain * 32 + 4 * q + s] = Aq[s];
 }
 
+// ---- round 6: the F_p inversion, one lane (inv<FpP>, Pornin's binary GCD) against the wave-cooperative form (coop_inv.hpp) ----
+// chains of `iters` dependent inversions x <- inv(x) + 1 (the +1 keeps the chain off the fixed points); one wavefront per workgroup
+__global__ __launch_bounds__(64) void k_inv_lane(uint32_t *io, int iters, int all_lanes) {
+    const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+    if (!all_lanes && threadIdx.x != 0) return;
+    fp x;
+    for (int i = 0; i < 12; i++) x.l[i] = io[t * 32 + i];
+    x.l[11] &= 0x0fffffffu;
+    const fp one_ = one<FpP>();
+    for (int it = 0; it < iters; it++) x = add(inv<FpP>(x), one_);
+    for (int i = 0; i < 12; i++) io[t * 32 + i] = x.l[i];
+}
+__global__ __launch_bounds__(64) void k_inv_coop(uint32_t *io, int iters) {
+    const uint32_t t = blockIdx.x * 64;                 // lane 0's operand
+    fp x;
+    for (int i = 0; i < 12; i++) x.l[i] = io[t * 32 + i];
+    x.l[11] &= 0x0fffffffu;
+    const fp one_ = one<FpP>();
+    for (int it = 0; it < iters; it++) x = add(wave_inv_fp(x, 0), one_);
+    if (threadIdx.x == 0) for (int i = 0; i < 12; i++) io[t * 32 + i] = x.l[i];
+}
+static void inversion_rows(uint32_t *d, const std::vector<uint32_t> &h, size_t words, int blocks) {
+    std::vector<uint32_t> a(words), b(words);
+    auto run = [&](int which, int nblocks, int iters, std::vector<uint32_t> *out) {
+        hipMemcpy(d, h.data(), words * 4, hipMemcpyHostToDevice);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0, 0);
+        if (which == 0) hipLaunchKernelGGL(k_inv_lane, dim3(nblocks), dim3(64), 0, 0, d, iters, 0);
+        else if (which == 1) hipLaunchKernelGGL(k_inv_coop, dim3(nblocks), dim3(64), 0, 0, d, iters);
+        else hipLaunchKernelGGL(k_inv_lane, dim3(nblocks), dim3(64), 0, 0, d, iters, 1);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (out) hipMemcpy(out->data(), d, words * 4, hipMemcpyDeviceToHost);
+        return (double)ms * 1e-3;
+    };
+    run(0, blocks, 3, &a); run(1, blocks, 3, &b);
+    size_t bad = 0;
+    for (int c = 0; c < blocks; c++) for (int i = 0; i < 12; i++) if (a[(size_t)c * 64 * 32 + i] != b[(size_t)c * 64 * 32 + i]) { bad++; break; }
+    printf("cooperative inversion == lane inversion on %d chains of 3 inversions: %s (%zu mismatches)\n", blocks, bad ? "NO" : "yes", bad);
+    const int it = 64;
+    for (int rep = 0; rep < 2; rep++) {
+        const double l1 = run(0, 1, it, nullptr), c1 = run(1, 1, it, nullptr), l64 = run(2, 1, it, nullptr);
+        printf("a single wavefront on the chip, chains of %d dependent inversions: one lane %.1f us per inversion, all 64 lanes (64 inversions) %.1f us, wave-cooperative %.1f us (x%.2f)\n",
+               it, l1 / it * 1e6, l64 / it * 1e6, c1 / it * 1e6, l1 / c1);
+        const double lb = run(0, blocks, it, nullptr), cb = run(1, blocks, it, nullptr);
+        printf("one wavefront per SIMD (%d wavefronts): one lane %.1f us per inversion, wave-cooperative %.1f us (x%.2f)\n", blocks, lb / it * 1e6, cb / it * 1e6, lb / cb);
+    }
+}
+
 int main() {
     hipDeviceProp_t pr; hipGetDeviceProperties(&pr, 0);
     const int cus = pr.multiProcessorCount;
@@ -87,6 +137,7 @@ int main() {
     uint64_t st = 88172645463325252ull;
     for (auto &w : h) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; w = (uint32_t)st; }
     uint32_t *d; hipMalloc(&d, words * 4);
+    inversion_rows(d, h, words, blocks);
     auto run = [&](bool quad, int iters, std::vector<uint32_t> *out) {
         hipMemcpy(d, h.data(), words * 4, hipMemcpyHostToDevice);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
