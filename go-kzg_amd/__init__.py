@@ -122,6 +122,7 @@ def lib():
         "kzg_hip_calibrate": (i32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "kzg_hip_bench_drop_in": (i32, [vp, i32, vp, u64, u64, u32, u32, vp, C.POINTER(C.c_double)]),
         "kzg_hip_coalesce_stats": (i32, [vp, i32, C.POINTER(u64)]),
+        "kzg_hip_lincomb_promotions": (i32, [vp, C.POINTER(u64), C.POINTER(u64)]),
         "kzg_hip_test_fp_inv": (i32, [vp, vp, u64, vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "kzg_hip_kzg_table_info": (i32, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(u64)]), "kzg_hip_kzg_table_additions": (u32, [vp]), "kzg_hip_kzg_set_projective_outputs": (i32, [vp, i32]),
         "kzg_hip_da_using_fk20_multi_batch": (i32, [vp, vp, u64, u64, vp]),
@@ -345,6 +346,12 @@ class FFTSettings:
         out = g1_empty(1)
         _chk(lib().kzg_hip_lincomb_g1(self.h, _p(numbers), _p(factors), numbers.shape[0], _p(out)))
         return out[0]
+
+    def lincomb_promotions(self):
+        """(point sets promoted so far, calls served by a promoted set): kzg_hip_lincomb_g1 turns a caller-supplied point set that keeps coming back into a cached one"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _chk(lib().kzg_hip_lincomb_promotions(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def to_compressed_g1(self, points):
         points = _g1(points)

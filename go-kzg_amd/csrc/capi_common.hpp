@@ -73,6 +73,7 @@ struct kzg_hip_fft {
     std::mutex mu;
     struct pool_slot { hipStream_t s = nullptr; uint8_t *h_pin = nullptr; size_t pin_cap = 0; };   // a stream + its pinned staging area (stream_lease)
     std::mutex pool_mu; std::condition_variable pool_cv; std::vector<pool_slot> pool_idle; int pool_total = 0;
+    struct lincomb_promo *promo = nullptr;   // kzg_hip_lincomb_g1's memory of recent caller-supplied point sets (capi_core.hip); created on first use
 };
 struct kzg_hip_kzg {
     kzg_hip_fft *fs = nullptr;

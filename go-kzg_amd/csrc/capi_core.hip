@@ -124,9 +124,11 @@ int kzg_hip_fft_settings_new(int device, unsigned max_scale, kzg_hip_fft **out) 
     return KZG_HIP_OK;
     KZG_CATCH
 }
+void lincomb_promo_free(kzg_hip_fft *fs);
 void kzg_hip_fft_settings_free(kzg_hip_fft *fs) {
     if (!fs) return;
     hipSetDevice(fs->device);
+    lincomb_promo_free(fs);                                 // promoted point sets hold tables and coalescers on this handle: they go first
     if (fs->stream) hipStreamSynchronize(fs->stream);
     hipFree(fs->d_expanded); hipFree(fs->d_reversed); hipFree(fs->d_expanded_l); hipFree(fs->d_reversed_l); hipFree(fs->d_inv_pow2); hipFree(fs->d_tw4096[0]); hipFree(fs->d_tw4096[1]); hipFree(fs->d_tw_das2048); hipFree(fs->d_glv_expanded); hipFree(fs->d_glv_reversed); hipFree(fs->d_wnaf_expanded); hipFree(fs->d_wnaf_reversed);
     if (fs->stream) hipStreamDestroy(fs->stream);
@@ -488,10 +490,113 @@ int kzg_hip_lincomb_points(kzg_hip_points *pts, const void *scalars_fr, uint64_t
     return kzg_hip_lincomb_points_batch(pts, scalars_fr, n, 1, out_g1);
 }
 
+// ---- bls.LinCombG1 on caller-supplied points: promotion of a REPEATED point set to a cached one (round 6) ----
+// The reference's call sites hand the same slice again and again (bls.LinCombG1(setup, coeffs): kzg_single_proofs.go:17-19, eth/helpers.go:99,159,199), but the C
+// signature carries no identity, so every call paid the one-shot pipeline: upload 590 KB of points, convert, sort into buckets, 120 dependent doublings -- 1.3 ms for
+// 4096 points against 0.25 ms on a cached set (kzg_hip_points: resident rows + a fixed-base table).  The handle therefore remembers the last few point sets it was
+// given and promotes one that keeps coming back:
+//   sighting 1: a 64-bit fingerprint of (n, first and last 4 KiB) -- costs a microsecond, lets one-off callers pass untouched;
+//   sighting 2: fingerprint known -> the points are COPIED (host memory, n x 144 B);
+//   sighting 3 (KZG_HIP_LINCOMB_PROMOTE_AFTER + 1): fingerprint known and memcmp against the copy equal -> kzg_hip_points_new on the copy, once (0.1-0.3 s: the
+//              table of the set is built; this call is the slow one), and from then on every call whose points compare EQUAL, byte for byte, to the copy runs on the set.
+// Identity is established by the full comparison on EVERY call (n x 144 B memcmp: 30-50 us for 4096 points), never by the fingerprint: a caller that changes one
+// coordinate between calls compares unequal and takes the one-shot path with its new points (tests/test_gpu_parity.py).  Results are the same group element either way
+// and both paths return the normalised image, so the bytes do not depend on which ran.  At most LINCOMB_PROMO_SETS promoted sets per handle (least recently used is
+// freed), each within KZG_HIP_POINTS_FB_BUDGET_GB of HBM (default min(32 GB, free - 24 GB)).  KZG_HIP_LINCOMB_PROMOTE=0 switches the whole mechanism off.
+struct lincomb_promo {
+    static constexpr int SLOTS = 6, LINCOMB_PROMO_SETS = 2;
+    struct entry {
+        uint64_t n = 0, fp = 0, last_use = 0; uint32_t sightings = 0;
+        std::vector<uint8_t> copy;                                         // the points as first compared (sighting 2 on)
+        std::shared_ptr<kzg_hip_points> set;                               // promoted: the cached set (kept alive by calls in flight)
+        bool building = false;
+    };
+    std::mutex mu; std::condition_variable built;
+    entry e[SLOTS];
+    uint64_t tick = 0, promoted = 0, served = 0;
+};
+namespace {
+uint64_t lincomb_fingerprint(const uint8_t *p, uint64_t n) {
+    const size_t bytes = (size_t)n * sizeof(g1j), head = bytes < 4096 ? bytes : 4096;
+    uint64_t h = 0x9e3779b97f4a7c15ull ^ n;
+    auto eat = [&](const uint8_t *q, size_t len) {
+        for (size_t i = 0; i + 8 <= len; i += 8) { uint64_t w; memcpy(&w, q + i, 8); h = (h ^ w) * 0xff51afd7ed558ccdull; h ^= h >> 29; }
+    };
+    eat(p, head);
+    if (bytes > head) eat(p + bytes - head, head);
+    return h;
+}
+bool lincomb_promotion_enabled() { static const bool on = [] { const char *e = getenv("KZG_HIP_LINCOMB_PROMOTE"); return !(e && e[0] == '0'); }(); return on; }
+uint32_t lincomb_promote_after() { static const uint32_t v = [] { const char *e = getenv("KZG_HIP_LINCOMB_PROMOTE_AFTER"); long x = e ? atol(e) : 2; return (uint32_t)(x < 1 ? 1 : x > 1000 ? 1000 : x); }(); return v; }
+// the cached set for these points if they are a promoted set (or become one with this call); null: take the one-shot path
+std::shared_ptr<kzg_hip_points> lincomb_promoted_set(kzg_hip_fft *fs, const void *points_g1, uint64_t n) {
+    if (!lincomb_promotion_enabled() || n < 64 || n > (1u << 20)) return nullptr;
+    const uint8_t *pb = (const uint8_t *)points_g1;
+    const size_t bytes = (size_t)n * sizeof(g1j);
+    const uint64_t fpv = lincomb_fingerprint(pb, n);
+    {   // the memory is created under the handle's mutex (first call only)
+        std::lock_guard<std::mutex> lk(fs->mu);
+        if (!fs->promo) fs->promo = new lincomb_promo;
+    }
+    lincomb_promo &pr = *fs->promo;
+    std::unique_lock<std::mutex> lk(pr.mu);
+    pr.tick++;
+    lincomb_promo::entry *hit = nullptr;
+    for (auto &x : pr.e) if (x.n == n && x.fp == fpv && x.sightings) { hit = &x; break; }
+    if (!hit) {   // sighting 1: remember the fingerprint in the least recently used slot that holds no promoted set (those leave only through the set limit below)
+        lincomb_promo::entry *v = nullptr;
+        for (auto &x : pr.e) if (!x.set && !x.building && (!v || x.last_use < v->last_use)) v = &x;
+        if (v) { v->n = n; v->fp = fpv; v->sightings = 1; v->last_use = pr.tick; v->copy.clear(); v->copy.shrink_to_fit(); }
+        return nullptr;
+    }
+    hit->last_use = pr.tick;
+    if (hit->copy.empty()) {   // sighting 2: take the copy every later call is compared with
+        hit->copy.assign(pb, pb + bytes);
+        hit->sightings = 2;
+        return nullptr;
+    }
+    while (hit->building) pr.built.wait(lk);                              // another thread is promoting this very set: wait for its table rather than build a second one
+    if (hit->copy.size() != bytes || memcmp(hit->copy.data(), pb, bytes) != 0) return nullptr;   // same fingerprint, different points (or changed in place): one-shot
+    if (hit->set) { pr.served++; return hit->set; }
+    if (++hit->sightings <= lincomb_promote_after() + 0u) return nullptr;
+    // promote: build the cached set from the copy (outside the lock: other sets keep being served)
+    hit->building = true;
+    std::vector<std::shared_ptr<kzg_hip_points>> evicted;                  // freed outside the lock, after their last call in flight
+    {
+        int have = 0; lincomb_promo::entry *old = nullptr;
+        for (auto &x : pr.e) if (x.set) { have++; if (!old || x.last_use < old->last_use) old = &x; }
+        if (have >= lincomb_promo::LINCOMB_PROMO_SETS && old) { evicted.push_back(std::move(old->set)); old->set.reset(); old->sightings = 0; old->n = 0; old->copy.clear(); old->copy.shrink_to_fit(); }
+    }
+    const uint8_t *src = hit->copy.data();
+    lk.unlock();
+    evicted.clear();
+    kzg_hip_points *raw = nullptr;
+    const int st = kzg_hip_points_new(fs, src, n, &raw);
+    lk.lock();
+    hit->building = false;
+    if (st == KZG_HIP_OK && raw) { hit->set = std::shared_ptr<kzg_hip_points>(raw, kzg_hip_points_free); pr.promoted++; }
+    else hit->sightings = 2;                                               // could not be built (memory): stays on the one-shot path, tried again later
+    pr.built.notify_all();
+    return hit->set;
+}
+}  // namespace
+void lincomb_promo_free(kzg_hip_fft *fs) { delete fs->promo; fs->promo = nullptr; }
+int kzg_hip_lincomb_promotions(kzg_hip_fft *fs, uint64_t *promoted, uint64_t *served) {
+    if (!fs) return KZG_HIP_ERR_BAD_ARG;
+    uint64_t a = 0, b = 0;
+    { std::lock_guard<std::mutex> lk0(fs->mu); if (fs->promo) { std::lock_guard<std::mutex> lk(fs->promo->mu); a = fs->promo->promoted; b = fs->promo->served; } }
+    if (promoted) *promoted = a;
+    if (served) *served = b;
+    return KZG_HIP_OK;
+}
+
 int kzg_hip_lincomb_g1(kzg_hip_fft *fs, const void *points_g1, const void *scalars_fr, uint64_t n, void *out_g1) {
     if (!fs || !out_g1) return KZG_HIP_ERR_BAD_ARG;
     if (n == 0) { set_inf_image(out_g1); return KZG_HIP_OK; }   // bls/bls_test.go:69-78
     if (!points_g1 || !scalars_fr) return KZG_HIP_ERR_BAD_ARG;
+    KZG_TRY
+    if (std::shared_ptr<kzg_hip_points> set = lincomb_promoted_set(fs, points_g1, n))   // the same points as before, byte for byte: the cached set's table walk
+        return kzg_hip_lincomb_points(set.get(), scalars_fr, n, out_g1);
     stream_lease lease(fs);     // its own stream: host-buffer calls from many threads run side by side
     hipStream_t s = lease.s;
     msm_plan p = classic_plan(n);                               // one-shot points: no 2^64 rows (computing them costs the 64 doublings they save)
@@ -507,6 +612,7 @@ int kzg_hip_lincomb_g1(kzg_hip_fft *fs, const void *points_g1, const void *scala
     HIPCHK(hipMemcpyAsync(out_g1, d_out.p, sizeof(g1j), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return KZG_HIP_OK;
+    KZG_CATCH
 }
 
 int kzg_hip_fr_from_le32(kzg_hip_fft *fs, const void *in_le32, uint64_t n, void *out_fr, int *all_ok) {

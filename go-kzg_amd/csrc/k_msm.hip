@@ -613,6 +613,9 @@ void launch_msm(hipStream_t s, const msm_plan &p, const g1a *table, const fr *sc
 #ifndef FB_FINISH_LANES_MAX
 #define FB_FINISH_LANES_MAX 4          // partial sums per blob up to which one lane per blob finishes (A/B builds: 0 = always the cooperative kernel)
 #endif
+#ifndef FB_KEEP
+#define FB_KEEP 16          // plain halves a lane of the GLV walk keeps between its phi pass and its plain pass (4096 coefficients on one 256-lane workgroup: 16)
+#endif
 #ifndef FB_ACC_WAVES
 #define FB_ACC_WAVES 2
 #endif
@@ -803,6 +806,12 @@ template <bool SPLIT> __global__ __launch_bounds__(FB_ACC_BLOCK, FB_ACC_WAVES) v
     const uint32_t wpg = SPLIT ? (nwin + wsplit - 1) / wsplit : nwin;
     const uint64_t nvh = SPLIT ? n * wsplit : n;
     bool in_phi = false;                                  // acc holds an un-mapped sum of phi-half entries
+    // Each scalar is split ONCE (round 6).  When the lanes of the blob divide its points evenly, the phi half and the plain half of point i land on the SAME lane,
+    // nvh / L iterations apart: the lane keeps the plain half (|k1|, its sign: 5 words) of each of its <= FB_KEEP points in a private array while it walks the phi
+    // half, and reads it back instead of repeating the Montgomery reduction + Barrett split (two of those per scalar were 1.6 % of the walk).
+    const bool keep_ok = !SPLIT && nvh % L == 0 && nvh / L <= FB_KEEP;
+    uint32_t kept[FB_KEEP][5];
+    uint32_t slot = 0;
     for (uint64_t v = (uint64_t)blk * FB_ACC_BLOCK + tid; v < 2 * nvh; v += L) {
         const bool phi = v < nvh;
         const uint64_t vh = phi ? v : v - nvh;
@@ -811,11 +820,26 @@ template <bool SPLIT> __global__ __launch_bounds__(FB_ACC_BLOCK, FB_ACC_WAVES) v
         const uint32_t w1 = SPLIT ? (w0 + wpg < nwin ? w0 + wpg : nwin) : nwin;
         if (SPLIT && w0 >= w1) continue;
         if (in_phi && !phi) { if (!acc.inf) acc.v.x = mulq(acc.v.x, unpackq(glv_beta())); in_phi = false; }   // the lane crosses into its plain halves: map the phi sum
-        const glv_halves h = glv_split_signed(from_mont<FrP>(sc[i]));
-        uint32_t m[4];
+        uint32_t m[4], sgn;
+        if (keep_ok && !phi) {
+            const uint32_t at = slot < FB_KEEP ? slot : 0; slot++;
 #pragma unroll
-        for (int j = 0; j < 4; j++) m[j] = phi ? h.k2[j] : h.k1[j];
-        const uint32_t sgn = phi ? h.neg2 : h.neg1;
+            for (int j = 0; j < 4; j++) m[j] = kept[at][j];
+            sgn = kept[at][4];
+            if (slot == (uint32_t)(nvh / L)) slot = 0;
+        } else {
+            const glv_halves h = glv_split_signed(from_mont<FrP>(sc[i]));
+#pragma unroll
+            for (int j = 0; j < 4; j++) m[j] = phi ? h.k2[j] : h.k1[j];
+            sgn = phi ? h.neg2 : h.neg1;
+            if (keep_ok) {                                // (phi pass) remember the plain half for this lane's iteration nvh / L from now
+                const uint32_t at = slot < FB_KEEP ? slot : 0; slot++;
+#pragma unroll
+                for (int j = 0; j < 4; j++) kept[at][j] = h.k1[j];
+                kept[at][4] = h.neg1;
+                if (slot == (uint32_t)(nvh / L)) slot = 0;
+            }
+        }
         uint32_t raw, carry = 0, mag, ng;
         if (SPLIT) {
 #pragma nounroll

@@ -510,6 +510,62 @@ def test_lincomb_matches_oracle(kz, fs16, n):
         fs16.lin_comb_g1(pts, ko.fr_empty(n + 1))
 
 
+def test_lincomb_promotes_a_repeated_point_set_and_notices_a_changed_point(kz, setup_1337):
+    """bls.LinCombG1(setup, coeffs) as the reference's callers use it (eth/helpers.go:99,159,199: the same slice every time): from the call after
+    KZG_HIP_LINCOMB_PROMOTE_AFTER + 1 sightings on, kzg_hip_lincomb_g1 serves the set from a cached table walk -- same bytes as the one-shot bucket pipeline and as the
+    oracle.  Identity is a byte-for-byte comparison on every call: one changed coordinate (in place, same pointer, same fingerprint window or not) takes the one-shot
+    path with the NEW points; the old set stays promoted for callers that still hold it.  Concurrent callers of one set get one table."""
+    import threading
+    fs = kz.FFTSettings(4)
+    n = 512
+    pts = setup_1337[:n].copy()
+    rng = np.random.default_rng(99)
+    sc = [rand_fr(rng, n) for _ in range(8)]
+    want = [ko.g1_affine(ko.lincomb_g1(pts, x))[0] for x in sc[:3]]
+    assert fs.lincomb_promotions() == (0, 0)
+    got = [fs.lin_comb_g1(pts, sc[0]), fs.lin_comb_g1(pts, sc[1])]          # sightings 1 and 2: one-shot
+    assert fs.lincomb_promotions() == (0, 0)
+    got.append(fs.lin_comb_g1(pts, sc[2]))                                  # sighting 3: promoted, served by the set
+    assert fs.lincomb_promotions() == (1, 0) or fs.lincomb_promotions() == (1, 1)
+    for g_, w_ in zip(got, want):
+        assert np.array_equal(g_, w_)
+    before = fs.lincomb_promotions()[1]
+    for x in sc[3:6]:
+        assert np.array_equal(fs.lin_comb_g1(pts, x), ko.g1_affine(ko.lincomb_g1(pts, x))[0])
+    assert fs.lincomb_promotions() == (1, before + 3)
+    # one point in the MIDDLE changes in place (outside the fingerprint's first / last 4 KiB): the comparison sees it, the result is that of the new points
+    changed = pts
+    changed[n // 2] = setup_1337[n + 7]
+    served = fs.lincomb_promotions()[1]
+    assert np.array_equal(fs.lin_comb_g1(changed, sc[6]), ko.g1_affine(ko.lincomb_g1(changed, sc[6]))[0])
+    assert fs.lincomb_promotions() == (1, served)                           # not served by the stale set
+    # ... and a change inside the first 4 KiB (a different fingerprint)
+    changed[1] = setup_1337[n + 9]
+    assert np.array_equal(fs.lin_comb_g1(changed, sc[7]), ko.g1_affine(ko.lincomb_g1(changed, sc[7]))[0])
+    # a caller that still holds the original points is still served
+    orig = setup_1337[:n].copy()
+    assert np.array_equal(fs.lin_comb_g1(orig, sc[0]), want[0]) and fs.lincomb_promotions()[1] == served + 1
+    # ragged use of a promoted pointer: a shorter prefix is a different set (n is part of the identity), correct either way
+    assert np.array_equal(fs.lin_comb_g1(orig[:100], sc[1][:100]), ko.g1_affine(ko.lincomb_g1(orig[:100], sc[1][:100]))[0])
+    # eight threads, one new set: one promotion, every result right
+    pts2 = setup_1337[1000:1000 + n].copy()
+    outs, errs = [None] * 8, []
+
+    def worker(t):
+        try:
+            for rep in range(4):
+                outs[t] = fs.lin_comb_g1(pts2, sc[t])
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    [t.start() for t in ths]; [t.join() for t in ths]
+    assert not errs, errs
+    for t in range(8):
+        assert np.array_equal(outs[t], ko.g1_affine(ko.lincomb_g1(pts2, sc[t]))[0]), t
+    assert fs.lincomb_promotions()[0] == 2
+    fs.close()
+
+
 LAMBDA = 0xac45a4010001a40200000000ffffffff
 
 
