@@ -120,7 +120,7 @@ def main():
     golden = os.path.join(ROOT, "tests", "golden")
     pins = json.load(open(os.path.join(golden, "fk20_pins.json")))
     pmc = {}
-    for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):   # counters of the committed rocprofv3 passes (tools/profile_round.sh)
+    for name in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):   # counters of the committed rocprofv3 passes (tools/profile_round.sh)
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             pmc["_file"] = "profiles/" + name
@@ -129,7 +129,7 @@ def main():
             continue
 
     shapes, shapes_file = [], None
-    for name in ("r05_kernel_shapes.json", "r04_kernel_shapes.json"):                 # (kernel, grid, workgroup) rows of the committed rocprofv3 kernel trace (tools/rocprof_summary.py)
+    for name in ("r06_kernel_shapes.json", "r05_kernel_shapes.json", "r04_kernel_shapes.json"):                 # (kernel, grid, workgroup) rows of the committed rocprofv3 kernel trace (tools/rocprof_summary.py)
         try:
             shapes = json.load(open(os.path.join(ROOT, "profiles", name)))["rows"]
             shapes_file = "profiles/" + name
