@@ -310,17 +310,17 @@ def test_bench_line_has_no_failed_leg():
 
 
 def test_roofline_arithmetic_reproduces_the_committed_profile():
-    """benchlib/roofline.py on the numbers of profiles/r05_*: the contract's `achieved` = algorithmic bytes / average launch time of the dominant kernel (the row of
+    """benchlib/roofline.py on the numbers of profiles/r06_*: the contract's `achieved` = algorithmic bytes / average launch time of the dominant kernel (the row of
     that launch shape in the committed kernel trace), counters matched on kernel, length and table shape, the multiply-add and issue fractions from the same inputs"""
     import json
     from benchlib import roofline as rl
-    shapes = json.load(open(os.path.join(ROOT, "profiles", "r05_kernel_shapes.json")))["rows"]
+    shapes = json.load(open(os.path.join(ROOT, "profiles", "r06_kernel_shapes.json")))["rows"]
     row, = [r for r in shapes if r["kernel"].startswith("k_fb_accumulate") and r["grid"] == 4096 * 256 and r["workgroup"] == 256]
-    pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc.json")))
-    line = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_line_unprofiled.json")))
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "r06_pmc.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_line_unprofiled.json")))
     avg_s = row["avg_us"] * 1e-6
     table = (16, 8, 8 * 4096 * 32768 * 96)
-    r, pm, sc = rl.walk_roofline("k_fb_accumulate", 4096, avg_s, table, pmc, "profiles/r05_pmc.json")
+    r, pm, sc = rl.walk_roofline("k_fb_accumulate", 4096, avg_s, table, pmc, "profiles/r06_pmc.json")
     assert r["algorithmic_bytes_per_launch"] == 4096 * 131168 + 393216 == 537657344
     assert abs(r["achieved"] - 0.537657344 / avg_s) < 1e-9 and 0.0015 < r["frac"] < 0.0018           # 13 GB/s of 8 TB/s: the kernel is issue-bound
     assert pm is not None and sc == 1.0 and r["traffic"] == pm["fetch_bytes_per_launch"] + pm["write_bytes_per_launch"] > 50 * r["algorithmic_bytes_per_launch"]
