@@ -27,7 +27,10 @@
 // 10 000).  On a timeout the communicators are aborted (ncclCommAbort, on a helper thread that is itself given the deadline), the entries' streams, events
 // and arenas that the stuck work may still touch are ABANDONED (never synchronised, freed only if they have drained by the time the handle is freed) and
 // replaced, and the next transport is probed on the fresh ones; the note names the timeout.  "rccl-hang" / "peer-hang" enqueue a kernel that spins on a
-// host flag nobody sets (bounded by its own clock: at most ~2 x the probe deadline, so it cannot wedge a box) in front of the exchange.
+// host flag nobody sets (bounded by its own clock: at most ~2 x the probe deadline, so it cannot wedge a box) in front of the exchange; the flag is set where a real
+// abort would take effect (before ncclCommAbort) resp. after the streams have been abandoned (the stuck peer exchange then completes late, into the abandoned arenas).
+// A stream that stays stuck for good may hold the hardware queue it shares with fresh streams: then the next probes time out too and the constructor returns the
+// error after at most three deadlines -- bounded either way.
 #include "capi_common.hpp"
 #include <rccl/rccl.h>   // types and prototypes; the functions are resolved at run time (rccl_api)
 #include <dlfcn.h>
@@ -440,6 +443,10 @@ int transport_self_test(kzg_hip_multi *m) {
             if (!drained) {
                 if (!abandon_streams(m)) { m->self_test = "failed: a transport hung and its streams could not be replaced"; g_last_error = "multi-device exchange: " + m->transport_note + "; " + g_last_error; return KZG_HIP_ERR_HIP; }
                 m->transport_note += "; streams and arenas of the hung exchange abandoned";
+                // injected peer hang: the stuck exchange is let go only NOW, so that it completes late, next to the probe of the next transport, and writes into the
+                // abandoned arenas -- the case the abandoning exists for.  (Left spinning it would also hold whatever hardware queue its stream shares with the fresh
+                // ones -- ROCm maps a process's streams onto a few queues -- which is a property of the injection, not of the code under test.)
+                if (kind == T_PEER && (m->fault & FAULT_PEER_HANG)) release_injected_hang(m);
             }
         } else if (kind == T_RCCL) {   // a communicator that failed once is not used again
             for (ncclComm_t c : m->comms) if (c) (void)m->nccl->CommDestroy(c);

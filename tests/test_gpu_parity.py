@@ -705,6 +705,28 @@ def test_bucket_pipeline_reduce_chunks(kz, setup_1337):
     ks.close(); fs.close()
 
 
+@pytest.mark.parametrize("batch", [1, 2, 3, 4, 5, 16, 17, 48, 65])
+def test_bucket_pipeline_combine_inversion_dispatch(kz, setup_1337, batch):
+    """k_msm_combine normalises one result per blob; a wavefront holds 16 blobs: with up to three live ones it inverts them one after the other with the
+    wave-cooperative form, with more in its lanes side by side (wave_inv_any, coop_inv.hpp).  Batch sizes on both sides of the switch, with rows whose sum is the point at
+    infinity (no operand for the inversion) mixed in, on the bucket pipeline of a cached set -- against the set's table walk and the oracle"""
+    fs = kz.FFTSettings(12)
+    n = 256
+    pts = setup_1337[:n].copy()
+    rng = np.random.default_rng(1000 + batch)
+    rows = np.stack([rand_fr(rng, n) for _ in range(batch)])
+    if batch >= 2:
+        rows[1] = 0                                              # all-zero scalars: the sum is infinity
+    cached = kz.G1Points(fs, pts)
+    want = cached.lin_comb_batch(rows)                         # fixed-base walk of the set (k_fb_finish / k_fb_finish_lanes)
+    cached.set_table_budget_gb(0)
+    got = cached.lin_comb_batch(rows)                          # bucket pipeline: k_msm_combine
+    assert np.array_equal(got, want)
+    for b in sorted({0, 1 % batch, batch - 1}):
+        assert_points_equal(got[b], ko.lincomb_g1(pts, rows[b]))
+    cached.close(); fs.close()
+
+
 def test_bucket_pipeline_forms_in_fresh_processes():
     """the balanced accumulate forced at every batch size (KZG_HIP_MSM_SEG=1: lone MSMs on caller-supplied points, ragged lengths, edge scalars) and
     never (=0), through the linear-combination tests"""
