@@ -507,13 +507,14 @@ struct lincomb_promo {
     static constexpr int SLOTS = 6, LINCOMB_PROMO_SETS = 2;
     struct entry {
         uint64_t n = 0, fp = 0, last_use = 0; uint32_t sightings = 0;
-        std::vector<uint8_t> copy;                                         // the points as first compared (sighting 2 on)
+        std::shared_ptr<const std::vector<uint8_t>> copy;                  // the points as first compared (sighting 2 on); immutable once taken, so calls compare against it OUTSIDE the lock
         std::shared_ptr<kzg_hip_points> set;                               // promoted: the cached set (kept alive by calls in flight)
         bool building = false;
     };
     std::mutex mu; std::condition_variable built;
     entry e[SLOTS];
-    uint64_t tick = 0, promoted = 0, served = 0;
+    uint64_t tick = 0, promoted = 0;
+    std::atomic<uint64_t> served{0};
 };
 namespace {
 uint64_t lincomb_fingerprint(const uint8_t *p, uint64_t n) {
@@ -546,18 +547,25 @@ std::shared_ptr<kzg_hip_points> lincomb_promoted_set(kzg_hip_fft *fs, const void
     if (!hit) {   // sighting 1: remember the fingerprint in the least recently used slot that holds no promoted set (those leave only through the set limit below)
         lincomb_promo::entry *v = nullptr;
         for (auto &x : pr.e) if (!x.set && !x.building && (!v || x.last_use < v->last_use)) v = &x;
-        if (v) { v->n = n; v->fp = fpv; v->sightings = 1; v->last_use = pr.tick; v->copy.clear(); v->copy.shrink_to_fit(); }
+        if (v) { v->n = n; v->fp = fpv; v->sightings = 1; v->last_use = pr.tick; v->copy.reset(); }
         return nullptr;
     }
     hit->last_use = pr.tick;
-    if (hit->copy.empty()) {   // sighting 2: take the copy every later call is compared with
-        hit->copy.assign(pb, pb + bytes);
+    if (!hit->copy) {   // sighting 2: take the copy every later call is compared with
+        hit->copy = std::make_shared<const std::vector<uint8_t>>(pb, pb + bytes);
         hit->sightings = 2;
         return nullptr;
     }
     while (hit->building) pr.built.wait(lk);                              // another thread is promoting this very set: wait for its table rather than build a second one
-    if (hit->copy.size() != bytes || memcmp(hit->copy.data(), pb, bytes) != 0) return nullptr;   // same fingerprint, different points (or changed in place): one-shot
-    if (hit->set) { pr.served++; return hit->set; }
+    if (hit->set) {   // the steady state: compare OUTSIDE the lock (the copy is immutable, both objects are kept alive by the shared pointers), so concurrent callers of one set do not queue behind each other's 590 KB memcmp
+        std::shared_ptr<const std::vector<uint8_t>> cp = hit->copy;
+        std::shared_ptr<kzg_hip_points> set = hit->set;
+        lk.unlock();
+        if (cp->size() != bytes || memcmp(cp->data(), pb, bytes) != 0) return nullptr;          // same fingerprint, different points (or changed in place): one-shot
+        pr.served.fetch_add(1, std::memory_order_relaxed);
+        return set;
+    }
+    if (hit->copy->size() != bytes || memcmp(hit->copy->data(), pb, bytes) != 0) return nullptr;   // same fingerprint, different points (or changed in place): one-shot
     if (++hit->sightings <= lincomb_promote_after() + 0u) return nullptr;
     // promote: build the cached set from the copy (outside the lock: other sets keep being served)
     hit->building = true;
@@ -565,9 +573,10 @@ std::shared_ptr<kzg_hip_points> lincomb_promoted_set(kzg_hip_fft *fs, const void
     {
         int have = 0; lincomb_promo::entry *old = nullptr;
         for (auto &x : pr.e) if (x.set) { have++; if (!old || x.last_use < old->last_use) old = &x; }
-        if (have >= lincomb_promo::LINCOMB_PROMO_SETS && old) { evicted.push_back(std::move(old->set)); old->set.reset(); old->sightings = 0; old->n = 0; old->copy.clear(); old->copy.shrink_to_fit(); }
+        if (have >= lincomb_promo::LINCOMB_PROMO_SETS && old) { evicted.push_back(std::move(old->set)); old->set.reset(); old->sightings = 0; old->n = 0; old->copy.reset(); }
     }
-    const uint8_t *src = hit->copy.data();
+    std::shared_ptr<const std::vector<uint8_t>> src_keep = hit->copy;
+    const uint8_t *src = src_keep->data();
     lk.unlock();
     evicted.clear();
     kzg_hip_points *raw = nullptr;
@@ -584,7 +593,7 @@ void lincomb_promo_free(kzg_hip_fft *fs) { delete fs->promo; fs->promo = nullptr
 int kzg_hip_lincomb_promotions(kzg_hip_fft *fs, uint64_t *promoted, uint64_t *served) {
     if (!fs) return KZG_HIP_ERR_BAD_ARG;
     uint64_t a = 0, b = 0;
-    { std::lock_guard<std::mutex> lk0(fs->mu); if (fs->promo) { std::lock_guard<std::mutex> lk(fs->promo->mu); a = fs->promo->promoted; b = fs->promo->served; } }
+    { std::lock_guard<std::mutex> lk0(fs->mu); if (fs->promo) { std::lock_guard<std::mutex> lk(fs->promo->mu); a = fs->promo->promoted; b = fs->promo->served.load(); } }
     if (promoted) *promoted = a;
     if (served) *served = b;
     return KZG_HIP_OK;
