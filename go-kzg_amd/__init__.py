@@ -124,6 +124,7 @@ def lib():
         "kzg_hip_coalesce_stats": (i32, [vp, i32, C.POINTER(u64)]),
         "kzg_hip_lincomb_promotions": (i32, [vp, C.POINTER(u64), C.POINTER(u64)]),
         "kzg_hip_test_fp_inv": (i32, [vp, vp, u64, vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "kzg_hip_test_fr_inv": (i32, [vp, vp, u64, vp, vp, vp]),
         "kzg_hip_kzg_table_info": (i32, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(u64)]), "kzg_hip_kzg_table_additions": (u32, [vp]), "kzg_hip_kzg_set_projective_outputs": (i32, [vp, i32]),
         "kzg_hip_da_using_fk20_multi_batch": (i32, [vp, vp, u64, u64, vp]),
         "kzg_hip_multi_settings_new": (i32, [C.POINTER(i32), u32, u32, vp, u64, pp]), "kzg_hip_multi_settings_free": (None, [vp]),

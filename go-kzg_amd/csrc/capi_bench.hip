@@ -211,6 +211,21 @@ int kzg_hip_test_fp_inv(kzg_hip_fft *fs, const void *in_fp, uint64_t n, void *ou
     HIPCHK(hipGetLastError());
     return KZG_HIP_OK;
 }
+int kzg_hip_test_fr_inv(kzg_hip_fft *fs, const void *in_fr, uint64_t n, void *out_coop, void *out_lane, void *out_block) {
+    if (!fs || !in_fr || !n || n > (1u << 20) || !out_coop || !out_lane || !out_block) return KZG_HIP_ERR_BAD_ARG;
+    dev_guard g(fs);
+    hipStream_t s = fs->stream;
+    dtmp<fr> d_in(s), d_a(s), d_b(s), d_c(s);
+    CHK(d_in.alloc(n)); CHK(d_a.alloc(n)); CHK(d_b.alloc(n)); CHK(d_c.alloc(n));
+    HIPCHK(hipMemcpyAsync(d_in.p, in_fr, n * sizeof(fr), hipMemcpyHostToDevice, s));
+    launch_fr_inv_test(s, d_in.p, n, d_a.p, d_b.p, d_c.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_coop, d_a.p, n * sizeof(fr), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out_lane, d_b.p, n * sizeof(fr), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out_block, d_c.p, n * sizeof(fr), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return KZG_HIP_OK;
+}
 int kzg_hip_coalesce_stats(kzg_hip_kzg *ks, int op, uint64_t out[8]) {
     if (!ks || !out || op < 0 || op > 1) return KZG_HIP_ERR_BAD_ARG;
     for (int i = 0; i < 8; i++) out[i] = 0;

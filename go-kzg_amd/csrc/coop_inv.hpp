@@ -30,7 +30,6 @@
 namespace kzg {
 namespace cinv {
 
-static constexpr int L = 13;
 static constexpr uint32_t M30 = 0x3fffffffu;
 
 KZG_HD int32_t sext30(uint32_t x) { return (int32_t)(x << 2) >> 2; }           // the low 30 bits, sign-extended (v_bfe_i32)
@@ -40,13 +39,13 @@ KZG_HD uint32_t limb30(const uint32_t *w, int nwords, int k) {                  
     if (i + 1 < nwords) v |= (uint64_t)w[i + 1] << 32;
     return (uint32_t)(v >> sh) & M30;
 }
-KZG_HD uint32_t r2_limb30(int k) {                                              // R'^2 mod p in 30-bit limbs
-    uint32_t w[12];
+template <class F> KZG_HD uint32_t r2_limb30(int k) {                            // R^2 mod m (R the field's Montgomery radix) in 30-bit limbs
+    uint32_t w[F::N];
 #pragma unroll
-    for (int i = 0; i < 12; i++) w[i] = FpP::r2(i);
-    return limb30(w, 12, k);
+    for (int i = 0; i < F::N; i++) w[i] = F::r2(i);
+    return limb30(w, F::N, k);
 }
-// -p^-1 mod 2^30 is FpP::INV30; the rounds need +p^-1: md = -cd p^-1 = cd INV30 (mod 2^30)
+// -m^-1 mod 2^30 is F::INV30; the rounds need the multiple of m that CLEARS the low limb: md = -cd m^-1 = cd INV30 (mod 2^30)
 
 // Up to 30 divsteps on the low 30 bits of f (odd) and g, variable time.  On return (u v; q r) is the transition matrix scaled by 2^30: M (f, g) = 2^30 (f', g').
 // |u| + |v| <= 2^30, |q| + |r| <= 2^30.  eta = -delta.
@@ -82,18 +81,19 @@ KZG_HD void split32(int32_t t, int32_t &lo, int32_t &hi) {
     hi = (t - lo) >> 30;
 }
 // the multiples of p that clear the low limb of u d + v e and q d + r e: centred, from the low limbs of d and e
-KZG_HD void de_multipliers(int32_t u, int32_t v, int32_t q, int32_t r, int32_t d0, int32_t e0, int32_t &md, int32_t &me) {
+template <class F> KZG_HD void de_multipliers(int32_t u, int32_t v, int32_t q, int32_t r, int32_t d0, int32_t e0, int32_t &md, int32_t &me) {
     const uint32_t cd = (uint32_t)u * (uint32_t)d0 + (uint32_t)v * (uint32_t)e0, ce = (uint32_t)q * (uint32_t)d0 + (uint32_t)r * (uint32_t)e0;
-    md = sext30(cd * FpP::INV30); me = sext30(ce * FpP::INV30);
+    md = sext30(cd * F::INV30); me = sext30(ce * F::INV30);
 }
-// the quotient estimate of the final reduction: round(d / p) from the two top limbs, single precision (|d| < 2^389: |error| < 2^-10)
-KZG_HD int32_t final_quotient(int32_t d12, int32_t d11) {
-    const float D = (float)d12 * 1073741824.0f + (float)d11;
-    const float inv_mt = (float)(1.0 / ((double)FpP::p30(12) * 1073741824.0 + (double)FpP::p30(11)));
+// the quotient estimate of the final reduction: round(d / m) from the two top limbs, single precision (|d| < 32 m: |error| < 2^-10)
+template <class F> KZG_HD int32_t final_quotient(int32_t d_top, int32_t d_next) {
+    const float D = (float)d_top * 1073741824.0f + (float)d_next;
+    const float inv_mt = (float)(1.0 / ((double)F::p30(F::N30 - 1) * 1073741824.0 + (double)F::p30(F::N30 - 2)));
     return (int32_t)__builtin_rintf(D * inv_mt);
 }
-// centred limbs w[0..12] of a value in (-p, p) -> the canonical 12-word image in [0, p)
-KZG_HD fp canonical_from_centred(const int32_t *w) {
+// centred limbs w[0 .. L-1] of a value in (-m, m) -> the canonical image in [0, m)
+template <class F> KZG_HD felem<F> canonical_from_centred(const int32_t *w) {
+    constexpr int L = F::N30;
     uint32_t a[L];
     int32_t c = 0;
 #pragma unroll
@@ -105,12 +105,12 @@ KZG_HD fp canonical_from_centred(const int32_t *w) {
     uint32_t k = 0;
 #pragma unroll
     for (int j = 0; j < L; j++) {
-        const uint32_t s = a[j] + (FpP::p30(j) & neg) + k;
+        const uint32_t s = a[j] + (F::p30(j) & neg) + k;
         if (j < L - 1) { a[j] = s & M30; k = s >> 30; } else a[j] = s;
     }
-    fp out;
+    felem<F> out;
 #pragma unroll
-    for (int i = 0; i < 12; i++) {
+    for (int i = 0; i < F::N; i++) {
         const int k0 = (32 * i) / 30, o = (32 * i) % 30;
         uint64_t acc = 0;
 #pragma unroll
@@ -147,20 +147,22 @@ __device__ __forceinline__ int32_t carry_keep(int64_t t) {
 #ifndef KZG_COOP_INV_MAX
 #define KZG_COOP_INV_MAX 3      // a wavefront serves up to this many of its lanes' operands cooperatively, one after the other (~20-25 us each); more: the lane form
 #endif
-// x R' -> x^-1 R' (0 -> 0) of lane `src`'s x, computed by the whole wavefront; every lane receives the result.  ALL 64 lanes must be active.
-__device__ __noinline__ fp wave_inv_fp(const fp &x, uint32_t src) {
+// x R -> x^-1 R (0 -> 0; R the field's Montgomery radix) of lane `src`'s x, computed by the whole wavefront; every lane receives the result.  ALL 64 lanes must be active.
+// F = FpP (13 limbs, R' = 2^390) or FrP (9 limbs, R = 2^256: 270 bits hold |d| < 32 r just as 390 hold 32 p).
+template <class F> __device__ __noinline__ felem<F> wave_inv(const felem<F> &x, uint32_t src) {
     using namespace cinv;
-    uint32_t xs[12];
+    constexpr int L = F::N30;
+    uint32_t xs[F::N];
     uint32_t any = 0;
 #pragma unroll
-    for (int i = 0; i < 12; i++) { xs[i] = (uint32_t)__builtin_amdgcn_readlane((int)x.l[i], (int)src); any |= xs[i]; }
-    if (any == 0) return zero<FpP>();
-    const uint32_t j = threadIdx.x & 15u;                                       // this lane's limb (lanes 13..15 of a row hold zeros; rows 1..3 replicate row 0)
+    for (int i = 0; i < F::N; i++) { xs[i] = (uint32_t)__builtin_amdgcn_readlane((int)x.l[i], (int)src); any |= xs[i]; }
+    if (any == 0) return zero<F>();
+    const uint32_t j = threadIdx.x & 15u;                                       // this lane's limb (the lanes above L - 1 of a row hold zeros; rows 1..3 replicate row 0)
     int32_t f = 0, g = 0, d = 0, e = 0, pj = 0;
 #pragma unroll
     for (int k = 0; k < L; k++) {
-        const uint32_t gk = limb30(xs, 12, k);                                  // wave-uniform
-        if (j == (uint32_t)k) { g = (int32_t)gk; pj = (int32_t)FpP::p30(k); e = (int32_t)r2_limb30(k); }
+        const uint32_t gk = limb30(xs, F::N, k);                                // wave-uniform
+        if (j == (uint32_t)k) { g = (int32_t)gk; pj = (int32_t)F::p30(k); e = (int32_t)r2_limb30<F>(k); }
     }
     f = pj;
     int32_t eta = -1;
@@ -170,19 +172,49 @@ __device__ __noinline__ fp wave_inv_fp(const fp &x, uint32_t src) {
         divsteps30_var(eta, f0, g0, u, v, q, r);                                // scalar unit: everything in it is wave-uniform
         const int64_t tf = (int64_t)u * f + (int64_t)v * g, tg = (int64_t)q * f + (int64_t)r * g;
         int32_t md, me;
-        de_multipliers(u, v, q, r, __builtin_amdgcn_readlane(d, 0), __builtin_amdgcn_readlane(e, 0), md, me);
+        de_multipliers<F>(u, v, q, r, __builtin_amdgcn_readlane(d, 0), __builtin_amdgcn_readlane(e, 0), md, me);
         const int64_t td = ((int64_t)u * d + (int64_t)v * e) + (int64_t)md * pj, te = ((int64_t)q * d + (int64_t)r * e) + (int64_t)me * pj;
         f = carry_div30(tf); g = carry_div30(tg);
         d = carry_div30(td); e = carry_div30(te);
     }
-    // f = +-1 (limb 0, exactly: the representation is unique below 2^30): the inverse is sign(f) d mod p
+    // f = +-1 (limb 0, exactly: the representation is unique below 2^30): the inverse is sign(f) d mod m
     if (__builtin_amdgcn_readlane(f, 0) < 0) d = -d;
-    const int32_t qe = final_quotient(__builtin_amdgcn_readlane(d, 12), __builtin_amdgcn_readlane(d, 11));
-    d = carry_keep((int64_t)d - (int64_t)qe * pj);                              // in (-p, p)
+    const int32_t qe = final_quotient<F>(__builtin_amdgcn_readlane(d, L - 1), __builtin_amdgcn_readlane(d, L - 2));
+    d = carry_keep((int64_t)d - (int64_t)qe * pj);                              // in (-m, m)
     int32_t w[L];
 #pragma unroll
     for (int k = 0; k < L; k++) w[k] = __builtin_amdgcn_readlane(d, k);
-    return canonical_from_centred(w);
+    return canonical_from_centred<F>(w);
+}
+__device__ __forceinline__ fp wave_inv_fp(const fp &x, uint32_t src) { return wave_inv<FpP>(x, src); }
+// Inverses of one non-zero value per lane of a WORKGROUP of 2^LOG lanes (LOG <= 10) with ONE inversion: a product tree in LDS (heap layout: node k has children 2 k and
+// 2 k + 1, the lanes' values are the leaves at [2^LOG, 2^(LOG+1))), the root inverted by the first wavefront cooperatively, then the inverses pushed down
+// (inv(left) = inv(node) right, inv(right) = inv(node) left).  2 LOG barriers + one cooperative inversion instead of one lane-form inversion per lane: the quotient
+// kernel of eth.ComputeKZGProof has 1 024 lanes, i.e. 16 wavefronts on one CU that each spent a full binary GCD.  `tree` holds 2^(LOG+1) elements.  Every lane calls.
+template <class F, int LOG> __device__ __forceinline__ felem<F> block_batch_inverse(const felem<F> &v, felem<F> *tree, uint32_t tid) {
+    constexpr uint32_t LANES = 1u << LOG;
+    tree[LANES + tid] = v;
+    __syncthreads();
+#pragma nounroll
+    for (uint32_t off = LANES >> 1; off >= 1; off >>= 1) {
+        if (tid < off) tree[off + tid] = mul(tree[2 * (off + tid)], tree[2 * (off + tid) + 1]);
+        __syncthreads();
+    }
+    if (tid < 64) {                                                            // the first wavefront, whole
+        const felem<F> ri = wave_inv<F>(tree[1], 0);
+        if (tid == 0) tree[1] = ri;
+    }
+    __syncthreads();
+#pragma nounroll
+    for (uint32_t off = 1; off < LANES; off <<= 1) {
+        if (tid < off) {
+            const uint32_t node = off + tid;
+            const felem<F> in = tree[node], l = tree[2 * node], r = tree[2 * node + 1];
+            tree[2 * node] = mul(in, r); tree[2 * node + 1] = mul(in, l);
+        }
+        __syncthreads();
+    }
+    return tree[LANES + tid];
 }
 // Call-site form: lanes with need == true hold an operand; returns its inverse to each of them (other lanes: unspecified).  ALL 64 lanes must call it together.
 __device__ __forceinline__ fp wave_inv_any(const fp &x, bool need) {

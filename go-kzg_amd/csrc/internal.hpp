@@ -82,6 +82,7 @@ void launch_g1_fft_direct(hipStream_t s, const g1j *in, uint64_t in_stride, uint
                           uint64_t W, const fr *scale, uint32_t max_logr = 4, int lanes = 1, uint32_t bits_done = 0, uint64_t n_out = 0);   // n_out: only the first n_out outputs are wanted (0 = all)
 // to_kilic: also leave the device-internal Montgomery domain (R' = 2^390) for Kilic's (2^384): every API output path ends here
 void launch_g1_normalize(hipStream_t s, const g1j *in, g1j *out, uint64_t n, bool to_kilic = false);
+void launch_fr_inv_test(hipStream_t s, const fr *in, uint64_t n, fr *out_coop, fr *out_lane, fr *out_block);   // test hook: F_r inversion three ways (k_fr.hip)
 void launch_fp_inv_both(hipStream_t s, const fp *in, fp *out_coop, fp *out_lane, uint64_t n, int mode);   // test / measurement hook: wave-cooperative (bit 0) and one-lane (bit 1) inversion of n elements, one wavefront each
 void launch_g1_from_kilic(hipStream_t s, g1j *data, uint64_t n);   // in place: caller-supplied points enter the internal domain
 void launch_g1_to_affine(hipStream_t s, const g1j *in, g1a *out, uint64_t n);

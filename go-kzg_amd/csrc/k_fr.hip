@@ -5,6 +5,7 @@
 #include "internal.hpp"
 #include "fr_fft4096.hpp"
 #include "fr_das2048.hpp"
+#include "coop_inv.hpp"
 #include <stdlib.h>
 #include <string.h>
 
@@ -505,7 +506,10 @@ void launch_fr_bitrev_gather(hipStream_t s, const fr *in, fr *out, uint64_t n) {
 // a zero quotient (its proof is never looked at) -- no host round trip between this kernel and the commitment of the quotients.
 __global__ __launch_bounds__(1024) void k_eth_quotient(const fr *poly_all, uint64_t poly_stride, const fr *domain, uint64_t dom_stride, uint64_t n, const fr *z_all,
                                                        uint64_t z_stride, const fr *inv_n, fr *q_all, fr *y_all, uint32_t *flag_all) {
-    __shared__ fr red[1024];
+    // dynamic LDS: the product tree of the workgroup's batch inversion (2048 elements, coop_inv.hpp); its first 1024 elements double as the reduction area below
+    extern __shared__ uint32_t eth_q_smem[];
+    fr *tree = reinterpret_cast<fr *>(eth_q_smem);
+    fr *red = tree;
     __shared__ uint32_t bad;
     const uint32_t tid = threadIdx.x;
     const uint64_t row = blockIdx.x;
@@ -532,7 +536,14 @@ __global__ __launch_bounds__(1024) void k_eth_quotient(const fr *poly_all, uint6
             }
         }
         if (hit) atomicOr(&bad, 1u);
+        // 1 / acc for all 1024 lanes with ONE inversion (round 6): a product tree in LDS, its root inverted by the first wavefront cooperatively, inverses pushed
+        // back down.  Through round 5 every lane ran its own binary GCD here: 16 wavefronts x ~26 k instructions on one CU, ~170 us of a lone ComputeKZGProof's 0.62 ms.
+        // (acc is never zero: a zero denominator was replaced by one above, and lanes beyond n hold one.)
+#ifdef KZG_ETH_QUOTIENT_LANE_INV
         fr ia = inv<FrP>(acc);
+#else
+        fr ia = block_batch_inverse<FrP, 10>(acc, tree, tid);
+#endif
 #pragma unroll
         for (int k = 3; k >= 0; k--) {
             if ((uint32_t)k < cnt) {
@@ -544,6 +555,7 @@ __global__ __launch_bounds__(1024) void k_eth_quotient(const fr *poly_all, uint6
             }
         }
     }
+    __syncthreads();                                            // (every lane has read its inverse out of the tree before the area is reused)
     red[tid] = part;
     __syncthreads();
     for (uint32_t off = 512; off >= 1; off >>= 1) {
@@ -560,10 +572,33 @@ __global__ __launch_bounds__(1024) void k_eth_quotient(const fr *poly_all, uint6
         q[i] = invalid ? zero<FrP>() : neg<FrP>(mul(sub(poly[i], y), di));   // (p_i - y) / (w_i - z)
     }
 }
+// test hook: element i inverted by wavefront i cooperatively (out_coop), by lane 0 of that wavefront alone (out_lane), and -- workgroups of 1024 consecutive elements, the
+// tail padded with ones -- by the workgroup batch inversion the quotient kernel uses (out_block)
+__global__ __launch_bounds__(64) void k_fr_inv_both(const fr *in, fr *out_coop, fr *out_lane) {
+    const fr x = in[blockIdx.x];
+    const fr y = wave_inv<FrP>(x, 0);
+    if (threadIdx.x == 0) { out_coop[blockIdx.x] = y; out_lane[blockIdx.x] = inv<FrP>(x); }
+}
+__global__ __launch_bounds__(1024) void k_fr_inv_block(const fr *in, uint64_t n, fr *out_block) {
+    extern __shared__ uint32_t inv_smem[];
+    const uint64_t i = blockIdx.x * 1024ull + threadIdx.x;
+    fr v = i < n ? in[i] : one<FrP>();
+    if (is_zero<FrP>(v)) v = one<FrP>();                           // (the batch form needs non-zero values, like its caller guarantees)
+    const fr y = block_batch_inverse<FrP, 10>(v, reinterpret_cast<fr *>(inv_smem), threadIdx.x);
+    if (i < n) out_block[i] = y;
+}
+void launch_fr_inv_test(hipStream_t s, const fr *in, uint64_t n, fr *out_coop, fr *out_lane, fr *out_block) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_fr_inv_both, dim3((uint32_t)n), dim3(64), 0, s, in, out_coop, out_lane);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fr_inv_block), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2048 * sizeof(fr)));
+    hipLaunchKernelGGL(k_fr_inv_block, dim3((uint32_t)((n + 1023) / 1024)), dim3(1024), 2048 * sizeof(fr), s, in, n, out_block);
+}
 void launch_eth_quotient(hipStream_t s, const fr *poly, uint64_t poly_stride, const fr *domain, uint64_t n, uint64_t batch, const fr *z, uint64_t z_stride,
                          const fr *inv_n, fr *q, fr *y_out, uint32_t *flag, uint64_t dom_stride) {
     if (!batch) return;
-    hipLaunchKernelGGL(k_eth_quotient, dim3((uint32_t)batch), dim3(1024), 0, s, poly, poly_stride, domain, dom_stride, n, z, z_stride, inv_n, q, y_out, flag);
+    constexpr size_t lds = 2048 * sizeof(fr);                    // 64 KiB: the batch inversion's product tree
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eth_quotient), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // (per device: set on every launch, like the F_r transforms)
+    hipLaunchKernelGGL(k_eth_quotient, dim3((uint32_t)batch), dim3(1024), lds, s, poly, poly_stride, domain, dom_stride, n, z, z_stride, inv_n, q, y_out, flag);
 }
 
 // bls.PolyLinComb (bls/globals.go:155-178) over resident rows: out[i] = sum_j scalars[j] * vectors[j][i]; a lane per coefficient, the scalars

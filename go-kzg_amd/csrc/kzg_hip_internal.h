@@ -42,6 +42,9 @@ int kzg_hip_coalesce_stats(kzg_hip_kzg *ks, int op, uint64_t out[8]);
 int kzg_hip_test_fp_inv(kzg_hip_fft *fs, const void *in_fp, uint64_t n, void *out_coop, void *out_lane, double *ms_coop, double *ms_lane);
 /* kzg_hip_lincomb_g1's promotion of repeated caller-supplied point sets (capi_core.hip): sets promoted so far on this handle, calls served by a promoted set */
 int kzg_hip_lincomb_promotions(kzg_hip_fft *fs, uint64_t *promoted, uint64_t *served);
+/* the same for F_r (Kilic's Montgomery images, 32 bytes each): wave-cooperative, one lane, and the workgroup batch inversion of the eth quotient kernel (one inversion per
+ * 1024 values; zero inputs are treated as one there) */
+int kzg_hip_test_fr_inv(kzg_hip_fft *fs, const void *in_fr, uint64_t n, void *out_coop, void *out_lane, void *out_block);
 /* test hook: SHA-256 of a host buffer through the transcript's implementation (x86 SHA extensions or the portable loop; no device needed) */
 void kzg_hip_test_sha256(const void *data, uint64_t len, void *out32);
 

@@ -76,6 +76,79 @@ template <int LOGR> static void fr_fft_long_emul(const fr *in, uint64_t n_in, fr
     }
     for (uint32_t k2 = 0; k2 < fr4::N; k2++) { if (scale) fr4::upper_lane<LOGR, true>(out, k2, roots_l.data(), W, scale); else fr4::upper_lane<LOGR, false>(out, k2, roots_l.data(), W, scale); }
 }
+// wave_inv_fp (coop_inv.hpp) lane by lane: 16 lanes hold one limb each of f, g, d, e; the hand-overs of carry_div30 / carry_keep are array shifts.  Same scalar
+// pieces as the device code (divsteps30_var, split64 / split32, de_multipliers, final_quotient, canonical_from_centred).  Also checks the invariants the device form
+// relies on: centred limbs stay within 2^29 + 2, products within 2^61, hand-overs of the top lane are zero.  *rounds / *iters: rounds run, inner iterations.
+template <class F> static felem<F> coop_inv_emul(const felem<F> &x, uint32_t *rounds, uint32_t *bad) {
+    using namespace cinv;
+    constexpr int L = F::N30;
+    if (is_zero<F>(x)) return zero<F>();
+    int32_t f[16] = {0}, g[16] = {0}, d[16] = {0}, e[16] = {0}, pj[16] = {0};
+    for (int k = 0; k < L; k++) { g[k] = (int32_t)limb30(x.l, F::N, k); pj[k] = (int32_t)F::p30(k); f[k] = pj[k]; e[k] = (int32_t)r2_limb30<F>(k); }
+    auto lim = [&](int64_t t) { if (t >= (1ll << 61) || t <= -(1ll << 61)) (*bad)++; };
+    auto div30 = [&](const int64_t *t, int32_t *out) {
+        int32_t lo[17] = {0}, hi[16], v[16], lo2[16], hi2[16];
+        for (int j = 0; j < 16; j++) { lim(t[j]); split64(t[j], lo[j], hi[j]); }
+        if (lo[0] != 0) (*bad)++;                                              // the low limb of a round's combination is zero by construction
+        for (int j = 0; j < 16; j++) { v[j] = lo[j + 1] + hi[j]; split32(v[j], lo2[j], hi2[j]); }
+        for (int j = 0; j < 16; j++) out[j] = lo2[j] + (j ? hi2[j - 1] : 0);
+        if (hi2[15] != 0 || hi2[L - 1] != 0) (*bad)++;
+        for (int j = 0; j < 16; j++) if (out[j] > (1 << 29) + 2 || out[j] < -(1 << 29) - 2 || (j >= L && out[j] != 0)) (*bad)++;
+    };
+    int32_t eta = -1;
+    uint32_t n = 0;
+    for (;;) {
+        bool nz = false;
+        for (int j = 0; j < 16; j++) nz |= g[j] != 0;
+        if (!nz) break;
+        if (++n > 64) { (*bad)++; break; }
+        int32_t u, v, q, r, md, me;
+        divsteps30_var(eta, (uint32_t)f[0], (uint32_t)g[0], u, v, q, r);
+        de_multipliers<F>(u, v, q, r, d[0], e[0], md, me);
+        int64_t tf[16], tg[16], td[16], te[16];
+        for (int j = 0; j < 16; j++) {
+            tf[j] = (int64_t)u * f[j] + (int64_t)v * g[j]; tg[j] = (int64_t)q * f[j] + (int64_t)r * g[j];
+            td[j] = ((int64_t)u * d[j] + (int64_t)v * e[j]) + (int64_t)md * pj[j]; te[j] = ((int64_t)q * d[j] + (int64_t)r * e[j]) + (int64_t)me * pj[j];
+        }
+        div30(tf, f); div30(tg, g); div30(td, d); div30(te, e);
+    }
+    if (rounds) *rounds = n;
+    if (!((f[0] == 1 || f[0] == -1))) (*bad)++;
+    for (int j = 1; j < 16; j++) if (f[j]) (*bad)++;
+    if (f[0] < 0) for (int j = 0; j < 16; j++) d[j] = -d[j];
+    const int32_t qe = final_quotient<F>(d[L - 1], d[L - 2]);
+    {
+        int32_t lo[16], hi[16], v[16], lo2[16], hi2[16];
+        for (int j = 0; j < 16; j++) split64((int64_t)d[j] - (int64_t)qe * pj[j], lo[j], hi[j]);
+        for (int j = 0; j < 16; j++) { v[j] = lo[j] + (j ? hi[j - 1] : 0); split32(v[j], lo2[j], hi2[j]); }
+        for (int j = 0; j < 16; j++) d[j] = lo2[j] + (j ? hi2[j - 1] : 0);
+        if (hi[L - 1] != 0 || hi2[L - 1] != 0) (*bad)++;
+    }
+    return canonical_from_centred<F>(d);
+}
+// n structured / random elements: the cooperative form == inv<F>() word for word; returns mismatches + violated invariants; *max_rounds, *sum_rounds
+template <class F> static uint64_t coop_stress(uint64_t n, uint64_t seed, uint32_t *max_rounds, uint64_t *sum_rounds) {
+    uint64_t bad = 0, st = seed;
+    auto next = [&]() { st += 0x9e3779b97f4a7c15ull; uint64_t z = st; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; return z ^ (z >> 31); };
+    *max_rounds = 0; *sum_rounds = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        felem<F> x;
+        uint64_t mode = next() % 4;
+        for (int w = 0; w < F::N; w++) {
+            uint64_t r = next();
+            x.l[w] = mode == 0 ? (uint32_t)r : mode == 1 ? (uint32_t)(r & (r >> 32)) & (uint32_t)next() : mode == 2 ? ((r & 7) ? 0u : (uint32_t)(r >> 8)) : ~((uint32_t)(r & (r >> 32)) & (uint32_t)next());
+        }
+        x.l[F::N - 1] &= (1u << ((F::BITS - 1) % 32)) - 1;                    // below the modulus
+        if (next() % 8 == 0) for (int w = (int)(next() % F::N); w < F::N; w++) x.l[w] = 0;   // short values
+        uint32_t rounds = 0, b = 0;
+        felem<F> y = coop_inv_emul<F>(x, &rounds, &b);
+        bad += b;
+        if (!equal<F>(y, inv<F>(x))) bad++;
+        if (rounds > *max_rounds) *max_rounds = rounds;
+        *sum_rounds += rounds;
+    }
+    return bad;
+}
 extern "C" {
 // the radix-4 4096-point transform of k_fr_fft4096_r4, lane by lane and pass by pass (a barrier between passes == finishing the loop over
 // the lanes): roots = W + 1 Kilic images (expanded or reversed), scale = null or the Kilic image of 1/n.  Also reports the largest raw limb
@@ -224,79 +297,10 @@ void he_fr_inv(fr *o, const fr *a) { *o = inv<FrP>(*a); }
 void he_fr_inv_fermat(fr *o, const fr *a) { *o = inv_fermat<FrP>(*a); }
 void he_fp_inv(fp *o, const fp *a) { *o = inv<FpP>(*a); }
 void he_fp_inv_fermat(fp *o, const fp *a) { *o = inv_fermat<FpP>(*a); }
-// wave_inv_fp (coop_inv.hpp) lane by lane: 16 lanes hold one limb each of f, g, d, e; the hand-overs of carry_div30 / carry_keep are array shifts.  Same scalar
-// pieces as the device code (divsteps30_var, split64 / split32, de_multipliers, final_quotient, canonical_from_centred).  Also checks the invariants the device form
-// relies on: centred limbs stay within 2^29 + 2, products within 2^61, hand-overs of the top lane are zero.  *rounds / *iters: rounds run, inner iterations.
-static fp coop_inv_emul(const fp &x, uint32_t *rounds, uint32_t *bad) {
-    using namespace cinv;
-    if (is_zero<FpP>(x)) return zero<FpP>();
-    int32_t f[16] = {0}, g[16] = {0}, d[16] = {0}, e[16] = {0}, pj[16] = {0};
-    for (int k = 0; k < L; k++) { g[k] = (int32_t)limb30(x.l, 12, k); pj[k] = (int32_t)FpP::p30(k); f[k] = pj[k]; e[k] = (int32_t)r2_limb30(k); }
-    auto lim = [&](int64_t t) { if (t >= (1ll << 61) || t <= -(1ll << 61)) (*bad)++; };
-    auto div30 = [&](const int64_t *t, int32_t *out) {
-        int32_t lo[17] = {0}, hi[16], v[16], lo2[16], hi2[16];
-        for (int j = 0; j < 16; j++) { lim(t[j]); split64(t[j], lo[j], hi[j]); }
-        if (lo[0] != 0) (*bad)++;                                              // the low limb of a round's combination is zero by construction
-        for (int j = 0; j < 16; j++) { v[j] = lo[j + 1] + hi[j]; split32(v[j], lo2[j], hi2[j]); }
-        for (int j = 0; j < 16; j++) out[j] = lo2[j] + (j ? hi2[j - 1] : 0);
-        if (hi2[15] != 0 || hi2[12] != 0) (*bad)++;
-        for (int j = 0; j < 16; j++) if (out[j] > (1 << 29) + 2 || out[j] < -(1 << 29) - 2 || (j >= L && out[j] != 0)) (*bad)++;
-    };
-    int32_t eta = -1;
-    uint32_t n = 0;
-    for (;;) {
-        bool nz = false;
-        for (int j = 0; j < 16; j++) nz |= g[j] != 0;
-        if (!nz) break;
-        if (++n > 64) { (*bad)++; break; }
-        int32_t u, v, q, r, md, me;
-        divsteps30_var(eta, (uint32_t)f[0], (uint32_t)g[0], u, v, q, r);
-        de_multipliers(u, v, q, r, d[0], e[0], md, me);
-        int64_t tf[16], tg[16], td[16], te[16];
-        for (int j = 0; j < 16; j++) {
-            tf[j] = (int64_t)u * f[j] + (int64_t)v * g[j]; tg[j] = (int64_t)q * f[j] + (int64_t)r * g[j];
-            td[j] = ((int64_t)u * d[j] + (int64_t)v * e[j]) + (int64_t)md * pj[j]; te[j] = ((int64_t)q * d[j] + (int64_t)r * e[j]) + (int64_t)me * pj[j];
-        }
-        div30(tf, f); div30(tg, g); div30(td, d); div30(te, e);
-    }
-    if (rounds) *rounds = n;
-    if (!((f[0] == 1 || f[0] == -1))) (*bad)++;
-    for (int j = 1; j < 16; j++) if (f[j]) (*bad)++;
-    if (f[0] < 0) for (int j = 0; j < 16; j++) d[j] = -d[j];
-    const int32_t qe = final_quotient(d[12], d[11]);
-    {
-        int32_t lo[16], hi[16], v[16], lo2[16], hi2[16];
-        for (int j = 0; j < 16; j++) split64((int64_t)d[j] - (int64_t)qe * pj[j], lo[j], hi[j]);
-        for (int j = 0; j < 16; j++) { v[j] = lo[j] + (j ? hi[j - 1] : 0); split32(v[j], lo2[j], hi2[j]); }
-        for (int j = 0; j < 16; j++) d[j] = lo2[j] + (j ? hi2[j - 1] : 0);
-        if (hi[12] != 0 || hi2[12] != 0) (*bad)++;
-    }
-    return canonical_from_centred(d);
-}
-void he_fp_inv_coop(fp *o, const fp *a, uint32_t *rounds, uint32_t *bad) { *o = coop_inv_emul(*a, rounds, bad); }
-// n structured / random elements: the cooperative form == inv<FpP>() word for word; returns mismatches + violated invariants; *max_rounds, *sum_rounds
-uint64_t he_fp_inv_coop_stress(uint64_t n, uint64_t seed, uint32_t *max_rounds, uint64_t *sum_rounds) {
-    uint64_t bad = 0, st = seed;
-    auto next = [&]() { st += 0x9e3779b97f4a7c15ull; uint64_t z = st; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; return z ^ (z >> 31); };
-    *max_rounds = 0; *sum_rounds = 0;
-    for (uint64_t i = 0; i < n; i++) {
-        fp x;
-        uint64_t mode = next() % 4;
-        for (int w = 0; w < 12; w++) {
-            uint64_t r = next();
-            x.l[w] = mode == 0 ? (uint32_t)r : mode == 1 ? (uint32_t)(r & (r >> 32)) & (uint32_t)next() : mode == 2 ? ((r & 7) ? 0u : (uint32_t)(r >> 8)) : ~((uint32_t)(r & (r >> 32)) & (uint32_t)next());
-        }
-        x.l[11] &= (1u << 28) - 1;                                            // below the modulus
-        if (next() % 8 == 0) for (int w = (int)(next() % 12); w < 12; w++) x.l[w] = 0;   // short values
-        uint32_t rounds = 0, b = 0;
-        fp y = coop_inv_emul(x, &rounds, &b);
-        bad += b;
-        if (!equal<FpP>(y, inv<FpP>(x))) bad++;
-        if (rounds > *max_rounds) *max_rounds = rounds;
-        *sum_rounds += rounds;
-    }
-    return bad;
-}
+void he_fp_inv_coop(fp *o, const fp *a, uint32_t *rounds, uint32_t *bad) { *o = coop_inv_emul<FpP>(*a, rounds, bad); }
+void he_fr_inv_coop(fr *o, const fr *a, uint32_t *rounds, uint32_t *bad) { *o = coop_inv_emul<FrP>(*a, rounds, bad); }
+uint64_t he_fp_inv_coop_stress(uint64_t n, uint64_t seed, uint32_t *max_rounds, uint64_t *sum_rounds) { return coop_stress<FpP>(n, seed, max_rounds, sum_rounds); }
+uint64_t he_fr_inv_coop_stress(uint64_t n, uint64_t seed, uint32_t *max_rounds, uint64_t *sum_rounds) { return coop_stress<FrP>(n, seed, max_rounds, sum_rounds); }
 uint64_t he_fr_inv_stress(uint64_t n, uint64_t seed) { return inv_stress<FrP>(n, seed); }
 uint64_t he_fp_inv_stress(uint64_t n, uint64_t seed) { return inv_stress<FpP>(n, seed); }
 void he_fr_from_u64(fr *o, uint64_t v) { *o = fr_from_u64(v); }

@@ -285,6 +285,24 @@ def test_cooperative_fp_inversion_matches_the_lane_form(kz):
     fs.close()
 
 
+def test_cooperative_fr_inversion_and_workgroup_batch_inversion(kz):
+    """the F_r instance of the cooperative inversion (9 limbs) and the workgroup batch inversion built on it (block_batch_inverse: a product tree in LDS, ONE inversion per
+    1024 values -- what eth.ComputeKZGProof's quotient kernel runs instead of a binary GCD per lane): word for word the lane form and Python's pow(x, -1, r)"""
+    r, Rr = ko.R_MOD, 1 << 256
+    rng = np.random.default_rng(607)
+    xs = [1, 2, 3, r - 1, r - 2, (r + 1) // 2, 1 << 254, 5, (1 << 30) - 1, 1 << 30, (1 << 240) + 1]
+    xs += [int.from_bytes(rng.bytes(32), "little") % (r - 1) + 1 for _ in range(3000 - len(xs))]     # 3000: two full workgroups and a ragged third
+    img = np.frombuffer(b"".join((x * Rr % r).to_bytes(32, "little") for x in xs), dtype=np.uint8).copy()
+    a, b, c = np.zeros_like(img), np.zeros_like(img), np.zeros_like(img)
+    fs = kz.FFTSettings(4)
+    st = kz.lib().kzg_hip_test_fr_inv(fs.h, img.ctypes.data, len(xs), a.ctypes.data, b.ctypes.data, c.ctypes.data)
+    assert st == 0, kz.lib().kzg_hip_last_error()
+    assert np.array_equal(a, b) and np.array_equal(c, b)
+    for i in list(range(16)) + [1023, 1024, 2047, 2048, 2999]:
+        assert int.from_bytes(c[32 * i:32 * i + 32].tobytes(), "little") == pow(xs[i], -1, r) * Rr % r, i
+    fs.close()
+
+
 def test_fr_fft4096_r16_ab_artefact_is_bit_exact():
     """the 256-lane x 16-register form of the 4096-point transform left the library in round 6 (25 % slower: profiles/r05_fr_fft_ab.md, r06_fr_r16_fate.md); its kernel
     lives on as a stand-alone A/B harness (tools/ab_fr_r16) that sends the same rows through it and through the library's kernel: still word for word the same"""

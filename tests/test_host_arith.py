@@ -101,6 +101,21 @@ def test_cooperative_inversion_emulation_matches_the_lane_form(he):
     mx, sm = C.c_uint32(0), C.c_uint64(0)
     assert he.he_fp_inv_coop_stress(20000, 2026, C.byref(mx), C.byref(sm)) == 0
     assert mx.value <= 30 and 20 < sm.value / 20000 < 28.5, (mx.value, sm.value / 20000)
+    # the F_r instance (9 limbs, R = 2^256: the workgroup batch inversion of eth.ComputeKZGProof's quotient kernel)
+    r_mod, R_r = ko.R_MOD, 1 << 256
+    for x in [0, 1, 2, r_mod - 1, r_mod - 2, (r_mod + 1) // 2, 1 << 254, 5, (1 << 30) - 1, 1 << 30, (1 << 240) + 1]:
+        img = np.frombuffer((x * R_r % r_mod).to_bytes(32, "little"), dtype=np.uint32).copy()
+        got, want = np.zeros(8, dtype=np.uint32), np.zeros(8, dtype=np.uint32)
+        rounds, bad = C.c_uint32(0), C.c_uint32(0)
+        he.he_fr_inv_coop(p(got), p(img), C.byref(rounds), C.byref(bad))
+        he.he_fr_inv(p(want), p(img))
+        assert bad.value == 0 and np.array_equal(got, want), hex(x)
+        if x % r_mod:
+            assert int.from_bytes(got.tobytes(), "little") == pow(x, -1, r_mod) * R_r % r_mod, hex(x)
+    he.he_fr_inv_coop_stress.restype = C.c_uint64
+    he.he_fr_inv_coop_stress.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+    assert he.he_fr_inv_coop_stress(20000, 2027, C.byref(mx), C.byref(sm)) == 0
+    assert mx.value <= 21 and 12 < sm.value / 20000 < 19.5, (mx.value, sm.value / 20000)
 
 
 def test_binary_gcd_inversion_stress(he):
