@@ -191,7 +191,9 @@ __device__ __forceinline__ fp wave_inv_fp(const fp &x, uint32_t src) { return wa
 // 2 k + 1, the lanes' values are the leaves at [2^LOG, 2^(LOG+1))), the root inverted by the first wavefront cooperatively, then the inverses pushed down
 // (inv(left) = inv(node) right, inv(right) = inv(node) left).  2 LOG barriers + one cooperative inversion instead of one lane-form inversion per lane: the quotient
 // kernel of eth.ComputeKZGProof has 1 024 lanes, i.e. 16 wavefronts on one CU that each spent a full binary GCD.  `tree` holds 2^(LOG+1) elements.  Every lane calls.
-template <class F, int LOG> __device__ __forceinline__ felem<F> block_batch_inverse(const felem<F> &v, felem<F> *tree, uint32_t tid) {
+// `side` runs on the SECOND wavefront while the first one inverts (an independent chain that would otherwise cost every lane its issue slots: z^n in the quotient kernel).
+struct no_side_job { __device__ void operator()() const {} };
+template <class F, int LOG, class Side = no_side_job> __device__ __forceinline__ felem<F> block_batch_inverse(const felem<F> &v, felem<F> *tree, uint32_t tid, Side side = Side()) {
     constexpr uint32_t LANES = 1u << LOG;
     tree[LANES + tid] = v;
     __syncthreads();
@@ -203,7 +205,7 @@ template <class F, int LOG> __device__ __forceinline__ felem<F> block_batch_inve
     if (tid < 64) {                                                            // the first wavefront, whole
         const felem<F> ri = wave_inv<F>(tree[1], 0);
         if (tid == 0) tree[1] = ri;
-    }
+    } else if (tid < 128) side();
     __syncthreads();
 #pragma nounroll
     for (uint32_t off = 1; off < LANES; off <<= 1) {

@@ -511,6 +511,7 @@ __global__ __launch_bounds__(1024) void k_eth_quotient(const fr *poly_all, uint6
     fr *tree = reinterpret_cast<fr *>(eth_q_smem);
     fr *red = tree;
     __shared__ uint32_t bad;
+    __shared__ fr zn_sh, y_sh;
     const uint32_t tid = threadIdx.x;
     const uint64_t row = blockIdx.x;
     const fr *poly = poly_all + row * poly_stride;
@@ -518,6 +519,13 @@ __global__ __launch_bounds__(1024) void k_eth_quotient(const fr *poly_all, uint6
     const fr z = z_all[row * z_stride];
     if (tid == 0) bad = 0;
     __syncthreads();
+#ifdef KZG_ETHQ_TIMING                                          // A/B builds: phase times of row 0 on stdout (100 MHz wall clock)
+    uint64_t tq[8]; int tqi = 0;
+#define ETHQ_T() do { __syncthreads(); tq[tqi++] = wall_clock64(); } while (0)
+#else
+#define ETHQ_T() do { } while (0)
+#endif
+    ETHQ_T();
     fr part = zero<FrP>();
     for (uint64_t base = 0; base < n; base += 4096) {
         fr d[4], pv[4], pre[4];
@@ -536,14 +544,23 @@ __global__ __launch_bounds__(1024) void k_eth_quotient(const fr *poly_all, uint6
             }
         }
         if (hit) atomicOr(&bad, 1u);
+        ETHQ_T();
         // 1 / acc for all 1024 lanes with ONE inversion (round 6): a product tree in LDS, its root inverted by the first wavefront cooperatively, inverses pushed
         // back down.  Through round 5 every lane ran its own binary GCD here: 16 wavefronts x ~26 k instructions on one CU, ~170 us of a lone ComputeKZGProof's 0.62 ms.
         // (acc is never zero: a zero denominator was replaced by one above, and lanes beyond n hold one.)
 #ifdef KZG_ETH_QUOTIENT_LANE_INV
         fr ia = inv<FrP>(acc);
 #else
-        fr ia = block_batch_inverse<FrP, 10>(acc, tree, tid);
+        // (z^n -- 12 dependent squarings that every one of the 1024 lanes used to run after the reduction: 64 us of a 184 us kernel with 16 wavefronts sharing the CU's
+        // issue slots -- is computed ONCE, by the second wavefront, while the first one inverts the root)
+        fr ia = block_batch_inverse<FrP, 10>(acc, tree, tid, [&]() {
+            if (base != 0) return;
+            fr t = z;
+            for (uint64_t m = 1; m < n; m <<= 1) t = sqr(t);
+            if (tid == 64) zn_sh = t;
+        });
 #endif
+        ETHQ_T();
 #pragma unroll
         for (int k = 3; k >= 0; k--) {
             if ((uint32_t)k < cnt) {
@@ -555,6 +572,7 @@ __global__ __launch_bounds__(1024) void k_eth_quotient(const fr *poly_all, uint6
             }
         }
     }
+    ETHQ_T();
     __syncthreads();                                            // (every lane has read its inverse out of the tree before the area is reused)
     red[tid] = part;
     __syncthreads();
@@ -562,15 +580,29 @@ __global__ __launch_bounds__(1024) void k_eth_quotient(const fr *poly_all, uint6
         if (tid < off) red[tid] = add(red[tid], red[tid + off]);
         __syncthreads();
     }
+    ETHQ_T();
+#ifdef KZG_ETH_QUOTIENT_LANE_INV
     fr zn = z;                                                  // z^n, n a power of two
     for (uint64_t m = 1; m < n; m <<= 1) zn = sqr(zn);
     const fr y = mul(mul(red[0], sub(zn, one<FrP>())), *inv_n);
+#else
+    if (tid == 0) y_sh = mul(mul(red[0], sub(zn_sh, one<FrP>())), *inv_n);    // one lane: y = (z^n - 1) / n * sum (eth/helpers.go:199-201)
+    __syncthreads();
+    const fr y = y_sh;
+#endif
+    ETHQ_T();
     const bool invalid = bad != 0;
     if (tid == 0) { y_all[row] = invalid ? zero<FrP>() : y; if (invalid) flag_all[row] = 1u; }
     for (uint64_t i = tid; i < n; i += 1024) {
         const fr di = q[i];
         q[i] = invalid ? zero<FrP>() : neg<FrP>(mul(sub(poly[i], y), di));   // (p_i - y) / (w_i - z)
     }
+    ETHQ_T();
+#ifdef KZG_ETHQ_TIMING
+    if (tid == 0 && row == 0 && n <= 4096) printf("ethq phases (us): load+prefix %.1f | inverse %.1f | unwind %.1f | reduce %.1f | z^n, y %.1f | final %.1f\n", (tq[1] - tq[0]) * 0.01, (tq[2] - tq[1]) * 0.01,
+                                    (tq[3] - tq[2]) * 0.01, (tq[4] - tq[3]) * 0.01, (tq[5] - tq[4]) * 0.01, (tq[6] - tq[5]) * 0.01);
+#endif
+#undef ETHQ_T
 }
 // test hook: element i inverted by wavefront i cooperatively (out_coop), by lane 0 of that wavefront alone (out_lane), and -- workgroups of 1024 consecutive elements, the
 // tail padded with ones -- by the workgroup batch inversion the quotient kernel uses (out_block)

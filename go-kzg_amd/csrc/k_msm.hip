@@ -672,6 +672,66 @@ __global__ __launch_bounds__(FB_BLOCK, 2) void k_fb_build_pass2(uint64_t lanes, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// QUAD-cooperative reduction trees (round 6).  The trees at the end of the walk and in the finish are chains of dependent XYZZ additions: pure latency, and for a lone
+// commitment they ARE the call (19 additions on the critical path).  Rounds 2-5 spread the products of an addition over the four WAVEFRONTS of the workgroup
+// (coop_xyzz_add: one product per wave and dependency level, results exchanged through LDS, one workgroup barrier per level: 2.2 us per level, 8.8 us per addition).
+// The four LANES of a quad do the same with DPP broadcasts -- no LDS, no barrier (g1_quad.hpp, the form k_msm_combine has used since round 3): ~1.5 us per level.
+// Column c of the 64 columns of a workgroup is quad c (lanes 4 c .. 4 c + 3, which hold replicas); tree levels fetch column c + off from lane + 4 off of the same
+// wavefront (DPP / ds_bpermute) or, for the two levels that cross wavefronts, through 32 + 16 LDS slots with one barrier each.
+// ---------------------------------------------------------------------------------------------------------
+// (hook for an A/B: the tree sites call the addition through this name)
+#ifdef KZG_QUAD_ADD_NOINLINE                                  // A/B builds: one out-of-line copy of the addition for all tree sites (measured: a lone commitment 0.225 -> 0.265 ms,
+                                                             // the 4096-blob walk unchanged: the call's traffic through scratch costs more than warm instructions save)
+__device__ __noinline__ void quad_acc_add_nl(g1x_acc &acc, const g1xq &w, bool winf, uint32_t role) { quad_acc_add(acc, w, winf, role); }
+#else
+__device__ __forceinline__ void quad_acc_add_nl(g1x_acc &acc, const g1xq &w, bool winf, uint32_t role) { quad_acc_add(acc, w, winf, role); }
+#endif
+template <int R> __device__ __forceinline__ void quad_point_bcast(g1xq &o, uint32_t &oinf, const g1xq &v, uint32_t vinf) {
+    o.x = quad_bcast<R>(v.x); o.y = quad_bcast<R>(v.y); o.zz = quad_bcast<R>(v.zz); o.zzz = quad_bcast<R>(v.zzz);
+    oinf = (uint32_t)__builtin_amdgcn_update_dpp((int)vinf, (int)vinf, R * 0x55, 0xf, 0xf, false);
+}
+// sum of the first `live` (<= 64) quad columns of a 256-lane workgroup into quad 0 (replicated on its lanes 0..3).  Called by all 256 threads (barriers inside).
+__device__ __forceinline__ void quad_tree_reduce(g1x_acc &col, fb_partial *buf, uint32_t tid, uint32_t live) {
+    const uint32_t role = tid & 3u, quad = tid >> 2;
+    uint32_t off = 1;
+    while (off < live) off *= 2;                          // smallest power of two >= live
+#pragma nounroll
+    for (off >>= 1; off >= 16; off >>= 1) {               // columns off .. 2 off - 1 live in other wavefronts than their receivers: through LDS
+        if (quad >= off && quad < 2 * off && role == 0) fb_partial_store(buf[quad], col);
+        __syncthreads();
+        if (quad < off) {                                 // (wave-uniform: 16 quads per wavefront)
+            const bool have = quad + off < live;
+            const fb_partial &src = buf[have ? quad + off : off];
+            g1xq w; fb_partial_load(src, w);
+            quad_acc_add_nl(col, w, !have || src.inf != 0, role);
+        }
+    }
+    if (tid < 64) {                                       // the rest is inside the first wavefront: column c + off is lane + 4 off
+#pragma nounroll
+        for (; off >= 1; off >>= 1) {
+            const bool have = quad < off && quad + off < live;
+            g1xq w; uint32_t wi;
+            point_down_any(w, wi, col.v, col.inf ? 1u : 0u, 4 * off);
+            quad_acc_add_nl(col, w, !have || wi != 0, role);
+        }
+    }
+}
+// Block-wide sum of the 256 lane accumulators of a table-walk workgroup into lane 0's: the four accumulators of a quad first (three additions), then the tree
+// over the 64 quads: 9 additions like the wave-cooperative form below, each ~6 us instead of 8.8.
+__device__ __forceinline__ void fb_block_reduce_quad(g1x_acc &acc, fb_partial *buf, uint32_t tid) {
+    const uint32_t role = tid & 3u;
+    if (acc.inf) acc.v = g1xq_from_affine(g1a_inf());      // defined limbs in empty accumulators (their additions are computed and dropped)
+    const uint32_t ainf = acc.inf ? 1u : 0u;
+    g1x_acc col;
+    { uint32_t vi; quad_point_bcast<0>(col.v, vi, acc.v, ainf); col.inf = vi != 0; }
+    { g1xq v; uint32_t vi; quad_point_bcast<1>(v, vi, acc.v, ainf); quad_acc_add_nl(col, v, vi != 0, role); }
+    { g1xq v; uint32_t vi; quad_point_bcast<2>(v, vi, acc.v, ainf); quad_acc_add_nl(col, v, vi != 0, role); }
+    { g1xq v; uint32_t vi; quad_point_bcast<3>(v, vi, acc.v, ainf); quad_acc_add_nl(col, v, vi != 0, role); }
+    quad_tree_reduce(col, buf, tid, 64);
+    acc = col;                                             // quad 0 (lanes 0..3) holds the block's sum
+}
+
 // Block-wide sum of the 256 lane accumulators of a table-walk workgroup into lane 0's, WAVE-COOPERATIVELY: while the tree runs, three of
 // the four wavefronts would idle, so each takes one product of a dependency level of the XYZZ addition instead (coop_xyzz_add: 4 levels
 // deep instead of 13 products).  Lane column c of every wave keeps a replica of column c's running sum: the waves publish their 64
@@ -728,7 +788,9 @@ __device__ __forceinline__ uint32_t scalar_bits(const fr &k, uint32_t off, uint3
 template <bool SPLIT> __global__ __launch_bounds__(FB_ACC_BLOCK, FB_ACC_WAVES) void k_fb_accumulate(const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, uint32_t D, const fr *scalars,
                                                             uint64_t sc_stride, uint64_t n, uint32_t blocks_per_blob, uint32_t wsplit, fb_partial *partials) {
     __shared__ fb_partial buf[64];
+#ifdef KZG_REDUCE_WAVE_COOP
     __shared__ coop_lds lds;
+#endif
     const uint32_t tid = threadIdx.x;
     const uint64_t blob = blockIdx.x / blocks_per_blob; const uint32_t blk = blockIdx.x % blocks_per_blob;
     const uint64_t L = (uint64_t)blocks_per_blob * FB_ACC_BLOCK;
@@ -778,7 +840,11 @@ template <bool SPLIT> __global__ __launch_bounds__(FB_ACC_BLOCK, FB_ACC_WAVES) v
             }
         }
     }
+#ifdef KZG_REDUCE_WAVE_COOP                                   // A/B builds: the four-wavefront form of rounds 2-5
     fb_block_reduce_coop(acc, buf, &lds, tid);
+#else
+    fb_block_reduce_quad(acc, buf, tid);
+#endif
     if (tid == 0) fb_partial_store(partials[blockIdx.x], acc);
 }
 // The same walk over a table HALF as large (round 5): every scalar is split on the device, k = s1 |k1| + s2 |k2| lambda with both magnitudes below
@@ -797,7 +863,9 @@ __device__ __forceinline__ uint32_t mag_bits(const uint32_t (&m)[4], uint32_t of
 template <bool SPLIT> __global__ __launch_bounds__(FB_ACC_BLOCK, FB_ACC_WAVES) void k_fb_accumulate_glv(const g1a *table, uint64_t table_n, uint32_t c, uint32_t nwin, uint32_t D, const fr *scalars,
                                                             uint64_t sc_stride, uint64_t n, uint32_t blocks_per_blob, uint32_t wsplit, fb_partial *partials) {
     __shared__ fb_partial buf[64];
+#ifdef KZG_REDUCE_WAVE_COOP
     __shared__ coop_lds lds;
+#endif
     const uint32_t tid = threadIdx.x;
     const uint64_t blob = blockIdx.x / blocks_per_blob; const uint32_t blk = blockIdx.x % blocks_per_blob;
     const uint64_t L = (uint64_t)blocks_per_blob * FB_ACC_BLOCK;
@@ -865,7 +933,11 @@ template <bool SPLIT> __global__ __launch_bounds__(FB_ACC_BLOCK, FB_ACC_WAVES) v
         }
     }
     if (in_phi && !acc.inf) acc.v.x = mulq(acc.v.x, unpackq(glv_beta()));   // a lane that only held phi halves
+#ifdef KZG_REDUCE_WAVE_COOP                                   // A/B builds: the four-wavefront form of rounds 2-5
     fb_block_reduce_coop(acc, buf, &lds, tid);
+#else
+    fb_block_reduce_quad(acc, buf, tid);
+#endif
     if (tid == 0) fb_partial_store(partials[blockIdx.x], acc);
 }
 // one workgroup of four cooperating wavefronts per blob (lane column j = partial sum j): the blob's partial sums are added by a
@@ -873,13 +945,13 @@ template <bool SPLIT> __global__ __launch_bounds__(FB_ACC_BLOCK, FB_ACC_WAVES) v
 // column 0 normalises (one inversion: 1 / (ZZ ZZZ)) and converts.  This kernel is pure latency: ~100 us instead of ~230.
 __global__ __launch_bounds__(256) void k_fb_finish(const fb_partial *partials, uint32_t blocks_per_blob, uint64_t batch, g1j *out, int to_kilic) {
     __shared__ fb_partial buf[64];
+    const uint64_t b = blockIdx.x;
+#ifdef KZG_REDUCE_WAVE_COOP                                   // A/B builds: the four-wavefront form of rounds 2-5 (lane column = partial sum, replicas across the wavefronts)
     __shared__ coop_lds lds;
     coop_ctx c; c.L = &lds; c.wave = threadIdx.x >> 6; c.col = threadIdx.x & 63u; c.set = 0;
-    const uint64_t b = blockIdx.x;
     const uint32_t col = c.col;
     g1x_acc acc; acc.init();
     acc.v = g1xq_from_affine(g1a_inf());                   // defined limbs while empty
-    // every wave holds a replica of its column's accumulator; columns beyond the partial count stay empty
     const uint32_t rounds = (blocks_per_blob + 63) / 64;
 #pragma nounroll
     for (uint32_t r = 0; r < rounds; r++) {
@@ -895,21 +967,38 @@ __global__ __launch_bounds__(256) void k_fb_finish(const fb_partial *partials, u
 #pragma nounroll
     for (off >>= 1; off >= 1; off >>= 1) {
         const bool have = col < off && col + off < live;
-#ifdef KZG_NO_WAVE_SHUFFLE
-        if (c.wave == 0) fb_partial_store(buf[col], acc);  // the replicas are identical: one wave publishes the columns
-        __syncthreads();
-        const uint32_t src = have ? col + off : col;
-        g1xq w; fb_partial_load(buf[src], w);
-        const bool winf = !have || buf[src].inf != 0;
-        __syncthreads();                                   // everyone has read before the next level overwrites
-#else
         g1xq w; uint32_t wi;                               // column col + off lives in lane col + off of the same wave (replicas)
         point_down_any(w, wi, acc.v, acc.inf ? 1u : 0u, off);
-        const bool winf = !have || wi != 0;
-#endif
-        coop_acc_add(acc, w, winf, c);
+        coop_acc_add(acc, w, !have || wi != 0, c);
     }
-    if (c.wave == 0) {                                      // wave-uniform: the whole first wavefront takes part in the inversion, its lane 0 (column 0) owns the result
+    const bool first_wave = c.wave == 0;
+#else
+    // quad column c = lanes 4 c .. 4 c + 3 (replicas) takes the partial sums c, c + 64, ...; then the quad tree; quad 0 ends with the blob's sum (k_msm.hip, above)
+    const uint32_t tid = threadIdx.x, role = tid & 3u, quad = tid >> 2, col = tid & 63u;
+#ifdef KZG_FINISH_TIMING
+    const uint64_t tf0 = wall_clock64();
+#endif
+    g1x_acc acc; acc.init();
+    acc.v = g1xq_from_affine(g1a_inf());                   // defined limbs while empty
+    const uint32_t rounds = (blocks_per_blob + 63) / 64;
+#pragma nounroll
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t j = r * 64 + quad;
+        const bool have = j < blocks_per_blob;
+        const fb_partial &pj = partials[b * blocks_per_blob + (have ? j : 0)];
+        g1xq w; fb_partial_load(pj, w);
+        quad_acc_add_nl(acc, w, !have || pj.inf != 0, role);
+    }
+#ifdef KZG_FINISH_TIMING
+    __syncthreads(); const uint64_t tf1 = wall_clock64();
+#endif
+    quad_tree_reduce(acc, buf, tid, blocks_per_blob < 64 ? blocks_per_blob : 64);
+#ifdef KZG_FINISH_TIMING
+    __syncthreads(); const uint64_t tf2 = wall_clock64();
+#endif
+    const bool first_wave = tid < 64;
+#endif
+    if (first_wave) {                                       // wave-uniform: the whole first wavefront takes part in the inversion, its lane 0 owns the result
         const bool own = col == 0;
         const g1x px = g1xq_pack(acc.v);                    // (defined limbs in every column: empty accumulators hold the affine image of infinity)
         // x = X / ZZ, y = Y / ZZZ with ONE inversion: i = 1 / (ZZ ZZZ), 1 / ZZ = i ZZZ, 1 / ZZZ = i ZZ -- spread over the wavefront's lanes (coop_inv.hpp)
@@ -930,6 +1019,9 @@ __global__ __launch_bounds__(256) void k_fb_finish(const fb_partial *partials, u
             out[b] = (to_kilic & 1) ? g1_to_kilic(r) : r;
         }
     }
+#if defined(KZG_FINISH_TIMING) && !defined(KZG_REDUCE_WAVE_COOP)
+    if (threadIdx.x == 0 && b == 0) printf("finish phases (us): %u rounds of load + add %.1f | tree %.1f | inversion + output %.1f\n", (blocks_per_blob + 63) / 64, (tf1 - tf0) * 0.01, (tf2 - tf1) * 0.01, (wall_clock64() - tf2) * 0.01);
+#endif
 }
 
 // The same for LARGE batches (at most 4 partial sums per blob: 128 blobs and more): one LANE per blob adds its few partials and
