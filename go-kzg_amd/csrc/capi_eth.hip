@@ -119,9 +119,10 @@ static int eth_proof_rows(kzg_hip_eth *eth, hipStream_t s, const fr *d_poly, uin
                           fr *d_y, uint32_t *d_bad) {
     const uint64_t n = eth->n;
     dtmp<fr> d_q(s); dtmp<g1j> d_out(s);
-    CHK(d_q.alloc(batch * n)); CHK(d_out.alloc(batch));
+    const uint64_t extra = eth_quotient_scratch_elems(n, batch);   // the row-split quotient of small batches keeps its shares behind the quotients: no allocation of its own
+    CHK(d_q.alloc(batch * n + extra)); CHK(d_out.alloc(batch));
     HIPCHK(hipMemsetAsync(d_bad, 0, batch * 4, s));
-    launch_eth_quotient(s, d_poly, poly_stride, eth->d_domain, n, batch, d_z, z_stride, eth->fs->d_inv_pow2 + ilog2(n), d_q.p, d_y, d_bad);
+    launch_eth_quotient(s, d_poly, poly_stride, eth->d_domain, n, batch, d_z, z_stride, eth->fs->d_inv_pow2 + ilog2(n), d_q.p, d_y, d_bad, 1, extra ? d_q.p + batch * n : nullptr);
     CHK(commit_rows(eth->ks, s, d_q.p, n, batch, d_out.p));                      // bls.LinCombG1(kzgSetupLagrange, quotient), eth/helpers.go:199
     launch_g1_from_kilic(s, d_out.p, batch);
     launch_g1_compress(s, d_out.p, d_out48, batch);
@@ -345,9 +346,10 @@ int kzg_hip_eth_compute_aggregated_poly_and_commitment(kzg_hip_eth *eth, const v
         HIPCHK(hipMemcpyAsync(&agg_c, d_out.p, sizeof(g1j), hipMemcpyDeviceToHost, s));
     }
     // y = EvaluatePolynomialInEvaluationForm(aggregatedPoly, evaluationChallenge) (eth/eth.go:166): the quotient kernel's first half
-    CHK(d_z.alloc(1)); CHK(d_y.alloc(1)); CHK(d_q.alloc(n));
+    const uint64_t extra = eth_quotient_scratch_elems(n, 1);
+    CHK(d_z.alloc(1)); CHK(d_y.alloc(1)); CHK(d_q.alloc(n + extra));
     HIPCHK(hipMemcpyAsync(d_z.p, &z, sizeof(fr), hipMemcpyHostToDevice, s));
-    launch_eth_quotient(s, d_agg.p, n, eth->d_domain, n, 1, d_z.p, 1, eth->fs->d_inv_pow2 + ilog2(n), d_q.p, d_y.p, d_flag.p + 1);
+    launch_eth_quotient(s, d_agg.p, n, eth->d_domain, n, 1, d_z.p, 1, eth->fs->d_inv_pow2 + ilog2(n), d_q.p, d_y.p, d_flag.p + 1, 1, extra ? d_q.p + n : nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(flag, d_flag.p, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&y, d_y.p, sizeof(fr), hipMemcpyDeviceToHost, s));
@@ -369,11 +371,12 @@ static int evaluate_in_evaluation_form(kzg_hip_fft *fs, const fr *d_roots, uint6
     fr y; uint32_t flag = 0;
     drain_on_exit drain(s);
     dtmp<fr> d_poly(s), d_x(s), d_y(s), d_q(s); dtmp<uint32_t> d_flag(s);
-    CHK(d_poly.alloc(n)); CHK(d_x.alloc(1)); CHK(d_y.alloc(1)); CHK(d_q.alloc(n)); CHK(d_flag.alloc(1));
+    const uint64_t extra = eth_quotient_scratch_elems(n, 1);
+    CHK(d_poly.alloc(n)); CHK(d_x.alloc(1)); CHK(d_y.alloc(1)); CHK(d_q.alloc(n + extra)); CHK(d_flag.alloc(1));
     HIPCHK(hipMemsetAsync(d_flag.p, 0, 4, s));
     HIPCHK(hipMemcpyAsync(d_poly.p, poly_fr, n * sizeof(fr), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_x.p, x_fr, sizeof(fr), hipMemcpyHostToDevice, s));
-    launch_eth_quotient(s, d_poly.p, n, d_roots, n, 1, d_x.p, 1, fs->d_inv_pow2 + ilog2(n), d_q.p, d_y.p, d_flag.p, root_stride);
+    launch_eth_quotient(s, d_poly.p, n, d_roots, n, 1, d_x.p, 1, fs->d_inv_pow2 + ilog2(n), d_q.p, d_y.p, d_flag.p, root_stride, extra ? d_q.p + n : nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(&y, d_y.p, sizeof(fr), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&flag, d_flag.p, 4, hipMemcpyDeviceToHost, s));

@@ -44,7 +44,8 @@ void launch_zero_unpad(hipStream_t s, const fr *root, uint64_t pad, uint64_t n_m
 void launch_fr_mul_table_rows(hipStream_t s, fr *data, const fr *table, uint64_t stride, uint64_t n, uint64_t batch);
 void launch_poly_lincomb(hipStream_t s, const fr *vectors, uint64_t stride, const fr *scalars, uint64_t count, uint64_t n, fr *out);   // bls.PolyLinComb
 void launch_eth_quotient(hipStream_t s, const fr *poly, uint64_t poly_stride, const fr *domain, uint64_t n, uint64_t batch, const fr *z, uint64_t z_stride,
-                         const fr *inv_n, fr *q, fr *y_out, uint32_t *flag, uint64_t dom_stride = 1);
+                         const fr *inv_n, fr *q, fr *y_out, uint32_t *flag, uint64_t dom_stride = 1, fr *scratch = nullptr);   // scratch: eth_quotient_scratch_elems(n, batch) elements (the row-split form of small batches) or null
+uint64_t eth_quotient_scratch_elems(uint64_t n, uint64_t batch);
 
 void launch_fr_scale_by_inv_powers(hipStream_t s, fr *c, const fr *x, uint64_t n, fr *xpow_n);   // c_i /= x^i; *xpow_n = x^n
 

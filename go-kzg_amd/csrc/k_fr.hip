@@ -604,6 +604,63 @@ __global__ __launch_bounds__(1024) void k_eth_quotient(const fr *poly_all, uint6
 #endif
 #undef ETHQ_T
 }
+// The same quotient with a row spread over S = n / 1024 workgroups (round 6; small batches, n >= 2048): ONE element per lane, so a lone ComputeKZGProof uses four CUs
+// instead of one and a lane has no local prefix products to build and unwind -- the single-workgroup kernel above spends 65 of its 130 us on them with 16 wavefronts
+// sharing one CU's issue slots.  Two launches, no cross-workgroup synchronisation: (1) each workgroup inverts its 1024 denominators (product tree + one cooperative
+// inversion), stashes 1 / (z - w_i) in q and writes its share of sum p_i w_i / (z - w_i) and its z^n; (2) every workgroup adds the row's S shares, forms y and finishes its
+// own 1024 elements.  shares: S + 1 elements per row (the last one z^n).
+__global__ __launch_bounds__(1024) void k_eth_quotient_parts(const fr *poly_all, uint64_t poly_stride, const fr *domain, uint64_t dom_stride, uint64_t n, uint32_t S, const fr *z_all,
+                                                             uint64_t z_stride, fr *q_all, uint32_t *flag_all, fr *shares) {
+    extern __shared__ uint32_t eth_q_smem[];
+    fr *tree = reinterpret_cast<fr *>(eth_q_smem);
+    fr *red = tree;
+    __shared__ uint32_t bad;
+    __shared__ fr zn_sh;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t row = blockIdx.x / S; const uint32_t part = blockIdx.x % S;
+    const fr *poly = poly_all + row * poly_stride;
+    fr *q = q_all + row * n;
+    const fr z = z_all[row * z_stride];
+    if (tid == 0) bad = 0;
+    __syncthreads();
+    const uint64_t i = (uint64_t)part * 1024u + tid;            // < n: n = 1024 S
+    const fr w = domain[i * dom_stride];
+    fr d = sub(z, w);
+    if (is_zero<FrP>(d)) { atomicOr(&bad, 1u); d = one<FrP>(); }
+    const fr pw = mul(poly[i], w);                              // (independent of the inverse: issued before the tree's barriers)
+    const fr di = block_batch_inverse<FrP, 10>(d, tree, tid, [&]() {
+        fr t = z;                                               // z^n on the second wavefront while the first one inverts
+        for (uint64_t m = 1; m < n; m <<= 1) t = sqr(t);
+        if (tid == 64) zn_sh = t;
+    });
+    q[i] = di;                                                  // stash 1 / (z - w_i); second use in the finishing launch
+    const fr term = mul(pw, di);
+    __syncthreads();                                            // (every lane has read its inverse out of the tree before the area is reused)
+    red[tid] = term;
+    __syncthreads();
+    for (uint32_t off = 512; off >= 1; off >>= 1) {
+        if (tid < off) red[tid] = add(red[tid], red[tid + off]);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        shares[row * (S + 1) + part] = red[0];
+        if (part == 0) shares[row * (S + 1) + S] = zn_sh;
+        if (bad) atomicOr(&flag_all[row], 1u);
+    }
+}
+__global__ __launch_bounds__(1024) void k_eth_quotient_finish(const fr *poly_all, uint64_t poly_stride, uint64_t n, uint32_t S, const fr *inv_n, fr *q_all, fr *y_all,
+                                                              const uint32_t *flag_all, const fr *shares) {
+    const uint32_t tid = threadIdx.x;
+    const uint64_t row = blockIdx.x / S; const uint32_t part = blockIdx.x % S;
+    fr sum = shares[row * (S + 1)];                             // (wave-uniform loads: every lane forms the same y)
+    for (uint32_t p = 1; p < S; p++) sum = add(sum, shares[row * (S + 1) + p]);
+    const fr y = mul(mul(sum, sub(shares[row * (S + 1) + S], one<FrP>())), *inv_n);   // y = (z^n - 1) / n * sum (eth/helpers.go:199-201)
+    const bool invalid = flag_all[row] != 0;
+    if (tid == 0 && part == 0) y_all[row] = invalid ? zero<FrP>() : y;
+    const uint64_t i = (uint64_t)part * 1024u + tid;
+    fr *q = q_all + row * n;
+    q[i] = invalid ? zero<FrP>() : neg<FrP>(mul(sub(poly_all[row * poly_stride + i], y), q[i]));   // (p_i - y) / (w_i - z)
+}
 // test hook: element i inverted by wavefront i cooperatively (out_coop), by lane 0 of that wavefront alone (out_lane), and -- workgroups of 1024 consecutive elements, the
 // tail padded with ones -- by the workgroup batch inversion the quotient kernel uses (out_block)
 __global__ __launch_bounds__(64) void k_fr_inv_both(const fr *in, fr *out_coop, fr *out_lane) {
@@ -625,10 +682,24 @@ void launch_fr_inv_test(hipStream_t s, const fr *in, uint64_t n, fr *out_coop, f
     hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fr_inv_block), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2048 * sizeof(fr)));
     hipLaunchKernelGGL(k_fr_inv_block, dim3((uint32_t)((n + 1023) / 1024)), dim3(1024), 2048 * sizeof(fr), s, in, n, out_block);
 }
+uint64_t eth_quotient_scratch_elems(uint64_t n, uint64_t batch) {   // elements the caller appends to its quotient buffer for the row-split form (0: not used at this shape)
+    static const bool one_wg = [] { const char *e = getenv("KZG_HIP_ETH_QUOTIENT"); return e && !strcmp(e, "one"); }();   // A/B and test hook: one workgroup per row at every size
+    const uint64_t S = n / 1024;
+    // small batches only: from ~64 rows on the one-workgroup rows fill the chip and their four elements per lane amortise the tree (512 rows: 87 k against 66 k proofs/s)
+    if (one_wg || n < 2048 || (n & (n - 1)) != 0 || S > 64 || batch * S > 256) return 0;
+    return batch * (S + 1);
+}
 void launch_eth_quotient(hipStream_t s, const fr *poly, uint64_t poly_stride, const fr *domain, uint64_t n, uint64_t batch, const fr *z, uint64_t z_stride,
-                         const fr *inv_n, fr *q, fr *y_out, uint32_t *flag, uint64_t dom_stride) {
+                         const fr *inv_n, fr *q, fr *y_out, uint32_t *flag, uint64_t dom_stride, fr *scratch) {
     if (!batch) return;
     constexpr size_t lds = 2048 * sizeof(fr);                    // 64 KiB: the batch inversion's product tree
+    if (scratch && eth_quotient_scratch_elems(n, batch)) {       // a row over S workgroups, two launches
+        const uint32_t S = (uint32_t)(n / 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eth_quotient_parts), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_eth_quotient_parts, dim3((uint32_t)(batch * S)), dim3(1024), lds, s, poly, poly_stride, domain, dom_stride, n, S, z, z_stride, q, flag, scratch);
+        hipLaunchKernelGGL(k_eth_quotient_finish, dim3((uint32_t)(batch * S)), dim3(1024), 0, s, poly, poly_stride, n, S, inv_n, q, y_out, flag, scratch);
+        return;
+    }
     hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eth_quotient), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // (per device: set on every launch, like the F_r transforms)
     hipLaunchKernelGGL(k_eth_quotient, dim3((uint32_t)batch), dim3(1024), lds, s, poly, poly_stride, domain, dom_stride, n, z, z_stride, inv_n, q, y_out, flag);
 }
