@@ -122,7 +122,7 @@ struct stream_lease {
         for (;;) {
             if (!f->pool_idle.empty()) { slot = f->pool_idle.back(); f->pool_idle.pop_back(); s = slot.s; return; }
             if (f->pool_total < POOL_MAX) {
-                if (hipStreamCreateWithFlags(&slot.s, hipStreamNonBlocking) == hipSuccess) { f->pool_total++; s = slot.s; return; }
+                if (hipStreamCreateWithFlags(&slot.s, hipStreamNonBlocking) == hipSuccess) { stream_cache_own(slot.s); f->pool_total++; s = slot.s; return; }
                 (void)hipGetLastError(); slot.s = nullptr;
                 if (f->pool_total == 0) { lk.unlock(); fallback = std::unique_lock<std::mutex>(f->mu); s = f->stream; return; }
             }
@@ -183,16 +183,36 @@ struct drain_on_exit {
     explicit drain_on_exit(hipStream_t st) : s(st) {}
     ~drain_on_exit() { (void)hipStreamSynchronize(s); }
 };
-// stream-ordered temporary
+// Stream-ordered temporaries.  hipMallocAsync / hipFreeAsync cost the host 2 + 8 us per pair (rocprofv3 --hip-runtime-trace, round 6), and a one-polynomial call makes
+// five to seven of them -- the frees AFTER its last synchronisation, i.e. on the caller's critical path: 50 of a lone eth.ComputeKZGProof's 450 us were spent freeing.
+// Small blocks (<= 8 MiB) of streams the LIBRARY owns are therefore kept in a per-stream cache of power-of-two size classes and handed to the next temporary of that
+// stream: reuse on the same stream is ordered behind every earlier use exactly as the runtime's own pool orders it.  Caller-supplied streams (the _dev entry points) are
+// never cached: the library cannot know when they die.  stream_cache_own() at creation, stream_cache_disown() before hipStreamDestroy (frees the stream's blocks).
+void stream_cache_own(hipStream_t s);                               // capi_core.hip
+void stream_cache_disown(hipStream_t s);
+void *stream_cache_take(hipStream_t s, size_t class_bytes);         // nullptr: nothing cached (or not an owned stream)
+bool stream_cache_give(hipStream_t s, void *p, size_t class_bytes); // false: not kept (the caller frees)
+inline size_t stream_cache_class(size_t bytes) {                    // 0: too large to cache
+    if (bytes > (8u << 20)) return 0;
+    size_t c = 256;
+    while (c < bytes) c <<= 1;
+    return c;
+}
 template <class T> struct dtmp {
-    T *p = nullptr; hipStream_t s;
+    T *p = nullptr; hipStream_t s; size_t cls = 0;
     dtmp(hipStream_t st) : s(st) {}
     int alloc(size_t count) {
         if (!count) count = 1;
-        HIPCHK(hipMallocAsync((void **)&p, count * sizeof(T), s));
+        size_t bytes = count * sizeof(T);
+        cls = stream_cache_class(bytes);
+        if (cls) {
+            if ((p = (T *)stream_cache_take(s, cls))) return KZG_HIP_OK;
+            bytes = cls;                                            // a block of the whole class, so that it can serve the class later
+        }
+        HIPCHK(hipMallocAsync((void **)&p, bytes, s));
         return KZG_HIP_OK;
     }
-    ~dtmp() { if (p) hipFreeAsync(p, s); }
+    ~dtmp() { if (p && !(cls && stream_cache_give(s, p, cls))) hipFreeAsync(p, s); }
 };
 
 // (ROCm maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues, default 4: kernels of streams that share a queue run one after

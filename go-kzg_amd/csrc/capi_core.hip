@@ -1,5 +1,6 @@
 // capi_core.hip -- library / device, FFTSettings and its transforms (a1-a5), conversions, bls.LinCombG1 and cached point sets (a6)
 #include "capi_common.hpp"
+#include <map>
 
 thread_local std::string g_last_error;
 
@@ -79,6 +80,7 @@ int kzg_hip_fft_settings_new(int device, unsigned max_scale, kzg_hip_fft **out) 
     kzg_hip_fft *fs = own.get();
     fs->device = device; fs->max_scale = max_scale; fs->W = 1ull << max_scale;
     HIPCHK(hipStreamCreateWithFlags(&fs->stream, hipStreamNonBlocking));
+    stream_cache_own(fs->stream);
     // expandRootOfUnity (fft.go:21-32): W + 1 powers, first and last are 1; reversed copy (fft.go:49-54)
     fr w = scale2_root_of_unity(max_scale);
     fs->h_expanded.resize(fs->W + 1); fs->h_reversed.resize(fs->W + 1);
@@ -124,6 +126,46 @@ int kzg_hip_fft_settings_new(int device, unsigned max_scale, kzg_hip_fft **out) 
     return KZG_HIP_OK;
     KZG_CATCH
 }
+// ---- per-stream cache of small stream-ordered blocks (capi_common.hpp, dtmp) ----
+namespace {
+struct stream_blocks { std::vector<void *> cls[16]; };              // class k: 256 B << k (256 B ... 8 MiB)
+std::mutex g_sc_mu;
+std::map<hipStream_t, stream_blocks> g_sc;
+inline int sc_index(size_t class_bytes) { int k = 0; while ((256u << k) < class_bytes) k++; return k; }
+constexpr size_t SC_KEEP = 4;                                       // blocks kept per stream and class
+}
+void stream_cache_own(hipStream_t s) { std::lock_guard<std::mutex> lk(g_sc_mu); g_sc[s]; }
+void stream_cache_disown(hipStream_t s) {
+    stream_blocks b;
+    {
+        std::lock_guard<std::mutex> lk(g_sc_mu);
+        auto it = g_sc.find(s);
+        if (it == g_sc.end()) return;
+        b = std::move(it->second);
+        g_sc.erase(it);
+    }
+    for (auto &v : b.cls) for (void *p : v) (void)hipFreeAsync(p, s);
+}
+void *stream_cache_take(hipStream_t s, size_t class_bytes) {
+    std::lock_guard<std::mutex> lk(g_sc_mu);
+    auto it = g_sc.find(s);
+    if (it == g_sc.end()) return nullptr;
+    auto &v = it->second.cls[sc_index(class_bytes)];
+    if (v.empty()) return nullptr;
+    void *p = v.back(); v.pop_back();
+    return p;
+}
+bool stream_cache_give(hipStream_t s, void *p, size_t class_bytes) {
+    static const bool off = [] { const char *e = getenv("KZG_HIP_STREAM_CACHE"); return e && e[0] == '0'; }();   // A/B and test hook
+    if (off) return false;
+    std::lock_guard<std::mutex> lk(g_sc_mu);
+    auto it = g_sc.find(s);
+    if (it == g_sc.end()) return false;
+    auto &v = it->second.cls[sc_index(class_bytes)];
+    if (v.size() >= SC_KEEP) return false;
+    v.push_back(p);
+    return true;
+}
 void lincomb_promo_free(kzg_hip_fft *fs);
 void kzg_hip_fft_settings_free(kzg_hip_fft *fs) {
     if (!fs) return;
@@ -131,9 +173,9 @@ void kzg_hip_fft_settings_free(kzg_hip_fft *fs) {
     lincomb_promo_free(fs);                                 // promoted point sets hold tables and coalescers on this handle: they go first
     if (fs->stream) hipStreamSynchronize(fs->stream);
     hipFree(fs->d_expanded); hipFree(fs->d_reversed); hipFree(fs->d_expanded_l); hipFree(fs->d_reversed_l); hipFree(fs->d_inv_pow2); hipFree(fs->d_tw4096[0]); hipFree(fs->d_tw4096[1]); hipFree(fs->d_tw_das2048); hipFree(fs->d_glv_expanded); hipFree(fs->d_glv_reversed); hipFree(fs->d_wnaf_expanded); hipFree(fs->d_wnaf_reversed);
-    if (fs->stream) hipStreamDestroy(fs->stream);
+    if (fs->stream) { stream_cache_disown(fs->stream); hipStreamDestroy(fs->stream); }
     if (fs->h_stage) hipHostFree(fs->h_stage);
-    for (auto &ps : fs->pool_idle) { hipStreamSynchronize(ps.s); hipStreamDestroy(ps.s); if (ps.h_pin) hipHostFree(ps.h_pin); }
+    for (auto &ps : fs->pool_idle) { hipStreamSynchronize(ps.s); stream_cache_disown(ps.s); hipStreamDestroy(ps.s); if (ps.h_pin) hipHostFree(ps.h_pin); }
     (void)hipGetLastError();
     delete fs;
 }

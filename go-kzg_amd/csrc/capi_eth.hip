@@ -1,6 +1,31 @@
 // capi_eth.hip -- eth/ byte-level prover path (f1), evaluation-form helpers, text / JSON setup loading (f4)
 #include "capi_common.hpp"
 
+// result rows of the coalesced one-polynomial calls, assembled ON THE DEVICE: row r = 48 commitment / proof bytes | (y, 32 bytes) | the 4-byte flag, padded to `pitch`, so that
+// ONE contiguous copy brings a batch's results to the pinned staging rows.  (Through round 5 the rows were gathered by two / three hipMemcpy2DAsync device -> host copies,
+// which ROCm 7 completes on a ~0.45 ms cadence whatever their size: a lone eth.ComputeKZGProof took 0.449 ms through four different kernel and allocation changes.)
+__global__ void k_eth_pack_rows(const uint8_t *c48, const fr *y, const uint32_t *bad, uint64_t rows, uint32_t pitch_words, uint32_t *out) {
+    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= rows * pitch_words) return;
+    const uint64_t r = t / pitch_words; const uint32_t w = (uint32_t)(t % pitch_words);
+    const uint32_t flag_at = y ? 20u : 12u;
+    uint32_t v = 0;
+    if (w < 12) v = reinterpret_cast<const uint32_t *>(c48)[r * 12 + w];
+    else if (y && w < 20) v = y[r].l[w - 12];
+    else if (w == flag_at) v = bad[r];
+    out[t] = v;
+}
+static int eth_rows_to_host(hipStream_t s, const uint8_t *d_c48, const fr *d_y, const uint32_t *d_bad, uint64_t rows, uint32_t pitch, uint8_t *h_out) {
+    dtmp<uint32_t> d_pack(s);
+    const uint64_t words = rows * (pitch / 4);
+    CHK(d_pack.alloc(words));
+    hipLaunchKernelGGL(k_eth_pack_rows, dim3((uint32_t)((words + 255) / 256)), dim3(256), 0, s, d_c48, d_y, d_bad, rows, pitch / 4, d_pack.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h_out, d_pack.p, words * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));                             // (the temporary is released after the copy has landed)
+    return KZG_HIP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // eth/ byte-level prover path (row f1)
 // ---------------------------------------------------------------------------------------------------------
@@ -72,10 +97,7 @@ int kzg_hip_eth_blob_to_kzg_commitment_batch(kzg_hip_eth *eth, const void *blobs
             launch_g1_from_kilic(s, d_out.p, rows);
             launch_g1_compress(s, d_out.p, d_c.p, rows);
             HIPCHK(hipGetLastError());
-            HIPCHK(hipMemcpy2DAsync(b.h_out, 64, d_c.p, 48, 48, rows, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipMemcpy2DAsync(b.h_out + 48, 64, d_bad.p, 4, 4, rows, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
-            return KZG_HIP_OK;
+            return eth_rows_to_host(s, d_c.p, nullptr, d_bad.p, rows, 64, b.h_out);
         };
         uint8_t row[64];
         int st = co->submit(blobs_le32, n * 32, n, 0, row, 64, exec, KZG_HIP_ERR_HIP);
@@ -195,12 +217,19 @@ int kzg_hip_eth_compute_kzg_proof(kzg_hip_eth *eth, const void *poly_fr, uint64_
             void *dp_in = nullptr;
             HIPCHK(hipHostGetDevicePointer(&dp_in, b.h_in, 0));
             const uint64_t stride = co->in_row_bytes() / sizeof(fr);
-            CHK(eth_proof_rows(eth, s, (const fr *)dp_in, stride, (const fr *)dp_in + n, stride, rows, d_c.p, d_y.p, d_bad.p));
-            HIPCHK(hipMemcpy2DAsync(b.h_out, 128, d_c.p, 48, 48, rows, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipMemcpy2DAsync(b.h_out + 48, 128, d_y.p, 32, 32, rows, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipMemcpy2DAsync(b.h_out + 80, 128, d_bad.p, 4, 4, rows, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
-            return KZG_HIP_OK;
+            // Few rows (a lone caller, a handful of goroutines): the quotient kernel reads every coefficient twice and is latency-bound, so the rows are copied to
+            // HBM first (one DMA of 128 KiB per row from the pinned staging area) instead of being read in place over PCIe; larger batches keep the in-place read, whose
+            // bandwidth the walk hides.
+            dtmp<fr> d_rows(s);
+            const fr *src = (const fr *)dp_in;
+            static const uint64_t stage_rows = [] { const char *e = getenv("KZG_HIP_ETH_STAGE_ROWS"); return e ? (uint64_t)atol(e) : 16ull; }();
+            if (rows <= stage_rows) {
+                CHK(d_rows.alloc(rows * stride));
+                HIPCHK(hipMemcpyAsync(d_rows.p, b.h_in, rows * co->in_row_bytes(), hipMemcpyHostToDevice, s));
+                src = d_rows.p;
+            }
+            CHK(eth_proof_rows(eth, s, src, stride, src + n, stride, rows, d_c.p, d_y.p, d_bad.p));
+            return eth_rows_to_host(s, d_c.p, d_y.p, d_bad.p, rows, 128, b.h_out);
         };
         int st = co->submit(poly_fr, n * sizeof(fr), n, 0, row, 128, exec, KZG_HIP_ERR_HIP, z_fr, sizeof(fr));
         if (st != KZG_HIP_OK) return st;

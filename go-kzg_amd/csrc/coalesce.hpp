@@ -29,6 +29,8 @@
 #pragma once
 #ifndef KZG_COALESCE_SIM
 #include <hip/hip_runtime.h>
+void stream_cache_own(hipStream_t s);      // capi_core.hip: small stream-ordered temporaries of library-owned streams are recycled per stream
+void stream_cache_disown(hipStream_t s);
 #endif
 #include <atomic>
 #include <chrono>
@@ -186,7 +188,7 @@ class coalescer {
         if (b.h_in) hipHostFree(b.h_in);
         if (b.h_out) hipHostFree(b.h_out);
         if (b.h_meta) hipHostFree(b.h_meta);
-        if (b.stream) hipStreamDestroy(b.stream);
+        if (b.stream) { stream_cache_disown(b.stream); hipStreamDestroy(b.stream); }
         (void)hipGetLastError();
 #else
         free(b.h_in); free(b.h_out); free(b.h_meta);
@@ -204,6 +206,7 @@ class coalescer {
             free_buf(b);
             return false;
         }
+        stream_cache_own(b.stream);
 #else
         // (simulation: KZG_COALESCE_SIM_MAX_BUFS staging buffers can be allocated, the next allocation fails -- pinned-memory pressure)
         if (const char *e = getenv("KZG_COALESCE_SIM_MAX_BUFS")) {

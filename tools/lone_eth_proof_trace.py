@@ -25,3 +25,5 @@ for _ in range(200):
     fn()
     ts.append((time.perf_counter() - t0) * 1e3)
 print("eth.ComputeKZGProof alone: median %.3f ms, min %.3f ms over 200 calls" % (float(np.median(ts)), min(ts)))
+ts.sort()
+print("percentiles (ms): p5 %.3f p25 %.3f p50 %.3f p75 %.3f p95 %.3f" % (ts[10], ts[50], ts[100], ts[150], ts[190]))
