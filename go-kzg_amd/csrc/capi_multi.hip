@@ -151,7 +151,7 @@ struct kzg_hip_multi {
     std::mutex mu;                         // sharded calls (collectives) on a handle run one at a time
     std::atomic<uint64_t> n_allgather{0};  // exchanges performed (tests and bench read it)
 };
-enum { FAULT_RCCL = 1, FAULT_RCCL_CORRUPT = 2, FAULT_PEER = 4, FAULT_PEER_CORRUPT = 8, FAULT_RCCL_HANG = 16, FAULT_PEER_HANG = 32 };
+enum { FAULT_RCCL = 1, FAULT_RCCL_CORRUPT = 2, FAULT_PEER = 4, FAULT_PEER_CORRUPT = 8, FAULT_RCCL_HANG = 16, FAULT_PEER_HANG = 32, FAULT_PEER_STUCK = 64 };
 struct kzg_hip_multi_eth { kzg_hip_multi *m = nullptr; std::vector<kzg_hip_eth *> eth; uint64_t n = 0; };
 struct kzg_hip_multi_fk20s { kzg_hip_multi *m = nullptr; std::vector<kzg_hip_fk20s *> fk; uint64_t n2 = 0; };
 struct kzg_hip_multi_fk20m { kzg_hip_multi *m = nullptr; std::vector<kzg_hip_fk20m *> fk; uint64_t n2 = 0, l = 1; };
@@ -446,7 +446,7 @@ int transport_self_test(kzg_hip_multi *m) {
                 // injected peer hang: the stuck exchange is let go only NOW, so that it completes late, next to the probe of the next transport, and writes into the
                 // abandoned arenas -- the case the abandoning exists for.  (Left spinning it would also hold whatever hardware queue its stream shares with the fresh
                 // ones -- ROCm maps a process's streams onto a few queues -- which is a property of the injection, not of the code under test.)
-                if (kind == T_PEER && (m->fault & FAULT_PEER_HANG)) release_injected_hang(m);
+                if (kind == T_PEER && (m->fault & FAULT_PEER_HANG) && !(m->fault & FAULT_PEER_STUCK)) release_injected_hang(m);
             }
         } else if (kind == T_RCCL) {   // a communicator that failed once is not used again
             for (ncclComm_t c : m->comms) if (c) (void)m->nccl->CommDestroy(c);
@@ -630,6 +630,7 @@ int kzg_hip_multi_settings_new(const int *devices, uint32_t n_devices, unsigned 
         if (has("peer-corrupt")) m->fault |= FAULT_PEER_CORRUPT;
         if (has("rccl-hang")) m->fault |= FAULT_RCCL_HANG;
         if (has("peer-hang")) m->fault |= FAULT_PEER_HANG;
+        if (has("peer-stuck")) m->fault |= FAULT_PEER_HANG | FAULT_PEER_STUCK;   // ... and is NOT let go after its streams were abandoned: stuck until the kernel's own clock runs out
     }
     try {   // one host thread per further entry, for the lifetime of the handle; a thread that cannot be started fails the constructor cleanly
         for (uint32_t i = 1; i < n_devices; i++) {

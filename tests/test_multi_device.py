@@ -326,6 +326,28 @@ def test_transport_self_test_steps_down_on_an_injected_fault(kz, monkeypatch, de
     m.close()
 
 
+def test_a_transport_that_stays_stuck_costs_bounded_time(kz, monkeypatch):
+    """`peer-stuck`: the injected hang is NOT released after its streams were abandoned (a copy that never completes).  Fresh streams may share a hardware queue with
+    the stuck one -- then the next probes time out too.  Either way the constructor must come back within a few deadlines: with host-staged proven, or with an error
+    whose text names the timeouts.  Nothing may block for good."""
+    import time
+    monkeypatch.setenv("KZG_HIP_FK20_FB_BUDGET_GB", "4")
+    monkeypatch.setenv("KZG_HIP_MULTI_FAULT", "peer-stuck")
+    monkeypatch.setenv("KZG_HIP_MULTI_PROBE_TIMEOUT_MS", "300")
+    setup33 = ko.generate_testing_setup_g1(S_TEST, 33)
+    t0 = time.time()
+    try:
+        m = kz.MultiKZGSettings([0, 0, 0, 0], 5, setup33)
+    except kz.KzgPanic as e:
+        assert time.time() - t0 < 10.0
+        assert "timeout" in str(e) and "peer-copy failed its self-test" in str(e), str(e)
+        return
+    assert time.time() - t0 < 10.0
+    assert m.transport == "host-staged" and "timeout" in m.transport_note, (m.transport, m.transport_note)
+    _vector_C_through(kz, m)
+    m.close()
+
+
 def test_forced_host_staged_and_out_of_range_ordinal(kz, monkeypatch):
     """host-staged as the FIRST choice (KZG_HIP_MULTI_TRANSPORT=host) never touches the broken peer leg; ordinals are bounded by what the runtime
     enumerates (hipGetDeviceCount), not by the number of gfx950 devices"""
