@@ -15,15 +15,17 @@ collective ("scaling": "weak"); value = commitments of all ranks / max-over-rank
 
 Extra objects on the JSON line:
   roofline      -- dominant kernel of the commitment step (k_fb_accumulate, the fixed-base table walk): algorithmic bytes per launch /
-                   HIP-event launch time vs 8 TB/s, the PMC traffic of the committed rocprofv3 passes (profiles/), and `mac`: the
-                   kernel's v_mad_u64_u32 rate against the rate MEASURED on this GPU in this run (kzg_hip_calibrate).
+                   HIP-event launch time OF THE TIMED STEPS (launches_timed, launch_over_step <= 1.002 asserted) vs 8 TB/s, the PMC traffic of the committed
+                   rocprofv3 passes (profiles/), and `mac`: the kernel's v_mad_u64_u32 rate against the rate MEASURED on this GPU in this run (kzg_hip_calibrate).
   roofline.secondary.fk20 -- the same for the FK20 half of the metric (dominant kernel k_g1_fft_stage).
   cpu_baseline  -- the oracle's restatement of bls.LinCombG1 (Kilic-style Pippenger) on the host: one core and all cores (one blob
-                   per core), CPU model and core count stated; the Go toolchain probe (rank 0, N = 1).
+                   per core), CPU model and core count stated; the Go toolchain probe; port_vs_published (the port against BENCH.md's transforms) (rank 0, N = 1).
+  cpu_baseline_fk20_4096 -- the FK20 half on the host: one oracle FK20Single on 512 coefficients, scaled to 4096 by the reference's MulG1 count (estimate, labelled).
   table_sweep   -- commitments/s against the HBM budget of the fixed-base table (5 / 9 / 17 / 60 / 110 GB).
-  drop_in       -- the reference's ONE-blob-per-call API from 1 .. 256 native host threads (host buffers, coalesced in the library).
+  drop_in       -- the reference's ONE-blob-per-call API from 1 .. 256 native host threads (host buffers, coalesced in the library): three runs per thread
+                   count (min / median / max) with the coalescer's own counters (batches, rows per batch, ms per batch by phase); coalescer_256 = the 256-caller run's.
   lincomb       -- variable-base bls.LinCombG1 on a cached point set (GLV bucket MSM), batch 1 / 64 / 512.
-  latency       -- single-call latencies of the reference-shaped entry points.
+  latency       -- single-call latencies of the reference-shaped entry points; LinCombG1 on NEW caller-supplied points (one-shot) and on the SAME points again (promoted).
   fk20          -- DAUsingFK20 (2048 coefficients -> 4096 proofs) all-proofs/s, own timed loop, self-checked against the byte pin.
   fk20_4096     -- the metric's literal input, a 4096-ELEMENT blob (BASELINE config 4b): FK20Single 4096 coefficients -> 4096 proofs and
                    DAUsingFK20 4096 -> 8192 at scale 13 on the 8192-point setup of the reference's test secret: batch rates, lone latencies,
