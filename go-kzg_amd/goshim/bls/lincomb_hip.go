@@ -76,6 +76,9 @@ func UnregisterG1Points(numbers []G1Point) {
 }
 
 // LinCombG1 replaces bls/bls_kilic.go:132-150.
+// Unregistered points: the library itself notices a slice whose CONTENT keeps coming back (byte-for-byte comparison on every call, round 6: capi_core.hip, lincomb_promo)
+// and serves it from a cached set from the fourth call on (1.3 -> 0.27 ms for 4096 points); a caller that modifies its points in place is seen and takes the one-shot
+// path.  RegisterG1Points remains the explicit form: no comparison per call, no warm-up, but the promise not to modify the points is the caller's.
 func LinCombG1(numbers []G1Point, factors []Fr) *G1Point {
 	if len(numbers) != len(factors) {
 		panic("got LinCombG1 numbers/factors length mismatch")
