@@ -20,7 +20,7 @@
 // buffer is read back and compared; a transport that errs or delivers wrong bytes is replaced by the next one -- rccl -> peer-copy ->
 // host-staged (device -> pinned host -> device, no peer mapping involved) -- with the reason in kzg_hip_multi_transport_note.
 // KZG_HIP_MULTI_FAULT (tests only; comma list of "rccl", "rccl-corrupt", "rccl-hang", "peer", "peer-corrupt", "peer-hang") makes the named leg fail so
-// that the fall-backs run on a one-GPU box.
+// that the fall-backs run on a one-GPU box ("rccl-block" / "rccl-init-block": the RCCL calls block on the HOST side).
 //
 // A transport that HANGS (round 6).  The usual failure of a misconfigured RCCL / P2P path is not an error code but a collective that never completes.  The
 // probe therefore never blocks on a stream: it polls hipStreamQuery on every entry's stream against a deadline (KZG_HIP_MULTI_PROBE_TIMEOUT_MS, default
@@ -151,7 +151,7 @@ struct kzg_hip_multi {
     std::mutex mu;                         // sharded calls (collectives) on a handle run one at a time
     std::atomic<uint64_t> n_allgather{0};  // exchanges performed (tests and bench read it)
 };
-enum { FAULT_RCCL = 1, FAULT_RCCL_CORRUPT = 2, FAULT_PEER = 4, FAULT_PEER_CORRUPT = 8, FAULT_RCCL_HANG = 16, FAULT_PEER_HANG = 32, FAULT_PEER_STUCK = 64 };
+enum { FAULT_RCCL = 1, FAULT_RCCL_CORRUPT = 2, FAULT_PEER = 4, FAULT_PEER_CORRUPT = 8, FAULT_RCCL_HANG = 16, FAULT_PEER_HANG = 32, FAULT_PEER_STUCK = 64, FAULT_RCCL_BLOCK = 128, FAULT_RCCL_INIT_BLOCK = 256 };
 struct kzg_hip_multi_eth { kzg_hip_multi *m = nullptr; std::vector<kzg_hip_eth *> eth; uint64_t n = 0; };
 struct kzg_hip_multi_fk20s { kzg_hip_multi *m = nullptr; std::vector<kzg_hip_fk20s *> fk; uint64_t n2 = 0; };
 struct kzg_hip_multi_fk20m { kzg_hip_multi *m = nullptr; std::vector<kzg_hip_fk20m *> fk; uint64_t n2 = 0, l = 1; };
@@ -365,6 +365,33 @@ std::string abort_communicators(kzg_hip_multi *m) {
     return bad ? "ncclCommAbort reported an error on " + std::to_string(bad) + " communicator(s)" : "communicators aborted";
 }
 
+// The host side of RCCL can block too (ncclGroupEnd waiting for a proxy connection that never comes up; ncclCommInitAll on a fabric that does not answer).  The probe's
+// ncclAllGather group and the communicators' creation therefore run on a helper thread that owns COPIES of everything it touches (never the handle), and the constructor
+// waits for it against a deadline.  A helper that is still inside RCCL when the deadline passes is left behind (detached; ncclCommAbort from the constructor's thread is
+// NCCL's documented way to unblock it); what it references -- the streams it enqueues on -- is abandoned, not destroyed.
+struct rccl_probe_job {
+    rccl_api *api; std::vector<ncclComm_t> comms; std::vector<int> devices; std::vector<hipStream_t> streams; std::vector<uint8_t *> bufs; size_t each; long block_ms;
+    std::atomic<bool> cancelled{false};                            // set by the constructor when it stops waiting: an injected block then returns without touching RCCL
+    std::promise<std::pair<int, std::string>> done;
+};
+void rccl_probe_enqueue(std::shared_ptr<rccl_probe_job> j) {
+    if (j->block_ms > 0) {                                                                           // injected: "rccl-block"
+        std::this_thread::sleep_for(std::chrono::milliseconds(j->block_ms));
+        if (j->cancelled.load()) { j->done.set_value({KZG_HIP_ERR_HIP, "cancelled"}); return; }       // (the communicators it holds have been aborted meanwhile)
+    }
+    ncclResult_t r = j->api->GroupStart();
+    hipError_t he = hipSuccess;
+    for (size_t i = 0; i < j->comms.size() && r == ncclSuccess && he == hipSuccess; i++) {
+        he = hipSetDevice(j->devices[i]);
+        if (he == hipSuccess) r = j->api->AllGather(j->bufs[i] + i * j->each, j->bufs[i], j->each, ncclUint8, j->comms[i], j->streams[i]);
+    }
+    const ncclResult_t r2 = j->api->GroupEnd();
+    if (r == ncclSuccess) r = r2;
+    if (he != hipSuccess) { j->done.set_value({KZG_HIP_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(he)}); return; }
+    if (r != ncclSuccess) { j->done.set_value({KZG_HIP_ERR_HIP, std::string("ncclAllGather failed: ") + j->api->GetErrorString(r)}); return; }
+    j->done.set_value({KZG_HIP_OK, std::string()});
+}
+
 // One exchange with known contents on transport `kind`: entry i fills its slice with bytes that depend on (i, offset), one all_gather_bytes,
 // every entry's whole buffer is read back and compared on the host.  KZG_HIP_OK and *why empty when every byte arrived everywhere.  *timed_out: the
 // exchange did not complete within the deadline -- the entries' streams still hold it and must not be waited for (the caller abandons them).
@@ -392,7 +419,26 @@ int transport_probe(kzg_hip_multi *m, int kind, std::string *why, bool *timed_ou
     if ((kind == T_RCCL && (m->fault & FAULT_RCCL_HANG)) || (kind == T_PEER && (m->fault & FAULT_PEER_HANG))) {
         int st = enqueue_injected_hang(m, D - 1); if (st) return fail(st);
     }
-    int st = all_gather_bytes(m, buf, each, kind);
+    int st;
+    if (kind == T_RCCL && !(m->fault & (FAULT_RCCL | FAULT_RCCL_CORRUPT))) {
+        // the enqueue itself against the deadline (rccl_probe_enqueue, above); the sharded calls later use all_gather_bytes directly: by then the transport is proven
+        auto job = std::make_shared<rccl_probe_job>();
+        job->api = m->nccl; job->comms = m->comms; job->each = each; job->block_ms = (m->fault & FAULT_RCCL_BLOCK) ? 3 * m->probe_timeout_ms : 0;
+        for (size_t i = 0; i < D; i++) { job->devices.push_back(m->d[i].device); job->streams.push_back(m->d[i].s); job->bufs.push_back(buf[i].p); }
+        std::future<std::pair<int, std::string>> fut = job->done.get_future();
+        m->n_allgather++;
+        try { std::thread(rccl_probe_enqueue, job).detach(); }
+        catch (const std::exception &e) { g_last_error = std::string("self-test: could not start the RCCL helper thread: ") + e.what(); return fail(KZG_HIP_ERR_HIP); }
+        if (fut.wait_for(std::chrono::milliseconds(m->probe_timeout_ms)) != std::future_status::ready) {
+            char t[220]; snprintf(t, sizeof t, "self-test: the RCCL calls did not return within %ld ms (KZG_HIP_MULTI_PROBE_TIMEOUT_MS): timeout on the host side", m->probe_timeout_ms);
+            *why = t; g_last_error = t; *timed_out = true;
+            job->cancelled.store(true);
+            return KZG_HIP_ERR_HIP;
+        }
+        const std::pair<int, std::string> res = fut.get();
+        st = res.first;
+        if (st) g_last_error = res.second;
+    } else st = all_gather_bytes(m, buf, each, kind);
     if (st) return fail(st);
     const int w = wait_streams_deadline(m, m->probe_timeout_ms);
     if (w == 1) {
@@ -629,6 +675,8 @@ int kzg_hip_multi_settings_new(const int *devices, uint32_t n_devices, unsigned 
         if (has("peer")) m->fault |= FAULT_PEER;
         if (has("peer-corrupt")) m->fault |= FAULT_PEER_CORRUPT;
         if (has("rccl-hang")) m->fault |= FAULT_RCCL_HANG;
+        if (has("rccl-block")) m->fault |= FAULT_RCCL_BLOCK;            // the RCCL calls of the probe block on the HOST side (the helper thread sleeps three deadlines)
+        if (has("rccl-init-block")) m->fault |= FAULT_RCCL_INIT_BLOCK;  // ncclCommInitAll does not return in time
         if (has("peer-hang")) m->fault |= FAULT_PEER_HANG;
         if (has("peer-stuck")) m->fault |= FAULT_PEER_HANG | FAULT_PEER_STUCK;   // ... and is NOT let go after its streams were abandoned: stuck until the kernel's own clock runs out
     }
@@ -665,10 +713,25 @@ int kzg_hip_multi_settings_new(const int *devices, uint32_t n_devices, unsigned 
         rccl_api *api = rccl_bind(&why);
         if (!api) m->transport_note = "RCCL not bound (" + why + ")";
         else {
-            m->comms.assign(n_devices, nullptr);
-            ncclResult_t r = api->CommInitAll(m->comms.data(), (int)n_devices, devices);
-            if (r != ncclSuccess) { m->transport_note = std::string("ncclCommInitAll: ") + api->GetErrorString(r); m->comms.clear(); }
-            else { m->nccl = api; m->tkind = T_RCCL; }
+            // ncclCommInitAll on a helper thread, against 6 x the probe deadline (creation legitimately takes seconds on 8 devices); a helper that does not come back is
+            // left behind with its own copies, and the handle goes on with peer copies
+            struct init_job { rccl_api *api; std::vector<int> devs; std::vector<ncclComm_t> comms; long block_ms; std::promise<ncclResult_t> done; };
+            auto job = std::make_shared<init_job>();
+            job->api = api; job->devs.assign(devices, devices + n_devices); job->comms.assign(n_devices, nullptr);
+            job->block_ms = (m->fault & FAULT_RCCL_INIT_BLOCK) ? 8 * m->probe_timeout_ms : 0;
+            std::future<ncclResult_t> fut = job->done.get_future();
+            std::thread([job] {
+                if (job->block_ms > 0) { std::this_thread::sleep_for(std::chrono::milliseconds(job->block_ms)); job->done.set_value(ncclSystemError); return; }
+                job->done.set_value(job->api->CommInitAll(job->comms.data(), (int)job->devs.size(), job->devs.data()));
+            }).detach();
+            if (fut.wait_for(std::chrono::milliseconds(6 * m->probe_timeout_ms)) != std::future_status::ready) {
+                char t[200]; snprintf(t, sizeof t, "ncclCommInitAll did not return within %ld ms: timeout (left behind on its thread)", 6 * m->probe_timeout_ms);
+                m->transport_note = t;
+            } else {
+                const ncclResult_t r = fut.get();
+                if (r != ncclSuccess) m->transport_note = std::string("ncclCommInitAll: ") + api->GetErrorString(r);
+                else { m->comms = job->comms; m->nccl = api; m->tkind = T_RCCL; }
+            }
         }
     } else if (!distinct) m->transport_note = "the device list repeats a device";
     m->transport = transport_name(m->tkind);

@@ -293,6 +293,9 @@ def _vector_C_through(kz, m):
     # a transport that HANGS instead of failing (a kernel spinning on a flag nobody sets sits in front of the exchange): the probe's deadline fires, the communicator
     # is aborted resp. the stuck streams and arenas are abandoned, and the next transport is proven on fresh ones
     ([0], "rccl", "rccl-hang", "peer-copy", "rccl failed its self-test (self-test: the all-gather did not complete within 400 ms (KZG_HIP_MULTI_PROBE_TIMEOUT_MS): timeout)"),
+    # ... and RCCL blocking on the HOST side: the probe's ncclAllGather group runs on a helper thread against the same deadline; ncclCommInitAll against six of them
+    ([0], "rccl", "rccl-block", "peer-copy", "rccl failed its self-test (self-test: the RCCL calls did not return within 400 ms (KZG_HIP_MULTI_PROBE_TIMEOUT_MS): timeout on the host side)"),
+    ([0], "rccl", "rccl-init-block", "peer-copy", "ncclCommInitAll did not return within 2400 ms: timeout"),
     ([0, 0], None, "peer-hang", "host-staged", "peer-copy failed its self-test (self-test: the all-gather did not complete within 400 ms (KZG_HIP_MULTI_PROBE_TIMEOUT_MS): timeout); streams and arenas of the hung exchange abandoned"),
 ])
 def test_transport_self_test_steps_down_on_an_injected_fault(kz, monkeypatch, devices, force, fault, transport, why):
@@ -304,7 +307,7 @@ def test_transport_self_test_steps_down_on_an_injected_fault(kz, monkeypatch, de
         monkeypatch.setenv("KZG_HIP_MULTI_TRANSPORT", force)
     if fault:
         monkeypatch.setenv("KZG_HIP_MULTI_FAULT", fault)
-    hang = bool(fault) and "hang" in fault
+    hang = bool(fault) and ("hang" in fault or "block" in fault)
     if hang:
         monkeypatch.setenv("KZG_HIP_MULTI_PROBE_TIMEOUT_MS", "400")
     import time
@@ -316,7 +319,7 @@ def test_transport_self_test_steps_down_on_an_injected_fault(kz, monkeypatch, de
         # AFTER which a blocking synchronise would have returned) and never "never"
         assert time.time() - t0 < 10.0, time.time() - t0
         assert "timeout" in m.transport_note
-        if fault == "rccl-hang":
+        if fault in ("rccl-hang", "rccl-block"):
             assert "communicators aborted" in m.transport_note or "ncclCommAbort" in m.transport_note, m.transport_note
     assert m.transport == transport, (m.transport, m.transport_note)
     assert why in m.transport_note, m.transport_note
