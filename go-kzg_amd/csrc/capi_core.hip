@@ -134,7 +134,9 @@ std::map<hipStream_t, stream_blocks> g_sc;
 inline int sc_index(size_t class_bytes) { int k = 0; while ((256u << k) < class_bytes) k++; return k; }
 constexpr size_t SC_KEEP = 4;                                       // blocks kept per stream and class
 }
-void stream_cache_own(hipStream_t s) { std::lock_guard<std::mutex> lk(g_sc_mu); g_sc[s]; }
+void stream_cache_own(hipStream_t s) {   // (never throws: a stream that cannot be entered simply is not cached)
+    try { std::lock_guard<std::mutex> lk(g_sc_mu); g_sc[s]; } catch (...) {}
+}
 void stream_cache_disown(hipStream_t s) {
     stream_blocks b;
     {
@@ -163,7 +165,7 @@ bool stream_cache_give(hipStream_t s, void *p, size_t class_bytes) {
     if (it == g_sc.end()) return false;
     auto &v = it->second.cls[sc_index(class_bytes)];
     if (v.size() >= SC_KEEP) return false;
-    v.push_back(p);
+    try { v.push_back(p); } catch (...) { return false; }          // (called from destructors: the block is then freed the ordinary way)
     return true;
 }
 void lincomb_promo_free(kzg_hip_fft *fs);
