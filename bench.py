@@ -354,6 +354,19 @@ def main():
                         eth.compute_aggregate_kzg_proof(blob_bytes[:nb])
                     agg["%d_blobs_ms" % nb] = (time.perf_counter() - t0_) / 10 * 1e3
                 eth_proof["compute_aggregate_kzg_proof_host_buffers"] = agg
+                # lone calls of the byte-level entry points (median of 30 after 3 warm-up calls, like `latency`)
+                def med_ms(fn, reps=30):
+                    for _ in range(3):
+                        fn()
+                    ts_ = []
+                    for _ in range(reps):
+                        t0_ = time.perf_counter()
+                        fn()
+                        ts_.append((time.perf_counter() - t0_) * 1e3)
+                    return float(np.median(ts_))
+                z_one = mont_blobs(4242, 1, 1).reshape(1, 4)
+                eth_proof["lone_call_ms"] = {"ComputeKZGProof": med_ms(lambda: eth.compute_kzg_proof(blobs_h[0], z_one)),
+                                             "BlobToKZGCommitment": med_ms(lambda: eth.blob_to_kzg_commitment(blob_bytes[0]))}
                 eth.close()
             except Exception as e:                              # noqa: BLE001
                 eth_proof = {"error": "%s: %s" % (type(e).__name__, e)}
