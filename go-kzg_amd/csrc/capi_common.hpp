@@ -253,7 +253,7 @@ int kzg_settings_build(kzg_hip_fft *fs, const void *points_g1, uint64_t n, kzg_h
 int ensure_fixed_table(kzg_hip_kzg *ks, hipStream_t);   // capi_kzg.hip
 const void *host_mapped_pointer(const void *host, size_t bytes);
 int h2d_copy(void *dst, const void *src, size_t bytes, hipStream_t s);   // capi_kzg.hip: cut at the boundaries of registered ranges   // capi_kzg.hip
-int commit_rows(kzg_hip_kzg *ks, hipStream_t s, const fr *d_sc, uint64_t n, uint64_t batch, g1j *d_out, uint64_t sc_stride = 0);   // capi_kzg.hip
+int commit_rows(kzg_hip_kzg *ks, hipStream_t s, const fr *d_sc, uint64_t n, uint64_t batch, g1j *d_out, uint64_t sc_stride = 0, bool to_kilic = true);   // capi_kzg.hip
 double table_budget_gb(const char *env, double cap_gb, double headroom_gb);   // capi_kzg.hip
 int lincomb_points_rows(kzg_hip_points *pts, hipStream_t s, const fr *d_sc, uint64_t n, uint64_t batch, g1j *d_out, uint64_t sc_stride = 0, bool holds_mu = false);   // capi_core.hip
 int lincomb_points_coalesced(kzg_hip_points *pts, const void *scalars_fr, uint64_t n, void *out_g1);   // capi_kzg.hip

@@ -93,8 +93,7 @@ int kzg_hip_eth_blob_to_kzg_commitment_batch(kzg_hip_eth *eth, const void *blobs
             void *dp_in = nullptr;
             HIPCHK(hipHostGetDevicePointer(&dp_in, b.h_in, 0));
             launch_fr_from_le32(s, (const uint8_t *)dp_in, d_poly.p, n, rows, d_bad.p);
-            CHK(commit_rows(eth->ks, s, d_poly.p, n, rows, d_out.p));
-            launch_g1_from_kilic(s, d_out.p, rows);
+            CHK(commit_rows(eth->ks, s, d_poly.p, n, rows, d_out.p, 0, false));     // (internal-domain points: straight into the compression)
             launch_g1_compress(s, d_out.p, d_c.p, rows);
             HIPCHK(hipGetLastError());
             return eth_rows_to_host(s, d_c.p, nullptr, d_bad.p, rows, 64, b.h_out);
@@ -120,8 +119,7 @@ int kzg_hip_eth_blob_to_kzg_commitment_batch(kzg_hip_eth *eth, const void *blobs
         src = d_in.p;
     }
     launch_fr_from_le32(s, src, d_poly.p, n, batch, d_bad.p);                    // BlobToPolynomial, eth/helpers.go:264-273
-    CHK(commit_rows(eth->ks, s, d_poly.p, n, batch, d_out.p));                  // PolynomialToKZGCommitment, eth/helpers.go:98-103
-    launch_g1_from_kilic(s, d_out.p, batch);                                    // commit_rows leaves Kilic images; compress wants internal
+    CHK(commit_rows(eth->ks, s, d_poly.p, n, batch, d_out.p, 0, false));        // PolynomialToKZGCommitment, eth/helpers.go:98-103 (internal-domain points: compress wants those)
     launch_g1_compress(s, d_out.p, d_c.p, batch);
     HIPCHK(hipGetLastError());
     std::vector<uint32_t> bad(batch);
@@ -145,8 +143,7 @@ static int eth_proof_rows(kzg_hip_eth *eth, hipStream_t s, const fr *d_poly, uin
     CHK(d_q.alloc(batch * n + extra)); CHK(d_out.alloc(batch));
     HIPCHK(hipMemsetAsync(d_bad, 0, batch * 4, s));
     launch_eth_quotient(s, d_poly, poly_stride, eth->d_domain, n, batch, d_z, z_stride, eth->fs->d_inv_pow2 + ilog2(n), d_q.p, d_y, d_bad, 1, extra ? d_q.p + batch * n : nullptr);
-    CHK(commit_rows(eth->ks, s, d_q.p, n, batch, d_out.p));                      // bls.LinCombG1(kzgSetupLagrange, quotient), eth/helpers.go:199
-    launch_g1_from_kilic(s, d_out.p, batch);
+    CHK(commit_rows(eth->ks, s, d_q.p, n, batch, d_out.p, 0, false));            // bls.LinCombG1(kzgSetupLagrange, quotient), eth/helpers.go:199
     launch_g1_compress(s, d_out.p, d_out48, batch);
     HIPCHK(hipGetLastError());
     return KZG_HIP_OK;
@@ -286,8 +283,7 @@ static int eth_aggregate(kzg_hip_eth *eth, hipStream_t s, const uint8_t *blobs, 
         if (!comm_in) {
             comm.resize(batch * 48);
             CHK(d_c.alloc(batch * 48)); CHK(d_out.alloc(batch));
-            CHK(commit_rows(eth->ks, s, d_poly.p, n, batch, d_out.p));
-            launch_g1_from_kilic(s, d_out.p, batch);
+            CHK(commit_rows(eth->ks, s, d_poly.p, n, batch, d_out.p, 0, false));
             launch_g1_compress(s, d_out.p, d_c.p, batch);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(comm.data(), d_c.p, batch * 48, hipMemcpyDeviceToHost, s));

@@ -112,7 +112,7 @@ int ensure_fixed_table(kzg_hip_kzg *ks, hipStream_t) {
 // MSM of `batch` resident scalar rows against SecretG1[:n]; out = batch normalised points (device).  The partial-sum / bucket
 // workspace is allocated per call, stream-ordered on the launch stream (hipMallocAsync pool: no device synchronisation after the
 // first use), so concurrent callers on different streams never share scratch memory.
-int commit_rows(kzg_hip_kzg *ks, hipStream_t s, const fr *d_sc, uint64_t n, uint64_t batch, g1j *d_out, uint64_t sc_stride) {
+int commit_rows(kzg_hip_kzg *ks, hipStream_t s, const fr *d_sc, uint64_t n, uint64_t batch, g1j *d_out, uint64_t sc_stride, bool to_kilic) {
     CHK(ensure_fixed_table(ks, s));
     bool fixed = ks->d_fixed != nullptr;
     if (!sc_stride) sc_stride = n;
@@ -121,8 +121,9 @@ int commit_rows(kzg_hip_kzg *ks, hipStream_t s, const fr *d_sc, uint64_t n, uint
     size_t ws_main = fixed ? fb_partials_bytes(n, batch) : msm_workspace_bytes(p, n, batch);
     dtmp<uint8_t> d_ws(s);
     CHK(d_ws.alloc(ws_main));
-    if (fixed) launch_fb_msm(s, ks->d_fixed, p.table_n, p.c, p.nwin, d_sc, sc_stride, n, batch, d_ws.p, d_out, true, p.glv != 0, ks->projective.load(std::memory_order_relaxed));   // sums, normalises (unless projective), converts
-    else launch_msm(s, p, ks->d_secret_a, d_sc, sc_stride, n, batch, d_ws.p, d_out, true);
+    // to_kilic = false (the eth byte paths: their results go on to the compression kernel): normalised points stay in the device-internal domain, no conversion back and forth
+    if (fixed) launch_fb_msm(s, ks->d_fixed, p.table_n, p.c, p.nwin, d_sc, sc_stride, n, batch, d_ws.p, d_out, to_kilic, p.glv != 0, to_kilic && ks->projective.load(std::memory_order_relaxed));   // sums, normalises (unless projective), converts
+    else launch_msm(s, p, ks->d_secret_a, d_sc, sc_stride, n, batch, d_ws.p, d_out, to_kilic);
     HIPCHK(hipGetLastError());
     return KZG_HIP_OK;
 }
