@@ -446,10 +446,20 @@ int kzg_hip_compute_proof_single(kzg_hip_kzg *ks, const void *poly_fr, uint64_t 
         { dev_guard g(ks->fs); CHK(ensure_fixed_table(ks, s)); }
         uint64_t n_max = 0;
         for (uint64_t i = 0; i < batch; i++) n_max = b.h_meta[i].n > n_max ? b.h_meta[i].n : n_max;
-        dtmp<fr> d_rows(s); dtmp<uint64_t> d_meta(s);
-        CHK(d_rows.alloc(batch * n_max)); CHK(d_meta.alloc(2 * batch));
         void *dp_out = nullptr;                                                    // results go straight into the pinned output rows
         HIPCHK(hipHostGetDevicePointer(&dp_out, b.h_out, 0));
+        if (batch == 1) {
+            // a lone caller: the quotient kernel reads each coefficient once, so the one row (and its x) is read IN PLACE from the pinned staging area -- no upload, no
+            // zero-tail launch (a single row has no tail: n_max is its own length)
+            void *dp_in = nullptr, *dp_meta = nullptr;
+            HIPCHK(hipHostGetDevicePointer(&dp_in, b.h_in, 0));
+            HIPCHK(hipHostGetDevicePointer(&dp_meta, b.h_meta, 0));
+            CHK(proof_single_rows(ks, s, (const fr *)dp_in, n_max, 1, (const uint64_t *)dp_meta + 1, 2, (g1j *)dp_out));
+            HIPCHK(hipStreamSynchronize(s));
+            return KZG_HIP_OK;
+        }
+        dtmp<fr> d_rows(s); dtmp<uint64_t> d_meta(s);
+        CHK(d_rows.alloc(batch * n_max)); CHK(d_meta.alloc(2 * batch));
         CHK(coalesce_upload_rows(b, batch, co->in_row_bytes(), n_max, d_rows.p, d_meta.p));
         // a shorter polynomial padded with zero high coefficients has the same quotient (followed by zeros)
         CHK(proof_single_rows(ks, s, d_rows.p, n_max, batch, d_meta.p + 1, 2, (g1j *)dp_out));
