@@ -981,13 +981,19 @@ __global__ __launch_bounds__(256) void k_fb_finish(const fb_partial *partials, u
     g1x_acc acc; acc.init();
     acc.v = g1xq_from_affine(g1a_inf());                   // defined limbs while empty
     const uint32_t rounds = (blocks_per_blob + 63) / 64;
+    // (the next round's partial sum is loaded before this round's addition: its HBM latency hides behind the addition)
+    g1xq wn; bool wn_inf;
+    { const bool have = quad < blocks_per_blob; const fb_partial &pj = partials[b * blocks_per_blob + (have ? quad : 0)]; fb_partial_load(pj, wn); wn_inf = !have || pj.inf != 0; }
 #pragma nounroll
     for (uint32_t r = 0; r < rounds; r++) {
-        const uint32_t j = r * 64 + quad;
-        const bool have = j < blocks_per_blob;
-        const fb_partial &pj = partials[b * blocks_per_blob + (have ? j : 0)];
-        g1xq w; fb_partial_load(pj, w);
-        quad_acc_add_nl(acc, w, !have || pj.inf != 0, role);
+        const g1xq w = wn; const bool winf = wn_inf;
+        if (r + 1 < rounds) {
+            const uint32_t j = (r + 1) * 64 + quad;
+            const bool have = j < blocks_per_blob;
+            const fb_partial &pj = partials[b * blocks_per_blob + (have ? j : 0)];
+            fb_partial_load(pj, wn); wn_inf = !have || pj.inf != 0;
+        }
+        quad_acc_add_nl(acc, w, winf, role);
     }
 #ifdef KZG_FINISH_TIMING
     __syncthreads(); const uint64_t tf1 = wall_clock64();
@@ -1011,6 +1017,27 @@ __global__ __launch_bounds__(256) void k_fb_finish(const fb_partial *partials, u
 #else
         const fp i = wave_inv_any(mul(px.zz, px.zzz), need);
 #endif
+#if !defined(KZG_REDUCE_WAVE_COOP) && !defined(KZG_NO_COOP_INV) && !defined(KZG_FINISH_NOINV)
+        // the affine image: x = X i ZZZ on lane 0, y = Y i ZZ on lane 1 (quad 0 holds replicas of the sum; the inverse is the owner's: handed to lane 1 by a DPP move), each
+        // followed by its own conversion to Kilic's image -- three dependent products per lane instead of six on one
+        const uint32_t aff = __builtin_amdgcn_readfirstlane((uint32_t)(!acc.inf && !(to_kilic & 2)));
+        if (aff) {
+            fp i1;
+#pragma unroll
+            for (int k = 0; k < 12; k++) i1.l[k] = (uint32_t)__builtin_amdgcn_readlane((int)i.l[k], 0);
+            if (tid < 2) {
+                fp c = mul(tid ? px.y : px.x, mul(i1, tid ? px.zz : px.zzz));
+                if (to_kilic & 1) c = fp_to_kilic(c);
+                fp *dst = tid ? &out[b].y : &out[b].x;
+                *dst = c;
+                if (tid == 0) out[b].z = (to_kilic & 1) ? fp_kilic_one() : one<FpP>();
+            }
+        } else if (own) {
+            g1j r;
+            if (acc.inf) r = g1_inf(); else r = g1x_to_jac(px);  // infinity, or the projective output (kzg_hip_kzg_set_projective_outputs): (X ZZ, Y ZZZ, ZZ), no inversion
+            out[b] = (to_kilic & 1) ? g1_to_kilic(r) : r;
+        }
+#else
         if (own) {
             g1j r;
             if (acc.inf) r = g1_inf();
@@ -1018,6 +1045,7 @@ __global__ __launch_bounds__(256) void k_fb_finish(const fb_partial *partials, u
             else { r.x = mul(px.x, mul(i, px.zzz)); r.y = mul(px.y, mul(i, px.zz)); r.z = one<FpP>(); }
             out[b] = (to_kilic & 1) ? g1_to_kilic(r) : r;
         }
+#endif
     }
 #if defined(KZG_FINISH_TIMING) && !defined(KZG_REDUCE_WAVE_COOP)
     if (threadIdx.x == 0 && b == 0) printf("finish phases (us): %u rounds of load + add %.1f | tree %.1f | inversion + output %.1f\n", (blocks_per_blob + 63) / 64, (tf1 - tf0) * 0.01, (tf2 - tf1) * 0.01, (wall_clock64() - tf2) * 0.01);
